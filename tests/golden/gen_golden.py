@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference here.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py
+
+What is the reference and what is a stand-in
+--------------------------------------------
+The reference's hot path is Python (subphaser/{Jellyfish,Seqs,Circos,Stats,Cluster}.py
+and SGConfig in __main__.py).  It is imported from /root/reference *unmodified*.
+Four third-party packages it imports are absent from this image; this script puts
+minimal stand-ins for them on sys.path (written to a temp dir, never committed
+as reference code):
+
+  xopen.xopen                     -> builtins.open / gzip.open
+  Bio.SeqIO.parse/write, Bio.Seq  -> 30-line FASTA reader + str subclass
+                                     (+ an empty Bio.Data.CodonTable so that
+                                     subphaser.__main__ imports; SGConfig lives there)
+  fisher.pvalue(a,b,c,d)          -> scipy.stats.hypergeom.sf(a-1, N, a+b, a+c)
+                                     (fisher 0.1.9 itself is absent: p-values are
+                                     "parity unpinned" against that package)
+  statsmodels ... multipletests   -> the 6-line BH step-up it documents
+
+The external `jellyfish` binary is absent too: dump files in its text format
+(`KMER COUNT` per line, canonical, count >= L) are produced by a definition-level
+brute-force counter (oracle/pyoracle.count_bruteforce) and then parsed by the
+reference's own JellyfishDump/JellyfishDumps code.
+
+Fixtures are data only: inputs (seeds/sequences/configs) and the outputs the
+reference produced for them.
+"""
+import gzip
+import io
+import json
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pyoracle as po  # noqa: E402
+from toygenome import make_toy_genome  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_standins(tmp):
+    def w(path, txt):
+        path = os.path.join(tmp, path)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(textwrap.dedent(txt))
+
+    w("xopen/__init__.py", """
+        import gzip, builtins
+        def xopen(path, mode='r', **kw):
+            if str(path).endswith('.gz'):
+                return gzip.open(path, mode if 't' in mode or 'b' in mode else mode + 't')
+            return builtins.open(path, mode)
+        """)
+    w("Bio/__init__.py", "")
+    w("Bio/Data/__init__.py", "")
+    w("Bio/Data/CodonTable.py", "# only imported (by the out-of-scope TEsorter module), never used here\n")
+    w("Bio/Seq.py", """
+        _C = str.maketrans('ACGTacgtNn', 'TGCAtgcaNn')
+        class Seq(str):
+            def reverse_complement(self):
+                return Seq(str(self).translate(_C)[::-1])
+            def upper(self):
+                return Seq(str.upper(self))
+        """)
+    w("Bio/SeqIO.py", """
+        from .Seq import Seq
+        class Rec:
+            def __init__(self, id, seq, desc=''):
+                self.id, self.seq, self.description = id, Seq(seq), desc
+        def parse(handle, fmt):
+            id, chunks = None, []
+            for line in handle:
+                line = line.rstrip('\\n').rstrip('\\r')
+                if line.startswith('>'):
+                    if id is not None:
+                        yield Rec(id, ''.join(chunks))
+                    id, chunks = line[1:].split()[0], []
+                elif id is not None:
+                    chunks.append(line.strip())
+            if id is not None:
+                yield Rec(id, ''.join(chunks))
+        def write(rc, fout, fmt):
+            recs = rc if isinstance(rc, (list, tuple)) else [rc]
+            for r in recs:
+                fout.write('>%s\\n' % r.id)
+                s = str(r.seq)
+                for i in range(0, len(s), 60):
+                    fout.write(s[i:i+60] + '\\n')
+        """)
+    w("fisher/__init__.py", """
+        from scipy.stats import hypergeom
+        CALLS = []   # margins the reference passed in (recorded in-process)
+        class _P:
+            def __init__(self, a, b, c, d):
+                self.right_tail = float(hypergeom.sf(a - 1, a + b + c + d, a + b, a + c))
+        def pvalue(a, b, c, d):
+            CALLS.append((int(a), int(b), int(c), int(d)))
+            return _P(int(a), int(b), int(c), int(d))
+        """)
+    w("statsmodels/__init__.py", "")
+    w("statsmodels/stats/__init__.py", "")
+    w("statsmodels/stats/multitest.py", """
+        import numpy as np
+        def multipletests(pvals, alpha=0.05, method='fdr_bh'):
+            assert method == 'fdr_bh'
+            pvals = np.asarray(pvals, float)
+            order = np.argsort(pvals)
+            ps = pvals[order]
+            n = len(ps)
+            ecdf = np.arange(1, n + 1) / float(n)
+            q = ps / ecdf
+            q = np.minimum.accumulate(q[::-1])[::-1]
+            q[q > 1] = 1
+            out = np.empty_like(q)
+            out[order] = q
+            return out <= alpha, out, None, None
+        """)
+    sys.path.insert(0, tmp)
+    sys.path.insert(0, REF)
+
+
+def write_dump(path, keys, counts, k):
+    with open(path, "w") as f:
+        for key, c in zip(keys, counts):
+            f.write("%s %d\n" % (po.decode(key, k), c))
+    open(path + ".ok", "w").close()
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="sp_golden_")
+    install_standins(tmp)
+    import logging
+    logging.disable(logging.CRITICAL)
+    from subphaser import Jellyfish, Seqs, Circos, Stats  # noqa
+    from subphaser.__main__ import SGConfig, add_prefix  # noqa
+    from subphaser.Cluster import Cluster  # noqa
+
+    out = {}
+
+    # ---------------------------------------------------------------- G8 configs
+    cfgs = {}
+    for name in sorted(os.listdir(os.path.join(REF, "example_data"))):
+        if not name.endswith("_sg.config"):
+            continue
+        p = os.path.join(REF, "example_data", name)
+        text = open(p).read()
+        ent = {"text": text, "parses": []}
+        for prefix in (None, "1-"):
+            cfg = SGConfig(p, prefix=prefix, sep="|")
+            ent["parses"].append({"prefix": prefix, "sgs": cfg.sgs, "chrs": cfg.chrs, "nsg": cfg.nsg})
+        cfgs[name] = ent
+    # hand-made config exercising comments, blank lines, singleton, trailing commas
+    extra = "# comment\nA1|c1\tB1|c2,B1b|c3,  # trailing\n\nsolo\nA2 B2 C2\n"
+    p = os.path.join(tmp, "extra_sg.config")
+    open(p, "w").write(extra)
+    ent = {"text": extra, "parses": []}
+    for prefix in (None, "x-"):
+        cfg = SGConfig(p, prefix=prefix, sep="|")
+        ent["parses"].append({"prefix": prefix, "sgs": cfg.sgs, "chrs": cfg.chrs, "nsg": cfg.nsg})
+    cfgs["extra_sg.config"] = ent
+    out["G8_sgconfig"] = cfgs
+
+    # ---------------------------------------------------------------- toy genome
+    k, L = 15, 3
+    toy = make_toy_genome(seed=7)
+    labels = toy["labels"]
+    seqs = toy["seqs"]
+    chromdir = os.path.join(tmp, "chromosomes")
+    os.makedirs(chromdir)
+    chromfiles, dumpfiles = [], []
+    dumps = []
+    for lab in labels:
+        cf = os.path.join(chromdir, lab + ".fasta")
+        with open(cf, "w") as f:
+            f.write(">%s\n" % lab)
+            s = seqs[lab]
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+        chromfiles.append(cf)
+        keys, cnts = po.count_bruteforce(seqs[lab], k, L)
+        dumps.append((keys, cnts))
+        df = "%s_%d.fa" % (cf, k)
+        write_dump(df, keys, cnts, k)
+        dumpfiles.append(df)
+
+    # G1: count tables (definition-level; not produced by the reference)
+    g1 = {"k": k, "lower": L, "toy_seed": 7,
+          "dumps": {lab: {"n": int(len(d[0])), "sum": int(d[1].astype(np.int64).sum()),
+                          "xor": int(np.bitwise_xor.reduce(d[0])) if len(d[0]) else 0,
+                          "head_keys": [int(x) for x in d[0][:8]],
+                          "head_counts": [int(x) for x in d[1][:8]],
+                          "max_count": int(d[1].max()) if len(d[1]) else 0}
+                    for lab, d in zip(labels, dumps)}}
+    out["G1_toy_dumps"] = g1
+
+    # ---------------------------------------------------------------- G2/G3 matrix+filter
+    def run_filter(sgs, **kw):
+        jd = Jellyfish.JellyfishDumps(dumpfiles, labels, ncpu=2, method="map", chunksize=None)
+        d_mat = jd.to_matrix()
+        res = {"n_union": len(d_mat), "lengths": [int(x) for x in jd.lengths]}
+        try:
+            d2 = jd.filter(d_mat, jd.lengths, sgs, outfig=os.path.join(tmp, "h.png"), **kw)
+        except ValueError as e:
+            res["error"] = str(e)
+            return res, None, jd
+        rows = sorted(d2.items())
+        res["n_rows"] = len(rows)
+        res["rows"] = [[kmer] + [repr(float(x)) for x in fr] for kmer, fr in rows]
+        return res, d2, jd
+
+    base_sgs = toy["sgs"]
+    grouped_sgs = toy["sgs_grouped"]
+    cases = {
+        "default": (base_sgs, dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=1, ratio=1)),
+        "baseline_last": (toy["sgs3"], dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=-1, ratio=1)),
+        "baseline_1_three": (toy["sgs3"], dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=1, ratio=1)),
+        "ratio_half": (base_sgs, dict(min_freq=30, max_freq=1e9, min_fold=3, baseline=1, ratio=0.5)),
+        "grouped_units": (grouped_sgs, dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=1, ratio=1)),
+        "with_singleton": (base_sgs + [[["A3"]]], dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=1, ratio=1)),
+        "min_prop": (base_sgs, dict(min_freq=30, max_freq=1e9, min_fold=2, baseline=1, ratio=1,
+                                    min_prop=2e-4, max_prop=5e-3)),
+        "max_freq_low": (base_sgs, dict(min_freq=30, max_freq=60, min_fold=2, baseline=1, ratio=1)),
+        "fold_1p5": (base_sgs, dict(min_freq=10, max_freq=1e9, min_fold=1.5, baseline=1, ratio=1)),
+        "err_minmax": (base_sgs, dict(min_freq=100, max_freq=50, min_fold=2)),
+        "err_singletons": ([[["A1"]], [["B1"]]], dict(min_freq=30, max_freq=1e9, min_fold=2)),
+        "err_nofold": (base_sgs, dict(min_freq=30, max_freq=1e9, min_fold=1e12)),
+    }
+    g2 = {}
+    d2_default = None
+    for name, (sgs, kw) in cases.items():
+        res, d2, jd = run_filter(sgs, **kw)
+        g2[name] = {"sgs": sgs, "kw": kw, "res": res}
+        if name == "default":
+            d2_default = d2
+            buf = io.StringIO()
+            jd.write_matrix(dict(sorted(d2.items())), buf)
+            out["G3_kmer_mat_text"] = buf.getvalue()
+    out["G2_filter"] = g2
+
+    # ---------------------------------------------------------------- G7 cluster.output_kmers
+    matfile = os.path.join(tmp, "toy.kmer.mat")
+    with open(matfile, "w") as f:
+        f.write(out["G3_kmer_mat_text"])
+    sg_assigned = toy["sg_assigned"]
+    cl = Cluster(matfile, n_clusters=2, sg_prefix="SG", sg_assigned=sg_assigned, bootstrap=False)
+    buf = io.StringIO()
+    d_kmers = cl.output_kmers(buf, max_pval=0.05, ncpu=2, test_method="ttest_ind")
+    out["G7_output_kmers"] = {"sg_assigned": sg_assigned, "d_sg": dict(cl.d_sg), "sg_names": cl.sg_names,
+                              "text": buf.getvalue(), "n_dkmers": len(d_kmers)}
+    sg_names = cl.sg_names
+    d_sg = dict(cl.d_sg)
+
+    # ---------------------------------------------------------------- G4 map_kmer3 / G5 stack_matrix
+    g4 = {}
+    for name, kw in {
+        "chunk2000_bin100": dict(window_size=2000, bin_size=100, chunk=True),
+        "chunk1500_bin100": dict(window_size=1500, bin_size=100, chunk=True),
+        "chunk10M_bin10k": dict(window_size=10e6, bin_size=10000, chunk=True),
+        "chunk5000_bin300": dict(window_size=5000, bin_size=300, chunk=True),
+    }.items():
+        buf = io.StringIO()
+        Seqs.map_kmer3(chromfiles, d_kmers, fout=buf, k=k, sg_names=sg_names, ncpu=2, method="map", **kw)
+        g4[name] = {"kw": kw, "text": buf.getvalue()}
+    out["G4_map_kmer3"] = g4
+
+    # feature mode: FASTA records named chrom:start-end (+ one odd id), lower-case and N inside
+    feats = toy["features"]
+    featfile = os.path.join(tmp, "features.fa")
+    with open(featfile, "w") as f:
+        for fid, s in feats:
+            f.write(">%s\n%s\n" % (fid, s))
+    buf = io.StringIO()
+    Seqs.map_kmer3([featfile], d_kmers, fout=buf, k=k, ncpu=2, bin_size=10000000, sg_names=sg_names,
+                   chunk=False, log=False, method="map")
+    out["G4_map_features"] = {"features": feats, "text": buf.getvalue()}
+
+    g5 = {}
+    binfile = os.path.join(tmp, "toy.bin.count")
+    open(binfile, "w").write(g4["chunk2000_bin100"]["text"])
+    for ws in (1000, 1500, 2500, 100000):
+        coords, counts = Circos.stack_matrix(binfile, window_size=ws)
+        g5[str(ws)] = {"coords": [[c, int(s), int(e)] for c, s, e in coords],
+                       "counts": [[int(x) for x in row] for row in counts]}
+    out["G5_stack_matrix"] = g5
+
+    # ---------------------------------------------------------------- G6 enrichment
+    g6 = {}
+    coords, counts = Circos.stack_matrix(binfile, window_size=2500)
+    f1, f2 = io.StringIO(), io.StringIO()
+    Stats.enrich_bin(f1, f2, d_sg, counts, colnames=sg_names, rownames=coords, max_pval=0.05, ncpu=2)
+    g6["toy_bin"] = {"window_size": 2500, "d_sg": d_sg, "sg_names": sg_names,
+                     "enrich_text": f1.getvalue(), "group_text": f2.getvalue()}
+    # feature enrichment (.custom.enrich); ids must match chrom:start-end (Stats.py:42)
+    featbin = os.path.join(tmp, "feat.bin.count")
+    open(featbin, "w").write(out["G4_map_features"]["text"])
+    fc, fcounts = Circos.stack_matrix(featbin, window_size=100000000)
+    ok = [(c, n) for c, n in zip(fc, fcounts) if ":" in c[0]]
+    f3 = io.StringIO()
+    Stats.enrich_ltr(f3, d_sg, [n for _, n in ok], colnames=sg_names, rownames=[c for c, _ in ok],
+                     max_pval=0.05, ncpu=2)
+    g6["toy_features"] = {"enrich_text": f3.getvalue()}
+    # synthetic tables: three subgenomes, clamp-active totals, underflow, ties, ratio<0.5, zero column
+    rng = np.random.RandomState(11)
+    tabs = {}
+    t1 = rng.poisson(40, size=(40, 3)).astype(np.int64)
+    t1[:10, 0] += rng.poisson(80, 10)
+    t1[10:20, 1] += rng.poisson(300, 10)
+    t1[20:24] = 0
+    t1[20:24, 2] = [1, 2, 3, 500]
+    t1[24] = [7, 7, 7]
+    t1[25] = [50, 50, 1]
+    tabs["three_sg_small"] = t1
+    t2 = rng.poisson(300, size=(30, 3)).astype(np.int64)
+    t2[:3] = rng.poisson(1e8, size=(3, 3))      # three giant windows push totals past MAX_INT
+    t2[3, 0] += 400
+    t2[4, 1] += 90
+    t2[5, 2] += 2500
+    t2[6] = [10, 5, 1]
+    t2[7] = [0, 0, 40]
+    tabs["clamp_active"] = t2
+    t3 = rng.poisson(5, size=(25, 2)).astype(np.int64)
+    t3[:5, 0] += 30
+    t3[5:8, 1] += 2000
+    tabs["two_sg"] = t3
+    t4 = rng.poisson(20, size=(12, 3)).astype(np.int64)
+    t4[:, 2] = 0
+    tabs["zero_column"] = t4
+    for name, t in tabs.items():
+        S = t.shape[1]
+        names = ["SG%d" % (i + 1) for i in range(S)]
+        rows = [("chrA" if i < len(t) // 2 else "chrB", i * 1000, i * 1000 + 1000) for i in range(len(t))]
+        dsg = {"chrA": "SG1", "chrB": "SG2"}
+        f1, f2 = io.StringIO(), io.StringIO()
+        with np.errstate(all="ignore"):
+            Stats.enrich_bin(f1, f2, dsg, [list(r) for r in t], colnames=names, rownames=rows,
+                             max_pval=0.05, ncpu=2)
+        total = t.sum(axis=0)
+        import fisher as _fisher_standin
+        cells = []
+        for r in t[:6]:   # margins as Stats.fisher_test itself hands them to fisher.pvalue
+            del _fisher_standin.CALLS[:]
+            Stats.fisher_test(list(map(int, r)), list(map(int, total)))
+            cells.append([list(c) for c in _fisher_standin.CALLS])
+        tabs[name] = {"counts": t.tolist(), "d_sg": dsg, "sg_names": names,
+                      "rows": [list(r) for r in rows], "enrich_text": f1.getvalue(),
+                      "group_text": f2.getvalue(), "cells_first6": cells}
+    g6["tables"] = tabs
+    out["G6_enrich"] = g6
+
+    # hypergeometric right tails to 30 digits (mpmath; independent of every implementation)
+    try:
+        import mpmath as mp
+        mp.mp.dps = 50
+        vec = []
+        for (a, b, c, d) in [(10, 6, 214748364, 214748364), (5, 11, 214748364, 214748364),
+                             (1, 15, 199999999, 214748364), (3, 0, 0, 4), (50, 100, 1000, 5000),
+                             (0, 5, 3, 2), (12, 3, 40, 200), (700, 900, 214748364, 214748364),
+                             (40, 1000, 214748364, 214748364), (2, 2, 2, 2), (300, 20, 1000, 100000),
+                             (25, 13, 99999, 214748364)]:
+            N, K, n = a + b + c + d, a + b, a + c
+            hi = min(K, n)
+
+            def lc(n_, k_):
+                return mp.loggamma(n_ + 1) - mp.loggamma(k_ + 1) - mp.loggamma(n_ - k_ + 1)
+            den = lc(N, n)
+            s = mp.mpf(0)
+            for x in range(a, hi + 1):
+                s += mp.e ** (lc(K, x) + lc(N - K, n - x) - den)
+            vec.append({"cells": [a, b, c, d], "p": mp.nstr(s, 30)})
+        out["G6_hypergeom_mp"] = vec
+    except ImportError:
+        pass
+
+    dst = os.path.join(HERE, "golden.json.gz")
+    with gzip.open(dst, "wt") as f:
+        json.dump(out, f, sort_keys=True)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()
