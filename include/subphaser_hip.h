@@ -1,0 +1,143 @@
+/*
+ * subphaser_hip.h -- C-ABI of libsubphaser_hip.so: the MI355X (gfx950) native
+ * implementation of SubPhaser's k-mer hot path.
+ *
+ * The reference has no FFI; its seam is five Python call sites in
+ * Pipeline.run() (subphaser/__main__.py:403-404, 409-433, 484-486, 491,
+ * 497-498).  Each entry point below names the reference interface it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SP_E* code on failure;
+ *     the message is available from sp_last_error(ctx) (ctx may be NULL for
+ *     errors raised before a context exists).  No C++ exception crosses.
+ *   - pointers named d_* are DEVICE pointers (HIP), all others are host.
+ *   - k-mers are uint64: 2 bits per base (A=0 C=1 G=2 T=3), first base in the
+ *     most significant used bits, always the canonical orientation
+ *     (min of the k-mer and its reverse complement).
+ *   - the caller owns every output buffer; the library owns device memory
+ *     inside the context; no caller pointer is retained after return.
+ *   - one context per process per GPU; calls on a context are serialised by
+ *     the caller.
+ */
+#ifndef SUBPHASER_HIP_H
+#define SUBPHASER_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL (-1)    /* bad argument / call order                     */
+#define SP_EUNSUP (-2)    /* k outside the supported range                 */
+#define SP_ENOMEM (-3)    /* hipMalloc failed                              */
+#define SP_EHIP (-4)      /* any other HIP runtime error                   */
+#define SP_ENODEV (-5)    /* no usable gfx950 device                       */
+#define SP_ESTATE (-6)    /* reference-level precondition (message mirrors
+                             the reference's ValueError text)              */
+
+typedef struct sp_ctx sp_ctx;
+
+int sp_version(void);
+const char *sp_last_error(const sp_ctx *ctx);
+
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL
+ * to let the library create its own. */
+int sp_ctx_create(int device, void *stream, sp_ctx **out);
+int sp_ctx_destroy(sp_ctx *ctx);
+int sp_sync(sp_ctx *ctx);
+/* the hipStream_t every kernel of this context is launched on */
+void *sp_stream(sp_ctx *ctx);
+
+/* ---- genome ingest (K0) -------------------------------------------------
+ * Replaces the per-chromosome FASTA files written by Seqs.split_genomes
+ * (Seqs.py:27-71) and read by jellyfish / chunk_chromfiles: the FASTA body of
+ * chromosome `chrom` (newlines removed, any case, IUPAC allowed) is packed to
+ * 2 bits/base + 1 validity bit/base in HBM.                                */
+int sp_genome_reset(sp_ctx *ctx, int n_chrom);
+int sp_genome_add(sp_ctx *ctx, int chrom, const uint8_t *ascii, int64_t len);
+int sp_genome_add_device(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64_t len);
+int sp_genome_len(sp_ctx *ctx, int chrom, int64_t *len);
+/* unpack back to upper-case ASCII ('N' for every invalid base) -- debugging / tests */
+int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
+
+/* ---- k-mer counting (K1 + K2) -------------------------------------------
+ * Replaces run_jellyfish_dumps (Jellyfish.py:671-704): for every chromosome,
+ * canonical k-mer counts, kept when count >= lower_count (`jellyfish dump -L`).
+ * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter. */
+int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
+/* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
+int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
+/* jellyfish-dump equivalent of one chromosome: keys ascending.  Two calls:
+ * sp_dump_size then sp_dump with buffers of that size.                      */
+int sp_dump_size(sp_ctx *ctx, int chrom, int64_t *n);
+int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t cap, int64_t *n);
+
+/* ---- matrix + differential filter (K3) ----------------------------------
+ * Replaces JellyfishDumps.to_matrix (Jellyfish.py:439-460) and .filter /
+ * _filter_kmer (:462-512, :611-648).  Homoeologous sets in CSR form: set s
+ * owns units [set_off[s], set_off[s+1]); unit u owns the chromosome indices
+ * unit_chrom[unit_off[u] .. unit_off[u+1]).  min_freq / max_freq are the
+ * already-resolved thresholds (min_prop/max_prop applied by the caller with
+ * sp_lengths).  Outputs: n_union = len(d_mat), n_rows = differential k-mers,
+ * n_hist = len(tot_freqs) (fold-passing k-mers, in or out of the freq range). */
+int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+              const int32_t *unit_chrom, double min_fold, int baseline, double min_freq,
+              double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist);
+/* rows in ascending canonical-key order; counts is row-major n_rows x C
+ * (thresholded counts: 0 where count < lower_count); freqs = count/length in
+ * fp64 exactly as Jellyfish.py:647 (may be NULL); tot = row sums (may be NULL) */
+int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot,
+                    int64_t cap_rows);
+/* tot of every fold-passing k-mer (the reference's tot_freqs histogram input) */
+int sp_filter_hist(sp_ctx *ctx, uint64_t *tot, int64_t cap);
+
+/* ---- subgenome-specific k-mer labels (K4) + bin mapping (K5) ------------
+ * sp_labels_set replaces the d_kmers dict handed to Seqs.map_kmer3
+ * (Cluster.py:174-175): canonical key -> subgenome index in [0, n_sg).
+ * sp_map_bins replaces Seqs.map_kmer3 / map_kmer_each4 (Seqs.py:74-119,
+ * 209-237) for one chromosome: counts by k-mer START position into
+ *   slot(s) = s / bin_size + chunk(s)
+ * where chunk(s) reproduces the reference's 10-Mb chunking (Seqs.py:121-139;
+ * chunk_size = 0 disables it), so that a bin straddling a chunk boundary is
+ * reported on two lines like the reference does.
+ * slot_counts: nslots x n_sg int32 (overwritten).                          */
+int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg);
+int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots);
+int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int32_t *slot_counts,
+                int64_t nslots, int64_t *n_mapped);
+/* feature mode (map_kmer3(..., chunk=False), __main__.py:509-511): n_feat
+ * sequences concatenated in `ascii`, feature f = [off[f], off[f+1]).
+ * counts: n_feat x n_sg int64 (whole-feature totals).                      */
+int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,
+                    int64_t *counts);
+/* number of distinct labelled k-mers seen by sp_map_bins/sp_map_features since
+ * sp_labels_set (the reference's "mapped kmers" log line, Seqs.py:109-117)  */
+int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit);
+
+/* ---- per-window enrichment (K6) -----------------------------------------
+ * Replaces Stats.enrich / _enrich / fisher_test / Pvalues.get_enriched
+ * (Stats.py:14-31, 140-192).  counts: W x S int64 window rows (host).
+ * Outputs (host): pvals W x S; argmin W; sig W; ratios W x S.              */
+int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
+              double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios);
+
+/* ---- profiling: per-kernel HIP-event timing on the context's stream ------ */
+int sp_prof_enable(sp_ctx *ctx, int on);
+int sp_prof_reset(sp_ctx *ctx);
+/* writes a JSON object {"kernel": {"calls": n, "ms": total}, ...} */
+int sp_prof_report(sp_ctx *ctx, char *buf, int64_t cap);
+
+/* ---- bench support (not part of the reference's interface) --------------
+ * Deterministic synthetic chromosome written as ASCII into a device buffer. */
+int sp_synth_chrom(sp_ctx *ctx, uint8_t *d_out, int64_t len, uint64_t seed, int set_id,
+                   int sg_id, int n_sg, int chrom_id, int exchange);
+/* device memory helpers so a non-torch caller can stage buffers */
+int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr);
+int sp_dev_free(sp_ctx *ctx, void *d_ptr);
+int sp_dev_copy_to_host(sp_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

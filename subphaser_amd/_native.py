@@ -1,0 +1,306 @@
+"""ctypes binding of libsubphaser_hip.so (C-ABI declared in include/subphaser_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is
+visible, every entry point raises.  PyTorch is never imported here; callers
+that want torch-owned memory/streams pass raw pointers (tensor.data_ptr(),
+torch.cuda.current_stream().cuda_stream).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsubphaser_hip.so")
+
+SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/subphaser_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
+    "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
+    "sp_count", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_filter", "sp_filter_fetch", "sp_filter_hist",
+    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_features", "sp_labels_hit",
+    "sp_enrich",
+    "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
+    "sp_synth_chrom", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host",
+]
+
+
+class NativeError(RuntimeError):
+    """HIP/runtime failure inside libsubphaser_hip.so."""
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "libsubphaser_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C subphaser_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl, ci = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int
+    P = C.POINTER
+    L.sp_version.restype = ci
+    L.sp_last_error.restype = C.c_char_p
+    L.sp_last_error.argtypes = [vp]
+    L.sp_ctx_create.argtypes = [ci, vp, P(vp)]
+    L.sp_ctx_destroy.argtypes = [vp]
+    L.sp_sync.argtypes = [vp]
+    L.sp_stream.restype = vp
+    L.sp_stream.argtypes = [vp]
+    L.sp_genome_reset.argtypes = [vp, ci]
+    L.sp_genome_add.argtypes = [vp, ci, vp, i64]
+    L.sp_genome_add_device.argtypes = [vp, ci, vp, i64]
+    L.sp_genome_len.argtypes = [vp, ci, P(i64)]
+    L.sp_genome_unpack.argtypes = [vp, ci, vp, i64]
+    L.sp_count.argtypes = [vp, ci, ci, ci]
+    L.sp_lengths.argtypes = [vp, vp]
+    L.sp_dump_size.argtypes = [vp, ci, P(i64)]
+    L.sp_dump.argtypes = [vp, ci, vp, vp, i64, P(i64)]
+    L.sp_filter.argtypes = [vp, ci, vp, vp, vp, dbl, ci, dbl, dbl, dbl, P(i64), P(i64), P(i64)]
+    L.sp_filter_fetch.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.sp_filter_hist.argtypes = [vp, vp, i64]
+    L.sp_labels_set.argtypes = [vp, vp, vp, i64, ci]
+    L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
+    L.sp_map_bins.argtypes = [vp, ci, i64, i64, vp, i64, P(i64)]
+    L.sp_map_features.argtypes = [vp, vp, vp, i64, vp]
+    L.sp_labels_hit.argtypes = [vp, P(i64)]
+    L.sp_enrich.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
+    L.sp_prof_enable.argtypes = [vp, ci]
+    L.sp_prof_reset.argtypes = [vp]
+    L.sp_prof_report.argtypes = [vp, C.c_char_p, i64]
+    L.sp_synth_chrom.argtypes = [vp, vp, i64, C.c_uint64, ci, ci, ci, ci, ci]
+    L.sp_dev_alloc.argtypes = [vp, i64, P(vp)]
+    L.sp_dev_free.argtypes = [vp, vp]
+    L.sp_dev_copy_to_host.argtypes = [vp, vp, vp, i64]
+    for name in SYMBOLS:
+        if name not in ("sp_last_error", "sp_stream"):
+            getattr(L, name).restype = ci
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def as_ascii(seq):
+    """str / bytes / uint8 array -> contiguous uint8 array (no copy when possible)."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    if isinstance(seq, (bytes, bytearray, memoryview)):
+        return np.frombuffer(seq, dtype=np.uint8)
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+class Context:
+    """One GPU context (one per process per GPU)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.sp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != SP_OK:
+            raise NativeError("sp_ctx_create failed (%d): %s" % (rc, self.L.sp_last_error(None).decode()))
+        self.h = h
+        self.n_chrom = 0
+        self.k = None
+
+    # -------------------------------------------------------------- plumbing
+    def _ck(self, rc):
+        if rc == SP_OK:
+            return
+        msg = self.L.sp_last_error(self.h).decode()
+        if rc in (SP_ESTATE, SP_EINVAL, SP_EUNSUP):
+            raise ValueError(msg)       # the reference raises ValueError for these
+        if rc == SP_ENOMEM:
+            raise MemoryError(msg)
+        raise NativeError("libsubphaser_hip error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._ck(self.L.sp_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.sp_stream(self.h)
+
+    # -------------------------------------------------------------- genome
+    def genome_reset(self, n_chrom):
+        self._ck(self.L.sp_genome_reset(self.h, int(n_chrom)))
+        self.n_chrom = int(n_chrom)
+
+    def genome_add(self, chrom, seq):
+        a = as_ascii(seq)
+        self._ck(self.L.sp_genome_add(self.h, int(chrom), _p(a), a.size))
+
+    def genome_add_device(self, chrom, d_ptr, length):
+        self._ck(self.L.sp_genome_add_device(self.h, int(chrom), C.c_void_p(int(d_ptr)), int(length)))
+
+    def genome_len(self, chrom):
+        n = C.c_int64()
+        self._ck(self.L.sp_genome_len(self.h, int(chrom), C.byref(n)))
+        return n.value
+
+    def genome_unpack(self, chrom):
+        n = self.genome_len(chrom)
+        out = np.empty(n, np.uint8)
+        self._ck(self.L.sp_genome_unpack(self.h, int(chrom), _p(out), n))
+        return out
+
+    # -------------------------------------------------------------- count
+    def count(self, k, lower_count=3, engine=0):
+        self._ck(self.L.sp_count(self.h, int(k), int(lower_count), int(engine)))
+        self.k = int(k)
+
+    def lengths(self):
+        out = np.zeros(self.n_chrom, np.int64)
+        self._ck(self.L.sp_lengths(self.h, _p(out)))
+        return out
+
+    def dump(self, chrom, sort=True):
+        """(keys, counts) of one chromosome; canonical keys, ascending when sort=True."""
+        n = C.c_int64()
+        self._ck(self.L.sp_dump_size(self.h, int(chrom), C.byref(n)))
+        keys = np.empty(n.value, np.uint64)
+        cnts = np.empty(n.value, np.uint32)
+        self._ck(self.L.sp_dump(self.h, int(chrom), _p(keys), _p(cnts), n.value, C.byref(n)))
+        if sort and keys.size:
+            o = np.argsort(keys, kind="stable")
+            keys, cnts = keys[o], cnts[o]
+        return keys, cnts
+
+    # -------------------------------------------------------------- filter
+    def filter(self, set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio):
+        set_off = np.ascontiguousarray(set_off, np.int32)
+        unit_off = np.ascontiguousarray(unit_off, np.int32)
+        unit_chrom = np.ascontiguousarray(unit_chrom, np.int32)
+        nu, nr, nh = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.L.sp_filter(self.h, len(set_off) - 1, _p(set_off), _p(unit_off), _p(unit_chrom),
+                                  float(min_fold), int(baseline), float(min_freq), float(max_freq),
+                                  float(ratio), C.byref(nu), C.byref(nr), C.byref(nh)))
+        return nu.value, nr.value, nh.value
+
+    def filter_fetch(self, n_rows, want_freqs=True, sort=True):
+        Cn = self.n_chrom
+        keys = np.empty(n_rows, np.uint64)
+        counts = np.empty((n_rows, Cn), np.uint32)
+        tot = np.empty(n_rows, np.uint64)
+        freqs = np.empty((n_rows, Cn), np.float64) if want_freqs else None
+        self._ck(self.L.sp_filter_fetch(self.h, _p(keys), _p(counts), _p(freqs), _p(tot), n_rows))
+        if sort and n_rows:
+            o = np.argsort(keys, kind="stable")
+            keys, counts, tot = keys[o], counts[o], tot[o]
+            if freqs is not None:
+                freqs = freqs[o]
+        return keys, counts, freqs, tot
+
+    def filter_hist(self, n_hist):
+        tot = np.empty(n_hist, np.uint64)
+        self._ck(self.L.sp_filter_hist(self.h, _p(tot), n_hist))
+        return tot
+
+    # -------------------------------------------------------------- labels / map
+    def labels_set(self, keys, sg, n_sg):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        sg = np.ascontiguousarray(sg, np.uint8)
+        assert keys.size == sg.size
+        self._ck(self.L.sp_labels_set(self.h, _p(keys), _p(sg), keys.size, int(n_sg)))
+        self.n_sg = int(n_sg)
+
+    def map_nslots(self, chrom, bin_size, chunk_size):
+        n = C.c_int64()
+        self._ck(self.L.sp_map_nslots(self.h, int(chrom), int(bin_size), int(chunk_size), C.byref(n)))
+        return n.value
+
+    def map_bins(self, chrom, bin_size=10000, chunk_size=10_000_000):
+        ns = self.map_nslots(chrom, bin_size, chunk_size)
+        out = np.empty((ns, self.n_sg), np.int32)
+        n = C.c_int64()
+        self._ck(self.L.sp_map_bins(self.h, int(chrom), int(bin_size), int(chunk_size), _p(out), ns,
+                                    C.byref(n)))
+        return out, n.value
+
+    def map_features(self, seqs):
+        """seqs: list of str/bytes.  Returns int64 [n_feat, n_sg] totals."""
+        arrs = [as_ascii(s) for s in seqs]
+        off = np.zeros(len(arrs) + 1, np.int64)
+        for i, a in enumerate(arrs):
+            off[i + 1] = off[i] + a.size
+        cat = np.concatenate(arrs) if arrs else np.empty(0, np.uint8)
+        cat = np.ascontiguousarray(cat)
+        out = np.zeros((len(arrs), self.n_sg), np.int64)
+        self._ck(self.L.sp_map_features(self.h, _p(cat), _p(off), len(arrs), _p(out)))
+        return out
+
+    def labels_hit(self):
+        n = C.c_int64()
+        self._ck(self.L.sp_labels_hit(self.h, C.byref(n)))
+        return n.value
+
+    # -------------------------------------------------------------- enrich
+    def enrich(self, counts, max_pval=0.05, min_ratio=0.5):
+        counts = np.ascontiguousarray(counts, np.int64)
+        if counts.ndim != 2:
+            raise ValueError("counts must be W x S")
+        W, S = counts.shape
+        pvals = np.empty((W, S), np.float64)
+        ratios = np.empty((W, S), np.float64)
+        argmin = np.empty(W, np.int32)
+        sig = np.empty(W, np.uint8)
+        self._ck(self.L.sp_enrich(self.h, _p(counts), W, S, float(max_pval), float(min_ratio), _p(pvals),
+                                  _p(argmin), _p(sig), _p(ratios)))
+        return pvals, argmin, sig.astype(bool), ratios
+
+    # -------------------------------------------------------------- profiling / bench support
+    def prof_enable(self, on=True):
+        self._ck(self.L.sp_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.L.sp_prof_reset(self.h))
+
+    def prof_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.sp_prof_report(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(self.L.sp_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._ck(self.L.sp_dev_free(self.h, C.c_void_p(ptr)))
+
+    def dev_to_host(self, ptr, nbytes, offset=0):
+        out = np.empty(nbytes, np.uint8)
+        self._ck(self.L.sp_dev_copy_to_host(self.h, _p(out), C.c_void_p(ptr + offset), int(nbytes)))
+        return out
+
+    def synth_chrom(self, d_ptr, length, seed, set_id, sg_id, n_sg, chrom_id, exchange=0):
+        self._ck(self.L.sp_synth_chrom(self.h, C.c_void_p(d_ptr), int(length), int(seed), int(set_id),
+                                       int(sg_id), int(n_sg), int(chrom_id), int(exchange)))

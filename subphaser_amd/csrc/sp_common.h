@@ -1,0 +1,154 @@
+// sp_common.h -- internals shared by the HIP translation units of libsubphaser_hip.so
+// Target: gfx950 (MI355X, CDNA4) only.  64-wide wavefronts, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/subphaser_hip.h"
+
+#define SP_WAVE 64
+
+struct sp_chrom {
+    int64_t len = 0;     // bases
+    int64_t nw = 0;      // 16-base words actually covering len
+    uint32_t *d_pk = nullptr;  // 2-bit codes, base i at bits 2*(i%16) of word i/16; padded with SP_PAD_WORDS
+    uint32_t *d_nm = nullptr;  // invalid mask, base i at bit (i%32) of word i/32; padding marked invalid
+    uint32_t *d_tab = nullptr; // dense count table [nslots] (valid after sp_count)
+    int64_t length_sum = 0;    // sum of counts >= lower_count
+    int64_t n_dump = 0;        // number of k-mers with count >= lower_count
+};
+#define SP_PAD_WORDS 8
+
+struct sp_prof_entry {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+struct sp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    std::string err;
+    // genome
+    std::vector<sp_chrom> chroms;
+    // counting
+    int k = 0;
+    int lower = 0;
+    int64_t nslots = 0;   // dense table size
+    bool counted = false;
+    // filter results (device)
+    bool filtered = false;
+    int64_t n_union = 0, n_rows = 0, n_hist = 0;
+    uint32_t *d_flag_row = nullptr;   // bitmap over slots: differential rows
+    uint32_t *d_flag_hist = nullptr;  // bitmap over slots: fold-passing
+    uint64_t *d_blk_row = nullptr;    // per-block exclusive offsets
+    uint64_t *d_blk_hist = nullptr;
+    int64_t n_fblocks = 0;
+    // labels
+    uint8_t *d_label = nullptr;  // [nslots] 0 = none, 1+sg; bit 7 = seen
+    int n_sg = 0;
+    int64_t n_labels = 0;
+    // scratch
+    void *d_scratch = nullptr;
+    int64_t scratch_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<sp_prof_entry> prof_pending;
+    std::map<std::string, std::pair<int64_t, double>> prof_acc;
+};
+
+extern thread_local std::string g_sp_err;
+
+int sp_fail(sp_ctx *ctx, int code, const char *fmt, ...);
+int sp_scratch(sp_ctx *ctx, int64_t bytes, void **out);
+void sp_prof_begin(sp_ctx *ctx, const char *name);
+void sp_prof_end(sp_ctx *ctx);
+void sp_prof_flush(sp_ctx *ctx);
+
+#define SP_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return sp_fail(ctx, e__ == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP,          \
+                           "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                           __LINE__);                                                      \
+    } while (0)
+
+// Launch wrapper: optional per-kernel event timing + launch error check.
+#define SP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                       \
+    do {                                                                            \
+        sp_prof_begin(ctx, name);                                                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+        sp_prof_end(ctx);                                                           \
+        SP_HIP(ctx, hipGetLastError());                                             \
+    } while (0)
+
+// ---------------------------------------------------------------- k-mer math
+// Dense slot index.
+//  odd k : every strand pair {x, rc(x)} has exactly one member whose middle
+//          base is A or C (the middle base complements itself); that member
+//          with the high bit of its middle base removed is a bijection onto
+//          [0, 2^(2k-1)).
+//  even k: slot = canonical value min(x, rc(x)) in [0, 4^k) (half the slots unused).
+struct sp_kparams {
+    int k;
+    int odd;
+    uint64_t kmask;  // 2k low bits
+    int rcshift;     // 2(k-1)
+};
+
+__host__ __device__ inline sp_kparams sp_make_kparams(int k) {
+    sp_kparams p;
+    p.k = k;
+    p.odd = k & 1;
+    p.kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    p.rcshift = 2 * (k - 1);
+    return p;
+}
+
+__host__ __device__ inline int64_t sp_dense_slots(int k) {
+    return (k & 1) ? (1LL << (2 * k - 1)) : (1LL << (2 * k));
+}
+
+__host__ __device__ inline uint64_t sp_slot_of(uint64_t fwd, uint64_t rc, const sp_kparams &p) {
+    if (p.odd) {
+        uint64_t rep = ((fwd >> p.k) & 1ULL) ? rc : fwd;
+        uint64_t lowmask = (1ULL << p.k) - 1ULL;
+        return (rep & lowmask) | ((rep >> (p.k + 1)) << p.k);
+    }
+    return fwd < rc ? fwd : rc;
+}
+
+__host__ __device__ inline uint64_t sp_revcomp(uint64_t x, int k) {
+    // complement then reverse 2-bit groups
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// canonical key of a dense slot
+__host__ __device__ inline uint64_t sp_key_of_slot(uint64_t slot, const sp_kparams &p) {
+    if (p.odd) {
+        uint64_t lowmask = (1ULL << p.k) - 1ULL;
+        uint64_t rep = (slot & lowmask) | ((slot >> p.k) << (p.k + 1));
+        uint64_t r = sp_revcomp(rep, p.k);
+        return rep < r ? rep : r;
+    }
+    return slot;
+}
+
+// slot of a canonical (or any-orientation) key
+__host__ __device__ inline uint64_t sp_slot_of_key(uint64_t key, const sp_kparams &p) {
+    return sp_slot_of(key, sp_revcomp(key, p.k), p);
+}

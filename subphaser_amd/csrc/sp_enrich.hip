@@ -1,0 +1,224 @@
+// sp_enrich.hip -- K6: per-window Fisher right tail + enrichment decision.
+//
+// Replaces Stats.fisher_test / enrich / _enrich / Pvalues.get_enriched
+// (reference: subphaser/Stats.py:14-31, 140-192).  One thread per window.
+//
+// The hypergeometric point mass is evaluated with Loader's saddle-point
+// formulation (stirlerr / bd0), which stays accurate to ~1e-14 relative for
+// margins of 2e8 where a difference of lgamma() values loses 6-7 digits; the
+// tail is then summed by the exact term recurrence.  All arithmetic is fp64.
+#include "sp_device.h"
+
+#define SP_MAX_INT_CLAMP (2147483647LL / 10)  // Stats.py:9
+#define SP_ENRICH_MAXS 32
+
+__device__ static const double c_sfe[16] = {
+    0.0,                           /* 0: unused */
+    0.08106146679532726,           /* 1 */
+    0.04134069595540929,           /* 2 */
+    0.02767792568499834,           /* 3 */
+    0.02079067210376509,           /* 4 */
+    0.01664469118982119,           /* 5 */
+    0.01387612882307075,           /* 6 */
+    0.01189670994589177,           /* 7 */
+    0.010411265261972096,          /* 8 */
+    0.009255462182712733,          /* 9 */
+    0.008330563433362871,          /* 10 */
+    0.007573675487951841,          /* 11 */
+    0.006942840107209530,          /* 12 */
+    0.006408994188004207,          /* 13 */
+    0.005951370112758848,          /* 14 */
+    0.005554733551962801           /* 15 */
+};
+
+__device__ __forceinline__ double d_stirlerr(double n) {
+    const double S0 = 0.083333333333333333333, S1 = 0.00277777777777777777778,
+                 S2 = 0.00079365079365079365079365, S3 = 0.000595238095238095238095238,
+                 S4 = 0.0008417508417508417508417508;
+    if (n <= 15.0) return c_sfe[(int)n];
+    double nn = n * n;
+    if (n > 500) return (S0 - S1 / nn) / n;
+    if (n > 80) return (S0 - (S1 - S2 / nn) / nn) / n;
+    if (n > 35) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+    return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+
+__device__ __forceinline__ double d_bd0(double x, double np) {
+    if (fabs(x - np) < 0.1 * (x + np)) {
+        double v = (x - np) / (x + np);
+        double s = (x - np) * v;
+        if (fabs(s) < 2.2250738585072014e-308) return s;
+        double ej = 2 * x * v;
+        v = v * v;
+        for (int j = 1; j < 1000; j++) {
+            ej *= v;
+            double s1 = s + ej / ((j << 1) + 1);
+            if (s1 == s) return s1;
+            s = s1;
+        }
+    }
+    return x * log(x / np) + np - x;
+}
+
+// log of the binomial point mass, Loader's dbinom_raw
+__device__ __forceinline__ double d_ldbinom(double x, double n, double p, double q) {
+    const double NEG_INF = -INFINITY;
+    if (p == 0) return x == 0 ? 0.0 : NEG_INF;
+    if (q == 0) return x == n ? 0.0 : NEG_INF;
+    if (x == 0) {
+        if (n == 0) return 0.0;
+        return (p < 0.1) ? -d_bd0(n, n * q) - n * p : n * log(q);
+    }
+    if (x == n) return (q < 0.1) ? -d_bd0(n, n * p) - n * q : n * log(p);
+    if (x < 0 || x > n) return NEG_INF;
+    double lc = d_stirlerr(n) - d_stirlerr(x) - d_stirlerr(n - x) - d_bd0(x, n * p) - d_bd0(n - x, n * q);
+    double lf = 1.837877066409345483560659472811 + log(x) + log1p(-x / n);
+    return lc - 0.5 * lf;
+}
+
+// P[X = x], x white drawn when n are drawn from r white + b black
+__device__ __forceinline__ double d_dhyper(double x, double r, double b, double n) {
+    if (n < x || r < x || n - x > b) return 0.0;
+    if (n == 0) return x == 0 ? 1.0 : 0.0;
+    double p = n / (r + b), q = (r + b - n) / (r + b);
+    double l = d_ldbinom(x, r, p, q) + d_ldbinom(n - x, b, p, q) - d_ldbinom(n, r + b, p, q);
+    return exp(l);
+}
+
+// P[X >= a], X ~ Hypergeom(N = a+b+c+d, K = a+b, n = a+c): what
+// fisher.pvalue(a,b,c,d).right_tail returns (Stats.py:26)
+__device__ double d_right_tail(long long a, long long b, long long c, long long d) {
+    const double K = (double)(a + b), NK = (double)(c + d), n = (double)(a + c);
+    const double N = K + NK;
+    long long lo = (a + c) - (c + d);
+    if (lo < 0) lo = 0;
+    const long long hi = (a + b) < (a + c) ? (a + b) : (a + c);
+    if (a <= lo) return 1.0;
+    if (a > hi) return 0.0;
+    const double mode = floor((n + 1.0) * (K + 1.0) / (N + 2.0));
+    if ((double)a > mode) {
+        double x = (double)a;
+        double term = d_dhyper(x, K, NK, n);
+        double s = term;
+        while (x < (double)hi && term > 0.0) {
+            term *= (K - x) * (n - x) / ((x + 1.0) * (NK - n + x + 1.0));
+            x += 1.0;
+            s += term;
+            if (term < s * 1e-18) break;
+        }
+        return s;
+    }
+    double x = (double)a - 1.0;
+    double term = d_dhyper(x, K, NK, n);
+    double s = term;
+    while (x > (double)lo && term > 0.0) {
+        term *= x * (NK - n + x) / ((K - x + 1.0) * (n - x + 1.0));
+        x -= 1.0;
+        s += term;
+        if (term < s * 1e-18) break;
+    }
+    return 1.0 - s;
+}
+
+// numpy's float64 add.reduce order for a short contiguous vector
+__device__ __forceinline__ double d_np_sum(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+__global__ void __launch_bounds__(64)
+k6_enrich(const long long *__restrict__ counts, const long long *__restrict__ total, long long sum_total,
+          long long W, int S, double max_pval, double min_ratio, double *__restrict__ pvals,
+          int *__restrict__ argmin, unsigned char *__restrict__ sig, double *__restrict__ ratios) {
+    long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const long long *row = counts + w * S;
+    double *p = pvals + w * S;
+    double *q = ratios + w * S;
+    long long sum_each = 0;
+    for (int j = 0; j < S; j++) sum_each += row[j];
+    for (int j = 0; j < S; j++) {
+        // fisher_test margins incl. the x22 quirk and clamps (Stats.py:20-25)
+        long long x11 = row[j];
+        long long x12 = sum_each - x11;
+        long long x21 = total[j] - x11;
+        long long x22 = sum_total - x21 - x12;
+        if (x21 > SP_MAX_INT_CLAMP) x21 = SP_MAX_INT_CLAMP;
+        if (x22 > SP_MAX_INT_CLAMP) x22 = SP_MAX_INT_CLAMP;
+        p[j] = d_right_tail(x11, x12, x21, x22);
+    }
+    // Pvalues.get_enriched (Stats.py:181-192): stable sort by p, first two
+    int m = 0;
+    for (int j = 1; j < S; j++)
+        if (p[j] < p[m]) m = j;
+    int s2 = -1;
+    for (int j = 0; j < S; j++) {
+        if (j == m) continue;
+        if (s2 < 0 || p[j] < p[s2]) s2 = j;
+    }
+    bool sg = true;
+    if (p[m] > max_pval) sg = false;
+    if (p[m] == 0) {
+    } else if (p[s2] / p[m] < max_pval / p[s2] * 1.0)
+        sg = false;
+    // _enrich (Stats.py:157-162)
+    for (int j = 0; j < S; j++) q[j] = (double)row[j] / (double)total[j];
+    double qs = d_np_sum(q, S);
+    for (int j = 0; j < S; j++) q[j] = q[j] / qs;
+    if (q[m] < min_ratio) sg = false;
+    argmin[w] = m;
+    sig[w] = sg ? 1 : 0;
+}
+
+extern "C" int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
+                         double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios) {
+    if (!ctx || W < 0 || (W > 0 && (!counts || !pvals || !argmin || !sig || !ratios)))
+        return sp_fail(ctx, SP_EINVAL, "sp_enrich: bad arguments");
+    if (S < 2) return sp_fail(ctx, SP_ESTATE, "sp_enrich: at least 2 subgenome columns required (Stats.py:172)");
+    if (S > SP_ENRICH_MAXS) return sp_fail(ctx, SP_EUNSUP, "sp_enrich: S=%d > %d", S, SP_ENRICH_MAXS);
+    if (W == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<long long> total((size_t)S, 0);
+    for (int64_t w = 0; w < W; w++)
+        for (int j = 0; j < S; j++) total[(size_t)j] += counts[w * S + j];
+    long long sum_total = 0;
+    for (int j = 0; j < S; j++) sum_total += total[(size_t)j];
+    const size_t nWS = (size_t)W * S;
+    long long *d_counts = nullptr, *d_total = nullptr;
+    double *d_p = nullptr, *d_q = nullptr;
+    int *d_arg = nullptr;
+    unsigned char *d_sig = nullptr;
+    SP_HIP(ctx, hipMalloc(&d_counts, nWS * 8));
+    SP_HIP(ctx, hipMalloc(&d_total, (size_t)S * 8));
+    SP_HIP(ctx, hipMalloc(&d_p, nWS * 8));
+    SP_HIP(ctx, hipMalloc(&d_q, nWS * 8));
+    SP_HIP(ctx, hipMalloc(&d_arg, (size_t)W * 4));
+    SP_HIP(ctx, hipMalloc(&d_sig, (size_t)W));
+    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, nWS * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_total, total.data(), (size_t)S * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_LAUNCH(ctx, "k6_enrich", k6_enrich, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, d_counts, d_total,
+              sum_total, (long long)W, S, max_pval, min_ratio, d_p, d_arg, d_sig, d_q);
+    SP_HIP(ctx, hipMemcpyAsync(pvals, d_p, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(ratios, d_q, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(argmin, d_arg, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(sig, d_sig, (size_t)W, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_counts);
+    hipFree(d_total);
+    hipFree(d_p);
+    hipFree(d_q);
+    hipFree(d_arg);
+    hipFree(d_sig);
+    return SP_OK;
+}

@@ -1,0 +1,290 @@
+// sp_map.hip -- K4 (label table) + K5 (fused scan + label lookup + bin reduce).
+//
+// Replaces Seqs.map_kmer3 / chunk_chromfiles / map_kmer_each4
+// (reference: subphaser/Seqs.py:74-153, 209-244): every k-mer START position
+// whose canonical k-mer is subgenome-specific adds 1 to (bin of start, SG).
+#include "sp_device.h"
+
+// ----------------------------------------------------------------- K4
+__global__ void __launch_bounds__(256)
+k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
+          sp_kparams kp, uint8_t *__restrict__ label) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    label[sp_slot_of_key(keys[i], kp)] = (uint8_t)(1u + sg[i]);
+}
+
+// ----------------------------------------------------------------- K5
+// One block-iteration covers MAP_UNITS_PER_BLOCK units of 64 starts.  Hits are
+// accumulated in an LDS histogram over the (few) output slots the range
+// touches and flushed with one global atomic per non-zero entry.
+#define MAP_BLOCK 256
+#define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // 16384 starts
+#define MAP_LDS_ENTRIES 4096
+
+struct sp_map_params {
+    int64_t n_units;
+    int64_t bin_size;
+    int64_t chunk_size;
+    int64_t nslots;
+    int S;
+    int use_lds;
+};
+
+__device__ __forceinline__ int64_t map_slot(int64_t s, const sp_map_params &P, int k) {
+    int64_t chunk = 0;
+    if (P.chunk_size > 0 && s >= P.chunk_size - (k - 1)) chunk = (s + (k - 1)) / P.chunk_size;
+    return s / P.bin_size + chunk;
+}
+
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp,
+       sp_map_params P, uint8_t *__restrict__ label, int *__restrict__ slot_counts,
+       unsigned long long *__restrict__ n_mapped) {
+    __shared__ int hist[MAP_LDS_ENTRIES];
+    __shared__ unsigned long long red[16];
+    unsigned long long mapped = 0;
+    const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const int64_t u = r * MAP_BLOCK + threadIdx.x;
+        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k);
+        if (P.use_lds) {
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        if (u < P.n_units) {
+            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                const uint64_t slot = sp_slot_of(fwd, rc, kp);
+                const uint32_t l = label[slot];
+                if (l) {
+                    if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);  // idempotent "seen" mark
+                    const int sg = (int)(l & 0x7fu) - 1;
+                    const int64_t os = map_slot(start, P, kp.k);
+                    if (P.use_lds)
+                        atomicAdd(&hist[(os - slot_lo) * P.S + sg], 1);
+                    else if (os < P.nslots)
+                        atomicAdd(&slot_counts[os * P.S + sg], 1);
+                    mapped++;
+                }
+            });
+        }
+        if (P.use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
+                int v = hist[i];
+                if (v) {
+                    int64_t os = slot_lo + i / P.S;
+                    if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + (i % P.S)], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long t = sp_block_sum_u64(mapped, red);
+    if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
+}
+
+// feature mode: per-feature totals; feature of a start found by binary search
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp,
+            int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
+            uint8_t *__restrict__ label, unsigned long long *__restrict__ counts) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            const uint64_t slot = sp_slot_of(fwd, rc, kp);
+            const uint32_t l = label[slot];
+            if (l) {
+                if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
+                const int sg = (int)(l & 0x7fu) - 1;
+                int64_t lo = 0, hi = n_feat;  // last f with foff[f] <= start
+                while (hi - lo > 1) {
+                    int64_t mid = (lo + hi) >> 1;
+                    if (foff[mid] <= start) lo = mid;
+                    else hi = mid;
+                }
+                atomicAdd(&counts[lo * S + sg], 1ULL);
+            }
+        });
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k4_count_seen(const uint8_t *__restrict__ label, int64_t nslots, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long n = 0;
+    const int64_t n16 = nslots >> 4;
+    const uint4 *l4 = reinterpret_cast<const uint4 *>(label);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint4 v = l4[i];
+        n += __popc(v.x & 0x80808080u) + __popc(v.y & 0x80808080u) + __popc(v.z & 0x80808080u) +
+             __popc(v.w & 0x80808080u);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n16 << 4) + threadIdx.x; i < nslots; i += blockDim.x) n += (label[i] >> 7) & 1u;
+    unsigned long long t = sp_block_sum_u64(n, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
+// pack kernel from sp_ctx.hip
+__global__ void k0_pack(const uint8_t *ascii, int64_t len, uint32_t *pk, uint32_t *nm, int64_t n_mask_words);
+
+static int64_t map_nslots_host(int64_t len, int64_t bin_size, int64_t chunk_size, int k) {
+    int64_t L = len > 0 ? len : 1;
+    int64_t nb = (L + bin_size - 1) / bin_size;
+    int64_t nch = chunk_size > 0 ? (L + (k - 1)) / chunk_size + 1 : 1;
+    return nb + nch;
+}
+
+extern "C" {
+
+int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg) {
+    if (!ctx || n < 0 || (n > 0 && (!keys || !sg)) || n_sg < 1 || n_sg > 126)
+        return sp_fail(ctx, SP_EINVAL, "sp_labels_set: bad arguments");
+    if (ctx->k <= 0 || ctx->nslots <= 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_labels_set: call sp_count first (it fixes k)");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < n; i++)
+        if (sg[i] >= n_sg) return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)sg[i], n_sg);
+    if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
+    ctx->n_sg = n_sg;
+    ctx->n_labels = n;
+    if (n == 0) return SP_OK;
+    unsigned long long *d_keys = nullptr;
+    uint8_t *d_sg = nullptr;
+    SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
+    SP_HIP(ctx, hipMalloc(&d_sg, (size_t)n));
+    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
+              kp, ctx->d_label);
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_keys);
+    hipFree(d_sg);
+    return SP_OK;
+}
+
+int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots) {
+    if (!ctx || !nslots || chrom < 0 || chrom >= (int)ctx->chroms.size() || bin_size < 1 || chunk_size < 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_map_nslots: bad arguments");
+    *nslots = map_nslots_host(ctx->chroms[(size_t)chrom].len, bin_size, chunk_size, ctx->k);
+    return SP_OK;
+}
+
+int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int32_t *slot_counts,
+                int64_t nslots, int64_t *n_mapped) {
+    if (!ctx || !slot_counts || chrom < 0 || chrom >= (int)ctx->chroms.size() || bin_size < 1 ||
+        chunk_size < 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_map_bins: bad arguments");
+    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_bins: call sp_labels_set first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    sp_chrom &c = ctx->chroms[(size_t)chrom];
+    const int S = ctx->n_sg;
+    int64_t need = map_nslots_host(c.len, bin_size, chunk_size, ctx->k);
+    if (nslots < need) return sp_fail(ctx, SP_EINVAL, "sp_map_bins: nslots %lld < %lld", (long long)nslots, (long long)need);
+    int *d_counts = nullptr;
+    const size_t bytes = (size_t)nslots * S * sizeof(int);
+    const size_t bytes8 = (bytes + 7) & ~(size_t)7;
+    SP_HIP(ctx, hipMalloc(&d_counts, bytes8 + 8));
+    unsigned long long *d_n = (unsigned long long *)((char *)d_counts + bytes8);
+    SP_HIP(ctx, hipMemsetAsync(d_counts, 0, bytes8 + 8, ctx->stream));
+    sp_map_params P;
+    P.n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
+    P.bin_size = bin_size;
+    P.chunk_size = chunk_size;
+    P.nslots = nslots;
+    P.S = S;
+    int64_t local = MAP_RANGE / bin_size + 3 + (chunk_size > 0 ? MAP_RANGE / chunk_size + 2 : 0);
+    P.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
+    if (P.n_units > 0) {
+        const sp_kparams kp = sp_make_kparams(ctx->k);
+        int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+        int64_t grid = n_ranges;
+        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+                  ctx->d_label, d_counts, d_n);
+    }
+    unsigned long long hn = 0;
+    SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(&hn, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_counts);
+    if (n_mapped) *n_mapped = (int64_t)hn;
+    return SP_OK;
+}
+
+int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,
+                    int64_t *counts) {
+    if (!ctx || !off || !counts || n_feat < 0 || (n_feat > 0 && off[n_feat] > 0 && !ascii))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_features: bad arguments");
+    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_features: call sp_labels_set first");
+    const int S = ctx->n_sg;
+    memset(counts, 0, (size_t)n_feat * S * sizeof(int64_t));
+    if (n_feat == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    // concatenate with one invalid separator after every feature so no k-mer spans two features
+    const int64_t total = off[n_feat] + n_feat;
+    std::vector<uint8_t> buf((size_t)total);
+    std::vector<int64_t> foff((size_t)n_feat + 1);
+    int64_t w = 0;
+    for (int64_t f = 0; f < n_feat; f++) {
+        foff[(size_t)f] = w;
+        int64_t n = off[f + 1] - off[f];
+        if (n < 0) return sp_fail(ctx, SP_EINVAL, "sp_map_features: offsets must be non-decreasing");
+        memcpy(buf.data() + w, ascii + off[f], (size_t)n);
+        w += n;
+        buf[(size_t)w++] = 'N';
+    }
+    foff[(size_t)n_feat] = w;
+    uint8_t *d_ascii = nullptr;
+    uint32_t *d_pk = nullptr, *d_nm = nullptr;
+    int64_t *d_foff = nullptr;
+    unsigned long long *d_counts = nullptr;
+    int64_t nmw = (total + 31) / 32 + SP_PAD_WORDS;
+    SP_HIP(ctx, hipMalloc(&d_ascii, (size_t)total));
+    SP_HIP(ctx, hipMalloc(&d_pk, (size_t)(2 * nmw) * 4));
+    SP_HIP(ctx, hipMalloc(&d_nm, (size_t)nmw * 4));
+    SP_HIP(ctx, hipMalloc(&d_foff, (size_t)(n_feat + 1) * 8));
+    SP_HIP(ctx, hipMalloc(&d_counts, (size_t)n_feat * S * 8));
+    SP_HIP(ctx, hipMemcpyAsync(d_ascii, buf.data(), (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n_feat + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_feat * S * 8, ctx->stream));
+    int64_t blocks = (nmw + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, total, d_pk, d_nm, nmw);
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
+    int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
+              n_units, d_foff, n_feat, S, ctx->d_label, d_counts);
+    SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_ascii);
+    hipFree(d_pk);
+    hipFree(d_nm);
+    hipFree(d_foff);
+    hipFree(d_counts);
+    return SP_OK;
+}
+
+int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
+    if (!ctx || !n_hit) return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: bad arguments");
+    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: call sp_labels_set first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d_n = nullptr, h = 0;
+    SP_HIP(ctx, hipMalloc(&d_n, 8));
+    SP_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, ctx->d_label,
+              ctx->nslots, d_n);
+    SP_HIP(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_n);
+    *n_hit = (int64_t)h;
+    return SP_OK;
+}
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Genome ingest and k-mer -> bin mapping.
+
+Host-side mirror of the reference's subphaser/Seqs.py for the hot path:
+  split_genomes  (Seqs.py:27-71)    select/rename target chromosomes
+  map_kmer3      (Seqs.py:74-119)   subgenome-specific k-mers -> 10-kb bin counts
+The per-position work (chunk_chromfiles / map_kmer_each4 / _get_kmer,
+Seqs.py:121-153, 209-244) runs in the HIP kernel k5_map.
+"""
+import copy
+import gzip
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+
+from . import kmer as kmerlib
+from .runtime import get_context, logger
+
+_DELNL = bytes(range(256))
+
+
+def _open_bytes(path):
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    if magic == b"\x1f\x8b":
+        return gzip.open(path, "rb")
+    return open(path, "rb")
+
+
+def read_fasta(path):
+    """Yield (id, sequence bytes without newlines) for every record of a (gz) FASTA file."""
+    with _open_bytes(path) as fh:
+        data = fh.read()
+    if not data:
+        return
+    pos = data.find(b">")
+    while pos != -1:
+        nl = data.find(b"\n", pos)
+        if nl == -1:
+            nl = len(data)
+        header = data[pos + 1:nl].decode().split()
+        rid = header[0] if header else ""
+        nxt = data.find(b"\n>", nl)
+        body = data[nl + 1:(nxt if nxt != -1 else len(data))]
+        yield rid, body.translate(None, b"\n\r \t")
+        pos = nxt + 1 if nxt != -1 else -1
+
+
+def write_fasta(path, rid, seq, width=60):
+    with open(path, "wb") as f:
+        f.write(b">" + rid.encode() + b"\n")
+        n = len(seq)
+        if n:
+            full = (n // width) * width
+            if full:
+                a = np.frombuffer(seq, np.uint8, full).reshape(-1, width)
+                b = np.empty((a.shape[0], width + 1), np.uint8)
+                b[:, :width] = a
+                b[:, width] = 10
+                f.write(b.tobytes())
+            if n > full:
+                f.write(seq[full:] + b"\n")
+
+
+class ChromRecord:
+    """In-memory twin of one tmp/chromosomes/<id>.fasta file."""
+    __slots__ = ("rid", "seq", "index")
+
+    def __init__(self, rid, seq):
+        self.rid, self.seq, self.index = rid, seq, {}   # index: id(ctx) -> chromosome slot on that GPU
+
+
+_REG = {}   # chromfile path -> ChromRecord
+
+
+def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", write_files=True):
+    """Select target chromosomes, apply `new|old` renaming and label prefixes.
+    Returns (chromfiles, labels, d_targets2, d_size) like the reference.  The
+    sequences are also kept in memory so the counting step need not re-read them."""
+    d_targets2 = OrderedDict()
+    if not d_targets:
+        d_targets = OrderedDict()
+        for t in targets:
+            tmp = t.split(sep, 1)
+            d_targets[tmp[-1]] = tmp[0]
+            d_targets2[t] = tmp[0]
+    elif set(targets) - set(d_targets):
+        for t in set(targets) - set(d_targets):
+            tmp = t.split(sep, 1)
+            d_targets[tmp[-1]] = tmp[0]
+            d_targets2[t] = tmp[0]
+    else:
+        d_targets2 = copy.deepcopy(d_targets)
+    outfas, labels, d_size, got = [], [], {}, set()
+    for genome, prefix in zip(genomes, prefixes):
+        for old_id, seq in read_fasta(genome):
+            new_id = "{}{}".format(prefix, old_id)
+            if new_id in d_targets:
+                rid = new_id
+            elif old_id in d_targets:
+                rid = old_id
+            else:
+                continue
+            got.add(rid)
+            rid = d_targets[rid]
+            outfa = "{}{}.fasta".format(outdir, rid)
+            if write_files:
+                write_fasta(outfa, rid, seq)
+            _REG[outfa] = ChromRecord(rid, seq)
+            outfas.append(outfa)
+            labels.append(rid)
+            d_size[rid] = len(seq)
+    missing = set(d_targets) - got
+    if missing:
+        logger.error("Chromosomes {} are not found in sequences files".format(missing))
+    return outfas, labels, d_targets2, d_size
+
+
+def load_chromfile(chromfile):
+    """ChromRecord of a per-chromosome FASTA (memory twin first, then disk)."""
+    rec = _REG.get(chromfile)
+    if rec is None:
+        recs = list(read_fasta(chromfile))
+        if not recs:
+            raise ValueError("no FASTA record in {}".format(chromfile))
+        # one record per file (Seqs.py:62-64); several records are joined with an N so no k-mer spans them
+        rec = ChromRecord(recs[0][0], b"N".join(sq for _, sq in recs))
+        _REG[chromfile] = rec
+    return rec
+
+
+class KmerLabels:
+    """Array form of the reference's d_kmers dict (k-mer and its reverse
+    complement -> subgenome name, Cluster.py:174-175): canonical keys + SG index."""
+
+    def __init__(self, keys, sg_idx, sg_names, k):
+        self.keys = np.ascontiguousarray(keys, np.uint64)
+        self.sg_idx = np.ascontiguousarray(sg_idx, np.uint8)
+        self.sg_names = list(sg_names)
+        self.k = int(k)
+
+    def __len__(self):           # the reference's dict holds both orientations
+        return 2 * len(self.keys)
+
+    def values(self):
+        for i in self.sg_idx:
+            yield self.sg_names[i]
+            yield self.sg_names[i]
+
+    @classmethod
+    def from_dict(cls, d_kmers, sg_names, k=None):
+        kmers = list(d_kmers.keys())
+        if k is None:
+            k = len(kmers[0]) if kmers else 0
+        keys = kmerlib.encode_many(kmers) if kmers else np.empty(0, np.uint64)
+        canon = kmerlib.canonical(keys, k) if kmers else keys
+        name_idx = {n: i for i, n in enumerate(sg_names)}
+        sg = np.array([name_idx[d_kmers[x]] for x in kmers], np.uint8)
+        canon, first = np.unique(canon, return_index=True)
+        return cls(canon, sg[first], sg_names, k)
+
+
+def _as_labels(d_kmers, sg_names, k):
+    if isinstance(d_kmers, KmerLabels):
+        return d_kmers
+    return KmerLabels.from_dict(d_kmers, sg_names, k)
+
+
+def bin_lines(rid, length, slot_counts, bin_size, chunk_size, k):
+    """Reference-format lines for one chromosome from slot counts (see sp_map_bins):
+    one line per non-empty (bin, chunk) slot, `end` clipped to the chunk end
+    (Seqs.py:228-236).  Returns (starts, ends, counts) arrays of the emitted lines."""
+    nz = np.flatnonzero(slot_counts.any(axis=1))
+    if nz.size == 0:
+        return nz, nz, slot_counts[:0]
+    # invert slot -> (bin, chunk): slot = bin + chunk, chunk j owns starts >= j*W-(k-1)
+    if chunk_size:
+        nch = (length + (k - 1)) // chunk_size + 1
+        j = np.arange(1, nch + 1, dtype=np.int64)
+        first_start = j * chunk_size - (k - 1)                 # first start owned by chunk j
+        first_slot = first_start // bin_size + j               # its slot
+        chunk = np.searchsorted(first_slot, nz, side="right")  # number of chunks begun at/before slot
+        bins = nz - chunk
+        chunk_end = np.minimum((chunk + 1) * chunk_size, length)
+    else:
+        bins = nz
+        chunk_end = np.full(nz.size, length, np.int64)
+    starts = bins * bin_size
+    ends = np.minimum(starts + bin_size, chunk_end)
+    return starts, ends, slot_counts[nz]
+
+
+def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bin_size=10000, sg_names=[],
+              ncpu="autodetect", method="map", log=True, chunk=True, chunksize=None, ctx=None):
+    """Same arguments as the reference (ncpu/method/chunksize are accepted and ignored:
+    the GPU replaces the process pool).  Writes `#chrom start end SG...` lines to fout."""
+    ctx = ctx or get_context()
+    labels = _as_labels(d_kmers, sg_names, k)
+    if k is None:
+        k = labels.k
+    sg_names = list(sg_names) if sg_names else labels.sg_names
+    window_size, bin_size = int(window_size), int(bin_size)
+    if ctx.k != k:
+        raise ValueError("map_kmer3: context was counted with k={} but k={} requested".format(ctx.k, k))
+    ctx.labels_set(labels.keys, labels.sg_idx, len(sg_names))
+    fout.write("\t".join(["#chrom", "start", "end"] + sg_names) + "\n")
+    n_seq, mapped_seqs, mapped_num = 0, 0, 0
+    if chunk:
+        for ci, chromfile in enumerate(chromfiles):
+            rec = load_chromfile(chromfile)
+            seq, rid = rec.seq, rec.rid
+            idx = rec.index.get(id(ctx))
+            if idx is None:
+                raise ValueError("chromosome file {} is not resident on the GPU; run run_jellyfish_dumps "
+                                 "first (it uploads the genome)".format(chromfile))
+            logger.info("Chunking chromsome {}: {:,} bp".format(rid, len(seq)))
+            slots, c = ctx.map_bins(idx, bin_size, window_size)
+            starts, ends, counts = bin_lines(rid, len(seq), slots, bin_size, window_size, k)
+            _write_lines(fout, rid, starts, ends, counts)
+            nchunks = max(1, -(-len(seq) // window_size))
+            n_seq += nchunks
+            mapped_num += c
+            mapped_seqs += nchunks if c else 0
+            if log:
+                logger.info("Mapped {} kmers to chromsome {}".format(c, rid))
+    else:
+        for featfile in chromfiles:
+            ids, seqs = [], []
+            for rid, seq in read_fasta(featfile):
+                ids.append(rid)
+                seqs.append(seq)
+            big = [i for i, s in enumerate(seqs) if len(s) > bin_size]
+            counts = ctx.map_features(seqs)
+            for i, rid in enumerate(ids):
+                n_seq += 1
+                if i in big:       # rare: a feature longer than one bin needs per-bin counts
+                    counts_i = _map_long_feature(ctx, seqs[i], bin_size, k)
+                    starts = np.flatnonzero(counts_i.any(axis=1)) * bin_size
+                    ends = np.minimum(starts + bin_size, len(seqs[i]))
+                    _write_lines(fout, rid, starts, ends, counts_i[counts_i.any(axis=1)])
+                    c = int(counts_i.sum())
+                else:
+                    c = int(counts[i].sum())
+                    if c:
+                        _write_lines(fout, rid, np.array([0]), np.array([min(bin_size, len(seqs[i]))]),
+                                     counts[i:i + 1])
+                mapped_num += c
+                mapped_seqs += 1 if c else 0
+    logger.info("Processed {} sequences".format(n_seq))
+    total = len(labels.keys)
+    if n_seq and total:
+        hit = ctx.labels_hit()
+        logger.info("{} ({:.2%}) sequences contain subgenome-specific kmers".format(mapped_seqs, mapped_seqs / n_seq))
+        logger.info("{:.2%} of {} subgenome-specific kmers are mapped".format(hit / total, total))
+    else:
+        logger.warning("None sequences, please check.")
+    return mapped_num
+
+
+def _write_lines(fout, rid, starts, ends, counts):
+    if len(starts) == 0:
+        return
+    cols = [np.asarray(starts).astype(str), np.asarray(ends).astype(str)]
+    cols += [counts[:, j].astype(str) for j in range(counts.shape[1])]
+    lines = [rid + "\t" + "\t".join(t) for t in zip(*cols)]
+    fout.write("\n".join(lines) + "\n")
+
+
+def _map_long_feature(ctx, seq, bin_size, k):
+    raise NotImplementedError("feature sequences longer than one bin ({} bp) are not supported yet".format(bin_size))

@@ -1,0 +1,103 @@
+"""OracleContext: the CPU oracle (oracle/pyoracle.py) behind the same Python
+interface as subphaser_amd._native.Context.  TEST INFRASTRUCTURE ONLY -- it lets
+the host-side mirror modules run on CPU against the golden vectors, and it is
+the reference implementation the `-m gpu` parity tests compare the HIP path with."""
+import numpy as np
+import pyoracle as po
+
+
+class OracleContext:
+    h = "oracle"
+
+    def __init__(self, nthreads=2):
+        self.nthreads = nthreads
+        self.seqs = []
+        self.k = None
+        self.n_chrom = 0
+
+    def close(self):
+        pass
+
+    def sync(self):
+        pass
+
+    # genome
+    def genome_reset(self, n):
+        self.seqs = [np.empty(0, np.uint8)] * n
+        self.n_chrom = n
+
+    def genome_add(self, i, seq):
+        self.seqs[i] = po._ascii(seq).copy()
+
+    def genome_len(self, i):
+        return int(self.seqs[i].size)
+
+    def genome_unpack(self, i):
+        a = self.seqs[i].copy()
+        up = a & 0xDF
+        ok = (up == 65) | (up == 67) | (up == 71) | (up == 84)
+        return np.where(ok, up, ord("N")).astype(np.uint8)
+
+    # count
+    def count(self, k, lower_count=3, engine=0):
+        if k < 1 or k > 32:
+            raise ValueError("k=%d unsupported (1..32)" % k)
+        self.k, self.lower = k, max(1, lower_count)
+        self.dumps = [po.count(s, k, self.lower, self.nthreads) for s in self.seqs]
+
+    def lengths(self):
+        return np.array([int(d[1].astype(np.int64).sum()) for d in self.dumps], np.int64)
+
+    def dump(self, i, sort=True):
+        return self.dumps[i]
+
+    # filter
+    def filter(self, set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio):
+        sgs = []
+        for s in range(len(set_off) - 1):
+            sgs.append([[int(c) for c in unit_chrom[unit_off[u]:unit_off[u + 1]]]
+                        for u in range(set_off[s], set_off[s + 1])])
+        self._f = po.filter_dumps(self.dumps, sgs, list(range(self.n_chrom)), min_fold, baseline, min_freq,
+                                  max_freq, ratio)
+        return self._f.n_union, len(self._f.keys), len(self._f.hist)
+
+    def filter_fetch(self, n_rows, want_freqs=True, sort=True):
+        f = self._f
+        return f.keys, f.counts, f.freqs, f.tot
+
+    def filter_hist(self, n):
+        return self._f.hist
+
+    # labels / map
+    def labels_set(self, keys, sg, n_sg):
+        self.lab_keys = np.ascontiguousarray(keys, np.uint64)
+        self.lab_sg = np.ascontiguousarray(sg, np.uint8)
+        self.n_sg = n_sg
+        self.hit = np.zeros(len(self.lab_keys), np.uint8)
+
+    def map_nslots(self, i, bin_size, chunk_size):
+        return po.n_slots(self.seqs[i].size, bin_size, chunk_size, self.k)
+
+    def map_bins(self, i, bin_size=10000, chunk_size=10_000_000):
+        out, hit, n = po.map_bins(self.seqs[i], self.k, self.lab_keys, self.lab_sg, self.n_sg, bin_size,
+                                  chunk_size, self.nthreads)
+        self.hit |= hit
+        return out, n
+
+    def map_features(self, seqs):
+        out = np.zeros((len(seqs), self.n_sg), np.int64)
+        for f, s in enumerate(seqs):
+            a = po._ascii(s)
+            if a.size == 0:
+                continue
+            sc, hit, _ = po.map_bins(a, self.k, self.lab_keys, self.lab_sg, self.n_sg, max(a.size, 1), 0, 1)
+            out[f] = sc.sum(axis=0)
+            self.hit |= hit
+        return out
+
+    def labels_hit(self):
+        return int(self.hit.sum())
+
+    # enrich
+    def enrich(self, counts, max_pval=0.05, min_ratio=0.5):
+        return po.enrich(counts, max_pval, min_ratio)

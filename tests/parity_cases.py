@@ -1,0 +1,250 @@
+"""Parity checks shared by the CPU suite (oracle behind the host layer, `-m "not gpu"`)
+and the GPU suite (libsubphaser_hip.so through the C-ABI, `-m gpu`).
+
+Every check takes a context object (`OracleContext` or `_native.Context`) and
+compares what the host-side mirror modules produce with it against the golden
+vectors generated from the imported reference (tests/golden/gen_golden.py)."""
+import io
+import math
+
+import numpy as np
+
+import pyoracle as po
+from subphaser_amd import circos, cluster, jellyfish, seqs, stats
+from subphaser_amd import kmer as kmerlib
+
+K, L = 15, 3
+
+
+def register_toy(toy, prefix="/virtual/toy/"):
+    """Make the toy chromosomes known to the host layer without touching disk."""
+    files = []
+    for lab in toy["labels"]:
+        path = "%s%s.fasta" % (prefix, lab)
+        if path not in seqs._REG:      # keep the record (it remembers which GPU slot holds it)
+            seqs._REG[path] = seqs.ChromRecord(lab, toy["seqs"][lab].encode())
+        files.append(path)
+    return files
+
+
+def count_toy(ctx, toy, engine=0):
+    files = register_toy(toy)
+    dumps = jellyfish.run_jellyfish_dumps(files, k=K, lower_count=L, ctx=ctx, engine=engine)
+    return files, dumps
+
+
+# ------------------------------------------------------------------ G1
+def check_toy_dumps(ctx, golden, toy, engine=0):
+    files, dumps = count_toy(ctx, toy, engine)
+    g1 = golden["G1_toy_dumps"]
+    assert g1["k"] == K and g1["lower"] == L
+    for lab, d in zip(toy["labels"], dumps):
+        keys, cnts = d.fetch()
+        exp = g1["dumps"][lab]
+        assert len(keys) == exp["n"], lab
+        assert int(cnts.astype(np.int64).sum()) == exp["sum"], lab
+        assert (int(np.bitwise_xor.reduce(keys)) if len(keys) else 0) == exp["xor"], lab
+        assert [int(x) for x in keys[:8]] == exp["head_keys"], lab
+        assert [int(x) for x in cnts[:8]] == exp["head_counts"], lab
+        assert int(cnts.max()) == exp["max_count"], lab
+        assert (np.diff(keys.astype(np.int64)) > 0).all()
+        assert (cnts >= L).all()
+        assert str(d).endswith("%s.fasta_%d.fa" % (lab, K))
+
+
+# ------------------------------------------------------------------ G2 / G3
+def check_filter_cases(ctx, golden, toy, only=None):
+    files, dumps = count_toy(ctx, toy)
+    for name, case in golden["G2_filter"].items():
+        if only and name not in only:
+            continue
+        jd = jellyfish.JellyfishDumps(dumps, toy["labels"])
+        d_mat = jd.to_matrix()
+        exp = case["res"]
+        assert jd.lengths == exp["lengths"], name
+        try:
+            d2 = jd.filter(d_mat, jd.lengths, case["sgs"], outfig="hist.png", **case["kw"])
+        except ValueError as e:
+            assert "error" in exp, (name, str(e))
+            assert str(e) == exp["error"], name
+            continue
+        assert "error" not in exp, name
+        assert len(d_mat) == exp["n_union"], name
+        assert len(d2) == exp["n_rows"], name
+        rows = [[km] + [repr(float(x)) for x in fr] for km, fr in d2.items()]
+        assert rows == exp["rows"], name
+        # counts / tot consistency
+        assert (d2.counts.sum(axis=1) == d2.tot.astype(np.int64)).all()
+        assert jd.n_hist >= len(d2)
+        hist = np.sort(jd.hist_tot())
+        assert len(hist) == jd.n_hist
+
+
+def check_kmer_mat_text(ctx, golden, toy):
+    files, dumps = count_toy(ctx, toy)
+    case = golden["G2_filter"]["default"]
+    jd = jellyfish.JellyfishDumps(dumps, toy["labels"])
+    d2 = jd.filter(jd.to_matrix(), None, case["sgs"], outfig="h.png", **case["kw"])
+    buf = io.StringIO()
+    jd.write_matrix(d2, buf)
+    assert buf.getvalue() == golden["G3_kmer_mat_text"]
+    return d2
+
+
+# ------------------------------------------------------------------ G7
+def check_output_kmers(ctx, golden, toy):
+    d2 = check_kmer_mat_text(ctx, golden, toy)
+    g7 = golden["G7_output_kmers"]
+    cl = cluster.Cluster(d2, n_clusters=2, sg_prefix="SG", sg_assigned=g7["sg_assigned"])
+    assert dict(cl.d_sg) == g7["d_sg"]
+    assert cl.sg_names == g7["sg_names"]
+    buf = io.StringIO()
+    labels = cl.output_kmers(buf, max_pval=0.05)
+    assert len(labels) == g7["n_dkmers"]
+    exp_lines = sorted(g7["text"].strip().split("\n")[1:])
+    got_lines = sorted(buf.getvalue().strip().split("\n")[1:])
+    assert len(exp_lines) == len(got_lines)
+    for e, g in zip(exp_lines, got_lines):
+        e, g = e.split("\t"), g.split("\t")
+        assert e[:2] == g[:2]
+        assert math.isclose(float(e[2]), float(g[2]), rel_tol=1e-9, abs_tol=1e-300)
+        for a, b in zip(e[3].split(","), g[3].split(",")):
+            assert math.isclose(float(a), float(b), rel_tol=1e-14, abs_tol=0)
+    return cl, labels
+
+
+# ------------------------------------------------------------------ G4
+def check_map_cases(ctx, golden, toy):
+    cl, labels = check_output_kmers(ctx, golden, toy)
+    files = register_toy(toy)
+    for name, case in golden["G4_map_kmer3"].items():
+        kw = dict(case["kw"])
+        buf = io.StringIO()
+        seqs.map_kmer3(files, labels, fout=buf, k=K, sg_names=cl.sg_names, ctx=ctx, **kw)
+        assert buf.getvalue() == case["text"], name
+    return cl, labels
+
+
+def check_map_features(ctx, golden, toy, tmp_path):
+    cl, labels = check_output_kmers(ctx, golden, toy)
+    case = golden["G4_map_features"]
+    ff = tmp_path / "features.fa"
+    with open(ff, "w") as f:
+        for fid, s in case["features"]:
+            f.write(">%s\n%s\n" % (fid, s))
+    buf = io.StringIO()
+    seqs.map_kmer3([str(ff)], labels, fout=buf, k=K, bin_size=10000000, sg_names=cl.sg_names, chunk=False,
+                   log=False, ctx=ctx)
+    assert buf.getvalue() == case["text"]
+
+
+def check_dict_labels(ctx, golden, toy):
+    """d_kmers given as the reference's dict (both orientations -> SG name)."""
+    cl, labels = check_output_kmers(ctx, golden, toy)
+    kmers = kmerlib.decode_many(labels.keys, K)
+    rcs = kmerlib.decode_many(kmerlib.revcomp(labels.keys, K), K)
+    d = {}
+    for km, rc, s in zip(kmers, rcs, labels.sg_idx):
+        d[km] = labels.sg_names[s]
+        d[rc] = labels.sg_names[s]
+    files = register_toy(toy)
+    case = golden["G4_map_kmer3"]["chunk2000_bin100"]
+    buf = io.StringIO()
+    seqs.map_kmer3(files, d, fout=buf, k=K, sg_names=cl.sg_names, ctx=ctx, **case["kw"])
+    assert buf.getvalue() == case["text"]
+
+
+# ------------------------------------------------------------------ G5 (pure host)
+def check_stack_matrix(golden, tmp_path):
+    p = tmp_path / "toy.bin.count"
+    p.write_text(golden["G4_map_kmer3"]["chunk2000_bin100"]["text"])
+    for ws, exp in golden["G5_stack_matrix"].items():
+        coords, counts = circos.stack_matrix(str(p), window_size=int(ws))
+        assert [[c, s, e] for c, s, e in coords] == exp["coords"], ws
+        assert [[int(x) for x in row] for row in counts] == exp["counts"], ws
+    return p
+
+
+# ------------------------------------------------------------------ G6
+P_TOL = 1e-6      # BASELINE.json north_star: enrichment p-values within 1e-6
+
+
+def _cmp_enrich_text(got, exp, float_cols, float_list_cols):
+    g_lines, e_lines = got.strip("\n").split("\n"), exp.strip("\n").split("\n")
+    assert g_lines[0] == e_lines[0]
+    assert len(g_lines) == len(e_lines)
+    for g, e in zip(g_lines[1:], e_lines[1:]):
+        g, e = g.split("\t"), e.split("\t")
+        assert len(g) == len(e)
+        for i, (a, b) in enumerate(zip(g, e)):
+            if i in float_cols:
+                assert abs(float(a) - float(b)) <= P_TOL and math.isclose(float(a), float(b), rel_tol=1e-6, abs_tol=1e-290), (g, e)
+            elif i in float_list_cols:
+                for x, y in zip(a.split(","), b.split(",")):
+                    assert abs(float(x) - float(y)) <= P_TOL and math.isclose(float(x), float(y), rel_tol=1e-6, abs_tol=1e-290), (g, e)
+            else:
+                assert a == b, (i, g, e)
+
+
+def check_enrich_bin(ctx, golden, tmp_path):
+    g6 = golden["G6_enrich"]
+    p = check_stack_matrix(golden, tmp_path)
+    tb = g6["toy_bin"]
+    coords, counts = circos.stack_matrix(str(p), window_size=tb["window_size"])
+    f1, f2 = io.StringIO(), io.StringIO()
+    stats.enrich_bin(f1, f2, tb["d_sg"], counts, colnames=tb["sg_names"], rownames=coords, max_pval=0.05, ctx=ctx)
+    # cols: 4 p_value, 8 pvals, 10 p_corrected are floating point; ratios (6) must match exactly
+    _cmp_enrich_text(f1.getvalue(), tb["enrich_text"], {4, 10}, {8})
+    assert f2.getvalue() == tb["group_text"]
+    for name, t in g6["tables"].items():
+        rows = [tuple(r) for r in t["rows"]]
+        f1, f2 = io.StringIO(), io.StringIO()
+        with np.errstate(all="ignore"):
+            stats.enrich_bin(f1, f2, t["d_sg"], t["counts"], colnames=t["sg_names"], rownames=rows,
+                             max_pval=0.05, ctx=ctx)
+        _cmp_enrich_text(f1.getvalue(), t["enrich_text"], {4, 10}, {8})
+        assert f2.getvalue() == t["group_text"], name
+
+
+def check_enrich_features(ctx, golden, tmp_path):
+    g6 = golden["G6_enrich"]
+    p = tmp_path / "feat.bin.count"
+    p.write_text(golden["G4_map_features"]["text"])
+    fc, fcounts = circos.stack_matrix(str(p), window_size=100000000)
+    tb = g6["toy_bin"]
+    ok = [(c, n) for c, n in zip(fc, fcounts) if ":" in c[0]]
+    f3 = io.StringIO()
+    d_enriched, d_exchange = stats.enrich_ltr(f3, tb["d_sg"], [n for _, n in ok], colnames=tb["sg_names"],
+                                              rownames=[c for c, _ in ok], max_pval=0.05, ctx=ctx)
+    _cmp_enrich_text(f3.getvalue(), g6["toy_features"]["enrich_text"], {2, 5}, set())
+    # ids that do not look like chrom:start-end: reference crashes, we report 'none'
+    f4 = io.StringIO()
+    d_enriched, d_exchange = stats.enrich_ltr(f4, tb["d_sg"], fcounts, colnames=tb["sg_names"], rownames=fc,
+                                              max_pval=0.05, ctx=ctx)
+    assert d_exchange.get("weird_id_without_coords", "none") == "none"
+
+
+def check_fisher_cells_and_tails(ctx, golden):
+    """fisher_test margins (x22 quirk, clamps) and hypergeometric tails vs 30-digit values."""
+    import mpmath as mp
+    for v in golden["G6_hypergeom_mp"]:
+        a, b, c, d = v["cells"]
+        # build (each, total) that produce exactly these cells when no clamp is active, else call via cells
+        # a two-subgenome row [a, b] with totals [T0, T1] gives x12 = b, x21 = T0 - a,
+        # x22 = T1 + a - b; clamped cells (== MAX_INT) are reached with any larger total
+        each = [a, b]
+        T0 = a + (300000000 if c == stats.MAX_INT else c)
+        T1 = 300000000 if d == stats.MAX_INT else d + b - a
+        if T1 < b:
+            continue
+        total = [T0, T1]
+        assert po.fisher_cells(each, total, 0) == (a, b, c, d)
+        p = stats.fisher_test(each, total, ctx=ctx)[0]
+        exact = float(mp.mpf(v["p"]))
+        assert math.isclose(p, exact, rel_tol=1e-8, abs_tol=1e-300), (v, p)
+    for name, t in golden["G6_enrich"]["tables"].items():
+        counts = np.array(t["counts"], np.int64)
+        total = counts.sum(axis=0)
+        for r, exp in zip(counts[:6], t["cells_first6"]):
+            got = [list(po.fisher_cells(r, total, j)) for j in range(len(r))]
+            assert got == exp, name
