@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- whole hot path (k-mer count + differential filter + window map + enrichment)
+on a synthetic genome resident in HBM.  One "step" = one full pass over the genome.
+
+    python bench.py --gpus 1 --steps K --warmup W [--config wheat|peanut|ara|small|tiny]
+
+Prints ONE JSON line (rank 0).  metric = genome Gbases/s (BASELINE.json); dtype names
+the arithmetic type of the dominant work (u32 counters); `roofline` prices the dominant
+kernel against 8 TB/s HBM using the ALGORITHMIC bytes of SURVEY.md section 8(d);
+`cpu_baseline` is the oracle (a C port, oracle/sp_oracle.c) timed on this box's host
+cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("SP_BENCH_CONFIG", "wheat"))
+    ap.add_argument("--scale", type=float, default=1.0, help="scale chromosome lengths (debugging only)")
+    ap.add_argument("--engine", type=int, default=int(os.environ.get("SP_ENGINE", "0")))
+    ap.add_argument("-k", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "40")))
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, bases, nslots, C, S, extra):
+    """SURVEY.md 8(d) per-unit figures x the units one launch processes."""
+    if kernel.startswith("k1_") or kernel.startswith("c2_"):
+        return 8.25 * bases                       # 0.25 B read + 4 B counter read + 4 B counter write per base
+    if kernel == "k5_map":
+        return 1.25 * bases + extra.get("nbins", 0) * S * 4
+    if kernel == "k3_eval":
+        return extra.get("sum_dump", 0) * 8.0 + extra.get("M", 0) * C * 8.0
+    if kernel == "k0_pack":
+        return 1.375 * bases                      # 1 B ASCII read + 0.375 B packed write (not in 8(d): input there is 2-bit)
+    if kernel == "k2_lengths":
+        return 4.0 * nslots
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from subphaser_amd import _native, cluster
+    from subphaser_amd.hotpath import HotPath
+    from subphaser_amd.synth import SynthGenome
+
+    gen = SynthGenome(args.config, args.scale)
+    ctx = _native.Context(local_rank)
+    C, S = len(gen.chroms), gen.S
+
+    if world > 1:
+        from subphaser_amd.dist import DistHotPath
+        runner = DistHotPath(ctx, gen, dist, torch, k=args.k, engine=args.engine)
+    else:
+        runner = None
+
+    # ---- synthetic genome straight into HBM (untimed) ----------------------------------------
+    t0 = time.perf_counter()
+    d_ascii = []
+    my = range(C) if runner is None else runner.my_chroms
+    for i in range(C):
+        if i in my:
+            c = gen.chroms[i]
+            p = ctx.dev_alloc(c["length"])
+            ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], S, c["chrom_id"], c["exchange"])
+            d_ascii.append(p)
+        else:
+            d_ascii.append(None)
+    ctx.sync()
+    t_synth = time.perf_counter() - t0
+
+    if runner is None:
+        hp = HotPath(ctx, gen.labels, [c["length"] for c in gen.chroms], gen.sgs, k=args.k, engine=args.engine)
+
+        def first_half():
+            return hp.count_and_filter(d_ascii)
+
+        def second_half(lab):
+            return hp.map_and_enrich(lab, S)
+    else:
+        def first_half():
+            return runner.count_and_filter(d_ascii)
+
+        def second_half(lab):
+            return runner.map_and_enrich(lab, S)
+
+    # ---- labels: the reference's unchanged Cluster step, computed once, untimed ---------------
+    r1 = first_half()
+
+    class _Mat:
+        pass
+    mat = _Mat()
+    mat.labels, mat.keys, mat.k = gen.labels, r1.keys, args.k
+    mat.freqs = r1.counts.astype(np.float64) / np.asarray(r1.kmer_lengths, np.float64)
+    if r1.n_rows == 0:
+        raise SystemExit("synthetic genome produced 0 differential k-mers")
+    cl = cluster.Cluster(mat, n_clusters=S, sg_assigned=gen.sg_assigned)
+    kmer_labels = cl.output_kmers(open(os.devnull, "w"), max_pval=0.05)
+    del mat
+
+    def step():
+        a = first_half()
+        b = second_half(kmer_labels)
+        return a, b
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    prof = ctx.prof_report()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    gbases = gen.total_bases / (dt / args.steps) / 1e9
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events per launch, on the context's stream) ------
+    nslots = 1 << (2 * args.k - 1) if args.k % 2 else 1 << (2 * args.k)
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        name, st = dom
+        launches_per_step = st["calls"] / args.steps
+        n_local = len(list(my))
+        bases_per_launch = sum(gen.chroms[i]["length"] for i in my) / max(1.0, launches_per_step) \
+            if launches_per_step >= n_local else sum(gen.chroms[i]["length"] for i in my)
+        extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
+                     sum_dump=int(sum(a.kmer_lengths)))
+        alg = algorithmic_bytes(name, bases_per_launch, nslots, C, S, extra)
+        avg_s = st["ms"] / st["calls"] / 1e3
+        if alg:
+            ach = alg / avg_s
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+                        "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
+    stages = {k_: {"calls_per_step": v["calls"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 3)}
+              for k_, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ---------------------
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(ctx, gen, d_ascii, kmer_labels, args)
+
+    out = {
+        "metric": "genome Gbases/s k-mer+enrichment, %s k=%d 1Mb windows" % (args.config, args.k),
+        "value": round(gbases, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s-like synthetic genome, %d chromosomes, %.3f Gbases, k=%d, lower_count=3, "
+                               "q=200 f=2, 10-kb bins, 1-Mb windows" % (args.config, C, gen.total_bases / 1e9, args.k),
+                   "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
+                   "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
+                   "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
+        "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "synth_s": round(t_synth, 2),
+    }
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, gen, d_ascii, kmer_labels, args):
+    """Oracle (C port of the same path) on the host cores over the first `cpu_sample_mb` Mb of
+    every chromosome of the first homoeologous set.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    n = int(args.cpu_sample_mb * 1e6)
+    first = gen.sgs[0]
+    labs = [c for unit in first for c in unit]
+    idx = [gen.labels.index(l) for l in labs]
+    seqs = [ctx.dev_to_host(d_ascii[i], min(n, gen.chroms[i]["length"])) for i in idx]
+    bases = sum(len(s) for s in seqs)
+    t0 = time.perf_counter()
+    dumps = [po.count(s, args.k, 3, nthreads=cores) for s in seqs]
+    t_count = time.perf_counter() - t0
+    try:
+        po.filter_dumps(dumps, [first], labs, 2.0, 1, 200 * bases / gen.total_bases, 1e9, 1.0)
+    except ValueError:
+        pass
+    t_filter = time.perf_counter() - t0 - t_count
+    S = gen.S
+    for s in seqs:
+        po.map_bins(s, args.k, kmer_labels.keys, kmer_labels.sg_idx, S, 10000, 10_000_000, nthreads=cores)
+    t_map = time.perf_counter() - t0 - t_count - t_filter
+    total = time.perf_counter() - t0
+    return {"value": round(bases / total / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "sample": "first %.0f Mb of each of the %d chromosomes of homoeologous set 1 (%.1f Mbases): "
+                      "oracle count %.2fs + matrix/filter %.2fs + map %.2fs"
+                      % (args.cpu_sample_mb, len(seqs), bases / 1e6, t_count, t_filter, t_map)}
+
+
+if __name__ == "__main__":
+    main()

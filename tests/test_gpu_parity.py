@@ -1,0 +1,283 @@
+"""GPU suite (`-m gpu`): libsubphaser_hip.so through the C-ABI vs the CPU oracle
+and the golden vectors.  Integer work is compared bit-exactly; p-values within
+the 1e-6 the north star states (they agree to ~1e-9 in practice)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_seq(rng, n, p_other=0.01, lower=0.1):
+    a = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, size=n)].copy()
+    m = rng.random_sample(n) < lower
+    a[m] |= 0x20
+    m = rng.random_sample(n) < p_other
+    a[m] = np.frombuffer(b"NRYKMSWnx-", np.uint8)[rng.randint(0, 10, size=int(m.sum()))]
+    return a
+
+
+def _count_both(ctx, seqs, k, lower, engine=1):
+    ctx.genome_reset(len(seqs))
+    for i, s in enumerate(seqs):
+        ctx.genome_add(i, s)
+    ctx.count(k, lower, engine)
+    out = []
+    for i, s in enumerate(seqs):
+        gk, gc = ctx.dump(i)
+        ok, oc = po.count(s, k, lower, nthreads=4)
+        assert gk.shape == ok.shape, (k, i, gk.shape, ok.shape)
+        assert (gk == ok).all() and (gc == oc).all(), (k, i)
+        out.append((gk, gc))
+    lens = ctx.lengths()
+    assert lens.tolist() == [int(c.astype(np.int64).sum()) for _, c in out]
+    return out
+
+
+def test_library_is_native(gpu_ctx):
+    import os
+    from subphaser_amd import _native
+    assert os.path.exists(_native.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libsubphaser_hip.so" in maps
+
+
+def test_pack_roundtrip(gpu_ctx):
+    rng = np.random.RandomState(1)
+    seqs = [_rand_seq(rng, n) for n in (0, 1, 15, 31, 32, 33, 63, 64, 65, 1000, 4097, 100003)]
+    gpu_ctx.genome_reset(len(seqs))
+    for i, s in enumerate(seqs):
+        gpu_ctx.genome_add(i, s)
+    for i, s in enumerate(seqs):
+        got = gpu_ctx.genome_unpack(i)
+        up = s & 0xDF
+        ok = (up == 65) | (up == 67) | (up == 71) | (up == 84)
+        exp = np.where(ok, up, ord("N")).astype(np.uint8)
+        assert got.shape == exp.shape and (got == exp).all(), i
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 9, 11, 12, 13, 14, 15])
+def test_count_random_k(gpu_ctx, k):
+    rng = np.random.RandomState(100 + k)
+    seqs = [_rand_seq(rng, n) for n in (5000, 70001, 333)]
+    _count_both(gpu_ctx, seqs, k, 1)
+    _count_both(gpu_ctx, seqs, k, 3)
+
+
+def test_count_edges(gpu_ctx):
+    k = 15
+    seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",
+            b"ACGTACGTACGTACGnACGTACGTACGTAC", b"acgtacgtacgtacgtacgtacgt", b"TTTAGGG" * 3000,
+            b"A" * 100000, (b"ACGT" * 20 + b"N") * 500, b"ACGTACGTACGTACG", b"ACGTACGTACGTAC"]
+    _count_both(gpu_ctx, seqs, k, 1)
+    _count_both(gpu_ctx, seqs, k, 3)
+
+
+def test_count_unit_boundaries(gpu_ctx):
+    """N runs and valid windows placed around the 64-start unit and 16/32-base word edges."""
+    rng = np.random.RandomState(5)
+    base = _rand_seq(rng, 4096, p_other=0, lower=0)
+    seqs = []
+    for pos in (47, 48, 49, 62, 63, 64, 65, 78, 79, 80, 127, 128, 129, 4080, 4095):
+        s = base.copy()
+        s[pos] = ord("N")
+        seqs.append(s)
+    for n in (64 + 14, 64 + 15, 128 + 14, 128, 127, 129):
+        seqs.append(base[:n].copy())
+    _count_both(gpu_ctx, seqs, 15, 1)
+    _count_both(gpu_ctx, seqs, 13, 1)
+
+
+def test_count_deterministic(gpu_ctx):
+    rng = np.random.RandomState(9)
+    seqs = [_rand_seq(rng, 200000)]
+    a = _count_both(gpu_ctx, seqs, 15, 2)
+    b = _count_both(gpu_ctx, seqs, 15, 2)
+    assert (a[0][0] == b[0][0]).all() and (a[0][1] == b[0][1]).all()
+
+
+def test_count_rejects_bad_k(gpu_ctx):
+    gpu_ctx.genome_reset(1)
+    gpu_ctx.genome_add(0, b"ACGT" * 10)
+    with pytest.raises(ValueError):
+        gpu_ctx.count(0, 1)
+    with pytest.raises(ValueError):
+        gpu_ctx.count(33, 1)
+
+
+def test_toy_dumps(gpu_ctx, golden, toy):
+    pc.check_toy_dumps(gpu_ctx, golden, toy, engine=1)
+
+
+def test_filter_cases(gpu_ctx, golden, toy):
+    pc.check_filter_cases(gpu_ctx, golden, toy)
+
+
+def test_filter_vs_oracle_random(gpu_ctx, oracle_ctx):
+    """Random multi-chromosome genomes, random set structures: matrix rows bit-exact vs the oracle."""
+    rng = np.random.RandomState(21)
+    k = 11
+    rep = [_rand_seq(rng, 300, 0, 0) for _ in range(6)]
+    seqs = []
+    for c in range(7):
+        s = _rand_seq(rng, 30000 + 1000 * c)
+        for _ in range(40):
+            r = rep[rng.randint(0, 3) + (3 if c % 2 else 0)]
+            p = rng.randint(0, s.size - 400)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    cfgs = [
+        ([[[0], [1]], [[2], [3]], [[4], [5]], [[6]]], dict(min_fold=2, baseline=1, min_freq=10, max_freq=1e9, ratio=1)),
+        ([[[0, 2], [1, 3]], [[4], [5], [6]]], dict(min_fold=1.5, baseline=-1, min_freq=5, max_freq=500, ratio=0.5)),
+        ([[[0], [1], [2], [3], [4], [5], [6]]], dict(min_fold=3, baseline=3, min_freq=1, max_freq=1e9, ratio=1)),
+    ]
+    from subphaser_amd.config import sets_to_csr
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.genome_reset(len(seqs))
+        for i, s in enumerate(seqs):
+            ctx.genome_add(i, s)
+        ctx.count(k, 2, 1)
+    assert gpu_ctx.lengths().tolist() == oracle_ctx.lengths().tolist()
+    for sgs, kw in cfgs:
+        csr = sets_to_csr(sgs, list(range(7)))
+        res = []
+        for ctx in (gpu_ctx, oracle_ctx):
+            nu, nr, nh = ctx.filter(*csr, kw["min_fold"], kw["baseline"], kw["min_freq"], kw["max_freq"], kw["ratio"])
+            keys, counts, freqs, tot = ctx.filter_fetch(nr)
+            hist = np.sort(ctx.filter_hist(nh))
+            res.append((nu, nr, nh, keys, counts, freqs, tot, hist))
+        g, o = res
+        assert g[:3] == o[:3], (sgs, g[:3], o[:3])
+        for a, b in zip(g[3:], o[3:]):
+            assert a.shape == b.shape and (a == b).all()
+        assert g[1] > 0
+
+
+def test_filter_errors(gpu_ctx):
+    rng = np.random.RandomState(2)
+    gpu_ctx.genome_reset(2)
+    gpu_ctx.genome_add(0, _rand_seq(rng, 5000))
+    gpu_ctx.genome_add(1, b"ACGT")           # no k-mers at all
+    gpu_ctx.count(11, 1, 1)
+    from subphaser_amd.config import sets_to_csr
+    csr = sets_to_csr([[[0], [1]]], [0, 1])
+    with pytest.raises(ValueError, match="have only 0 kmers"):
+        gpu_ctx.filter(*csr, 2, 1, 1, 1e9, 1)
+    with pytest.raises(ValueError, match="should be lower than"):
+        gpu_ctx.filter(*csr, 2, 1, 100, 50, 1)
+    csr1 = sets_to_csr([[[0]], [[1]]], [0, 1])
+    with pytest.raises(ValueError, match="All singletons"):
+        gpu_ctx.filter(*csr1, 2, 1, 1, 1e9, 1)
+
+
+def test_kmer_mat_text(gpu_ctx, golden, toy):
+    pc.check_kmer_mat_text(gpu_ctx, golden, toy)
+
+
+def test_map_cases(gpu_ctx, golden, toy):
+    pc.check_map_cases(gpu_ctx, golden, toy)
+
+
+def test_map_features(gpu_ctx, golden, toy, tmp_path):
+    pc.check_map_features(gpu_ctx, golden, toy, tmp_path)
+
+
+def test_map_dict_labels(gpu_ctx, golden, toy):
+    pc.check_dict_labels(gpu_ctx, golden, toy)
+
+
+def test_map_vs_oracle_random(gpu_ctx):
+    rng = np.random.RandomState(33)
+    k = 13
+    s = _rand_seq(rng, 250000)
+    rep = _rand_seq(rng, 500, 0, 0)
+    for _ in range(100):
+        p = rng.randint(0, s.size - 600)
+        s[p:p + 500] = rep
+    gpu_ctx.genome_reset(1)
+    gpu_ctx.genome_add(0, s)
+    gpu_ctx.count(k, 1, 1)
+    keys, cnts = gpu_ctx.dump(0)
+    sel = keys[cnts >= 20]
+    sg = (np.arange(sel.size) % 3).astype(np.uint8)
+    gpu_ctx.labels_set(sel, sg, 3)
+    for bin_size, chunk in ((10000, 10_000_000), (100, 2000), (7, 0), (333, 1000), (1, 0), (50000, 100000)):
+        got, n = gpu_ctx.map_bins(0, bin_size, chunk)
+        exp, hit, n2 = po.map_bins(s, k, sel, sg, 3, bin_size, chunk, nthreads=4)
+        assert got.shape == exp.shape, (bin_size, chunk)
+        assert (got == exp).all() and n == n2, (bin_size, chunk)
+    assert gpu_ctx.labels_hit() == int(hit.sum())
+    assert int(got.sum()) == int(cnts[cnts >= 20].astype(np.int64).sum())   # every occurrence mapped once
+
+
+def test_enrich_bin(gpu_ctx, golden, tmp_path):
+    pc.check_enrich_bin(gpu_ctx, golden, tmp_path)
+
+
+def test_enrich_features(gpu_ctx, golden, tmp_path):
+    pc.check_enrich_features(gpu_ctx, golden, tmp_path)
+
+
+def test_fisher_cells_and_tails(gpu_ctx, golden):
+    pc.check_fisher_cells_and_tails(gpu_ctx, golden)
+
+
+def test_enrich_vs_oracle_random(gpu_ctx):
+    rng = np.random.RandomState(44)
+    for S, W, scale in ((2, 300, 30), (3, 500, 200), (5, 200, 5), (3, 64, 3e6), (9, 50, 50)):
+        t = rng.poisson(scale, size=(W, S)).astype(np.int64)
+        t[: W // 5, 0] += rng.poisson(scale * 2 + 5, W // 5)
+        t[W // 5: W // 4] = 0
+        with np.errstate(all="ignore"):
+            gp, ga, gs, gr = gpu_ctx.enrich(t, 0.05, 0.5)
+            op, oa, os_, orr = po.enrich(t, 0.05, 0.5)
+        assert np.allclose(gp, op, rtol=1e-7, atol=1e-300), (S, np.abs(gp - op).max())
+        assert np.abs(gp - op).max() <= 1e-6
+        same = np.isclose(gp, op, rtol=1e-12, atol=0).all(axis=1)   # decisions can only differ on p ties
+        assert (ga[same] == oa[same]).all()
+        assert (gs[same] == os_[same]).all()
+        assert ((gr == orr) | (np.isnan(gr) & np.isnan(orr))).all()
+
+
+def test_enrich_needs_two_columns(gpu_ctx):
+    with pytest.raises(ValueError):
+        gpu_ctx.enrich(np.ones((3, 1), np.int64))
+
+
+def test_full_size_properties(gpu_ctx):
+    """Size-independent invariants on a chromosome too large for the pure-Python checks:
+    the sum of all counts equals the number of valid windows; counting twice is idempotent;
+    mapping with every dumped k-mer labelled maps exactly sum(counts) positions."""
+    n = 20_000_000
+    d = gpu_ctx.dev_alloc(n)
+    try:
+        gpu_ctx.synth_chrom(d, n, seed=5, set_id=0, sg_id=0, n_sg=2, chrom_id=0)
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.genome_add_device(0, d, n)
+        host = gpu_ctx.dev_to_host(d, n)
+    finally:
+        gpu_ctx.sync()
+        gpu_ctx.dev_free(d)
+    k = 15
+    gpu_ctx.count(k, 1, 1)
+    total = int(gpu_ctx.lengths()[0])
+    up = host & 0xDF
+    ok = ((up == 65) | (up == 67) | (up == 71) | (up == 84)).astype(np.int64)
+    run = np.zeros(n, np.int64)
+    c = np.cumsum(ok)
+    reset = np.where(ok == 0, c, 0)
+    np.maximum.accumulate(reset, out=reset)
+    run = c - reset
+    assert total == int((run >= k).sum())
+    keys, cnts = gpu_ctx.dump(0)
+    ok_keys, ok_cnts = po.count(host, k, 1, nthreads=8)
+    assert (keys == ok_keys).all() and (cnts == ok_cnts).all()
+    gpu_ctx.count(k, 3, 1)
+    keys3, cnts3 = gpu_ctx.dump(0)
+    assert (keys3 == keys[cnts >= 3]).all() and (cnts3 == cnts[cnts >= 3]).all()
+    gpu_ctx.labels_set(keys3, np.zeros(keys3.size, np.uint8), 1)
+    got, nmap = gpu_ctx.map_bins(0, 10000, 10_000_000)
+    assert nmap == int(cnts3.astype(np.int64).sum()) == int(got.sum())
+    assert gpu_ctx.labels_hit() == keys3.size
