@@ -142,6 +142,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if runner is None:
+        hp.wall.clear()
     ctx.prof_reset()
     ctx.prof_enable(True)
     barrier()
@@ -203,6 +205,8 @@ def main():
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "synth_s": round(t_synth, 2),
+        "host_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 2) for k_, v in hp.wall.items()}
+                                  if runner is None else None),
     }
     print(json.dumps(out))
     sys.stdout.flush()

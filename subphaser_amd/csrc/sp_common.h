@@ -17,6 +17,7 @@
 struct sp_chrom {
     int64_t len = 0;     // bases
     int64_t nw = 0;      // 16-base words actually covering len
+    int64_t cap_mw = 0;  // capacity of d_pk/d_nm in mask words (buffers are reused across sp_genome_reset)
     uint32_t *d_pk = nullptr;  // 2-bit codes, base i at bits 2*(i%16) of word i/16; padded with SP_PAD_WORDS
     uint32_t *d_nm = nullptr;  // invalid mask, base i at bit (i%32) of word i/32; padding marked invalid
     uint32_t *d_tab = nullptr; // dense count table [nslots] (valid after sp_count)
@@ -24,6 +25,13 @@ struct sp_chrom {
     int64_t n_dump = 0;        // number of k-mers with count >= lower_count
 };
 #define SP_PAD_WORDS 8
+
+// growth-only device buffer: hipMalloc/hipFree are slow (a hipMalloc that follows the release of
+// tens of GiB was measured at 1.4-2.3 s on MI355X), so hot-path buffers are kept and reused.
+struct sp_buf {
+    void *p = nullptr;
+    int64_t cap = 0;
+};
 
 struct sp_prof_entry {
     std::string name;
@@ -58,6 +66,9 @@ struct sp_ctx {
     // scratch
     void *d_scratch = nullptr;
     int64_t scratch_bytes = 0;
+    void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
+    int64_t ws2_bytes = 0;
+    sp_buf b_map, b_emit, b_fpar;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter
     // profiling
     bool prof = false;
     std::vector<sp_prof_entry> prof_pending;
@@ -68,6 +79,9 @@ extern thread_local std::string g_sp_err;
 
 int sp_fail(sp_ctx *ctx, int code, const char *fmt, ...);
 int sp_scratch(sp_ctx *ctx, int64_t bytes, void **out);
+struct sp_ctx;
+int sp_buf_ensure(sp_ctx *ctx, sp_buf &b, int64_t bytes);
+void sp_buf_free(sp_buf &b);
 void sp_prof_begin(sp_ctx *ctx, const char *name);
 void sp_prof_end(sp_ctx *ctx);
 void sp_prof_flush(sp_ctx *ctx);

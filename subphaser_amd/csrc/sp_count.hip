@@ -141,6 +141,7 @@ static int grid_for(sp_ctx *ctx, int64_t work_items, int per_block, int max_per_
 
 int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower,
                      unsigned long long *d_len2);  // sp_count2.hip
+bool sp_engine2_supported(int64_t nslots);
 
 extern "C" {
 
@@ -184,7 +185,7 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
         if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
         if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots * sizeof(uint32_t)));
         int eng = engine;
-        if (eng == 0) eng = 1;
+        if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
         if (eng == 2) {
             rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 2 * ci);
             if (rc) return rc;

@@ -1,7 +1,370 @@
-// sp_count2.hip -- K1 engine 2: LDS radix-partition counter (placeholder until measured design lands).
+// sp_count2.hip -- K1 engine 2: LDS radix-partition k-mer counter.
+//
+// Random 4-byte read-modify-writes into a 2-GiB table run at ~19 G updates/s on
+// MI355X (profiles/r01_ubench_mi355x.txt), LDS atomics at ~600 G/s.  This engine
+// turns the random updates into streaming traffic:
+//
+//   c2_hist   scan the packed chromosome, histogram the top B1+B2 slot bits
+//             (LDS histogram per block, one global atomic per non-empty bin)
+//   c2_part1  scan again; LDS counting sort of a 16K-key tile on the top B1
+//             bits; each bucket run is written as one coalesced burst (u32 keys)
+//   c2_part2  per level-1 bucket: LDS counting sort of 16K-key tiles on the next
+//             B2 bits; only the low 15 slot bits survive, written as u16
+//   c2_count  one workgroup per fine bucket (2^15 consecutive slots): 128 KiB of
+//             u32 counters in LDS, LDS atomics, then ONE streaming write of the
+//             table slice, fused with K2 (sum and number of counts >= lower)
+//
+// All table writes and all key reads/writes are coalesced; the only random
+// accesses left are LDS atomics.  Physical HBM bytes per base (k = 15):
+//   0.375 x3 (scans) + 4 w + 4 r + 2 w + 2 r + 4 x slots/base (table write).
 #include "sp_device.h"
 
+#define C2_B3 15                      // slot bits resolved inside LDS
+#define C2_FINE (1 << C2_B3)          // slots per fine bucket
+#define C2_TILE_THREADS 256
+#define C2_TILE_KEYS (C2_TILE_THREADS * SP_UNIT)  // 16384 keys per tile
+#define C2_MAXF 256                   // max fan-out per level
+
+struct c2_plan {
+    int T;        // log2(nslots)
+    int B1, B2;   // partition bits
+    int F1, F2;
+    int64_t n_fine;  // F1*F2
+};
+
+static bool c2_make_plan(int64_t nslots, c2_plan &p) {
+    int T = 0;
+    while ((1LL << T) < nslots) T++;
+    if ((1LL << T) != nslots) return false;
+    int R = T - C2_B3;
+    if (R < 2) return false;
+    p.T = T;
+    p.B1 = (R + 1) / 2;
+    p.B2 = R / 2;
+    if (p.B1 > 8 || p.B2 > 8) return false;
+    p.F1 = 1 << p.B1;
+    p.F2 = 1 << p.B2;
+    p.n_fine = (int64_t)p.F1 * p.F2;
+    return true;
+}
+
+// ---------------------------------------------------------------- c2_hist
+__global__ void __launch_bounds__(C2_TILE_THREADS)
+c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
+        sp_kparams kp, int shift_fine /* = B3 */, int n_fine,
+        unsigned long long *__restrict__ ghist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
+    for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+            uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
+            atomicAdd(&lh[slot >> shift_fine], 1u);
+        });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_fine; i += blockDim.x) {
+        uint32_t v = lh[i];
+        if (v) atomicAdd(&ghist[i], (unsigned long long)v);
+    }
+}
+
+// exclusive scan of the fine histogram (n_fine <= 65536) -> off_fine[n_fine+1];
+// also level-1 bucket offsets off1[F1+1] = off_fine[b*F2] and tile starts for part2
+__global__ void __launch_bounds__(1024)
+c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2,
+           unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1,
+           unsigned long long *__restrict__ tile_start /*F1+1*/) {
+    __shared__ unsigned long long part[1024];
+    const int T = 1024;
+    int per = (n_fine + T - 1) / T;
+    int lo = threadIdx.x * per, hi = lo + per;
+    if (hi > n_fine) hi = n_fine;
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; i++) s += ghist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < T; i++) {
+            unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        off_fine[n_fine] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) {
+        off_fine[i] = run;
+        run += ghist[i];
+    }
+    __syncthreads();
+    __threadfence_block();
+    if (threadIdx.x == 0) {
+        unsigned long long tiles = 0;
+        for (int b = 0; b < F1; b++) {
+            unsigned long long o = off_fine[(size_t)b * F2];
+            unsigned long long e = off_fine[(size_t)(b + 1) * F2];
+            off1[b] = o;
+            tile_start[b] = tiles;
+            tiles += (e - o + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+        }
+        off1[F1] = off_fine[n_fine];
+        tile_start[F1] = tiles;
+    }
+}
+
+// block-wide exclusive scan of hist[0..F) (F <= 256 = blockDim) -> start[]; returns total
+__device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *start, int F,
+                                              uint32_t *wsum /*>=4*/) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v = (t < F) ? hist[t] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+        uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    if (t < F) start[t] = base + incl - v;
+    __syncthreads();
+    return total;
+}
+
+// ---------------------------------------------------------------- c2_part1
+__global__ void __launch_bounds__(C2_TILE_THREADS)
+c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
+         sp_kparams kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
+         unsigned long long *__restrict__ cursor1 /*F1, zeroed*/, uint32_t *__restrict__ buf1) {
+    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
+    __shared__ unsigned long long gbase[C2_MAXF];
+    __shared__ uint32_t keys[C2_TILE_KEYS];
+    const int64_t n_tiles = (n_units + C2_TILE_THREADS - 1) / C2_TILE_THREADS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t u = tile * C2_TILE_THREADS + threadIdx.x;
+        if (threadIdx.x < F1) hist[threadIdx.x] = 0;
+        __syncthreads();
+        if (u < n_units)
+            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+                uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
+                atomicAdd(&hist[slot >> shift1], 1u);
+            });
+        __syncthreads();
+        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
+        if (threadIdx.x < F1) {
+            uint32_t c = hist[threadIdx.x];
+            gbase[threadIdx.x] = off1[threadIdx.x] + (c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL);
+            cur[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (u < n_units)
+            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+                uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
+                uint32_t b = slot >> shift1;
+                uint32_t pos = start[b] + atomicAdd(&cur[b], 1u);
+                keys[pos] = slot;
+            });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += C2_TILE_THREADS) {
+            uint32_t s = keys[i];
+            uint32_t b = s >> shift1;
+            buf1[gbase[b] + (i - start[b])] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- c2_part2
+__global__ void __launch_bounds__(C2_TILE_THREADS)
+c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+         const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
+         const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
+         uint16_t *__restrict__ buf2) {
+    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
+    __shared__ unsigned long long gbase[C2_MAXF];
+    __shared__ uint32_t keys[C2_TILE_KEYS];
+    __shared__ int s_bucket;
+    const unsigned long long n_tiles = tile_start[F1];
+    const uint32_t mask2 = (uint32_t)F2 - 1u;
+    for (unsigned long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) {  // bucket of this tile: last b with tile_start[b] <= tile
+            int lo = 0, hi = F1;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (tile_start[mid] <= tile) lo = mid;
+                else hi = mid;
+            }
+            s_bucket = lo;
+        }
+        if (threadIdx.x < F2) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int b1 = s_bucket;
+        const unsigned long long base = off1[b1] + (tile - tile_start[b1]) * C2_TILE_KEYS;
+        const unsigned long long end = off1[b1 + 1];
+        uint32_t my[SP_UNIT];
+        int nmine = 0;
+#pragma unroll
+        for (int j = 0; j < SP_UNIT; j++) {
+            unsigned long long idx = base + (unsigned long long)j * C2_TILE_THREADS + threadIdx.x;
+            if (idx < end) {
+                my[j] = buf1[idx];
+                atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
+                nmine = j + 1;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = c2_scan_F(hist, start, F2, wsum);
+        if (threadIdx.x < F2) {
+            uint32_t c = hist[threadIdx.x];
+            size_t fine = (size_t)b1 * F2 + threadIdx.x;
+            gbase[threadIdx.x] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+            cur[threadIdx.x] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SP_UNIT; j++) {
+            if (j < nmine) {
+                uint32_t b = (my[j] >> shift2) & mask2;
+                uint32_t pos = start[b] + atomicAdd(&cur[b], 1u);
+                keys[pos] = my[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += C2_TILE_THREADS) {
+            uint32_t s = keys[i];
+            uint32_t b = (s >> shift2) & mask2;
+            buf2[gbase[b] + (i - start[b])] = (uint16_t)(s & (C2_FINE - 1));
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- c2_count
+#define C2_COUNT_THREADS 1024
+__global__ void __launch_bounds__(C2_COUNT_THREADS)
+c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict__ off_fine,
+         int64_t n_fine, uint32_t lower, uint32_t *__restrict__ tab,
+         unsigned long long *__restrict__ out2 /*[0]=sum,[1]=n*/) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE
+    __shared__ unsigned long long red[16];
+    unsigned long long s = 0, n = 0;
+    for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const unsigned long long lo = off_fine[fb], hi = off_fine[fb + 1];
+        // 8-byte aligned body: four u16 keys per load
+        unsigned long long a = (lo + 3ULL) & ~3ULL;
+        if (a > hi) a = hi;
+        for (unsigned long long i = lo + threadIdx.x; i < a; i += C2_COUNT_THREADS) atomicAdd(&cnt[buf2[i]], 1u);
+        const unsigned long long n4 = (hi - a) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a);
+        for (unsigned long long i = threadIdx.x; i < n4; i += C2_COUNT_THREADS) {
+            uint2 v = p2[i];
+            atomicAdd(&cnt[v.x & 0xffffu], 1u);
+            atomicAdd(&cnt[v.x >> 16], 1u);
+            atomicAdd(&cnt[v.y & 0xffffu], 1u);
+            atomicAdd(&cnt[v.y >> 16], 1u);
+        }
+        for (unsigned long long i = a + (n4 << 2) + threadIdx.x; i < hi; i += C2_COUNT_THREADS)
+            atomicAdd(&cnt[buf2[i]], 1u);
+        __syncthreads();
+        uint4 *t4 = reinterpret_cast<uint4 *>(tab + fb * C2_FINE);
+        for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
+            uint4 v = c4[i];
+            t4[i] = v;
+            if (v.x >= lower) { s += v.x; n++; }
+            if (v.y >= lower) { s += v.y; n++; }
+            if (v.z >= lower) { s += v.z; n++; }
+            if (v.w >= lower) { s += v.w; n++; }
+        }
+        __syncthreads();
+    }
+    unsigned long long ts = sp_block_sum_u64(s, red);
+    unsigned long long tn = sp_block_sum_u64(n, red);
+    if (threadIdx.x == 0) {
+        if (ts) atomicAdd(&out2[0], ts);
+        if (tn) atomicAdd(&out2[1], tn);
+    }
+}
+
+bool sp_engine2_supported(int64_t nslots) {
+    c2_plan p;
+    return c2_make_plan(nslots, p);
+}
+
 int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, unsigned long long *d_len2) {
-    (void)c; (void)kp; (void)lower; (void)d_len2;
-    return sp_fail(ctx, SP_EUNSUP, "count engine 2 is not built yet");
+    c2_plan P;
+    if (!c2_make_plan(ctx->nslots, P))
+        return sp_fail(ctx, SP_EUNSUP, "count engine 2 needs a dense table of 2^17..2^31 slots (k=%d)", kp.k);
+    const int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
+    if (n_units == 0) {
+        SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots * 4, ctx->stream));
+        return SP_OK;
+    }
+    // workspace: ghist | off_fine | off1 | tile_start | cursor1 | cursor2 | buf1 (u32 x len) | buf2 (u16 x len)
+    const size_t nf = (size_t)P.n_fine;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_ghist = 0;
+    size_t o_offf = o_ghist + al(nf * 8);
+    size_t o_off1 = o_offf + al((nf + 1) * 8);
+    size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 8);
+    size_t o_cur1 = o_tile + al((size_t)(P.F1 + 1) * 8);
+    size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
+    size_t o_buf1 = o_cur2 + al(nf * 8);
+    size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64);
+    size_t total = o_buf2 + al((size_t)c.len * 2 + 64);
+    if ((int64_t)total > ctx->ws2_bytes) {
+        if (ctx->d_ws2) {
+            SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SP_HIP(ctx, hipFree(ctx->d_ws2));
+            ctx->d_ws2 = nullptr;
+            ctx->ws2_bytes = 0;
+        }
+        SP_HIP(ctx, hipMalloc(&ctx->d_ws2, total));
+        ctx->ws2_bytes = (int64_t)total;
+    }
+    char *ws = (char *)ctx->d_ws2;
+    unsigned long long *ghist = (unsigned long long *)(ws + o_ghist);
+    unsigned long long *off_fine = (unsigned long long *)(ws + o_offf);
+    unsigned long long *off1 = (unsigned long long *)(ws + o_off1);
+    unsigned long long *tile_start = (unsigned long long *)(ws + o_tile);
+    unsigned long long *cur1 = (unsigned long long *)(ws + o_cur1);
+    unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
+    uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
+    uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
+    // zero ghist .. cursor2 in one memset (they are contiguous)
+    SP_HIP(ctx, hipMemsetAsync(ws, 0, o_buf1, ctx->stream));
+
+    const int64_t n_tiles = (n_units + C2_TILE_THREADS - 1) / C2_TILE_THREADS;
+    int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
+    size_t sh_hist = nf * 4;
+    if (sh_hist > 64 * 1024)
+        hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist);
+    int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
+    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_TILE_THREADS), sh_hist, c.d_pk, c.d_nm,
+              n_units, kp, C2_B3, (int)nf, ghist);
+    SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
+              off1, tile_start);
+    SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_TILE_THREADS), 0, c.d_pk, c.d_nm, n_units,
+              kp, P.T - P.B1, P.F1, off1, cur1, buf1);
+    // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
+    int64_t max_tiles2 = n_tiles + P.F1;
+    int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
+    SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_TILE_THREADS), 0, buf1, off1, tile_start, P.F1,
+              P.F2, C2_B3, off_fine, cur2, buf2);
+    hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4);
+    int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
+    SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, off_fine,
+              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len2);
+    return SP_OK;
 }

@@ -31,6 +31,25 @@ int sp_scratch(sp_ctx *ctx, int64_t bytes, void **out) {
     return SP_OK;
 }
 
+int sp_buf_ensure(sp_ctx *ctx, sp_buf &b, int64_t bytes) {
+    if (bytes <= b.cap) return SP_OK;
+    if (b.p) {
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SP_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    int64_t want = bytes + bytes / 8 + 4096;
+    SP_HIP(ctx, hipMalloc(&b.p, (size_t)want));
+    b.cap = want;
+    return SP_OK;
+}
+void sp_buf_free(sp_buf &b) {
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
 void sp_prof_begin(sp_ctx *ctx, const char *name) {
     if (!ctx->prof) return;
     sp_prof_entry e;
@@ -114,6 +133,10 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     free_filter(ctx);
     if (ctx->d_label) hipFree(ctx->d_label);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
+    if (ctx->d_ws2) hipFree(ctx->d_ws2);
+    sp_buf_free(ctx->b_map);
+    sp_buf_free(ctx->b_emit);
+    sp_buf_free(ctx->b_fpar);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SP_OK;
@@ -130,10 +153,20 @@ int sp_genome_reset(sp_ctx *ctx, int n_chrom) {
     if (!ctx || n_chrom < 0) return sp_fail(ctx, SP_EINVAL, "sp_genome_reset: bad arguments");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &c : ctx->chroms) free_chrom(c);
-    ctx->chroms.assign((size_t)n_chrom, sp_chrom());
+    if ((size_t)n_chrom == ctx->chroms.size()) {
+        // same shape as before: keep every device buffer (packed genome, tables) for reuse
+        for (auto &c : ctx->chroms) {
+            c.len = 0;
+            c.nw = 0;
+            c.length_sum = 0;
+            c.n_dump = 0;
+        }
+    } else {
+        for (auto &c : ctx->chroms) free_chrom(c);
+        ctx->chroms.assign((size_t)n_chrom, sp_chrom());
+    }
     ctx->counted = false;
-    free_filter(ctx);
+    ctx->filtered = false;
     return SP_OK;
 }
 }  // extern "C"
@@ -204,12 +237,20 @@ k0_unpack(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int6
 
 static int genome_add_impl(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64_t len) {
     sp_chrom &c = ctx->chroms[(size_t)chrom];
-    free_chrom(c);
     c.len = len;
+    c.length_sum = 0;
+    c.n_dump = 0;
     int64_t nmw = (len + 31) / 32 + SP_PAD_WORDS;  // mask words incl. padding
     c.nw = (len + 15) / 16;
-    SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(2 * nmw) * sizeof(uint32_t)));
-    SP_HIP(ctx, hipMalloc(&c.d_nm, (size_t)nmw * sizeof(uint32_t)));
+    if (nmw > c.cap_mw) {
+        if (c.d_pk) hipFree(c.d_pk);
+        if (c.d_nm) hipFree(c.d_nm);
+        c.d_pk = c.d_nm = nullptr;
+        c.cap_mw = 0;
+        SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(2 * nmw) * sizeof(uint32_t)));
+        SP_HIP(ctx, hipMalloc(&c.d_nm, (size_t)nmw * sizeof(uint32_t)));
+        c.cap_mw = nmw;
+    }
     int64_t blocks = (nmw + 255) / 256;
     if (blocks > 8LL * ctx->n_cu * 8) blocks = 8LL * ctx->n_cu * 8;
     if (blocks < 1) blocks = 1;

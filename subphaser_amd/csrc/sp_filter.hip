@@ -231,15 +231,18 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
         if (unit_chrom[j] < 0 || unit_chrom[j] >= C)
             return sp_fail(ctx, SP_EINVAL, "sp_filter: chromosome index %d out of range", unit_chrom[j]);
 
-    free_filter_buffers(ctx);
     const int64_t nslots = ctx->nslots;
     const int64_t nblk = (nslots + F_SLOTS_PER_BLOCK - 1) / F_SLOTS_PER_BLOCK;
     const int64_t ngroups = (nslots + 63) / 64;
+    ctx->filtered = false;
+    if (!ctx->d_flag_row || ctx->n_fblocks != nblk) {   // bitmaps are reused across calls
+        free_filter_buffers(ctx);
+        SP_HIP(ctx, hipMalloc(&ctx->d_flag_row, (size_t)ngroups * 8));
+        SP_HIP(ctx, hipMalloc(&ctx->d_flag_hist, (size_t)ngroups * 8));
+        SP_HIP(ctx, hipMalloc(&ctx->d_blk_row, (size_t)(nblk + 1) * 8));
+        SP_HIP(ctx, hipMalloc(&ctx->d_blk_hist, (size_t)(nblk + 1) * 8));
+    }
     ctx->n_fblocks = nblk;
-    SP_HIP(ctx, hipMalloc(&ctx->d_flag_row, (size_t)ngroups * 8));
-    SP_HIP(ctx, hipMalloc(&ctx->d_flag_hist, (size_t)ngroups * 8));
-    SP_HIP(ctx, hipMalloc(&ctx->d_blk_row, (size_t)(nblk + 1) * 8));
-    SP_HIP(ctx, hipMalloc(&ctx->d_blk_hist, (size_t)(nblk + 1) * 8));
 
     // device copies of the set structure + per-unit denominators
     std::vector<double> den((size_t)n_units);
@@ -251,16 +254,17 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     size_t b_set = (size_t)(n_sets + 1) * 4, b_uo = (size_t)(n_units + 1) * 4, b_uc = (size_t)(n_uc > 0 ? n_uc : 1) * 4,
            b_den = (size_t)n_units * 8;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t tot_b = al(b_set) + al(b_uo) + al(b_uc) + al(b_den) + al(C * sizeof(void *)) + 64;
-    char *d_par = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_par, tot_b));
+    size_t tot_b = al(b_set) + al(b_uo) + al(b_uc) + al(b_den) + al(C * sizeof(void *)) + 256;
+    int rcb = sp_buf_ensure(ctx, ctx->b_fpar, (int64_t)tot_b);
+    if (rcb) return rcb;
+    char *d_par = (char *)ctx->b_fpar.p;
     char *p = d_par;
     int32_t *d_set = (int32_t *)p; p += al(b_set);
     int32_t *d_uo = (int32_t *)p; p += al(b_uo);
     int32_t *d_uc = (int32_t *)p; p += al(b_uc);
     double *d_den = (double *)p; p += al(b_den);
     const uint32_t **d_tabs = (const uint32_t **)p; p += al(C * sizeof(void *));
-    unsigned long long *d_nuni = (unsigned long long *)p;
+    unsigned long long *d_nuni = (unsigned long long *)p;   // [0] union count, [1..2] scan totals
     std::vector<const uint32_t *> htabs((size_t)C);
     for (int i = 0; i < C; i++) htabs[(size_t)i] = ctx->chroms[(size_t)i].d_tab;
     hipError_t e = hipSuccess;
@@ -272,11 +276,10 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     cp(d_uc, unit_chrom, (size_t)n_uc * 4);
     cp(d_den, den.data(), b_den);
     cp(d_tabs, htabs.data(), C * sizeof(void *));
-    if (e == hipSuccess) e = hipMemsetAsync(d_nuni, 0, 8, ctx->stream);
-    if (e != hipSuccess) {
-        hipFree(d_par);
+    if (e == hipSuccess) e = hipMemsetAsync(d_nuni, 0, 32, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // host staging vectors go out of scope
+    if (e != hipSuccess)
         return sp_fail(ctx, SP_EHIP, "sp_filter: parameter upload failed: %s", hipGetErrorString(e));
-    }
     sp_filter_params P;
     P.C = C;
     P.n_sets = n_sets;
@@ -288,17 +291,14 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     P.ratio = ratio;
     P.nslots = nslots;
     size_t shmem = (size_t)4 * C * 64 * sizeof(uint32_t);
-    if (shmem > 150 * 1024) {
-        hipFree(d_par);
+    if (shmem > 150 * 1024)
         return sp_fail(ctx, SP_EUNSUP, "sp_filter: %d chromosomes exceed the LDS staging budget", C);
-    }
     if (shmem > 64 * 1024)
         hipFuncSetAttribute((const void *)k3_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     SP_LAUNCH(ctx, "k3_eval", k3_eval, dim3((unsigned)nblk), dim3(F_BLOCK), shmem, d_tabs, P, d_set, d_uo,
               d_uc, d_den, (unsigned long long *)ctx->d_flag_row, (unsigned long long *)ctx->d_flag_hist,
               (unsigned long long *)ctx->d_blk_row, (unsigned long long *)ctx->d_blk_hist, d_nuni);
-    unsigned long long *d_tot = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_tot, 16));
+    unsigned long long *d_tot = d_nuni + 1;
     SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0,
               (unsigned long long *)ctx->d_blk_row, nblk, d_tot);
     SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0,
@@ -307,8 +307,6 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     SP_HIP(ctx, hipMemcpyAsync(h, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(h + 2, d_nuni, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_tot);
-    hipFree(d_par);
     ctx->n_rows = (int64_t)h[0];
     ctx->n_hist = (int64_t)h[1];
     ctx->n_union = (int64_t)h[2];
@@ -334,10 +332,18 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     unsigned long long *d_keys = nullptr, *d_tot = nullptr;
     uint32_t *d_counts = nullptr;
     double *d_freqs = nullptr;
-    if (keys) SP_HIP(ctx, hipMalloc(&d_keys, (size_t)M * 8));
-    if (tot) SP_HIP(ctx, hipMalloc(&d_tot, (size_t)M * 8));
-    if (counts) SP_HIP(ctx, hipMalloc(&d_counts, (size_t)M * C * 4));
-    if (freqs) SP_HIP(ctx, hipMalloc(&d_freqs, (size_t)M * C * 8));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t need = (keys ? al((size_t)M * 8) : 0) + (tot ? al((size_t)M * 8) : 0) +
+                  (counts ? al((size_t)M * C * 4) : 0) + (freqs ? al((size_t)M * C * 8) : 0);
+    rc = sp_buf_ensure(ctx, ctx->b_emit, (int64_t)need);
+    if (rc) return rc;
+    {
+        char *q = (char *)ctx->b_emit.p;
+        if (keys) { d_keys = (unsigned long long *)q; q += al((size_t)M * 8); }
+        if (tot) { d_tot = (unsigned long long *)q; q += al((size_t)M * 8); }
+        if (counts) { d_counts = (uint32_t *)q; q += al((size_t)M * C * 4); }
+        if (freqs) { d_freqs = (double *)q; q += al((size_t)M * C * 8); }
+    }
     const sp_kparams kp = sp_make_kparams(ctx->k);
     SP_LAUNCH(ctx, hist ? "k3_emit_hist" : "k3_emit", k3_emit, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0,
               d_tabs, C, (uint32_t)ctx->lower, ctx->nslots, kp,
@@ -349,10 +355,6 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     if (counts) SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (freqs) SP_HIP(ctx, hipMemcpyAsync(freqs, d_freqs, (size_t)M * C * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d_keys) hipFree(d_keys);
-    if (d_tot) hipFree(d_tot);
-    if (d_counts) hipFree(d_counts);
-    if (d_freqs) hipFree(d_freqs);
     return SP_OK;
 }
 

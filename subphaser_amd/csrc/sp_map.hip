@@ -186,10 +186,11 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     const int S = ctx->n_sg;
     int64_t need = map_nslots_host(c.len, bin_size, chunk_size, ctx->k);
     if (nslots < need) return sp_fail(ctx, SP_EINVAL, "sp_map_bins: nslots %lld < %lld", (long long)nslots, (long long)need);
-    int *d_counts = nullptr;
     const size_t bytes = (size_t)nslots * S * sizeof(int);
     const size_t bytes8 = (bytes + 7) & ~(size_t)7;
-    SP_HIP(ctx, hipMalloc(&d_counts, bytes8 + 8));
+    int rcb = sp_buf_ensure(ctx, ctx->b_map, (int64_t)bytes8 + 8);
+    if (rcb) return rcb;
+    int *d_counts = (int *)ctx->b_map.p;
     unsigned long long *d_n = (unsigned long long *)((char *)d_counts + bytes8);
     SP_HIP(ctx, hipMemsetAsync(d_counts, 0, bytes8 + 8, ctx->stream));
     sp_map_params P;
@@ -212,7 +213,6 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(&hn, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_counts);
     if (n_mapped) *n_mapped = (int64_t)hn;
     return SP_OK;
 }

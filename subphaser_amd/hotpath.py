@@ -9,6 +9,8 @@ sharded across ranks for K0-K2 and K5; the filter is sharded by k-mer slot
 range after an all-to-all of table slices (the one real exchange step of the
 path), see `DistPlan` below and DESIGN.md "Multi-GPU".
 """
+import time
+
 import numpy as np
 
 from .circos import stack_bins
@@ -30,26 +32,41 @@ class HotPath:
         self.bin_size, self.chunk_size, self.window_size, self.max_pval = (
             bin_size, chunk_size, window_size, max_pval)
         self.csr = sets_to_csr(sgs, self.labels)
+        self.wall = {}     # host wall-clock per phase (seconds, accumulated), for bench.py
+
+    def _t(self, name, t0):
+        self.ctx.sync()
+        t1 = time.perf_counter()
+        self.wall[name] = self.wall.get(name, 0.0) + (t1 - t0)
+        return t1
 
     # ---- first half: K0..K3 ------------------------------------------------
     def count_and_filter(self, d_ascii, want_freqs=False, sort=False):
         """d_ascii: device pointers of the ASCII chromosomes (already in HBM)."""
         ctx = self.ctx
+        t = time.perf_counter()
         ctx.genome_reset(len(self.labels))
+        t = self._t("genome_reset", t)
         for i, (ptr, n) in enumerate(zip(d_ascii, self.lengths)):
             ctx.genome_add_device(i, ptr, n)
+        t = self._t("pack", t)
         ctx.count(self.k, self.lower_count, self.engine)
+        t = self._t("count", t)
         r = HotPathResult()
         r.kmer_lengths = ctx.lengths()
         r.n_union, r.n_rows, r.n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                                    self.max_freq, self.ratio)
+        t = self._t("filter", t)
         r.keys, r.counts, r.freqs, r.tot = ctx.filter_fetch(r.n_rows, want_freqs=want_freqs, sort=sort)
+        t = self._t("filter_fetch", t)
         return r
 
     # ---- second half: K4..K6 -----------------------------------------------
     def map_and_enrich(self, kmer_labels, n_sg):
         ctx = self.ctx
+        t = time.perf_counter()
         ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
+        t = self._t("labels_set", t)
         r = HotPathResult()
         r.bins, coords, rows, r.n_mapped = [], [], [], 0
         for i, (lab, n) in enumerate(zip(self.labels, self.lengths)):
@@ -73,7 +90,9 @@ class HotPath:
             rows.append(summed)
         r.coords = coords
         r.window_counts = np.concatenate(rows) if rows else np.zeros((0, n_sg), np.int64)
+        t = self._t("map_bins+stack", t)
         if len(r.window_counts):
             with np.errstate(all="ignore"):
                 r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)
+        t = self._t("enrich", t)
         return r

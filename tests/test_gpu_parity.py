@@ -66,6 +66,31 @@ def test_count_random_k(gpu_ctx, k):
     _count_both(gpu_ctx, seqs, k, 3)
 
 
+@pytest.mark.parametrize("k", [9, 10, 11, 12, 13, 14, 15])
+def test_count_engine2_random_k(gpu_ctx, k):
+    """LDS radix-partition engine vs the oracle (and, transitively, engine 1)."""
+    rng = np.random.RandomState(200 + k)
+    seqs = [_rand_seq(rng, n) for n in (5000, 1_200_001, 64, 333)]
+    seqs.append(np.concatenate([np.frombuffer(b"A" * 30000, np.uint8), _rand_seq(rng, 50000),
+                                np.frombuffer(b"TTTAGGG" * 5000, np.uint8)]))
+    _count_both(gpu_ctx, seqs, k, 1, engine=2)
+    _count_both(gpu_ctx, seqs, k, 3, engine=2)
+
+
+def test_count_engine2_edges(gpu_ctx):
+    seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"ACGTACGTACGTACGnACGTACGTACGTAC", b"TTTAGGG" * 3000,
+            b"A" * 300000, (b"ACGT" * 20 + b"N") * 500]
+    _count_both(gpu_ctx, seqs, 15, 1, engine=2)
+    _count_both(gpu_ctx, seqs, 13, 2, engine=2)
+
+
+def test_count_engine2_unsupported_small_k(gpu_ctx):
+    gpu_ctx.genome_reset(1)
+    gpu_ctx.genome_add(0, b"ACGT" * 100)
+    with pytest.raises(ValueError):
+        gpu_ctx.count(5, 1, 2)
+
+
 def test_count_edges(gpu_ctx):
     k = 15
     seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",
@@ -274,7 +299,8 @@ def test_full_size_properties(gpu_ctx):
     keys, cnts = gpu_ctx.dump(0)
     ok_keys, ok_cnts = po.count(host, k, 1, nthreads=8)
     assert (keys == ok_keys).all() and (cnts == ok_cnts).all()
-    gpu_ctx.count(k, 3, 1)
+    gpu_ctx.count(k, 3, 2)            # engine 2 on the same chromosome: identical tables
+    assert int(gpu_ctx.lengths()[0]) == int(cnts[cnts >= 3].astype(np.int64).sum())
     keys3, cnts3 = gpu_ctx.dump(0)
     assert (keys3 == keys[cnts >= 3]).all() and (cnts3 == cnts[cnts >= 3]).all()
     gpu_ctx.labels_set(keys3, np.zeros(keys3.size, np.uint8), 1)
