@@ -61,6 +61,7 @@ struct sp_ctx {
     int64_t n_fblocks = 0;
     // labels
     uint8_t *d_label = nullptr;  // [nslots] 0 = none, 1+sg; bit 7 = seen
+    uint32_t *d_bloom = nullptr; // 2^25-bit pre-filter over hashed slots (4 MiB: L2-resident)
     int n_sg = 0;
     int64_t n_labels = 0;
     // scratch

@@ -12,14 +12,14 @@
 // always-correct fallback and as the parity cross-check for engine 2.
 __global__ void __launch_bounds__(256)
 k1_count_atomic(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
-                sp_kparams kp, uint32_t *__restrict__ tab) {
+                sp_kparams32 kp, uint32_t *__restrict__ tab) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
-        uint64_t last = ~0ULL;
+        uint32_t last = 0xFFFFFFFFu;
         uint32_t acc = 0;
-        sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-            uint64_t slot = sp_slot_of(fwd, rc, kp);
+        sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+            const uint32_t slot = sp_slot_of32(fwd, rc, kp);
             if (slot == last) {
                 acc++;  // homopolymer runs collapse into one atomic
             } else {
@@ -196,7 +196,7 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
         if (n_units > 0) {
             int grid = grid_for(ctx, n_units, 256, 16);
             SP_LAUNCH(ctx, "k1_count_atomic", k1_count_atomic, dim3(grid), dim3(256), 0, c.d_pk, c.d_nm,
-                      n_units, kp, c.d_tab);
+                      n_units, sp_make_kparams32(k), c.d_tab);
         }
         int grid2 = grid_for(ctx, nslots / 4, 256, 16);
         SP_LAUNCH(ctx, "k2_lengths", k2_lengths, dim3(grid2), dim3(256), 0, c.d_tab, nslots,

@@ -21,8 +21,12 @@
 
 #define C2_B3 15                      // slot bits resolved inside LDS
 #define C2_FINE (1 << C2_B3)          // slots per fine bucket
-#define C2_TILE_THREADS 256
-#define C2_TILE_KEYS (C2_TILE_THREADS * SP_UNIT)  // 16384 keys per tile
+#define C2_TILE_KEYS 16384            // keys per LDS counting-sort tile
+#define C2_P1_THREADS 512             // part1: 512 threads x 32 k-mer starts
+#define C2_P1_UNIT 32
+#define C2_P2_THREADS 1024            // part2: 1024 threads x 16 keys
+#define C2_P2_PER 16
+#define C2_HIST_THREADS 512
 #define C2_MAXF 256                   // max fan-out per level
 
 struct c2_plan {
@@ -49,18 +53,17 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
 }
 
 // ---------------------------------------------------------------- c2_hist
-__global__ void __launch_bounds__(C2_TILE_THREADS)
+__global__ void __launch_bounds__(C2_HIST_THREADS)
 c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
-        sp_kparams kp, int shift_fine /* = B3 */, int n_fine,
+        sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine,
         unsigned long long *__restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
-        sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-            uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
-            atomicAdd(&lh[slot >> shift_fine], 1u);
+        sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+            atomicAdd(&lh[sp_slot_of32(fwd, rc, kp) >> shift_fine], 1u);
         });
     }
     __syncthreads();
@@ -116,7 +119,7 @@ c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int
     }
 }
 
-// block-wide exclusive scan of hist[0..F) (F <= 256 = blockDim) -> start[]; returns total
+// block-wide exclusive scan of hist[0..F) (F <= 256 <= blockDim) -> start[]; returns total
 __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *start, int F,
                                               uint32_t *wsum /*>=4*/) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -127,7 +130,7 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
         uint32_t n = __shfl_up(incl, o, 64);
         if (lane >= o) incl += n;
     }
-    if (lane == 63) wsum[wave] = incl;
+    if (lane == 63 && wave < 4) wsum[wave] = incl;
     __syncthreads();
     uint32_t base = 0, total = 0;
     for (int w = 0; w < 4; w++) {
@@ -141,22 +144,21 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 }
 
 // ---------------------------------------------------------------- c2_part1
-__global__ void __launch_bounds__(C2_TILE_THREADS)
-c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
-         sp_kparams kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
+         sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
          unsigned long long *__restrict__ cursor1 /*F1, zeroed*/, uint32_t *__restrict__ buf1) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
     __shared__ uint32_t keys[C2_TILE_KEYS];
-    const int64_t n_tiles = (n_units + C2_TILE_THREADS - 1) / C2_TILE_THREADS;
+    const int64_t n_tiles = (n_units + C2_P1_THREADS - 1) / C2_P1_THREADS;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t u = tile * C2_TILE_THREADS + threadIdx.x;
+        const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
         if (threadIdx.x < F1) hist[threadIdx.x] = 0;
         __syncthreads();
         if (u < n_units)
-            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-                uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
-                atomicAdd(&hist[slot >> shift1], 1u);
+            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+                atomicAdd(&hist[sp_slot_of32(fwd, rc, kp) >> shift1], 1u);
             });
         __syncthreads();
         const uint32_t total = c2_scan_F(hist, start, F1, wsum);
@@ -167,16 +169,15 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
         }
         __syncthreads();
         if (u < n_units)
-            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-                uint32_t slot = (uint32_t)sp_slot_of(fwd, rc, kp);
-                uint32_t b = slot >> shift1;
-                uint32_t pos = start[b] + atomicAdd(&cur[b], 1u);
-                keys[pos] = slot;
+            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+                const uint32_t b = slot >> shift1;
+                keys[start[b] + atomicAdd(&cur[b], 1u)] = slot;
             });
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += C2_TILE_THREADS) {
-            uint32_t s = keys[i];
-            uint32_t b = s >> shift1;
+        for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
+            const uint32_t s = keys[i];
+            const uint32_t b = s >> shift1;
             buf1[gbase[b] + (i - start[b])] = s;
         }
         __syncthreads();
@@ -184,7 +185,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
 }
 
 // ---------------------------------------------------------------- c2_part2
-__global__ void __launch_bounds__(C2_TILE_THREADS)
+__global__ void __launch_bounds__(C2_P2_THREADS)
 c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
@@ -210,11 +211,11 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
         const int b1 = s_bucket;
         const unsigned long long base = off1[b1] + (tile - tile_start[b1]) * C2_TILE_KEYS;
         const unsigned long long end = off1[b1 + 1];
-        uint32_t my[SP_UNIT];
+        uint32_t my[C2_P2_PER];
         int nmine = 0;
 #pragma unroll
-        for (int j = 0; j < SP_UNIT; j++) {
-            unsigned long long idx = base + (unsigned long long)j * C2_TILE_THREADS + threadIdx.x;
+        for (int j = 0; j < C2_P2_PER; j++) {
+            unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
             if (idx < end) {
                 my[j] = buf1[idx];
                 atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
@@ -231,7 +232,7 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < SP_UNIT; j++) {
+        for (int j = 0; j < C2_P2_PER; j++) {
             if (j < nmine) {
                 uint32_t b = (my[j] >> shift2) & mask2;
                 uint32_t pos = start[b] + atomicAdd(&cur[b], 1u);
@@ -239,7 +240,7 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
             }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += C2_TILE_THREADS) {
+        for (uint32_t i = threadIdx.x; i < total; i += C2_P2_THREADS) {
             uint32_t s = keys[i];
             uint32_t b = (s >> shift2) & mask2;
             buf2[gbase[b] + (i - start[b])] = (uint16_t)(s & (C2_FINE - 1));
@@ -345,22 +346,25 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     // zero ghist .. cursor2 in one memset (they are contiguous)
     SP_HIP(ctx, hipMemsetAsync(ws, 0, o_buf1, ctx->stream));
 
-    const int64_t n_tiles = (n_units + C2_TILE_THREADS - 1) / C2_TILE_THREADS;
+    const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
+    const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
+    const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
     int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
     size_t sh_hist = nf * 4;
     if (sh_hist > 64 * 1024)
         hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist);
-    int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
-    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_TILE_THREADS), sh_hist, c.d_pk, c.d_nm,
-              n_units, kp, C2_B3, (int)nf, ghist);
+    int64_t hist_blocks = (n_units + C2_HIST_THREADS - 1) / C2_HIST_THREADS;
+    int grid_hist = (int)(hist_blocks < (int64_t)ctx->n_cu * 2 ? hist_blocks : (int64_t)ctx->n_cu * 2);
+    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_HIST_THREADS), sh_hist, c.d_pk, c.d_nm,
+              n_units, kp32, C2_B3, (int)nf, ghist);
     SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
               off1, tile_start);
-    SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_TILE_THREADS), 0, c.d_pk, c.d_nm, n_units,
-              kp, P.T - P.B1, P.F1, off1, cur1, buf1);
+    SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_nm, n_units32,
+              kp32, P.T - P.B1, P.F1, off1, cur1, buf1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
     int64_t max_tiles2 = n_tiles + P.F1;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
-    SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_TILE_THREADS), 0, buf1, off1, tile_start, P.F1,
+    SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, buf1, off1, tile_start, P.F1,
               P.F2, C2_B3, off_fine, cur2, buf2);
     hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4);
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);

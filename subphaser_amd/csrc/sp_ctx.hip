@@ -132,6 +132,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     for (auto &c : ctx->chroms) free_chrom(c);
     free_filter(ctx);
     if (ctx->d_label) hipFree(ctx->d_label);
+    if (ctx->d_bloom) hipFree(ctx->d_bloom);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
     sp_buf_free(ctx->b_map);

@@ -12,32 +12,64 @@
 // (Seqs.py:121-139).
 #define SP_UNIT 64
 
-template <typename F>
-__device__ __forceinline__ void sp_scan_unit(const uint32_t *__restrict__ pk,
-                                             const uint32_t *__restrict__ nm, int64_t s0,
-                                             const sp_kparams &kp, F &&emit) {
+// 32-bit k-mer arithmetic for the dense-table kernels (2k <= 32 bits)
+struct sp_kparams32 {
+    int k, odd, rcshift;
+    uint32_t kmask;
+};
+__host__ __device__ inline sp_kparams32 sp_make_kparams32(int k) {
+    sp_kparams32 p;
+    p.k = k;
+    p.odd = k & 1;
+    p.rcshift = 2 * (k - 1);
+    p.kmask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    return p;
+}
+__device__ __forceinline__ uint32_t sp_slot_of32(uint32_t fwd, uint32_t rc, const sp_kparams32 &p) {
+    if (p.odd) {
+        const uint32_t rep = ((fwd >> p.k) & 1u) ? rc : fwd;
+        const uint32_t lowmask = (1u << p.k) - 1u;
+        return (rep & lowmask) | ((rep >> (p.k + 1)) << p.k);
+    }
+    return fwd < rc ? fwd : rc;
+}
+
+// UNIT consecutive k-mer START positions [s0, s0+UNIT), s0 a multiple of UNIT (UNIT = 32 or 64),
+// emit(start, fwd, rc) for every start whose k bases are all valid.
+template <int UNIT, typename F>
+__device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk,
+                                               const uint32_t *__restrict__ nm, int64_t s0,
+                                               const sp_kparams32 &kp, F &&emit) {
+    constexpr int MW = UNIT / 16;  // code words owned by the unit
     const int64_t w0 = s0 >> 4;
-    const uint4 main4 = *reinterpret_cast<const uint4 *>(pk + w0);
-    const uint32_t h0 = pk[w0 + 4], h1 = pk[w0 + 5];
-    const uint32_t m0 = nm[(s0 >> 5)], m1 = nm[(s0 >> 5) + 1], m2 = nm[(s0 >> 5) + 2];
-    const uint64_t mlo = (uint64_t)m0 | ((uint64_t)m1 << 32);
-    uint32_t words[6] = {main4.x, main4.y, main4.z, main4.w, h0, h1};
-    uint64_t fwd = 0, rc = 0;
+    uint32_t words[MW + 2];
+    if (MW == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + w0);
+        words[0] = v.x; words[1] = v.y; words[2] = v.z; words[3] = v.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(pk + w0);
+        words[0] = v.x; words[1] = v.y;
+    }
+    words[MW] = pk[w0 + MW];
+    words[MW + 1] = pk[w0 + MW + 1];
+    const uint64_t mlo = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+    const uint32_t mhi = (MW == 4) ? nm[(s0 >> 5) + 2] : 0u;
+    uint32_t fwd = 0, rc = 0;
     int run = 0;
     const int k = kp.k;
-    const int total = SP_UNIT + k - 1;  // bases to consume
+    const int total = UNIT + k - 1;  // bases to consume
 #pragma unroll
-    for (int w = 0; w < 6; w++) {
-        uint32_t cw = words[w];
-        uint32_t mw = (w < 4) ? (uint32_t)((mlo >> (16 * w)) & 0xffffu)
-                              : (uint32_t)((m2 >> (16 * (w - 4))) & 0xffffu);
+    for (int w = 0; w < MW + 2; w++) {
+        const uint32_t cw = words[w];
+        const uint32_t mw = (w < 4) ? (uint32_t)((mlo >> (16 * w)) & 0xffffu)
+                                    : (uint32_t)((mhi >> (16 * (w - 4))) & 0xffffu);
         if (w * 16 >= total) break;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int b = w * 16 + j;
-            uint32_t c = (cw >> (2 * j)) & 3u;
+            const uint32_t c = (cw >> (2 * j)) & 3u;
             fwd = ((fwd << 2) | c) & kp.kmask;
-            rc = (rc >> 2) | ((uint64_t)(3u - c) << kp.rcshift);
+            rc = (rc >> 2) | ((3u - c) << kp.rcshift);
             run = ((mw >> j) & 1u) ? 0 : run + 1;
             if (run >= k && b < total) emit(s0 + b - (k - 1), fwd, rc);
         }

@@ -6,12 +6,27 @@
 #include "sp_device.h"
 
 // ----------------------------------------------------------------- K4
+// Two-level label lookup.  A random 1-byte gather from the 512-MiB label table
+// runs at ~54 G lookups/s on MI355X while a gather from a 4-MiB (L2-resident)
+// structure runs at ~250 G/s (profiles/r01_ubench_mi355x.txt).  Most genome
+// positions do not carry a subgenome-specific k-mer, so every position first
+// probes a hashed 2^25-bit Bloom-style bitmap that fits each XCD's 4-MiB L2 and
+// only positions that pass it touch the exact table.
+#define MAP_BLOOM_BITS 25
+__host__ __device__ __forceinline__ uint32_t map_bloom_idx(uint64_t slot) {
+    uint32_t x = (uint32_t)slot ^ (uint32_t)(slot >> 32);
+    return (x * 0x9E3779B1u) >> (32 - MAP_BLOOM_BITS);
+}
+
 __global__ void __launch_bounds__(256)
 k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
-          sp_kparams kp, uint8_t *__restrict__ label) {
+          sp_kparams kp, uint8_t *__restrict__ label, uint32_t *__restrict__ bloom) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    label[sp_slot_of_key(keys[i], kp)] = (uint8_t)(1u + sg[i]);
+    const uint64_t slot = sp_slot_of_key(keys[i], kp);
+    label[slot] = (uint8_t)(1u + sg[i]);
+    const uint32_t b = map_bloom_idx(slot);
+    atomicOr(&bloom[b >> 5], 1u << (b & 31));
 }
 
 // ----------------------------------------------------------------- K5
@@ -38,9 +53,9 @@ __device__ __forceinline__ int64_t map_slot(int64_t s, const sp_map_params &P, i
 }
 
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp,
-       sp_map_params P, uint8_t *__restrict__ label, int *__restrict__ slot_counts,
-       unsigned long long *__restrict__ n_mapped) {
+k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
+       sp_map_params P, uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom,
+       int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
     unsigned long long mapped = 0;
@@ -53,8 +68,10 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
             __syncthreads();
         }
         if (u < P.n_units) {
-            sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                const uint64_t slot = sp_slot_of(fwd, rc, kp);
+            sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+                const uint32_t bi = map_bloom_idx(slot);
+                if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return;   // L2-resident pre-filter
                 const uint32_t l = label[slot];
                 if (l) {
                     if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);  // idempotent "seen" mark
@@ -86,14 +103,17 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
 
 // feature mode: per-feature totals; feature of a start found by binary search
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp,
+k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
             int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
-            uint8_t *__restrict__ label, unsigned long long *__restrict__ counts) {
+            uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom,
+            unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
-        sp_scan_unit(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-            const uint64_t slot = sp_slot_of(fwd, rc, kp);
+        sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+            const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+            const uint32_t bi = map_bloom_idx(slot);
+            if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return;
             const uint32_t l = label[slot];
             if (l) {
                 if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
@@ -149,7 +169,9 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
     for (int64_t i = 0; i < n; i++)
         if (sg[i] >= n_sg) return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)sg[i], n_sg);
     if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
+    if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, (size_t)(1u << MAP_BLOOM_BITS) / 8));
     SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, (size_t)(1u << MAP_BLOOM_BITS) / 8, ctx->stream));
     ctx->n_sg = n_sg;
     ctx->n_labels = n;
     if (n == 0) return SP_OK;
@@ -161,7 +183,7 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
     SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     const sp_kparams kp = sp_make_kparams(ctx->k);
     SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
-              kp, ctx->d_label);
+              kp, ctx->d_label, ctx->d_bloom);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_keys);
     hipFree(d_sg);
@@ -202,12 +224,12 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     int64_t local = MAP_RANGE / bin_size + 3 + (chunk_size > 0 ? MAP_RANGE / chunk_size + 2 : 0);
     P.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
     if (P.n_units > 0) {
-        const sp_kparams kp = sp_make_kparams(ctx->k);
+        const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
         SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                  ctx->d_label, d_counts, d_n);
+                  ctx->d_label, ctx->d_bloom, d_counts, d_n);
     }
     unsigned long long hn = 0;
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -256,12 +278,12 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     int64_t blocks = (nmw + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, total, d_pk, d_nm, nmw);
-    const sp_kparams kp = sp_make_kparams(ctx->k);
+    const sp_kparams32 kp = sp_make_kparams32(ctx->k);
     int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-              n_units, d_foff, n_feat, S, ctx->d_label, d_counts);
+              n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, d_counts);
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_ascii);

@@ -13,7 +13,6 @@ import time
 
 import numpy as np
 
-from .circos import stack_bins
 from .config import sets_to_csr
 
 
@@ -84,8 +83,11 @@ class HotPath:
                 bins = nz - np.searchsorted(first_slot, nz, side="right")
             else:
                 bins = nz
-            wins, summed = stack_bins(bins * self.bin_size, slots[nz].astype(np.int64), self.window_size)
-            for w in wins.tolist():
+            # bins ascend, so each window is one contiguous run: segment sums instead of a scatter-add
+            win = (bins * self.bin_size) // self.window_size
+            seg = np.concatenate(([0], np.flatnonzero(np.diff(win)) + 1))
+            summed = np.add.reduceat(slots[nz].astype(np.int64), seg, axis=0)
+            for w in win[seg].tolist():
                 coords.append((lab, int(w * self.window_size), int(w * self.window_size + self.window_size)))
             rows.append(summed)
         r.coords = coords
