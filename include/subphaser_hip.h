@@ -68,8 +68,10 @@ int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
 /* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
 int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
-/* jellyfish-dump equivalent of one chromosome: keys ascending.  Two calls:
- * sp_dump_size then sp_dump with buffers of that size.                      */
+/* jellyfish-dump equivalent of one chromosome.  Two calls: sp_dump_size then
+ * sp_dump with buffers of that size.  Entries come in ascending order of the
+ * internal dense slot (deterministic; jellyfish's own order is hash order);
+ * the Python binding sorts them by canonical key.                           */
 int sp_dump_size(sp_ctx *ctx, int chrom, int64_t *n);
 int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t cap, int64_t *n);
 
@@ -84,7 +86,8 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
 int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
               const int32_t *unit_chrom, double min_fold, int baseline, double min_freq,
               double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist);
-/* rows in ascending canonical-key order; counts is row-major n_rows x C
+/* rows in ascending dense-slot order (deterministic; the Python binding sorts by
+ * canonical key); counts is row-major n_rows x C
  * (thresholded counts: 0 where count < lower_count); freqs = count/length in
  * fp64 exactly as Jellyfish.py:647 (may be NULL); tot = row sums (may be NULL) */
 int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot,
@@ -106,6 +109,11 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
 int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots);
 int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int32_t *slot_counts,
                 int64_t nslots, int64_t *n_mapped);
+/* every chromosome in one call: chromosome c owns slots [slot_off[c], slot_off[c+1]) of
+ * slot_counts (total x n_sg int32), sized with sp_map_nslots; n_mapped: C int64 (may be NULL).
+ * One launch per chromosome back to back, one device->host copy.               */
+int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int64_t *slot_off,
+                    int32_t *slot_counts, int64_t *n_mapped);
 /* feature mode (map_kmer3(..., chunk=False), __main__.py:509-511): n_feat
  * sequences concatenated in `ascii`, feature f = [off[f], off[f+1]).
  * counts: n_feat x n_sg int64 (whole-feature totals).                      */
@@ -132,6 +140,10 @@ int sp_prof_report(sp_ctx *ctx, char *buf, int64_t cap);
  * Deterministic synthetic chromosome written as ASCII into a device buffer. */
 int sp_synth_chrom(sp_ctx *ctx, uint8_t *d_out, int64_t len, uint64_t seed, int set_id,
                    int sg_id, int n_sg, int chrom_id, int exchange);
+/* page-locked host memory: device->host copies into it run at PCIe speed; plain
+ * (pageable) buffers are accepted everywhere but copy several times slower.     */
+int sp_host_alloc(sp_ctx *ctx, int64_t bytes, void **h_ptr);
+int sp_host_free(sp_ctx *ctx, void *h_ptr);
 /* device memory helpers so a non-torch caller can stage buffers */
 int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr);
 int sp_dev_free(sp_ctx *ctx, void *d_ptr);

@@ -22,10 +22,10 @@ SYMBOLS = [
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
     "sp_count", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter", "sp_filter_fetch", "sp_filter_hist",
-    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_features", "sp_labels_hit",
+    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
-    "sp_synth_chrom", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host",
+    "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host",
 ]
 
 
@@ -71,7 +71,10 @@ def load():
     L.sp_labels_set.argtypes = [vp, vp, vp, i64, ci]
     L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
     L.sp_map_bins.argtypes = [vp, ci, i64, i64, vp, i64, P(i64)]
+    L.sp_map_bins_all.argtypes = [vp, i64, i64, vp, vp, vp]
     L.sp_map_features.argtypes = [vp, vp, vp, i64, vp]
+    L.sp_host_alloc.argtypes = [vp, i64, P(vp)]
+    L.sp_host_free.argtypes = [vp, vp]
     L.sp_labels_hit.argtypes = [vp, P(i64)]
     L.sp_enrich.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
     L.sp_prof_enable.argtypes = [vp, ci]
@@ -113,6 +116,7 @@ class Context:
         self.h = h
         self.n_chrom = 0
         self.k = None
+        self._pinned = {}     # tag -> (ptr, nbytes): reusable page-locked staging buffers
 
     # -------------------------------------------------------------- plumbing
     def _ck(self, rc):
@@ -127,8 +131,28 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ptr, _ in self._pinned.values():
+                self.L.sp_host_free(self.h, C.c_void_p(ptr))
+            self._pinned = {}
             self.L.sp_ctx_destroy(self.h)
             self.h = None
+
+    def pinned_empty(self, tag, shape, dtype):
+        """numpy array over page-locked memory owned by the context.  The buffer named `tag` is
+        reused (and overwritten) by the next request with the same tag."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr, cap = self._pinned.get(tag, (None, 0))
+        if n > cap:
+            if ptr:
+                self.L.sp_host_free(self.h, C.c_void_p(ptr))
+            p = C.c_void_p()
+            want = n + n // 8 + 4096
+            self._ck(self.L.sp_host_alloc(self.h, want, C.byref(p)))
+            ptr, cap = p.value, want
+            self._pinned[tag] = (ptr, cap)
+        buf = (C.c_uint8 * max(n, 1)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def __del__(self):
         try:
@@ -205,12 +229,20 @@ class Context:
                                   float(ratio), C.byref(nu), C.byref(nr), C.byref(nh)))
         return nu.value, nr.value, nh.value
 
-    def filter_fetch(self, n_rows, want_freqs=True, sort=True):
+    def filter_fetch(self, n_rows, want_freqs=True, sort=True, pinned=False):
+        """pinned=True returns views of context-owned page-locked buffers (valid until the next
+        filter_fetch): the copy then runs at PCIe speed instead of through pageable staging."""
         Cn = self.n_chrom
-        keys = np.empty(n_rows, np.uint64)
-        counts = np.empty((n_rows, Cn), np.uint32)
-        tot = np.empty(n_rows, np.uint64)
-        freqs = np.empty((n_rows, Cn), np.float64) if want_freqs else None
+        if pinned and not sort:
+            keys = self.pinned_empty("ff_keys", (n_rows,), np.uint64)
+            counts = self.pinned_empty("ff_counts", (n_rows, Cn), np.uint32)
+            tot = self.pinned_empty("ff_tot", (n_rows,), np.uint64)
+            freqs = self.pinned_empty("ff_freqs", (n_rows, Cn), np.float64) if want_freqs else None
+        else:
+            keys = np.empty(n_rows, np.uint64)
+            counts = np.empty((n_rows, Cn), np.uint32)
+            tot = np.empty(n_rows, np.uint64)
+            freqs = np.empty((n_rows, Cn), np.float64) if want_freqs else None
         self._ck(self.L.sp_filter_fetch(self.h, _p(keys), _p(counts), _p(freqs), _p(tot), n_rows))
         if sort and n_rows:
             o = np.argsort(keys, kind="stable")
@@ -244,6 +276,18 @@ class Context:
         self._ck(self.L.sp_map_bins(self.h, int(chrom), int(bin_size), int(chunk_size), _p(out), ns,
                                     C.byref(n)))
         return out, n.value
+
+    def map_bins_all(self, bin_size=10000, chunk_size=10_000_000):
+        """All chromosomes in one call: (list of [nslots_c, n_sg] int32 views, n_mapped int64 [C]).
+        The views alias one array (self.last_map = (array, slot offsets)) in page-locked memory."""
+        off = np.zeros(self.n_chrom + 1, np.int64)
+        for i in range(self.n_chrom):
+            off[i + 1] = off[i] + self.map_nslots(i, bin_size, chunk_size)
+        out = self.pinned_empty("map_all", (int(off[-1]), self.n_sg), np.int32)
+        nm = np.zeros(self.n_chrom, np.int64)
+        self._ck(self.L.sp_map_bins_all(self.h, int(bin_size), int(chunk_size), _p(off), _p(out), _p(nm)))
+        self.last_map = (out, off)
+        return [out[off[i]:off[i + 1]] for i in range(self.n_chrom)], nm
 
     def map_features(self, seqs):
         """seqs: list of str/bytes.  Returns int64 [n_feat, n_sg] totals."""

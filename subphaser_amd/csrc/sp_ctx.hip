@@ -342,6 +342,17 @@ int sp_prof_report(sp_ctx *ctx, char *buf, int64_t cap) {
     return SP_OK;
 }
 
+int sp_host_alloc(sp_ctx *ctx, int64_t bytes, void **h_ptr) {
+    if (!ctx || !h_ptr || bytes < 0) return sp_fail(ctx, SP_EINVAL, "sp_host_alloc: bad arguments");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipHostMalloc(h_ptr, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+    return SP_OK;
+}
+int sp_host_free(sp_ctx *ctx, void *h_ptr) {
+    if (!ctx) return SP_EINVAL;
+    SP_HIP(ctx, hipHostFree(h_ptr));
+    return SP_OK;
+}
 int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr || bytes < 0) return sp_fail(ctx, SP_EINVAL, "sp_dev_alloc: bad arguments");
     SP_HIP(ctx, hipSetDevice(ctx->device));

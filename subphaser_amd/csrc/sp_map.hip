@@ -239,6 +239,54 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     return SP_OK;
 }
 
+int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int64_t *slot_off,
+                    int32_t *slot_counts, int64_t *n_mapped) {
+    if (!ctx || !slot_off || !slot_counts || bin_size < 1 || chunk_size < 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: bad arguments");
+    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: call sp_labels_set first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int C = (int)ctx->chroms.size();
+    const int S = ctx->n_sg;
+    for (int i = 0; i < C; i++) {
+        int64_t need = map_nslots_host(ctx->chroms[(size_t)i].len, bin_size, chunk_size, ctx->k);
+        if (slot_off[i + 1] - slot_off[i] < need)
+            return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: chromosome %d needs %lld slots", i, (long long)need);
+    }
+    const int64_t total = slot_off[C];
+    const size_t bytes = (size_t)total * S * sizeof(int);
+    const size_t bytes8 = (bytes + 7) & ~(size_t)7;
+    int rcb = sp_buf_ensure(ctx, ctx->b_map, (int64_t)(bytes8 + 8 * (size_t)C));
+    if (rcb) return rcb;
+    int *d_counts = (int *)ctx->b_map.p;
+    unsigned long long *d_n = (unsigned long long *)((char *)d_counts + bytes8);
+    SP_HIP(ctx, hipMemsetAsync(d_counts, 0, bytes8 + 8 * (size_t)C, ctx->stream));
+    const sp_kparams32 kp = sp_make_kparams32(ctx->k);
+    int64_t local = MAP_RANGE / bin_size + 3 + (chunk_size > 0 ? MAP_RANGE / chunk_size + 2 : 0);
+    for (int i = 0; i < C; i++) {
+        sp_chrom &c = ctx->chroms[(size_t)i];
+        sp_map_params P;
+        P.n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
+        P.bin_size = bin_size;
+        P.chunk_size = chunk_size;
+        P.nslots = slot_off[i + 1] - slot_off[i];
+        P.S = S;
+        P.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
+        if (P.n_units == 0) continue;
+        int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+        int64_t grid = n_ranges;
+        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+                  ctx->d_label, ctx->d_bloom, d_counts + slot_off[i] * S, d_n + i);
+    }
+    SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> hn((size_t)C, 0);
+    SP_HIP(ctx, hipMemcpyAsync(hn.data(), d_n, 8 * (size_t)C, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_mapped)
+        for (int i = 0; i < C; i++) n_mapped[i] = (int64_t)hn[(size_t)i];
+    return SP_OK;
+}
+
 int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,
                     int64_t *counts) {
     if (!ctx || !off || !counts || n_feat < 0 || (n_feat > 0 && off[n_feat] > 0 && !ascii))

@@ -56,7 +56,8 @@ class HotPath:
         r.n_union, r.n_rows, r.n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                                    self.max_freq, self.ratio)
         t = self._t("filter", t)
-        r.keys, r.counts, r.freqs, r.tot = ctx.filter_fetch(r.n_rows, want_freqs=want_freqs, sort=sort)
+        r.keys, r.counts, r.freqs, r.tot = ctx.filter_fetch(r.n_rows, want_freqs=want_freqs, sort=sort,
+                                                            pinned=not sort)
         t = self._t("filter_fetch", t)
         return r
 
@@ -67,32 +68,33 @@ class HotPath:
         ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
         t = self._t("labels_set", t)
         r = HotPathResult()
-        r.bins, coords, rows, r.n_mapped = [], [], [], 0
-        for i, (lab, n) in enumerate(zip(self.labels, self.lengths)):
-            slots, nm = ctx.map_bins(i, self.bin_size, self.chunk_size)
-            r.n_mapped += nm
-            r.bins.append(slots)
-            nz = np.flatnonzero(slots.any(axis=1))
-            if nz.size == 0:
-                continue
-            # slot -> bin start (boundary bins split across two slots are summed by the window stack)
+        coords = []
+        all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
+        t = self._t("map_bins", t)
+        r.n_mapped = int(n_mapped.sum())
+        r.bins = all_slots
+        # window stack of every chromosome at once (Circos.stack_matrix semantics: window =
+        # bin start // window_size; the two slots of a chunk-boundary bin fall in the same window)
+        big, off = ctx.last_map
+        nz = np.flatnonzero(big.any(axis=1))
+        rows = []
+        if nz.size:
+            chrom = np.searchsorted(off, nz, side="right") - 1
+            local = nz - off[chrom]
             if self.chunk_size:
-                nch = (n + (self.k - 1)) // self.chunk_size + 1
+                nch = (max(self.lengths) + (self.k - 1)) // self.chunk_size + 1
                 j = np.arange(1, nch + 1, dtype=np.int64)
                 first_slot = (j * self.chunk_size - (self.k - 1)) // self.bin_size + j
-                bins = nz - np.searchsorted(first_slot, nz, side="right")
-            else:
-                bins = nz
-            # bins ascend, so each window is one contiguous run: segment sums instead of a scatter-add
-            win = (bins * self.bin_size) // self.window_size
-            seg = np.concatenate(([0], np.flatnonzero(np.diff(win)) + 1))
-            summed = np.add.reduceat(slots[nz].astype(np.int64), seg, axis=0)
-            for w in win[seg].tolist():
-                coords.append((lab, int(w * self.window_size), int(w * self.window_size + self.window_size)))
-            rows.append(summed)
+                local = local - np.searchsorted(first_slot, local, side="right")
+            win = (local * self.bin_size) // self.window_size
+            key = chrom * (1 << 40) + win            # ascending: one contiguous run per (chromosome, window)
+            seg = np.concatenate(([0], np.flatnonzero(np.diff(key)) + 1))
+            rows.append(np.add.reduceat(big[nz].astype(np.int64), seg, axis=0))
+            ws = self.window_size
+            coords = [(self.labels[c], w * ws, w * ws + ws) for c, w in zip(chrom[seg].tolist(), win[seg].tolist())]
         r.coords = coords
         r.window_counts = np.concatenate(rows) if rows else np.zeros((0, n_sg), np.int64)
-        t = self._t("map_bins+stack", t)
+        t = self._t("stack", t)
         if len(r.window_counts):
             with np.errstate(all="ignore"):
                 r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)

@@ -12,7 +12,7 @@ import numpy as np
 
 
 def summarize(in_tsv, out=sys.stdout):
-    d_count, ids, sgs = {}, set(), set()
+    d_count, ids, sgs, width = {}, set(), set(), 0
     for line in open(in_tsv):
         if line.startswith("#"):
             continue
@@ -20,6 +20,7 @@ def summarize(in_tsv, out=sys.stdout):
         if len(t) < 4:
             continue
         fid, subgenome, counts = t[0], t[1], np.array(list(map(int, t[3].split(","))))
+        width = max(width, len(counts))
         key = (fid.split("-")[0], subgenome)
         if key not in d_count:
             d_count[key] = [1, counts]
@@ -31,7 +32,9 @@ def summarize(in_tsv, out=sys.stdout):
     for ann in sorted(ids):
         num, count = [], None
         for sg in sorted(sgs):
-            n, c = d_count.get((ann, sg), (0, np.array([0] * len(sgs))))
+            # (the reference sizes this zero vector by the number of subgenome labels, which breaks
+            #  as soon as a `None` row is present; the count vectors' own width is what is meant)
+            n, c = d_count.get((ann, sg), (0, np.zeros(width, dtype=int)))
             num.append(n)
             count = c.copy() if count is None else count + c
         out.write("\t".join(map(str, [ann] + num + list(count))) + "\n")

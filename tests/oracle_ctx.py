@@ -61,7 +61,7 @@ class OracleContext:
                                   max_freq, ratio)
         return self._f.n_union, len(self._f.keys), len(self._f.hist)
 
-    def filter_fetch(self, n_rows, want_freqs=True, sort=True):
+    def filter_fetch(self, n_rows, want_freqs=True, sort=True, pinned=False):
         f = self._f
         return f.keys, f.counts, f.freqs, f.tot
 
@@ -83,6 +83,12 @@ class OracleContext:
                                   chunk_size, self.nthreads)
         self.hit |= hit
         return out, n
+
+    def map_bins_all(self, bin_size=10000, chunk_size=10_000_000):
+        res = [self.map_bins(i, bin_size, chunk_size) for i in range(self.n_chrom)]
+        off = np.concatenate(([0], np.cumsum([len(r[0]) for r in res]))).astype(np.int64)
+        self.last_map = (np.concatenate([r[0] for r in res]), off)
+        return [r[0] for r in res], np.array([r[1] for r in res], np.int64)
 
     def map_features(self, seqs):
         out = np.zeros((len(seqs), self.n_sg), np.int64)

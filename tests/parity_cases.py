@@ -248,3 +248,19 @@ def check_fisher_cells_and_tails(ctx, golden):
         for r, exp in zip(counts[:6], t["cells_first6"]):
             got = [list(po.fisher_cells(r, total, j)) for j in range(len(r))]
             assert got == exp, name
+
+
+# ------------------------------------------------------------------ array fast path (bench / pipeline)
+def check_hotpath_stack(ctx, golden, toy):
+    """HotPath.map_and_enrich (no text round trip) == map_kmer3 text -> stack_matrix of the reference."""
+    from subphaser_amd.hotpath import HotPath
+    cl, labels = check_output_kmers(ctx, golden, toy)
+    lens = [len(toy["seqs"][lab]) for lab in toy["labels"]]
+    for ws in (1000, 1500, 2500, 100000):
+        hp = HotPath(ctx, toy["labels"], lens, toy["sgs"], k=K, lower_count=L, bin_size=100, chunk_size=2000,
+                     window_size=ws)
+        r = hp.map_and_enrich(labels, len(cl.sg_names))
+        exp = golden["G5_stack_matrix"][str(ws)]
+        assert [[c, s, e] for c, s, e in r.coords] == exp["coords"], ws
+        assert r.window_counts.tolist() == exp["counts"], ws
+        assert r.pvals.shape == r.window_counts.shape

@@ -1,0 +1,134 @@
+"""CPU suite: the C-ABI library loads and exports every declared symbol (no compute
+without a GPU), and the pure-host pieces (config grammar, codec, writers) match the goldens."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "subphaser_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from subphaser_amd import _native
+    lib = _native.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "libsubphaser_hip.so lacks %s" % name
+    assert sorted(_native.SYMBOLS) == declared     # the binding covers the whole header
+    assert lib.sp_version() >= 100
+
+
+def test_no_gpu_means_loud_failure():
+    """There is no CPU fallback: without a device the context cannot be created."""
+    import ctypes
+    from subphaser_amd import _native
+    lib = _native.load()
+    n = ctypes.c_int(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        have_gpu = hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_native.NativeError, match="no HIP device"):
+        _native.Context(0)
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "subphaser_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "sp_oracle" not in txt and "oracle_ctx" not in txt, f
+
+
+def test_sgconfig_matches_reference(golden, tmp_path):
+    from subphaser_amd.config import SGConfig
+    for name, ent in golden["G8_sgconfig"].items():
+        p = tmp_path / name
+        p.write_text(ent["text"])
+        for parse in ent["parses"]:
+            cfg = SGConfig(str(p), prefix=parse["prefix"], sep="|")
+            assert cfg.sgs == parse["sgs"], (name, parse["prefix"])
+            assert cfg.chrs == parse["chrs"], name
+            assert cfg.nsg == parse["nsg"], name
+
+
+def test_idmap_and_duplicates(tmp_path):
+    from subphaser_amd.config import check_duplicates, parse_idmap
+    p = tmp_path / "t.map"
+    p.write_text("# c\nold1 new1\n3|old2  # trailing\n\nold3\n")
+    d = parse_idmap(str(p))
+    assert list(d.items()) == [("old1", "new1"), ("3|old2", "old2"), ("old3", "old3")]
+    assert parse_idmap(None) is None
+    with pytest.raises(ValueError, match="Duplicates"):
+        check_duplicates(["a", "b", "a"])
+
+
+def test_kmer_codec_roundtrip():
+    from subphaser_amd import kmer
+    rng = np.random.RandomState(0)
+    for k in (1, 5, 15, 21, 31, 32):
+        keys = rng.randint(0, 2 ** 62, size=50, dtype=np.int64).astype(np.uint64) & np.uint64((1 << (2 * k)) - 1 if k < 32 else 2 ** 64 - 1)
+        s = kmer.decode_many(keys, k)
+        assert (kmer.encode_many(s) == keys).all()
+        rc = kmer.revcomp(keys, k)
+        assert (kmer.revcomp(rc, k) == keys).all()
+        comp = str.maketrans("ACGT", "TGCA")
+        assert kmer.decode_many(rc, k) == [x.translate(comp)[::-1] for x in s]
+        assert (kmer.canonical(keys, k) == np.minimum(keys, rc)).all()
+    assert kmer.encode("ACGT") == 0b00011011 and kmer.decode(0b00011011, 4) == "ACGT"
+    with pytest.raises(ValueError):
+        kmer.encode("ACNT")
+
+
+def test_fasta_reader_and_split(tmp_path):
+    from subphaser_amd import seqs
+    fa = tmp_path / "g.fa"
+    fa.write_text(">chr1 desc here\nACGT\nacgtNN\n\n>chr2\nTTTT\n>other\nGG\n")
+    recs = list(seqs.read_fasta(str(fa)))
+    assert recs == [("chr1", b"ACGTacgtNN"), ("chr2", b"TTTT"), ("other", b"GG")]
+    import gzip
+    gz = tmp_path / "g.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fa.read_bytes())
+    assert list(seqs.read_fasta(str(gz))) == recs
+    out = str(tmp_path) + "/chrom_"
+    files, labels, d_targets, d_size = seqs.split_genomes([str(fa)], [""], ["A|chr1", "chr2"], out)
+    assert labels == ["A", "chr2"] and d_size == {"A": 10, "chr2": 4}
+    assert list(d_targets.items()) == [("A|chr1", "A"), ("chr2", "chr2")]
+    assert open(files[0]).read() == ">A\nACGTacgtNN\n"
+    assert seqs.load_chromfile(files[1]).seq == b"TTTT"
+
+
+def test_stat_enrich_summary(tmp_path):
+    from subphaser_amd.stat_enrich import summarize
+    p = tmp_path / "e.tsv"
+    p.write_text("#id\tsubgenome\tp_value\tcounts\tpotential_exchange\tp_corrected\n"
+                 "LTR-1\tSG1\t0.01\t5,1\tno\t0.02\nLTR-2\tSG1\t0.01\t7,0\tno\t0.02\n"
+                 "LTR-3\tSG2\t0.01\t0,9\tno\t0.02\nGENE-1\tNone\t0.5\t1,1\tnone\t0.5\n")
+    buf = io.StringIO()
+    summarize(str(p), buf)
+    assert buf.getvalue() == "GENE\t1\t0\t0\t1\t1\nLTR\t0\t2\t1\t12\t10\n"
+
+
+def test_cli_parses_reference_flags():
+    from subphaser_amd.pipeline import makeArgparse
+    a = makeArgparse("-i g.fa -c sg.cfg -pre x/y -k 15 -q 200 -f 2 -window_size 1000000 -disable_ltr "
+                     "-disable_circos -sg_assigned t.tsv -custom_features te.fa -p 8".split())
+    assert a.prefix == "x_y" and a.outdir == "x_yphase-results" and a.tmpdir == "x_ytmp"
+    assert a.k == 15 and a.min_freq == 200 and a.min_fold == 2.0 and a.lower_count == 3
+    assert a.max_freq == 1e9 and a.baseline == 1 and a.ratio == 1 and a.max_pval == 0.05
+    assert a.custom_features == ["te.fa"] and a.ncpu == 8

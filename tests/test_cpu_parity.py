@@ -65,6 +65,10 @@ def test_map_dict_labels(oracle_ctx, golden, toy):
     pc.check_dict_labels(oracle_ctx, golden, toy)
 
 
+def test_hotpath_stack(oracle_ctx, golden, toy):
+    pc.check_hotpath_stack(oracle_ctx, golden, toy)
+
+
 def test_stack_matrix(golden, tmp_path):
     pc.check_stack_matrix(golden, tmp_path)
 

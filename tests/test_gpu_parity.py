@@ -213,6 +213,10 @@ def test_map_dict_labels(gpu_ctx, golden, toy):
     pc.check_dict_labels(gpu_ctx, golden, toy)
 
 
+def test_hotpath_stack(gpu_ctx, golden, toy):
+    pc.check_hotpath_stack(gpu_ctx, golden, toy)
+
+
 def test_map_vs_oracle_random(gpu_ctx):
     rng = np.random.RandomState(33)
     k = 13
@@ -233,6 +237,8 @@ def test_map_vs_oracle_random(gpu_ctx):
         exp, hit, n2 = po.map_bins(s, k, sel, sg, 3, bin_size, chunk, nthreads=4)
         assert got.shape == exp.shape, (bin_size, chunk)
         assert (got == exp).all() and n == n2, (bin_size, chunk)
+    allb, nm = gpu_ctx.map_bins_all(50000, 100000)       # batched entry point, same numbers
+    assert (allb[0] == exp).all() and int(nm[0]) == n2
     assert gpu_ctx.labels_hit() == int(hit.sum())
     assert int(got.sum()) == int(cnts[cnts >= 20].astype(np.int64).sum())   # every occurrence mapped once
 
