@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--engine", type=int, default=int(os.environ.get("SP_ENGINE", "0")))
     ap.add_argument("-k", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU code path (RCCL process group, table exchange) even with one rank")
     ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "40")))
     return ap.parse_args()
 
@@ -65,9 +67,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -79,7 +82,7 @@ def main():
     ctx = _native.Context(local_rank)
     C, S = len(gen.chroms), gen.S
 
-    if world > 1:
+    if dist is not None:
         from subphaser_amd.dist import DistHotPath
         runner = DistHotPath(ctx, gen, dist, torch, k=args.k, engine=args.engine)
     else:

@@ -66,6 +66,11 @@ int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
  * canonical k-mer counts, kept when count >= lower_count (`jellyfish dump -L`).
  * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter. */
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
+/* number of slots of the dense count table for this k (2^(2k-1) for odd k, 4^k for even k) */
+int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
+/* use caller-owned device memory (nslots x uint32) as the count table of `chrom`, so that the
+ * caller (e.g. a torch tensor handed to RCCL) can exchange it; NULL unbinds.  Call before sp_count. */
+int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table);
 /* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
 int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
 /* jellyfish-dump equivalent of one chromosome.  Two calls: sp_dump_size then
@@ -83,6 +88,12 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
  * already-resolved thresholds (min_prop/max_prop applied by the caller with
  * sp_lengths).  Outputs: n_union = len(d_mat), n_rows = differential k-mers,
  * n_hist = len(tot_freqs) (fold-passing k-mers, in or out of the freq range). */
+/* Multi-GPU: make sp_filter / sp_filter_fetch work on a slot-range VIEW instead of the local
+ * tables: C device pointers, each to nslots_view uint32 counts of slots [slot_base,
+ * slot_base + nslots_view) of one chromosome (all chromosomes of the genome, gathered from their
+ * owner ranks), plus the global `lengths`.  d_tabs = NULL returns to the local tables.       */
+int sp_filter_view(sp_ctx *ctx, int C, const void *const *d_tabs, int64_t slot_base,
+                   int64_t nslots_view, const int64_t *lengths, int k, int lower_count);
 int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
               const int32_t *unit_chrom, double min_fold, int baseline, double min_freq,
               double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist);

@@ -41,7 +41,7 @@ def lib():
     L.spo_counts_fetch.argtypes = [vp, u32, vp, vp]
     L.spo_counts_free.argtypes = [vp]
     L.spo_filter.restype = vp
-    L.spo_filter.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, dbl, C.c_int, dbl, dbl, dbl]
+    L.spo_filter.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, dbl, C.c_int, dbl, dbl, dbl, vp]
     for name in ("spo_filtered_n_union", "spo_filtered_n_rows", "spo_filtered_n_hist"):
         getattr(L, name).restype = i64
         getattr(L, name).argtypes = [vp]
@@ -156,7 +156,7 @@ def sets_to_csr(sgs, labels):
 
 
 def filter_dumps(dumps, sgs, labels, min_fold=2, baseline=1, min_freq=200, max_freq=1e9,
-                 ratio=1, min_prop=None, max_prop=None):
+                 ratio=1, min_prop=None, max_prop=None, lengths=None):
     """dumps: list (per chromosome) of (keys ascending, counts)."""
     L = lib()
     Cn = len(dumps)
@@ -175,7 +175,8 @@ def filter_dumps(dumps, sgs, labels, min_fold=2, baseline=1, min_freq=200, max_f
     set_off, unit_off, unit_chrom = sets_to_csr(sgs, labels)
     h = L.spo_filter(Cn, _p(off), _p(keys_all), _p(cnts_all), len(set_off) - 1, _p(set_off),
                      _p(unit_off), _p(unit_chrom), float(min_fold), int(baseline),
-                     float(min_freq), float(max_freq), float(ratio))
+                     float(min_freq), float(max_freq), float(ratio),
+                     _p(np.ascontiguousarray(lengths, np.int64)) if lengths is not None else None)
     if not h:
         raise ValueError(L.spo_last_error().decode())
     try:

@@ -216,7 +216,8 @@ static int cmp_desc(const void *a, const void *b) {
 spo_filtered *spo_filter(int C, const int64_t *dump_off, const uint64_t *keys_all,
                          const uint32_t *counts_all, int n_sets, const int32_t *set_off,
                          const int32_t *unit_off, const int32_t *unit_chrom, double min_fold,
-                         int baseline, double min_freq, double max_freq, double ratio) {
+                         int baseline, double min_freq, double max_freq, double ratio,
+                         const int64_t *lengths_override) {
     /* Jellyfish.py:474-475 */
     if (min_freq > max_freq) {
         snprintf(g_err, sizeof g_err, "`min_freq` (%g) should be lower than `max_freq` (%g)",
@@ -236,6 +237,9 @@ spo_filtered *spo_filter(int C, const int64_t *dump_off, const uint64_t *keys_al
     /* lengths[i] = tot of dump i (Jellyfish.py:97,449) */
     for (int c = 0; c < C; c++)
         for (int64_t i = dump_off[c]; i < dump_off[c + 1]; i++) f->lengths[c] += counts_all[i];
+    /* a slot-range shard of the matrix is filtered against the GLOBAL lengths (multi-GPU tests) */
+    if (lengths_override)
+        for (int c = 0; c < C; c++) f->lengths[c] = lengths_override[c];
     /* Jellyfish.py:487-489 */
     for (int c = 0; c < C; c++)
         if (f->lengths[c] == 0) {

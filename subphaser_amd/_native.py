@@ -20,8 +20,8 @@ SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -
 SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
-    "sp_count", "sp_lengths", "sp_dump_size", "sp_dump",
-    "sp_filter", "sp_filter_fetch", "sp_filter_hist",
+    "sp_count", "sp_nslots", "sp_tables_bind", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
@@ -62,6 +62,9 @@ def load():
     L.sp_genome_len.argtypes = [vp, ci, P(i64)]
     L.sp_genome_unpack.argtypes = [vp, ci, vp, i64]
     L.sp_count.argtypes = [vp, ci, ci, ci]
+    L.sp_nslots.argtypes = [vp, ci, P(i64)]
+    L.sp_tables_bind.argtypes = [vp, ci, vp]
+    L.sp_filter_view.argtypes = [vp, ci, vp, i64, i64, vp, ci, ci]
     L.sp_lengths.argtypes = [vp, vp]
     L.sp_dump_size.argtypes = [vp, ci, P(i64)]
     L.sp_dump.argtypes = [vp, ci, vp, vp, i64, P(i64)]
@@ -201,6 +204,28 @@ class Context:
         self._ck(self.L.sp_count(self.h, int(k), int(lower_count), int(engine)))
         self.k = int(k)
 
+    def nslots(self, k):
+        n = C.c_int64()
+        self._ck(self.L.sp_nslots(self.h, int(k), C.byref(n)))
+        return n.value
+
+    def tables_bind(self, chrom, d_ptr):
+        self._ck(self.L.sp_tables_bind(self.h, int(chrom), C.c_void_p(int(d_ptr)) if d_ptr else None))
+
+    def filter_view(self, d_ptrs, slot_base, nslots_view, lengths, k, lower_count):
+        """Point sp_filter at slot-range slices (device pointers, one per chromosome of the whole
+        genome).  d_ptrs=None returns to the local tables."""
+        if d_ptrs is None:
+            self._ck(self.L.sp_filter_view(self.h, 0, None, 0, 0, None, 0, 0))
+            self._view_C = None
+            return
+        arr = (C.c_void_p * len(d_ptrs))(*[int(p) for p in d_ptrs])
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        self._ck(self.L.sp_filter_view(self.h, len(d_ptrs), arr, int(slot_base), int(nslots_view), _p(lengths),
+                                       int(k), int(lower_count)))
+        self._view_C = len(d_ptrs)
+        self.k = int(k)
+
     def lengths(self):
         out = np.zeros(self.n_chrom, np.int64)
         self._ck(self.L.sp_lengths(self.h, _p(out)))
@@ -232,7 +257,7 @@ class Context:
     def filter_fetch(self, n_rows, want_freqs=True, sort=True, pinned=False):
         """pinned=True returns views of context-owned page-locked buffers (valid until the next
         filter_fetch): the copy then runs at PCIe speed instead of through pageable staging."""
-        Cn = self.n_chrom
+        Cn = getattr(self, "_view_C", None) or self.n_chrom
         if pinned and not sort:
             keys = self.pinned_empty("ff_keys", (n_rows,), np.uint64)
             counts = self.pinned_empty("ff_counts", (n_rows, Cn), np.uint32)

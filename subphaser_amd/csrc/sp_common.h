@@ -15,6 +15,7 @@
 #define SP_WAVE 64
 
 struct sp_chrom {
+    bool tab_external = false;  // d_tab is caller-owned (sp_tables_bind): never freed here
     int64_t len = 0;     // bases
     int64_t nw = 0;      // 16-base words actually covering len
     int64_t cap_mw = 0;  // capacity of d_pk/d_nm in mask words (buffers are reused across sp_genome_reset)
@@ -51,6 +52,12 @@ struct sp_ctx {
     int lower = 0;
     int64_t nslots = 0;   // dense table size
     bool counted = false;
+    // filter view: which tables / slot range sp_filter works on (default: the local chromosomes,
+    // all slots).  Multi-GPU runs point it at slot-range slices gathered from every rank.
+    bool fv_on = false;
+    std::vector<const uint32_t *> fv_tabs;
+    std::vector<int64_t> fv_lengths;
+    int64_t fv_slot_base = 0, fv_nslots = 0;
     // filter results (device)
     bool filtered = false;
     int64_t n_union = 0, n_rows = 0, n_hist = 0;

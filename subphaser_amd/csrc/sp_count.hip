@@ -161,8 +161,9 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (auto &c : ctx->chroms)
             if (c.d_tab) {
-                hipFree(c.d_tab);
+                if (!c.tab_external) hipFree(c.d_tab);
                 c.d_tab = nullptr;
+                c.tab_external = false;
             }
         if (ctx->d_label) {
             hipFree(ctx->d_label);
@@ -211,6 +212,27 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
         ctx->chroms[ci].n_dump = (int64_t)h[2 * ci + 1];
     }
     ctx->counted = true;
+    return SP_OK;
+}
+
+int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {
+    if (!nslots || k < 1 || k > 15) return sp_fail(ctx, SP_EUNSUP, "sp_nslots: dense tables exist for k = 1..15");
+    *nslots = sp_dense_slots(k);
+    return SP_OK;
+}
+
+int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table) {
+    if (!ctx || chrom < 0 || chrom >= (int)ctx->chroms.size())
+        return sp_fail(ctx, SP_EINVAL, "sp_tables_bind: bad arguments");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    sp_chrom &c = ctx->chroms[(size_t)chrom];
+    if (c.d_tab && !c.tab_external) {
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(c.d_tab);
+    }
+    c.d_tab = (uint32_t *)d_table;
+    c.tab_external = d_table != nullptr;
+    ctx->counted = false;
     return SP_OK;
 }
 

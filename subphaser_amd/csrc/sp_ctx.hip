@@ -110,7 +110,7 @@ int sp_ctx_create(int device, void *stream, sp_ctx **out) {
 static void free_chrom(sp_chrom &c) {
     if (c.d_pk) hipFree(c.d_pk);
     if (c.d_nm) hipFree(c.d_nm);
-    if (c.d_tab) hipFree(c.d_tab);
+    if (c.d_tab && !c.tab_external) hipFree(c.d_tab);
     c = sp_chrom();
 }
 

@@ -119,7 +119,7 @@ __global__ void scan_excl_u64(unsigned long long *a, int64_t n, unsigned long lo
 
 __global__ void __launch_bounds__(F_BLOCK)
 k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t nslots,
-        sp_kparams kp, const unsigned long long *__restrict__ bm,
+        int64_t slot_base, sp_kparams kp, const unsigned long long *__restrict__ bm,
         const unsigned long long *__restrict__ blk_off, const double *__restrict__ chrom_len,
         unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
         double *__restrict__ freqs, unsigned long long *__restrict__ tots) {
@@ -152,7 +152,7 @@ k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t
                 if (counts) counts[r * C + c] = v;
                 if (freqs) freqs[r * C + c] = (double)v / chrom_len[c];  // :647
             }
-            if (keys) keys[r] = sp_key_of_slot((uint64_t)slot, kp);
+            if (keys) keys[r] = sp_key_of_slot((uint64_t)(slot_base + slot), kp);
             if (tots) tots[r] = tot;
         }
         off += __popcll(bits);
@@ -175,8 +175,18 @@ struct filter_dev {
     double *chrom_len;
 };
 
+static int filter_C(sp_ctx *ctx) { return ctx->fv_on ? (int)ctx->fv_tabs.size() : (int)ctx->chroms.size(); }
+static const uint32_t *filter_tab(sp_ctx *ctx, int i) {
+    return ctx->fv_on ? ctx->fv_tabs[(size_t)i] : ctx->chroms[(size_t)i].d_tab;
+}
+static int64_t filter_len(sp_ctx *ctx, int i) {
+    return ctx->fv_on ? ctx->fv_lengths[(size_t)i] : ctx->chroms[(size_t)i].length_sum;
+}
+static int64_t filter_nslots(sp_ctx *ctx) { return ctx->fv_on ? ctx->fv_nslots : ctx->nslots; }
+static int64_t filter_base(sp_ctx *ctx) { return ctx->fv_on ? ctx->fv_slot_base : 0; }
+
 static int upload_tabs(sp_ctx *ctx, const uint32_t ***d_tabs, double **d_len) {
-    const size_t C = ctx->chroms.size();
+    const size_t C = (size_t)filter_C(ctx);
     size_t bytes = C * sizeof(void *) + C * sizeof(double);
     void *scr = nullptr;
     int rc = sp_scratch(ctx, (int64_t)bytes + 4096, &scr);
@@ -184,8 +194,8 @@ static int upload_tabs(sp_ctx *ctx, const uint32_t ***d_tabs, double **d_len) {
     std::vector<const uint32_t *> h(C);
     std::vector<double> hl(C);
     for (size_t i = 0; i < C; i++) {
-        h[i] = ctx->chroms[i].d_tab;
-        hl[i] = (double)ctx->chroms[i].length_sum;
+        h[i] = filter_tab(ctx, (int)i);
+        hl[i] = (double)filter_len(ctx, (int)i);
     }
     SP_HIP(ctx, hipMemcpyAsync(scr, h.data(), C * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync((char *)scr + C * sizeof(void *), hl.data(), C * sizeof(double),
@@ -198,14 +208,46 @@ static int upload_tabs(sp_ctx *ctx, const uint32_t ***d_tabs, double **d_len) {
 
 extern "C" {
 
+int sp_filter_view(sp_ctx *ctx, int C, const void *const *d_tabs, int64_t slot_base, int64_t nslots_view,
+                   const int64_t *lengths, int k, int lower_count) {
+    if (!ctx) return SP_EINVAL;
+    if (!d_tabs) {   // back to the local chromosomes
+        ctx->fv_on = false;
+        ctx->fv_tabs.clear();
+        ctx->fv_lengths.clear();
+        ctx->filtered = false;
+        return SP_OK;
+    }
+    if (C <= 0 || !lengths || slot_base < 0 || nslots_view <= 0 || (slot_base % 64) != 0 || k < 1 || k > 15)
+        return sp_fail(ctx, SP_EINVAL, "sp_filter_view: bad arguments (slot_base must be a multiple of 64)");
+    ctx->fv_tabs.assign((size_t)C, nullptr);
+    ctx->fv_lengths.assign((size_t)C, 0);
+    for (int i = 0; i < C; i++) {
+        if (!d_tabs[i]) return sp_fail(ctx, SP_EINVAL, "sp_filter_view: table %d is NULL", i);
+        ctx->fv_tabs[(size_t)i] = (const uint32_t *)d_tabs[i];
+        ctx->fv_lengths[(size_t)i] = lengths[i];
+    }
+    ctx->fv_slot_base = slot_base;
+    ctx->fv_nslots = nslots_view;
+    ctx->fv_on = true;
+    ctx->filtered = false;
+    if (ctx->k == 0) {   // a rank that owns no chromosome still filters its slot range
+        ctx->k = k;
+        ctx->nslots = sp_dense_slots(k);
+    }
+    if (ctx->k != k) return sp_fail(ctx, SP_EINVAL, "sp_filter_view: k=%d but the context counted with k=%d", k, ctx->k);
+    ctx->lower = lower_count < 1 ? 1 : lower_count;
+    return SP_OK;
+}
+
 int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
               const int32_t *unit_chrom, double min_fold, int baseline, double min_freq,
               double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist) {
     if (!ctx || !set_off || !unit_off || !unit_chrom || n_sets <= 0)
         return sp_fail(ctx, SP_EINVAL, "sp_filter: bad arguments");
-    if (!ctx->counted) return sp_fail(ctx, SP_EINVAL, "sp_filter: call sp_count first");
+    if (!ctx->counted && !ctx->fv_on) return sp_fail(ctx, SP_EINVAL, "sp_filter: call sp_count first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    const int C = (int)ctx->chroms.size();
+    const int C = filter_C(ctx);
     // the reference's precondition checks, same messages (Jellyfish.py:474-489)
     if (min_freq > max_freq)
         return sp_fail(ctx, SP_ESTATE, "`min_freq` (%g) should be lower than `max_freq` (%g)", min_freq,
@@ -224,14 +266,14 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     }
     if (n_single == n_sets) return sp_fail(ctx, SP_ESTATE, "All singletons are not allowed");
     for (int i = 0; i < C; i++)
-        if (ctx->chroms[(size_t)i].length_sum == 0)
+        if (filter_len(ctx, i) == 0)
             return sp_fail(ctx, SP_ESTATE, "Chromosomes `[%d]` have only 0 kmers", i);
     const int n_uc = unit_off[n_units];
     for (int j = 0; j < n_uc; j++)
         if (unit_chrom[j] < 0 || unit_chrom[j] >= C)
             return sp_fail(ctx, SP_EINVAL, "sp_filter: chromosome index %d out of range", unit_chrom[j]);
 
-    const int64_t nslots = ctx->nslots;
+    const int64_t nslots = filter_nslots(ctx);
     const int64_t nblk = (nslots + F_SLOTS_PER_BLOCK - 1) / F_SLOTS_PER_BLOCK;
     const int64_t ngroups = (nslots + 63) / 64;
     ctx->filtered = false;
@@ -248,7 +290,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     std::vector<double> den((size_t)n_units);
     for (int u = 0; u < n_units; u++) {
         int64_t d = 0;
-        for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += ctx->chroms[(size_t)unit_chrom[j]].length_sum;
+        for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += filter_len(ctx, unit_chrom[j]);
         den[(size_t)u] = (double)d;
     }
     size_t b_set = (size_t)(n_sets + 1) * 4, b_uo = (size_t)(n_units + 1) * 4, b_uc = (size_t)(n_uc > 0 ? n_uc : 1) * 4,
@@ -266,7 +308,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     const uint32_t **d_tabs = (const uint32_t **)p; p += al(C * sizeof(void *));
     unsigned long long *d_nuni = (unsigned long long *)p;   // [0] union count, [1..2] scan totals
     std::vector<const uint32_t *> htabs((size_t)C);
-    for (int i = 0; i < C; i++) htabs[(size_t)i] = ctx->chroms[(size_t)i].d_tab;
+    for (int i = 0; i < C; i++) htabs[(size_t)i] = filter_tab(ctx, i);
     hipError_t e = hipSuccess;
     auto cp = [&](void *d, const void *h, size_t n) {
         if (e == hipSuccess && n) e = hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream);
@@ -324,7 +366,7 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (cap < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap, (long long)M);
     if (M == 0) return SP_OK;
-    const int C = (int)ctx->chroms.size();
+    const int C = filter_C(ctx);
     const uint32_t **d_tabs = nullptr;
     double *d_len = nullptr;
     int rc = upload_tabs(ctx, &d_tabs, &d_len);
@@ -346,7 +388,7 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     }
     const sp_kparams kp = sp_make_kparams(ctx->k);
     SP_LAUNCH(ctx, hist ? "k3_emit_hist" : "k3_emit", k3_emit, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0,
-              d_tabs, C, (uint32_t)ctx->lower, ctx->nslots, kp,
+              d_tabs, C, (uint32_t)ctx->lower, filter_nslots(ctx), filter_base(ctx), kp,
               (const unsigned long long *)(hist ? ctx->d_flag_hist : ctx->d_flag_row),
               (const unsigned long long *)(hist ? ctx->d_blk_hist : ctx->d_blk_row), d_len, d_keys, d_counts,
               d_freqs, d_tot);

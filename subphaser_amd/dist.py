@@ -1,0 +1,179 @@
+"""Multi-GPU hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Sharding (DESIGN.md "Multi-GPU"):
+  * K0-K2 (pack, count) and K5 (bin map): by CHROMOSOME, longest-processing-time assignment.
+  * K3 (matrix + differential filter): by dense-table SLOT RANGE.  The one real exchange step of
+    the path: every rank sends slice r of each of its count tables to rank r
+    (`all_to_all_single`, one round per locally-owned chromosome), so rank r holds
+    slots [r*n/N, (r+1)*n/N) of ALL chromosomes and filters them locally.
+    With N-1 direct xGMI links per GPU an all-to-all uses every link at once; a ring
+    all-reduce of the same 2-GiB tables would be bound by one link.
+  * small reductions: `lengths` (all_reduce), surviving rows and window rows (all_gather).
+
+Everything that touches torch is passed in (`dist`, `torch`), so the same code runs on CPU
+tensors over gloo in the tests (tests/test_dist_gloo.py) with an oracle-backed context.
+"""
+import numpy as np
+
+from .config import sets_to_csr
+from .hotpath import HotPathResult
+
+
+def lpt_assign(lengths, n_ranks):
+    """Longest-processing-time-first assignment of chromosomes to ranks -> list of index lists."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    load = [0] * n_ranks
+    owned = [[] for _ in range(n_ranks)]
+    for i in order:
+        r = min(range(n_ranks), key=lambda j: (load[j], j))
+        owned[r].append(i)
+        load[r] += lengths[i]
+    return [sorted(o) for o in owned]
+
+
+class DistHotPath:
+    def __init__(self, ctx, gen, dist, torch, k=15, lower_count=3, engine=0, device=None, **kw):
+        self.ctx, self.gen, self.dist, self.torch = ctx, gen, dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.k, self.lower_count, self.engine = k, lower_count, engine
+        self.labels = gen.labels
+        self.lengths_bp = [c["length"] for c in gen.chroms]
+        self.C = len(self.labels)
+        self.owned = lpt_assign(self.lengths_bp, self.world)
+        self.my_chroms = self.owned[self.rank]
+        self.max_local = max(len(o) for o in self.owned)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.nslots = ctx.nslots(k)
+        if self.nslots % (64 * self.world):
+            raise ValueError("dense table of %d slots cannot be cut into %d aligned slices" % (self.nslots, self.world))
+        self.chunk = self.nslots // self.world
+        self.csr = sets_to_csr(gen.sgs, self.labels)
+        self.kw = kw
+        t = torch
+        # count tables of the local chromosomes live in ONE torch tensor so RCCL can send them
+        self.tabs = t.zeros((max(1, len(self.my_chroms)), self.nslots), dtype=t.int32, device=self.device)
+        self.dummy = None
+        # receive side: round i, source rank s -> slice of rank s's i-th chromosome
+        self.recv = t.zeros((self.max_local, self.world, self.chunk), dtype=t.int32, device=self.device)
+        self.min_fold = kw.get("min_fold", 2.0)
+        self.baseline = kw.get("baseline", 1)
+        self.min_freq = kw.get("min_freq", 200)
+        self.max_freq = kw.get("max_freq", 1e9)
+        self.ratio = kw.get("ratio", 1.0)
+        self.bin_size = kw.get("bin_size", 10000)
+        self.chunk_size = kw.get("chunk_size", 10_000_000)
+        self.window_size = kw.get("window_size", 1_000_000)
+        self.max_pval = kw.get("max_pval", 0.05)
+
+    # ------------------------------------------------------------------ helpers
+    def _ptr(self, tensor):
+        return tensor.data_ptr()
+
+    def _all_gather_rows(self, arr, dtype):
+        """all_gather of a [m, w] host array with rank-dependent m -> concatenated host array."""
+        t, dist = self.torch, self.dist
+        arr = np.ascontiguousarray(arr)
+        w = arr.shape[1] if arr.ndim == 2 else 1
+        m = t.tensor([arr.shape[0]], dtype=t.int64, device=self.device)
+        ms = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(ms, m)
+        ms = [int(x.item()) for x in ms]
+        mmax = max(max(ms), 1)
+        pad = t.zeros((mmax, w), dtype=dtype, device=self.device)
+        if arr.shape[0]:
+            pad[: arr.shape[0]] = t.from_numpy(arr.reshape(arr.shape[0], w)).to(self.device)
+        outs = [t.zeros((mmax, w), dtype=dtype, device=self.device) for _ in range(self.world)]
+        dist.all_gather(outs, pad)
+        return np.concatenate([o[:n].cpu().numpy() for o, n in zip(outs, ms)], axis=0)
+
+    # ------------------------------------------------------------------ first half
+    def count_and_filter(self, d_ascii):
+        """d_ascii: list over ALL chromosomes; entries of chromosomes owned elsewhere are None."""
+        ctx, t, dist = self.ctx, self.torch, self.dist
+        mine = self.my_chroms
+        ctx.genome_reset(len(mine))
+        for li, gi in enumerate(mine):
+            ctx.tables_bind(li, self._ptr(self.tabs[li]))
+            ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
+        if mine:
+            ctx.count(self.k, self.lower_count, self.engine)
+            ctx.sync()
+        # global `lengths` (sum of dumped counts per chromosome): one small all-reduce
+        lens = t.zeros(self.C, dtype=t.int64, device=self.device)
+        if mine:
+            lens[t.tensor(mine, device=self.device)] = t.from_numpy(ctx.lengths()).to(self.device)
+        dist.all_reduce(lens)
+        lengths = lens.cpu().numpy()
+        # the exchange: slot-range slices of every table to their filter rank
+        for i in range(self.max_local):
+            if i < len(mine):
+                send = self.tabs[i].view(self.world, self.chunk)
+            else:
+                if self.dummy is None:
+                    self.dummy = t.zeros((self.world, self.chunk), dtype=t.int32, device=self.device)
+                send = self.dummy
+            dist.all_to_all_single(self.recv[i].view(-1), send.reshape(-1))
+        ptrs = [0] * self.C
+        for s, owned in enumerate(self.owned):
+            for i, gi in enumerate(owned):
+                ptrs[gi] = self._ptr(self.recv[i, s])
+        if hasattr(t, "cuda") and self.device.type == "cuda":
+            t.cuda.synchronize()
+        ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count)
+        n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
+                                             self.max_freq, self.ratio)
+        keys, counts, _, tot = ctx.filter_fetch(n_rows, want_freqs=False, sort=False)
+        ctx.filter_view(None, 0, 0, None, 0, 0)
+        # survivors of every slot range -> every rank (M x C is small)
+        r = HotPathResult()
+        r.kmer_lengths = lengths
+        r.keys = self._all_gather_rows(keys.astype(np.int64).reshape(-1, 1), t.int64).ravel().astype(np.uint64)
+        r.counts = self._all_gather_rows(counts.astype(np.int32), t.int32).astype(np.uint32)
+        stats = t.tensor([n_union, n_rows, n_hist], dtype=t.int64, device=self.device)
+        dist.all_reduce(stats)
+        r.n_union, r.n_rows, r.n_hist = (int(x) for x in stats.cpu().numpy())
+        r.tot = r.counts.sum(axis=1).astype(np.uint64)
+        r.freqs = None
+        return r
+
+    # ------------------------------------------------------------------ second half
+    def map_and_enrich(self, kmer_labels, n_sg):
+        ctx, t, dist = self.ctx, self.torch, self.dist
+        mine = self.my_chroms
+        r = HotPathResult()
+        r.bins, r.n_mapped = [], 0
+        rows = np.zeros((0, 2 + n_sg), np.int64)       # (chromosome, window, counts...)
+        if mine:
+            ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
+            all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
+            r.bins = all_slots
+            r.n_mapped = int(n_mapped.sum())
+            big, off = ctx.last_map
+            nz = np.flatnonzero(big.any(axis=1))
+            if nz.size:
+                chrom = np.searchsorted(off, nz, side="right") - 1
+                local = nz - off[chrom]
+                if self.chunk_size:
+                    nch = (max(self.lengths_bp) + (self.k - 1)) // self.chunk_size + 1
+                    j = np.arange(1, nch + 1, dtype=np.int64)
+                    first_slot = (j * self.chunk_size - (self.k - 1)) // self.bin_size + j
+                    local = local - np.searchsorted(first_slot, local, side="right")
+                win = (local * self.bin_size) // self.window_size
+                key = chrom * (1 << 40) + win
+                seg = np.concatenate(([0], np.flatnonzero(np.diff(key)) + 1))
+                summed = np.add.reduceat(big[nz].astype(np.int64), seg, axis=0)
+                gchrom = np.asarray(mine, np.int64)[chrom[seg]]
+                rows = np.concatenate([gchrom[:, None], win[seg][:, None], summed], axis=1)
+        allrows = self._all_gather_rows(rows, t.int64)
+        order = np.lexsort((allrows[:, 1], allrows[:, 0]))
+        allrows = allrows[order]
+        ws = self.window_size
+        r.coords = [(self.labels[c], w * ws, w * ws + ws) for c, w in zip(allrows[:, 0].tolist(), allrows[:, 1].tolist())]
+        r.window_counts = np.ascontiguousarray(allrows[:, 2:])
+        nm = t.tensor([r.n_mapped], dtype=t.int64, device=self.device)
+        dist.all_reduce(nm)
+        r.n_mapped = int(nm.item())
+        if self.rank == 0 and len(r.window_counts):
+            with np.errstate(all="ignore"):
+                r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)
+        return r

@@ -63,3 +63,32 @@ def revcomp(keys, k):
 def canonical(keys, k):
     keys = np.asarray(keys, np.uint64)
     return np.minimum(keys, revcomp(keys, k))
+
+
+def dense_slots(k):
+    """size of the dense count table (csrc/sp_common.h sp_dense_slots)"""
+    return 1 << (2 * k - 1) if k % 2 else 1 << (2 * k)
+
+
+def slots_of_keys(keys, k):
+    """dense-table slot of k-mers (any orientation); mirrors sp_slot_of_key in csrc/sp_common.h:
+    odd k  -> the strand whose middle base is A/C, with the high bit of that base removed;
+    even k -> the canonical value itself."""
+    keys = np.asarray(keys, np.uint64)
+    rc = revcomp(keys, k)
+    if k % 2 == 0:
+        return np.minimum(keys, rc)
+    one = np.uint64(1)
+    rep = np.where(((keys >> np.uint64(k)) & one).astype(bool), rc, keys)
+    low = rep & ((one << np.uint64(k)) - one)
+    return low | ((rep >> np.uint64(k + 1)) << np.uint64(k))
+
+
+def keys_of_slots(slots, k):
+    """canonical k-mer of dense-table slots (sp_key_of_slot)"""
+    slots = np.asarray(slots, np.uint64)
+    if k % 2 == 0:
+        return slots.copy()
+    one = np.uint64(1)
+    rep = (slots & ((one << np.uint64(k)) - one)) | ((slots >> np.uint64(k)) << np.uint64(k + 1))
+    return np.minimum(rep, revcomp(rep, k))

@@ -107,3 +107,65 @@ class OracleContext:
     # enrich
     def enrich(self, counts, max_pval=0.05, min_ratio=0.5):
         return po.enrich(counts, max_pval, min_ratio)
+
+
+class OracleDistContext(OracleContext):
+    """OracleContext + the multi-GPU entry points (dense tables in caller-owned memory,
+    slot-range filter views), for the gloo tests of subphaser_amd/dist.py.  Pointers are
+    addresses of CPU torch tensors."""
+
+    def __init__(self, nthreads=1):
+        super().__init__(nthreads)
+        self.bound = {}
+        self.view = None
+
+    def nslots(self, k):
+        from subphaser_amd import kmer
+        return kmer.dense_slots(k)
+
+    @staticmethod
+    def _view_i32(ptr, n):
+        import ctypes
+        return np.frombuffer((ctypes.c_uint32 * n).from_address(int(ptr)), dtype=np.uint32)
+
+    def tables_bind(self, i, ptr):
+        self.bound[i] = ptr
+
+    def genome_add_device(self, i, arr, n):
+        self.genome_add(i, np.asarray(arr[:n], np.uint8))
+
+    def count(self, k, lower_count=3, engine=0):
+        from subphaser_amd import kmer
+        super().count(k, lower_count, engine)
+        n = kmer.dense_slots(k)
+        for i, s in enumerate(self.seqs):
+            if i in self.bound:
+                keys, cnts = po.count(s, k, 1, self.nthreads)     # raw counts, threshold applied on read
+                tab = self._view_i32(self.bound[i], n)
+                tab[:] = 0
+                tab[kmer.slots_of_keys(keys, k).astype(np.int64)] = cnts
+
+    def filter_view(self, ptrs, slot_base, nview, lengths, k, lower_count):
+        self.view = None if ptrs is None else (list(ptrs), int(slot_base), int(nview), np.array(lengths), k, lower_count)
+        if ptrs is not None:
+            self.k = k
+
+    def filter(self, set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio):
+        if self.view is None:
+            return super().filter(set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio)
+        from subphaser_amd import kmer
+        ptrs, base, nview, lengths, k, L = self.view
+        dumps = []
+        for p in ptrs:
+            arr = self._view_i32(p, nview)
+            idx = np.flatnonzero(arr >= L)
+            keys = kmer.keys_of_slots((idx + base).astype(np.uint64), k)
+            o = np.argsort(keys, kind="stable")
+            dumps.append((keys[o], arr[idx][o].astype(np.uint32)))
+        sgs = []
+        for s in range(len(set_off) - 1):
+            sgs.append([[int(c) for c in unit_chrom[unit_off[u]:unit_off[u + 1]]]
+                        for u in range(set_off[s], set_off[s + 1])])
+        self._f = po.filter_dumps(dumps, sgs, list(range(len(ptrs))), min_fold, baseline, min_freq, max_freq,
+                                  ratio, lengths=lengths)
+        return self._f.n_union, len(self._f.keys), len(self._f.hist)

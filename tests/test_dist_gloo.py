@@ -1,0 +1,101 @@
+"""Multi-GPU path on CPU: world_size 2 over gloo, oracle-backed contexts.  Checks that the
+chromosome-sharded count + slot-range-sharded filter (all_to_all of table slices) + sharded map
+reproduce the single-process result exactly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+class _Gen:
+    """Minimal stand-in for subphaser_amd.synth.SynthGenome built from the toy genome."""
+
+    def __init__(self, toy):
+        self.labels = toy["labels"]
+        self.sgs = toy["sgs"]
+        self.chroms = [dict(label=l, length=len(toy["seqs"][l])) for l in self.labels]
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from oracle_ctx import OracleContext, OracleDistContext
+    from subphaser_amd import cluster
+    from subphaser_amd.dist import DistHotPath
+    from subphaser_amd.hotpath import HotPath
+    from toygenome import make_toy_genome
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        toy = make_toy_genome(seed=7)
+        gen = _Gen(toy)
+        k, L = 9, 3        # k = 9 -> 2^17 dense slots: small enough to ship as CPU tensors
+        kw = dict(min_freq=30, bin_size=100, chunk_size=2000, window_size=2500)
+        ctx = OracleDistContext()
+        runner = DistHotPath(ctx, gen, dist, torch, k=k, lower_count=L, device=torch.device("cpu"), **kw)
+        ascii_ = [np.frombuffer(toy["seqs"][l].encode(), np.uint8) if i in runner.my_chroms else None
+                  for i, l in enumerate(gen.labels)]
+        a = runner.count_and_filter(ascii_)
+        # single-process reference on the same genome
+        ref = OracleContext()
+        ref.genome_reset(len(gen.labels))
+        for i, l in enumerate(gen.labels):
+            ref.genome_add(i, toy["seqs"][l])
+        ref.count(k, L)
+        hp = HotPath(ref, gen.labels, [c["length"] for c in gen.chroms], gen.sgs, k=k, lower_count=L, **kw)
+        nu, nr, nh = ref.filter(*hp.csr, hp.min_fold, hp.baseline, hp.min_freq, hp.max_freq, hp.ratio)
+        rk, rc, _, rt = ref.filter_fetch(nr)
+        assert (a.n_union, a.n_rows, a.n_hist) == (nu, nr, nh), (rank, a.n_union, a.n_rows, a.n_hist, nu, nr, nh)
+        assert a.kmer_lengths.tolist() == ref.lengths().tolist()
+        o = np.argsort(a.keys, kind="stable")
+        assert (a.keys[o] == rk).all() and (a.counts[o] == rc).all()
+        assert nr > 0
+
+        class _Mat:
+            pass
+        mat = _Mat()
+        mat.labels, mat.keys, mat.k = gen.labels, rk, k
+        mat.freqs = rc.astype(np.float64) / ref.lengths().astype(np.float64)
+        cl = cluster.Cluster(mat, n_clusters=2, sg_assigned=toy["sg_assigned"])
+        labels = cl.output_kmers(open(os.devnull, "w"), max_pval=0.05)
+        b = runner.map_and_enrich(labels, 2)
+        rb = hp.map_and_enrich(labels, 2)
+        assert b.coords == rb.coords
+        assert (b.window_counts == rb.window_counts).all()
+        assert b.n_mapped == rb.n_mapped
+        if rank == 0:
+            assert np.allclose(b.pvals, rb.pvals, rtol=0, atol=0)
+            assert (b.sig == rb.sig).all()
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lpt_assign_balances():
+    from subphaser_amd.dist import lpt_assign
+    lens = [700, 650, 600, 580, 560, 500, 480, 450, 440, 400, 390, 380, 370, 360, 350, 340, 330, 320, 310, 300, 290]
+    for n in (1, 2, 4, 8):
+        owned = lpt_assign(lens, n)
+        assert sorted(i for o in owned for i in o) == list(range(len(lens)))
+        loads = [sum(lens[i] for i in o) for o in owned]
+        assert max(loads) <= sum(lens) / n * 1.15 + 1
+
+
+def test_two_rank_hot_path_over_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
