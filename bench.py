@@ -168,6 +168,11 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         return
 
     # ---- roofline of the dominant kernel (HIP events per launch, on the context's stream) ------
@@ -211,11 +216,20 @@ def main():
         "host_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 2) for k_, v in hp.wall.items()}
                                   if runner is None else None),
     }
-    print(json.dumps(out))
-    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a banner through C stdio; flush it first so that the JSON is the LAST line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        time.sleep(1.0)       # let the other ranks' buffered library output drain first
+    print(json.dumps(out))
+    sys.stdout.flush()
 
 
 def cpu_baseline(ctx, gen, d_ascii, kmer_labels, args):

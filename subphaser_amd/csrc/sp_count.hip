@@ -160,10 +160,9 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
     if (ctx->k != k || ctx->nslots != nslots) {
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (auto &c : ctx->chroms)
-            if (c.d_tab) {
-                if (!c.tab_external) hipFree(c.d_tab);
+            if (c.d_tab && !c.tab_external) {   // caller-bound tables are sized by the caller for this k
+                hipFree(c.d_tab);
                 c.d_tab = nullptr;
-                c.tab_external = false;
             }
         if (ctx->d_label) {
             hipFree(ctx->d_label);

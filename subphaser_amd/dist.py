@@ -105,7 +105,7 @@ class DistHotPath:
         dist.all_reduce(lens)
         lengths = lens.cpu().numpy()
         # the exchange: slot-range slices of every table to their filter rank
-        for i in range(self.max_local):
+        for i in range(self.max_local if self.world > 1 else 0):
             if i < len(mine):
                 send = self.tabs[i].view(self.world, self.chunk)
             else:
@@ -116,7 +116,8 @@ class DistHotPath:
         ptrs = [0] * self.C
         for s, owned in enumerate(self.owned):
             for i, gi in enumerate(owned):
-                ptrs[gi] = self._ptr(self.recv[i, s])
+                # one rank: its own tables ARE the slices (a 1-rank all-to-all may be elided by the backend)
+                ptrs[gi] = self._ptr(self.recv[i, s]) if self.world > 1 else self._ptr(self.tabs[i])
         if hasattr(t, "cuda") and self.device.type == "cuda":
             t.cuda.synchronize()
         ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count)
