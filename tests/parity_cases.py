@@ -264,3 +264,47 @@ def check_hotpath_stack(ctx, golden, toy):
         assert [[c, s, e] for c, s, e in r.coords] == exp["coords"], ws
         assert r.window_counts.tolist() == exp["counts"], ws
         assert r.pvals.shape == r.window_counts.shape
+
+
+# ------------------------------------------------------------------ end-to-end CLI (modules 1-2)
+def check_pipeline_cli(ctx, golden, toy, tmp_path):
+    """`subphaser -i genome.fa -c sg.config -sg_assigned ...` on the toy genome: the files the
+    reference would write for modules 1-2, compared with the goldens."""
+    import gzip
+    from subphaser_amd import pipeline, runtime
+    fa = tmp_path / "toy.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for lab in toy["labels"]:
+            s = toy["seqs"][lab]
+            f.write(">%s some description\n" % lab)
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+        f.write(">unplaced_scaffold\nACGTACGTNNNN\n")
+    cfg = tmp_path / "sg.config"
+    cfg.write_text("# toy\n" + "\n".join("\t".join(",".join(u) for u in sg) for sg in toy["sgs"]) + "\n")
+    asg = tmp_path / "assigned.tsv"
+    asg.write_text("".join("%s\t%s\n" % kv for kv in toy["sg_assigned"].items()))
+    feats = tmp_path / "features.fa"
+    with open(feats, "w") as f:
+        for fid, sq in golden["G4_map_features"]["features"]:
+            f.write(">%s\n%s\n" % (fid, sq))
+    out, tmpd = tmp_path / "out", tmp_path / "tmp"
+    old = runtime._ctx
+    runtime.set_context(ctx)
+    try:
+        pipeline.main(["-i", str(fa), "-c", str(cfg), "-sg_assigned", str(asg), "-q", "30", "-k", str(K),
+                       "-o", str(out), "-tmpdir", str(tmpd), "-window_size", "2500", "-custom_features", str(feats),
+                       "-disable_ltr", "-disable_circos", "-figfmt", "png"])
+    finally:
+        runtime._ctx = old
+    base = out / ("k%d_q30_f2" % K)
+    assert open(str(base) + ".kmer.mat").read() == golden["G3_kmer_mat_text"]
+    assert open(str(base) + ".subgenome.bin.count").read() == golden["G4_map_kmer3"]["chunk10M_bin10k"]["text"]
+    assert open(str(base) + ".custom.bin.count").read() == golden["G4_map_features"]["text"]
+    sig = open(str(base) + ".sig.kmer-subgenome.tsv").read().strip().split("\n")
+    assert len(sig) - 1 == golden["G7_output_kmers"]["n_dkmers"] // 2
+    assert open(str(base) + ".chrom-subgenome.tsv").read().startswith("#chrom\tsubgenome\tbootstrap\n")
+    for ext in (".bin.enrich", ".bin.group", ".custom.enrich"):
+        assert len(open(str(base) + ext).read().strip().split("\n")) > 1, ext
+    assert (tmpd / "split.ok").exists() and (tmpd / ("k%d_q30_f2.kmer.mat.ok" % K)).exists()
+    assert (tmpd / "chromosomes" / "A1.fasta").exists()

@@ -69,6 +69,10 @@ def test_hotpath_stack(oracle_ctx, golden, toy):
     pc.check_hotpath_stack(oracle_ctx, golden, toy)
 
 
+def test_pipeline_cli(oracle_ctx, golden, toy, tmp_path):
+    pc.check_pipeline_cli(oracle_ctx, golden, toy, tmp_path)
+
+
 def test_stack_matrix(golden, tmp_path):
     pc.check_stack_matrix(golden, tmp_path)
 

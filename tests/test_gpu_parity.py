@@ -217,6 +217,10 @@ def test_hotpath_stack(gpu_ctx, golden, toy):
     pc.check_hotpath_stack(gpu_ctx, golden, toy)
 
 
+def test_pipeline_cli(gpu_ctx, golden, toy, tmp_path):
+    pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
+
+
 def test_map_vs_oracle_random(gpu_ctx):
     rng = np.random.RandomState(33)
     k = 13
