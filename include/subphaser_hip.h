@@ -125,6 +125,12 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
  * One launch per chromosome back to back, one device->host copy.               */
 int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int64_t *slot_off,
                     int32_t *slot_counts, int64_t *n_mapped);
+/* window stack of the slot counts left on the device by the last sp_map_bins_all
+ * (replaces Circos.stack_matrix, Circos.py:734-742, 831-842, without the text round trip):
+ * window = (bin start) / window_size; chromosome c owns windows [win_off[c], win_off[c+1]),
+ * at least len/window_size + 2 each; win_counts: total x n_sg int64 (overwritten).          */
+int sp_stack_windows(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
+                     const int64_t *slot_off, const int64_t *win_off, int64_t *win_counts);
 /* feature mode (map_kmer3(..., chunk=False), __main__.py:509-511): n_feat
  * sequences concatenated in `ascii`, feature f = [off[f], off[f+1]).
  * counts: n_feat x n_sg int64 (whole-feature totals).                      */

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsubphaser_hip.so")
+LIB_PATH = os.environ.get("SUBPHASER_HIP_LIB") or os.path.join(_HERE, "lib", "libsubphaser_hip.so")
 
 SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
@@ -22,7 +22,7 @@ SYMBOLS = [
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
     "sp_count", "sp_nslots", "sp_tables_bind", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_hist",
-    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_map_features", "sp_labels_hit",
+    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host",
@@ -75,6 +75,7 @@ def load():
     L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
     L.sp_map_bins.argtypes = [vp, ci, i64, i64, vp, i64, P(i64)]
     L.sp_map_bins_all.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.sp_stack_windows.argtypes = [vp, i64, i64, i64, vp, vp, vp]
     L.sp_map_features.argtypes = [vp, vp, vp, i64, vp]
     L.sp_host_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_host_free.argtypes = [vp, vp]
@@ -313,6 +314,18 @@ class Context:
         self._ck(self.L.sp_map_bins_all(self.h, int(bin_size), int(chunk_size), _p(off), _p(out), _p(nm)))
         self.last_map = (out, off)
         return [out[off[i]:off[i + 1]] for i in range(self.n_chrom)], nm
+
+    def stack_windows(self, bin_size, chunk_size, window_size, lengths):
+        """Window counts of the last map_bins_all, summed on the device.
+        Returns (win_counts int64 [total, n_sg], win_off int64 [C+1])."""
+        out, off = self.last_map
+        woff = np.zeros(self.n_chrom + 1, np.int64)
+        for i, n in enumerate(lengths):
+            woff[i + 1] = woff[i] + (int(n) + int(window_size) - 1) // int(window_size) + 1
+        win = self.pinned_empty("win_all", (int(woff[-1]), self.n_sg), np.int64)
+        self._ck(self.L.sp_stack_windows(self.h, int(bin_size), int(chunk_size), int(window_size), _p(off),
+                                         _p(woff), _p(win)))
+        return win, woff
 
     def map_features(self, seqs):
         """seqs: list of str/bytes.  Returns int64 [n_feat, n_sg] totals."""

@@ -76,7 +76,8 @@ struct sp_ctx {
     int64_t scratch_bytes = 0;
     void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
     int64_t ws2_bytes = 0;
-    sp_buf b_map, b_emit, b_fpar;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter
+    sp_buf b_map, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
+    bool map_all_valid = false;
     // profiling
     bool prof = false;
     std::vector<sp_prof_entry> prof_pending;

@@ -21,11 +21,18 @@
 
 #define C2_B3 15                      // slot bits resolved inside LDS
 #define C2_FINE (1 << C2_B3)          // slots per fine bucket
-#define C2_TILE_KEYS 16384            // keys per LDS counting-sort tile
+#ifndef C2_P1_THREADS
 #define C2_P1_THREADS 512             // part1: 512 threads x 32 k-mer starts
+#endif
 #define C2_P1_UNIT 32
-#define C2_P2_THREADS 1024            // part2: 1024 threads x 16 keys
-#define C2_P2_PER 16
+#define C2_P1_KEYS (C2_P1_THREADS * C2_P1_UNIT)   // starts (<= keys) per part1 tile
+#ifndef C2_P2_THREADS
+#define C2_P2_THREADS 512             // part2: 512 threads x 8 keys (4 K-key tiles: 4 blocks per CU, measured best)
+#endif
+#ifndef C2_P2_PER
+#define C2_P2_PER 8
+#endif
+#define C2_TILE_KEYS (C2_P2_THREADS * C2_P2_PER)  // keys per part2 tile
 #define C2_HIST_THREADS 512
 #define C2_MAXF 256                   // max fan-out per level
 
@@ -150,7 +157,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
          unsigned long long *__restrict__ cursor1 /*F1, zeroed*/, uint32_t *__restrict__ buf1) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
-    __shared__ uint32_t keys[C2_TILE_KEYS];
+    __shared__ uint32_t keys[C2_P1_KEYS];
     const int64_t n_tiles = (n_units + C2_P1_THREADS - 1) / C2_P1_THREADS;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;

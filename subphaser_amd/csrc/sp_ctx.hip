@@ -138,6 +138,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_emit);
     sp_buf_free(ctx->b_fpar);
+    sp_buf_free(ctx->b_win);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SP_OK;

@@ -101,6 +101,37 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
     if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
 }
 
+// Window stack on the device (Circos.stack_matrix semantics, Circos.py:734-742): the window of a
+// slot is (bin start) / window_size, bin = slot - chunk(slot); the two slots of a chunk-boundary bin
+// land in the same window.
+__global__ void __launch_bounds__(256)
+k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
+         const long long *__restrict__ slot_off, const long long *__restrict__ win_off, int64_t bin_size,
+         int64_t chunk_size, int64_t window_size, int k, unsigned long long *__restrict__ win_counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_slots * S) return;
+    const int v = slot_counts[i];
+    if (!v) return;
+    const int64_t gslot = i / S;
+    const int sg = (int)(i - gslot * S);
+    int lo = 0, hi = C;  // chromosome of the slot
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (slot_off[mid] <= gslot) lo = mid;
+        else hi = mid;
+    }
+    const int64_t slot = gslot - slot_off[lo];
+    int64_t chunk = 0;
+    if (chunk_size > 0) {
+        // first slot of chunk j >= 1: (j*W - (k-1)) / b + j ; chunk(slot) = #{j : first(j) <= slot}
+        chunk = slot * bin_size / (chunk_size + bin_size);
+        while ((((chunk + 1) * chunk_size - (k - 1)) / bin_size + (chunk + 1)) <= slot) chunk++;
+        while (chunk > 0 && ((chunk * chunk_size - (k - 1)) / bin_size + chunk) > slot) chunk--;
+    }
+    const int64_t win = (slot - chunk) * bin_size / window_size;
+    atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
+}
+
 // feature mode: per-feature totals; feature of a start found by binary search
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
@@ -210,6 +241,7 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     if (nslots < need) return sp_fail(ctx, SP_EINVAL, "sp_map_bins: nslots %lld < %lld", (long long)nslots, (long long)need);
     const size_t bytes = (size_t)nslots * S * sizeof(int);
     const size_t bytes8 = (bytes + 7) & ~(size_t)7;
+    ctx->map_all_valid = false;
     int rcb = sp_buf_ensure(ctx, ctx->b_map, (int64_t)bytes8 + 8);
     if (rcb) return rcb;
     int *d_counts = (int *)ctx->b_map.p;
@@ -284,6 +316,39 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_mapped)
         for (int i = 0; i < C; i++) n_mapped[i] = (int64_t)hn[(size_t)i];
+    ctx->map_all_valid = true;   // b_map holds the slot counts of every chromosome (for sp_stack_windows)
+    return SP_OK;
+}
+
+int sp_stack_windows(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
+                     const int64_t *slot_off, const int64_t *win_off, int64_t *win_counts) {
+    if (!ctx || !slot_off || !win_off || !win_counts || bin_size < 1 || chunk_size < 0 || window_size < 1)
+        return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: bad arguments");
+    if (!ctx->map_all_valid) return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: call sp_map_bins_all first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int C = (int)ctx->chroms.size();
+    const int S = ctx->n_sg;
+    for (int i = 0; i < C; i++) {
+        int64_t need = (ctx->chroms[(size_t)i].len + window_size - 1) / window_size + 1;
+        if (win_off[i + 1] - win_off[i] < need)
+            return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: chromosome %d needs %lld windows", i, (long long)need);
+    }
+    const int64_t total_slots = slot_off[C], total_win = win_off[C];
+    const size_t wbytes = (size_t)total_win * S * 8;
+    int rcb = sp_buf_ensure(ctx, ctx->b_win, (int64_t)(wbytes + 16 * (size_t)(C + 1)));
+    if (rcb) return rcb;
+    unsigned long long *d_win = (unsigned long long *)ctx->b_win.p;
+    long long *d_soff = (long long *)((char *)d_win + wbytes);
+    long long *d_woff = d_soff + (C + 1);
+    SP_HIP(ctx, hipMemsetAsync(d_win, 0, wbytes, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_soff, slot_off, 8 * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_woff, win_off, 8 * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (total_slots > 0)
+        SP_LAUNCH(ctx, "k5_stack", k5_stack, dim3((unsigned)((total_slots * S + 255) / 256)), dim3(256), 0,
+                  (const int *)ctx->b_map.p, total_slots, S, C, d_soff, d_woff, bin_size, chunk_size, window_size,
+                  ctx->k, d_win);
+    SP_HIP(ctx, hipMemcpyAsync(win_counts, d_win, wbytes, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }
 

@@ -149,22 +149,13 @@ class DistHotPath:
             all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
             r.bins = all_slots
             r.n_mapped = int(n_mapped.sum())
-            big, off = ctx.last_map
-            nz = np.flatnonzero(big.any(axis=1))
+            win, woff = ctx.stack_windows(self.bin_size, self.chunk_size, self.window_size,
+                                          [self.lengths_bp[i] for i in mine])
+            nz = np.flatnonzero(win.any(axis=1))
             if nz.size:
-                chrom = np.searchsorted(off, nz, side="right") - 1
-                local = nz - off[chrom]
-                if self.chunk_size:
-                    nch = (max(self.lengths_bp) + (self.k - 1)) // self.chunk_size + 1
-                    j = np.arange(1, nch + 1, dtype=np.int64)
-                    first_slot = (j * self.chunk_size - (self.k - 1)) // self.bin_size + j
-                    local = local - np.searchsorted(first_slot, local, side="right")
-                win = (local * self.bin_size) // self.window_size
-                key = chrom * (1 << 40) + win
-                seg = np.concatenate(([0], np.flatnonzero(np.diff(key)) + 1))
-                summed = np.add.reduceat(big[nz].astype(np.int64), seg, axis=0)
-                gchrom = np.asarray(mine, np.int64)[chrom[seg]]
-                rows = np.concatenate([gchrom[:, None], win[seg][:, None], summed], axis=1)
+                chrom = np.searchsorted(woff, nz, side="right") - 1
+                gchrom = np.asarray(mine, np.int64)[chrom]
+                rows = np.concatenate([gchrom[:, None], (nz - woff[chrom])[:, None], win[nz].astype(np.int64)], axis=1)
         allrows = self._all_gather_rows(rows, t.int64)
         order = np.lexsort((allrows[:, 1], allrows[:, 0]))
         allrows = allrows[order]

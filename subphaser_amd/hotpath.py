@@ -73,25 +73,14 @@ class HotPath:
         t = self._t("map_bins", t)
         r.n_mapped = int(n_mapped.sum())
         r.bins = all_slots
-        # window stack of every chromosome at once (Circos.stack_matrix semantics: window =
-        # bin start // window_size; the two slots of a chunk-boundary bin fall in the same window)
-        big, off = ctx.last_map
-        nz = np.flatnonzero(big.any(axis=1))
-        rows = []
-        if nz.size:
-            chrom = np.searchsorted(off, nz, side="right") - 1
-            local = nz - off[chrom]
-            if self.chunk_size:
-                nch = (max(self.lengths) + (self.k - 1)) // self.chunk_size + 1
-                j = np.arange(1, nch + 1, dtype=np.int64)
-                first_slot = (j * self.chunk_size - (self.k - 1)) // self.bin_size + j
-                local = local - np.searchsorted(first_slot, local, side="right")
-            win = (local * self.bin_size) // self.window_size
-            key = chrom * (1 << 40) + win            # ascending: one contiguous run per (chromosome, window)
-            seg = np.concatenate(([0], np.flatnonzero(np.diff(key)) + 1))
-            rows.append(np.add.reduceat(big[nz].astype(np.int64), seg, axis=0))
-            ws = self.window_size
-            coords = [(self.labels[c], w * ws, w * ws + ws) for c, w in zip(chrom[seg].tolist(), win[seg].tolist())]
+        # window stack on the device (Circos.stack_matrix semantics), then only the non-empty windows
+        win, woff = ctx.stack_windows(self.bin_size, self.chunk_size, self.window_size, self.lengths)
+        nz = np.flatnonzero(win.any(axis=1))
+        rows = [win[nz].astype(np.int64)]
+        chrom = np.searchsorted(woff, nz, side="right") - 1
+        w = nz - woff[chrom]
+        ws = self.window_size
+        coords = [(self.labels[c], x * ws, x * ws + ws) for c, x in zip(chrom.tolist(), w.tolist())]
         r.coords = coords
         r.window_counts = np.concatenate(rows) if rows else np.zeros((0, n_sg), np.int64)
         t = self._t("stack", t)

@@ -90,6 +90,27 @@ class OracleContext:
         self.last_map = (np.concatenate([r[0] for r in res]), off)
         return [r[0] for r in res], np.array([r[1] for r in res], np.int64)
 
+    def stack_windows(self, bin_size, chunk_size, window_size, lengths):
+        big, off = self.last_map
+        woff = np.zeros(self.n_chrom + 1, np.int64)
+        for i, n in enumerate(lengths):
+            woff[i + 1] = woff[i] + (int(n) + int(window_size) - 1) // int(window_size) + 1
+        win = np.zeros((int(woff[-1]), self.n_sg), np.int64)
+        for c in range(self.n_chrom):
+            for slot in range(int(off[c]), int(off[c + 1])):
+                row = big[slot]
+                if not row.any():
+                    continue
+                local = slot - int(off[c])
+                chunk = 0
+                if chunk_size:
+                    j = 1
+                    while (j * chunk_size - (self.k - 1)) // bin_size + j <= local:
+                        chunk = j
+                        j += 1
+                win[woff[c] + (local - chunk) * bin_size // window_size] += row
+        return win, woff
+
     def map_features(self, seqs):
         out = np.zeros((len(seqs), self.n_sg), np.int64)
         for f, s in enumerate(seqs):
