@@ -34,6 +34,13 @@ struct sp_buf {
     int64_t cap = 0;
 };
 
+// k > 15: per-chromosome sorted (canonical key, count >= lower_count) arrays
+struct sp_sparse_chrom {
+    uint64_t *d_keys = nullptr;
+    uint32_t *d_cnts = nullptr;
+    int64_t n = 0, cap = 0, length_sum = 0;
+};
+
 struct sp_prof_entry {
     std::string name;
     hipEvent_t e0, e1;
@@ -76,6 +83,14 @@ struct sp_ctx {
     int64_t scratch_bytes = 0;
     void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
     int64_t ws2_bytes = 0;
+    // sparse engine (k = 16..32)
+    bool sparse_mode = false;
+    std::vector<sp_sparse_chrom> sparse;
+    sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist;
+    int64_t sf_n = 0;
+    uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers
+    uint8_t *d_hlab = nullptr;
+    int64_t hcap = 0;
     sp_buf b_map, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
     bool map_all_valid = false;
     // profiling

@@ -142,18 +142,36 @@ static int grid_for(sp_ctx *ctx, int64_t work_items, int per_block, int max_per_
 int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower,
                      unsigned long long *d_len2);  // sp_count2.hip
 bool sp_engine2_supported(int64_t nslots);
+int sp_sparse_count(sp_ctx *ctx, int k, int lower);                                   // sp_sparse.hip
+int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
 extern "C" {
 
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
     if (!ctx) return SP_EINVAL;
     if (k < 1 || k > 32) return sp_fail(ctx, SP_EUNSUP, "k=%d unsupported (1..32)", k);
-    if (k > 15)
-        return sp_fail(ctx, SP_EUNSUP,
-                       "k=%d: only the dense-table path (k <= 15) is implemented in this build", k);
     if (lower_count < 1) lower_count = 1;
     if (ctx->chroms.empty()) return sp_fail(ctx, SP_EINVAL, "sp_count: no chromosomes loaded");
     SP_HIP(ctx, hipSetDevice(ctx->device));
+    if (k > 15) {   // 64-bit keys: sort-based sparse engine (`engine` is ignored)
+        for (auto &c : ctx->chroms)
+            if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "a chromosome is not loaded");
+        ctx->counted = false;
+        ctx->filtered = false;
+        if (ctx->d_label && ctx->k != k) {
+            hipFree(ctx->d_label);
+            ctx->d_label = nullptr;
+        }
+        ctx->k = k;
+        ctx->lower = lower_count;
+        ctx->nslots = 0;
+        ctx->sparse_mode = true;
+        int rcs = sp_sparse_count(ctx, k, lower_count);
+        if (rcs) return rcs;
+        ctx->counted = true;
+        return SP_OK;
+    }
+    ctx->sparse_mode = false;
     const sp_kparams kp = sp_make_kparams(k);
     const int64_t nslots = sp_dense_slots(k);
     // a new k invalidates old tables
@@ -215,6 +233,7 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
 }
 
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {
+    (void)ctx;
     if (!nslots || k < 1 || k > 15) return sp_fail(ctx, SP_EUNSUP, "sp_nslots: dense tables exist for k = 1..15");
     *nslots = sp_dense_slots(k);
     return SP_OK;
@@ -223,6 +242,7 @@ int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {
 int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table) {
     if (!ctx || chrom < 0 || chrom >= (int)ctx->chroms.size())
         return sp_fail(ctx, SP_EINVAL, "sp_tables_bind: bad arguments");
+    if (ctx->sparse_mode && d_table) return sp_fail(ctx, SP_EUNSUP, "sp_tables_bind: dense tables exist for k <= 15 only");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_chrom &c = ctx->chroms[(size_t)chrom];
     if (c.d_tab && !c.tab_external) {
@@ -260,6 +280,7 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
     if (cap < c.n_dump) return sp_fail(ctx, SP_EINVAL, "sp_dump: capacity %lld < %lld", (long long)cap,
                                        (long long)c.n_dump);
     if (c.n_dump == 0) return SP_OK;
+    if (ctx->sparse_mode) return sp_sparse_dump(ctx, chrom, keys, counts);
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t nblk = (ctx->nslots + DUMP_SLOTS - 1) / DUMP_SLOTS;
     unsigned long long *d_blk = nullptr, *d_keys = nullptr;

@@ -140,7 +140,8 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
     if (lane == 63 && wave < 4) wsum[wave] = incl;
     __syncthreads();
     uint32_t base = 0, total = 0;
-    for (int w = 0; w < 4; w++) {
+    const int nwv = (int)(blockDim.x >> 6) < 4 ? (int)(blockDim.x >> 6) : 4;
+    for (int w = 0; w < nwv; w++) {
         uint32_t s = wsum[w];
         if (w < wave) base += s;
         total += s;

@@ -78,6 +78,8 @@ void sp_prof_flush(sp_ctx *ctx) {
     ctx->prof_pending.clear();
 }
 
+void sp_sparse_release(sp_ctx *ctx);   // sp_sparse.hip
+
 extern "C" {
 
 int sp_version(void) { return 100; }
@@ -131,6 +133,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_prof_flush(ctx);
     for (auto &c : ctx->chroms) free_chrom(c);
     free_filter(ctx);
+    sp_sparse_release(ctx);
     if (ctx->d_label) hipFree(ctx->d_label);
     if (ctx->d_bloom) hipFree(ctx->d_bloom);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);

@@ -36,10 +36,10 @@ __device__ __forceinline__ uint32_t sp_slot_of32(uint32_t fwd, uint32_t rc, cons
 
 // UNIT consecutive k-mer START positions [s0, s0+UNIT), s0 a multiple of UNIT (UNIT = 32 or 64),
 // emit(start, fwd, rc) for every start whose k bases are all valid.
-template <int UNIT, typename F>
-__device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk,
+template <int UNIT, typename KeyT, typename KP, typename F>
+__device__ __forceinline__ void sp_scan_unit_t(const uint32_t *__restrict__ pk,
                                                const uint32_t *__restrict__ nm, int64_t s0,
-                                               const sp_kparams32 &kp, F &&emit) {
+                                               const KP &kp, F &&emit) {
     constexpr int MW = UNIT / 16;  // code words owned by the unit
     const int64_t w0 = s0 >> 4;
     uint32_t words[MW + 2];
@@ -54,10 +54,10 @@ __device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk,
     words[MW + 1] = pk[w0 + MW + 1];
     const uint64_t mlo = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     const uint32_t mhi = (MW == 4) ? nm[(s0 >> 5) + 2] : 0u;
-    uint32_t fwd = 0, rc = 0;
+    KeyT fwd = 0, rc = 0;
     int run = 0;
     const int k = kp.k;
-    const int total = UNIT + k - 1;  // bases to consume
+    const int total = UNIT + k - 1;  // bases to consume (k - 1 <= 31 halo bases: two extra words)
 #pragma unroll
     for (int w = 0; w < MW + 2; w++) {
         const uint32_t cw = words[w];
@@ -69,11 +69,23 @@ __device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk,
             const int b = w * 16 + j;
             const uint32_t c = (cw >> (2 * j)) & 3u;
             fwd = ((fwd << 2) | c) & kp.kmask;
-            rc = (rc >> 2) | ((3u - c) << kp.rcshift);
+            rc = (rc >> 2) | ((KeyT)(3u - c) << kp.rcshift);
             run = ((mw >> j) & 1u) ? 0 : run + 1;
             if (run >= k && b < total) emit(s0 + b - (k - 1), fwd, rc);
         }
     }
+}
+
+// 32-bit keys (k <= 16: the dense-table kernels) and 64-bit keys (k <= 32: the sparse engine)
+template <int UNIT, typename F>
+__device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
+                                               int64_t s0, const sp_kparams32 &kp, F &&emit) {
+    sp_scan_unit_t<UNIT, uint32_t>(pk, nm, s0, kp, emit);
+}
+template <int UNIT, typename F>
+__device__ __forceinline__ void sp_scan_unit64(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
+                                               int64_t s0, const sp_kparams &kp, F &&emit) {
+    sp_scan_unit_t<UNIT, uint64_t>(pk, nm, s0, kp, emit);
 }
 
 // wave-level inclusive/exclusive helpers (64 lanes)

@@ -26,6 +26,58 @@ struct sp_filter_params {
     int64_t nslots;
 };
 
+// The per-k-mer decision of _filter_kmer (Jellyfish.py:611-648), shared by the dense (k3_eval) and
+// the sparse (k > 15) engines.  cnt[c * stride] = thresholded count of chromosome c.
+struct sp_fsets {
+    int n_sets, baseline;
+    const int32_t *set_off, *unit_off, *unit_chrom;
+    const double *unit_den;
+    double min_fold, min_freq, max_freq, ratio;
+};
+
+__device__ __forceinline__ void sp_filter_decide(const uint32_t *cnt, int stride, unsigned long long tot,
+                                                 const sp_fsets &F, bool &is_row, bool &is_hist) {
+    is_row = is_hist = false;
+    int include = 0, all = 0;
+    for (int s = 0; s < F.n_sets; s++) {
+        const int u0 = F.set_off[s], nu = F.set_off[s + 1] - u0;
+        if (nu == 1) continue;  // singleton ignored (Jellyfish.py:621-622)
+        all++;
+        double f[F_MAXU];
+#pragma unroll
+        for (int u = 0; u < F_MAXU; u++) {
+            f[u] = 0.0;
+            if (u < nu) {
+                unsigned long long num = 0;
+                for (int j = F.unit_off[u0 + u]; j < F.unit_off[u0 + u + 1]; j++)
+                    num += cnt[F.unit_chrom[j] * stride];
+                f[u] = (double)num / F.unit_den[u0 + u];  // count/len or sum/sum (:630,:634)
+            }
+        }
+        // descending order statistic: hi = f_(0), lo = f_(bi)   (:637-639)
+        const int bi = F.baseline < 0 ? nu + F.baseline : F.baseline;
+        double hi = f[0], lo = f[0];
+#pragma unroll
+        for (int u = 0; u < F_MAXU; u++) {
+            if (u < nu) {
+                hi = f[u] > hi ? f[u] : hi;
+                int rank = 0;
+#pragma unroll
+                for (int v = 0; v < F_MAXU; v++)
+                    if (v < nu && (f[v] > f[u] || (f[v] == f[u] && v < u))) rank++;
+                if (rank == bi) lo = f[u];
+            }
+        }
+        if (1.0 * hi / (lo + 1e-20) >= F.min_fold) include++;  // :640-641
+    }
+    const double r = 1.0 * (double)include / (double)all;  // :642
+    if (!(r < F.ratio)) {
+        is_hist = true;
+        const double t = (double)tot;
+        is_row = !(t < F.min_freq || t > F.max_freq);  // :645-646
+    }
+}
+
 __global__ void __launch_bounds__(F_BLOCK)
 k3_eval(const uint32_t *const *__restrict__ tabs, sp_filter_params P,
         const int32_t *__restrict__ set_off, const int32_t *__restrict__ unit_off,
@@ -53,44 +105,18 @@ k3_eval(const uint32_t *const *__restrict__ tabs, sp_filter_params P,
         }
         bool is_row = false, is_hist = false;
         if (tot > 0) {
-            int include = 0, all = 0;
-            for (int s = 0; s < P.n_sets; s++) {
-                const int u0 = set_off[s], nu = set_off[s + 1] - u0;
-                if (nu == 1) continue;  // singleton ignored (Jellyfish.py:621-622)
-                all++;
-                double f[F_MAXU];
-#pragma unroll
-                for (int u = 0; u < F_MAXU; u++) {
-                    f[u] = 0.0;
-                    if (u < nu) {
-                        unsigned long long num = 0;
-                        for (int j = unit_off[u0 + u]; j < unit_off[u0 + u + 1]; j++)
-                            num += mine[unit_chrom[j] * 64 + lane];
-                        f[u] = (double)num / unit_den[u0 + u];  // count/len or sum/sum (:630,:634)
-                    }
-                }
-                // descending order statistic: hi = f_(0), lo = f_(bi)   (:637-639)
-                const int bi = P.baseline < 0 ? nu + P.baseline : P.baseline;
-                double hi = f[0], lo = f[0];
-#pragma unroll
-                for (int u = 0; u < F_MAXU; u++) {
-                    if (u < nu) {
-                        hi = f[u] > hi ? f[u] : hi;
-                        int rank = 0;
-#pragma unroll
-                        for (int v = 0; v < F_MAXU; v++)
-                            if (v < nu && (f[v] > f[u] || (f[v] == f[u] && v < u))) rank++;
-                        if (rank == bi) lo = f[u];
-                    }
-                }
-                if (1.0 * hi / (lo + 1e-20) >= P.min_fold) include++;  // :640-641
-            }
-            const double r = 1.0 * (double)include / (double)all;  // :642
-            if (!(r < P.ratio)) {
-                is_hist = true;
-                const double t = (double)tot;
-                is_row = !(t < P.min_freq || t > P.max_freq);  // :645-646
-            }
+            sp_fsets F;
+            F.n_sets = P.n_sets;
+            F.baseline = P.baseline;
+            F.set_off = set_off;
+            F.unit_off = unit_off;
+            F.unit_chrom = unit_chrom;
+            F.unit_den = unit_den;
+            F.min_fold = P.min_fold;
+            F.min_freq = P.min_freq;
+            F.max_freq = P.max_freq;
+            F.ratio = P.ratio;
+            sp_filter_decide(mine + lane, 64, tot, F, is_row, is_hist);
         }
         const unsigned long long b_row = __ballot(is_row), b_hist = __ballot(is_hist),
                                  b_uni = __ballot(tot > 0);
@@ -206,11 +232,17 @@ static int upload_tabs(sp_ctx *ctx, const uint32_t ***d_tabs, double **d_len) {
     return SP_OK;
 }
 
+int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+                     const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
+                     double min_freq, double max_freq, double ratio);                      // sp_sparse.hip
+int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot);
+
 extern "C" {
 
 int sp_filter_view(sp_ctx *ctx, int C, const void *const *d_tabs, int64_t slot_base, int64_t nslots_view,
                    const int64_t *lengths, int k, int lower_count) {
     if (!ctx) return SP_EINVAL;
+    if (d_tabs && ctx->sparse_mode) return sp_fail(ctx, SP_EUNSUP, "sp_filter_view: k <= 15 only");
     if (!d_tabs) {   // back to the local chromosomes
         ctx->fv_on = false;
         ctx->fv_tabs.clear();
@@ -273,6 +305,21 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
         if (unit_chrom[j] < 0 || unit_chrom[j] >= C)
             return sp_fail(ctx, SP_EINVAL, "sp_filter: chromosome index %d out of range", unit_chrom[j]);
 
+    if (ctx->sparse_mode) {
+        std::vector<double> den_s((size_t)n_units);
+        for (int u = 0; u < n_units; u++) {
+            int64_t d = 0;
+            for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += ctx->chroms[(size_t)unit_chrom[j]].length_sum;
+            den_s[(size_t)u] = (double)d;
+        }
+        int rcs = sp_sparse_filter(ctx, n_sets, set_off, unit_off, unit_chrom, den_s, min_fold, baseline, min_freq,
+                                   max_freq, ratio);
+        if (rcs) return rcs;
+        if (n_union) *n_union = ctx->n_union;
+        if (n_rows) *n_rows = ctx->n_rows;
+        if (n_hist) *n_hist = ctx->n_hist;
+        return SP_OK;
+    }
     const int64_t nslots = filter_nslots(ctx);
     const int64_t nblk = (nslots + F_SLOTS_PER_BLOCK - 1) / F_SLOTS_PER_BLOCK;
     const int64_t ngroups = (nslots + 63) / 64;
@@ -366,6 +413,7 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (cap < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap, (long long)M);
     if (M == 0) return SP_OK;
+    if (ctx->sparse_mode) return sp_sparse_fetch(ctx, hist, keys, counts, freqs, tot);
     const int C = filter_C(ctx);
     const uint32_t **d_tabs = nullptr;
     double *d_len = nullptr;

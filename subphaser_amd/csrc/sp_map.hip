@@ -189,16 +189,27 @@ static int64_t map_nslots_host(int64_t len, int64_t bin_size, int64_t chunk_size
     return nb + nch;
 }
 
+int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n);          // sp_sparse.hip
+int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *d_counts, unsigned long long *d_n);
+int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units,
+                          const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts);
+int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n);
+
 extern "C" {
 
 int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg) {
     if (!ctx || n < 0 || (n > 0 && (!keys || !sg)) || n_sg < 1 || n_sg > 126)
         return sp_fail(ctx, SP_EINVAL, "sp_labels_set: bad arguments");
-    if (ctx->k <= 0 || ctx->nslots <= 0)
+    if (ctx->k <= 0 || (ctx->nslots <= 0 && !ctx->sparse_mode))
         return sp_fail(ctx, SP_EINVAL, "sp_labels_set: call sp_count first (it fixes k)");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     for (int64_t i = 0; i < n; i++)
         if (sg[i] >= n_sg) return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)sg[i], n_sg);
+    if (ctx->sparse_mode) {
+        ctx->n_sg = n_sg;
+        ctx->n_labels = n;
+        return sp_sparse_labels_set(ctx, keys, sg, n);
+    }
     if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
     if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, (size_t)(1u << MAP_BLOOM_BITS) / 8));
     SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
@@ -233,7 +244,8 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     if (!ctx || !slot_counts || chrom < 0 || chrom >= (int)ctx->chroms.size() || bin_size < 1 ||
         chunk_size < 0)
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins: bad arguments");
-    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_bins: call sp_labels_set first");
+    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_bins: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_chrom &c = ctx->chroms[(size_t)chrom];
     const int S = ctx->n_sg;
@@ -255,7 +267,10 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     P.S = S;
     int64_t local = MAP_RANGE / bin_size + 3 + (chunk_size > 0 ? MAP_RANGE / chunk_size + 2 : 0);
     P.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
-    if (P.n_units > 0) {
+    if (ctx->sparse_mode) {
+        int rcs = sp_sparse_map_launch(ctx, c, P, d_counts, d_n);
+        if (rcs) return rcs;
+    } else if (P.n_units > 0) {
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
@@ -275,7 +290,8 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
                     int32_t *slot_counts, int64_t *n_mapped) {
     if (!ctx || !slot_off || !slot_counts || bin_size < 1 || chunk_size < 0)
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: bad arguments");
-    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: call sp_labels_set first");
+    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int C = (int)ctx->chroms.size();
     const int S = ctx->n_sg;
@@ -304,6 +320,11 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
         P.S = S;
         P.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
         if (P.n_units == 0) continue;
+        if (ctx->sparse_mode) {
+            int rcs = sp_sparse_map_launch(ctx, c, P, d_counts + slot_off[i] * S, d_n + i);
+            if (rcs) return rcs;
+            continue;
+        }
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
@@ -356,7 +377,8 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
                     int64_t *counts) {
     if (!ctx || !off || !counts || n_feat < 0 || (n_feat > 0 && off[n_feat] > 0 && !ascii))
         return sp_fail(ctx, SP_EINVAL, "sp_map_features: bad arguments");
-    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_map_features: call sp_labels_set first");
+    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_features: call sp_labels_set first");
     const int S = ctx->n_sg;
     memset(counts, 0, (size_t)n_feat * S * sizeof(int64_t));
     if (n_feat == 0) return SP_OK;
@@ -391,12 +413,17 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     int64_t blocks = (nmw + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, total, d_pk, d_nm, nmw);
-    const sp_kparams32 kp = sp_make_kparams32(ctx->k);
     int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
-    int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
-    if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-    SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-              n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, d_counts);
+    if (ctx->sparse_mode) {
+        int rcs = sp_sparse_feat_launch(ctx, d_pk, d_nm, n_units, d_foff, n_feat, S, d_counts);
+        if (rcs) return rcs;
+    } else {
+        const sp_kparams32 kp = sp_make_kparams32(ctx->k);
+        int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
+                  n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, d_counts);
+    }
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_ascii);
@@ -409,13 +436,19 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
 
 int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
     if (!ctx || !n_hit) return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: bad arguments");
-    if (!ctx->d_label) return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: call sp_labels_set first");
+    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+        return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long *d_n = nullptr, h = 0;
     SP_HIP(ctx, hipMalloc(&d_n, 8));
     SP_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
-    SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, ctx->d_label,
-              ctx->nslots, d_n);
+    if (ctx->sparse_mode) {
+        int rcs = sp_sparse_hit(ctx, d_n);
+        if (rcs) return rcs;
+    } else {
+        SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, ctx->d_label,
+                  ctx->nslots, d_n);
+    }
     SP_HIP(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_n);

@@ -1,0 +1,616 @@
+// sp_sparse.hip -- the k = 16..32 engine ("sparse": 64-bit keys, sorted (key, count) arrays
+// instead of dense tables).  BASELINE.json config 5 sweeps k = 17 / 21.
+//
+//   count : 64-bit scan -> canonical key per start position (sentinel where the window is broken)
+//           -> radix sort -> run-length encode -> keep count >= lower_count   (per chromosome)
+//   filter: concatenate the C sorted arrays as (key, chrom|count) pairs -> sort by key ->
+//           one thread per run of equal keys rebuilds the row and applies the same
+//           sp_filter_decide() as the dense engine -> ordered compaction (ascending key)
+//   map   : labelled k-mers in an open-addressing hash table (+ the L2-resident pre-filter),
+//           same binning code path as the dense engine
+//
+// The sort and the run-length encode are rocPRIM device primitives (plain library ops on this
+// secondary path); everything specific to the problem is hand-written.  k <= 15 never comes here.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "sp_device.h"
+
+#define SPS_SENTINEL (~0ULL)
+#define SPS_MAXC 64
+
+__device__ __forceinline__ uint64_t sps_mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+// ------------------------------------------------------------------ count
+__global__ void __launch_bounds__(256)
+sps_keygen(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units, sp_kparams kp,
+           unsigned long long *__restrict__ keys /* pre-filled with the sentinel */,
+           unsigned long long *__restrict__ n_valid) {
+    __shared__ unsigned long long red[16];
+    unsigned long long nv = 0;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            keys[start] = fwd < rc ? fwd : rc;
+            nv++;
+        });
+    }
+    unsigned long long t = sp_block_sum_u64(nv, red);
+    if (threadIdx.x == 0 && t) atomicAdd(n_valid, t);
+}
+
+#define SEL_PER_THREAD 16
+#define SEL_BLOCK 256
+#define SEL_SPAN (SEL_PER_THREAD * SEL_BLOCK)
+
+// runs with count >= lower: per-block tally (+ sum of those counts = `lengths`)
+__global__ void __launch_bounds__(SEL_BLOCK)
+sps_sel_count(const uint32_t *__restrict__ counts, int64_t n, uint32_t lower, unsigned long long *__restrict__ blk,
+              unsigned long long *__restrict__ sum_out) {
+    __shared__ unsigned long long red[16];
+    const int64_t base = (int64_t)blockIdx.x * SEL_SPAN;
+    unsigned long long c = 0, s = 0;
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+        int64_t i = base + (int64_t)j * SEL_BLOCK + threadIdx.x;
+        if (i < n && counts[i] >= lower) {
+            c++;
+            s += counts[i];
+        }
+    }
+    unsigned long long tc = sp_block_sum_u64(c, red);
+    unsigned long long ts = sp_block_sum_u64(s, red);
+    if (threadIdx.x == 0) {
+        blk[blockIdx.x] = tc;
+        if (ts) atomicAdd(sum_out, ts);
+    }
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK)
+sps_sel_write(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, int64_t n,
+              uint32_t lower, const unsigned long long *__restrict__ blk, unsigned long long *__restrict__ out_keys,
+              uint32_t *__restrict__ out_counts) {
+    __shared__ uint32_t lds[16];
+    const int64_t base = (int64_t)blockIdx.x * SEL_SPAN;
+    unsigned long long off = blk[blockIdx.x];
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+        int64_t i = base + (int64_t)j * SEL_BLOCK + threadIdx.x;
+        uint32_t c = (i < n) ? counts[i] : 0u;
+        bool p = (i < n) && c >= lower;
+        uint32_t tot;
+        uint32_t my = sp_block_excl_count(p, lds, tot);
+        if (p) {
+            out_keys[off + my] = keys[i];
+            out_counts[off + my] = c;
+        }
+        off += tot;
+    }
+}
+
+// scan kernel of sp_count.hip
+__global__ void scan_excl_u64(unsigned long long *a, int64_t n, unsigned long long *total);
+
+// ------------------------------------------------------------------ filter
+__global__ void __launch_bounds__(256)
+sps_concat(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, int64_t n, int chrom,
+           unsigned long long *__restrict__ out_keys, unsigned long long *__restrict__ out_vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_keys[i] = keys[i];
+    out_vals[i] = ((unsigned long long)chrom << 32) | counts[i];
+}
+
+struct sps_filter_args {
+    int C;
+    sp_fsets F;
+};
+
+// flags per entry: bit0 = differential row, bit1 = fold-passing (hist), bit2 = head of a run (union)
+__global__ void __launch_bounds__(SEL_BLOCK)
+sps_eval(const unsigned long long *__restrict__ K, const unsigned long long *__restrict__ V, int64_t n,
+         sps_filter_args A, uint8_t *__restrict__ flags, unsigned long long *__restrict__ blk_row,
+         unsigned long long *__restrict__ blk_hist, unsigned long long *__restrict__ n_union) {
+    __shared__ unsigned long long red[16];
+    const int64_t base = (int64_t)blockIdx.x * SEL_SPAN;
+    unsigned long long nrow = 0, nhist = 0, nuni = 0;
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+        const int64_t i = base + (int64_t)j * SEL_BLOCK + threadIdx.x;
+        if (i >= n) continue;
+        uint8_t fl = 0;
+        const unsigned long long key = K[i];
+        if (i == 0 || K[i - 1] != key) {
+            uint32_t row[SPS_MAXC];
+            for (int c = 0; c < A.C; c++) row[c] = 0;
+            unsigned long long tot = 0;
+            for (int64_t q = i; q < n && K[q] == key; q++) {
+                const unsigned long long v = V[q];
+                row[(int)(v >> 32)] = (uint32_t)v;
+                tot += (uint32_t)v;
+            }
+            bool is_row, is_hist;
+            sp_filter_decide(row, 1, tot, A.F, is_row, is_hist);
+            fl = 4 | (is_row ? 1 : 0) | (is_hist ? 2 : 0);
+            nuni++;
+            nrow += is_row;
+            nhist += is_hist;
+        }
+        flags[i] = fl;
+    }
+    unsigned long long t_row = sp_block_sum_u64(nrow, red);
+    unsigned long long t_hist = sp_block_sum_u64(nhist, red);
+    unsigned long long t_uni = sp_block_sum_u64(nuni, red);
+    if (threadIdx.x == 0) {
+        blk_row[blockIdx.x] = t_row;
+        blk_hist[blockIdx.x] = t_hist;
+        if (t_uni) atomicAdd(n_union, t_uni);
+    }
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK)
+sps_emit(const unsigned long long *__restrict__ K, const unsigned long long *__restrict__ V, int64_t n, int C,
+         const uint8_t *__restrict__ flags, uint8_t bit, const unsigned long long *__restrict__ blk,
+         unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_counts,
+         unsigned long long *__restrict__ out_tot) {
+    __shared__ uint32_t lds[16];
+    const int64_t base = (int64_t)blockIdx.x * SEL_SPAN;
+    unsigned long long off = blk[blockIdx.x];
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+        const int64_t i = base + (int64_t)j * SEL_BLOCK + threadIdx.x;
+        const bool p = (i < n) && (flags[i] & bit);
+        uint32_t tot_blk;
+        const uint32_t my = sp_block_excl_count(p, lds, tot_blk);
+        if (p) {
+            const unsigned long long r = off + my, key = K[i];
+            unsigned long long tot = 0;
+            if (out_counts)
+                for (int c = 0; c < C; c++) out_counts[r * C + c] = 0;
+            for (int64_t q = i; q < n && K[q] == key; q++) {
+                const unsigned long long v = V[q];
+                if (out_counts) out_counts[r * C + (int)(v >> 32)] = (uint32_t)v;
+                tot += (uint32_t)v;
+            }
+            if (out_keys) out_keys[r] = key;
+            if (out_tot) out_tot[r] = tot;
+        }
+        off += tot_blk;
+    }
+}
+
+// ------------------------------------------------------------------ labels + map
+__global__ void __launch_bounds__(256)
+sps_hash_insert(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
+                unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
+                uint32_t *__restrict__ bloom) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    uint64_t h = sps_mix(key) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&hkeys[h], SPS_SENTINEL, key);
+        if (prev == SPS_SENTINEL || prev == key) break;
+        h = (h + 1) & mask;
+    }
+    hlab[h] = (uint8_t)(1u + sg[i]);
+    const uint32_t b = map_bloom_idx(key);
+    atomicOr(&bloom[b >> 5], 1u << (b & 31));
+}
+
+__device__ __forceinline__ int sps_lookup(uint64_t key, const unsigned long long *__restrict__ hkeys,
+                                          uint8_t *__restrict__ hlab, uint64_t mask,
+                                          const uint32_t *__restrict__ bloom) {
+    const uint32_t bi = map_bloom_idx(key);
+    if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return -1;
+    uint64_t h = sps_mix(key) & mask;
+    for (;;) {
+        const unsigned long long kk = hkeys[h];
+        if (kk == key) break;
+        if (kk == SPS_SENTINEL) return -1;
+        h = (h + 1) & mask;
+    }
+    const uint32_t l = hlab[h];
+    if (!(l & 0x80u)) hlab[h] = (uint8_t)(l | 0x80u);
+    return (int)(l & 0x7fu) - 1;
+}
+
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, sp_map_params P,
+              const unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
+              const uint32_t *__restrict__ bloom, int *__restrict__ slot_counts,
+              unsigned long long *__restrict__ n_mapped) {
+    __shared__ int hist[MAP_LDS_ENTRIES];
+    __shared__ unsigned long long red[16];
+    unsigned long long mapped = 0;
+    const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const int64_t u = r * MAP_BLOCK + threadIdx.x;
+        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k);
+        if (P.use_lds) {
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        if (u < P.n_units) {
+            sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                const int sg = sps_lookup(fwd < rc ? fwd : rc, hkeys, hlab, mask, bloom);
+                if (sg < 0) return;
+                const int64_t os = map_slot(start, P, kp.k);
+                if (P.use_lds)
+                    atomicAdd(&hist[(os - slot_lo) * P.S + sg], 1);
+                else if (os < P.nslots)
+                    atomicAdd(&slot_counts[os * P.S + sg], 1);
+                mapped++;
+            });
+        }
+        if (P.use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
+                int v = hist[i];
+                if (v) {
+                    int64_t os = slot_lo + i / P.S;
+                    if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + (i % P.S)], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long t = sp_block_sum_u64(mapped, red);
+    if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
+}
+
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
+                   const int64_t *__restrict__ foff, int64_t n_feat, int S,
+                   const unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
+                   const uint32_t *__restrict__ bloom, unsigned long long *__restrict__ counts) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            const int sg = sps_lookup(fwd < rc ? fwd : rc, hkeys, hlab, mask, bloom);
+            if (sg < 0) return;
+            int64_t lo = 0, hi = n_feat;
+            while (hi - lo > 1) {
+                int64_t mid = (lo + hi) >> 1;
+                if (foff[mid] <= start) lo = mid;
+                else hi = mid;
+            }
+            atomicAdd(&counts[lo * S + sg], 1ULL);
+        });
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sps_count_seen(const uint8_t *__restrict__ hlab, int64_t n, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        c += (hlab[i] >> 7) & 1u;
+    unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
+// ================================================================== host side
+static void sps_free_chrom(sp_sparse_chrom &c) {
+    if (c.d_keys) hipFree(c.d_keys);
+    if (c.d_cnts) hipFree(c.d_cnts);
+    c = sp_sparse_chrom();
+}
+
+void sp_sparse_release(sp_ctx *ctx) {
+    for (auto &c : ctx->sparse) sps_free_chrom(c);
+    ctx->sparse.clear();
+    if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
+    if (ctx->d_hlab) hipFree(ctx->d_hlab);
+    ctx->d_hkeys = nullptr;
+    ctx->d_hlab = nullptr;
+    ctx->hcap = 0;
+    sp_buf_free(ctx->b_sp_a);
+    sp_buf_free(ctx->b_sp_b);
+    sp_buf_free(ctx->b_sp_c);
+    sp_buf_free(ctx->b_sp_tmp);
+    sp_buf_free(ctx->b_sf_keys);
+    sp_buf_free(ctx->b_sf_counts);
+    sp_buf_free(ctx->b_sf_tot);
+    sp_buf_free(ctx->b_sf_hist);
+}
+
+static int sps_ordered_select(sp_ctx *ctx, const unsigned long long *d_keys, const uint32_t *d_counts, int64_t n,
+                              uint32_t lower, sp_sparse_chrom &out, unsigned long long *d_small /*>= 4 u64*/) {
+    // d_small[0] = sum of kept counts, d_small[1] = kept runs
+    const int64_t nblk = (n + SEL_SPAN - 1) / SEL_SPAN;
+    int rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (nblk + 2) * 8);
+    if (rc) return rc;
+    unsigned long long *d_blk = (unsigned long long *)ctx->b_sp_tmp.p;
+    SP_HIP(ctx, hipMemsetAsync(d_small, 0, 32, ctx->stream));
+    if (n == 0) {
+        out.n = 0;
+        return SP_OK;
+    }
+    SP_LAUNCH(ctx, "sps_sel_count", sps_sel_count, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, d_counts, n, lower, d_blk,
+              d_small);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_blk, nblk, d_small + 1);
+    unsigned long long h[2] = {0, 0};
+    SP_HIP(ctx, hipMemcpyAsync(h, d_small, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t keep = (int64_t)h[1];
+    if (keep > out.cap) {
+        if (out.d_keys) hipFree(out.d_keys);
+        if (out.d_cnts) hipFree(out.d_cnts);
+        out.d_keys = nullptr;
+        out.d_cnts = nullptr;
+        out.cap = 0;
+        SP_HIP(ctx, hipMalloc(&out.d_keys, (size_t)(keep + 1) * 8));
+        SP_HIP(ctx, hipMalloc(&out.d_cnts, (size_t)(keep + 1) * 4));
+        out.cap = keep;
+    }
+    out.n = keep;
+    out.length_sum = (int64_t)h[0];
+    if (keep)
+        SP_LAUNCH(ctx, "sps_sel_write", sps_sel_write, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, d_keys, d_counts, n,
+                  lower, d_blk, (unsigned long long *)out.d_keys, out.d_cnts);
+    return SP_OK;
+}
+
+int sp_sparse_count(sp_ctx *ctx, int k, int lower) {
+    const size_t C = ctx->chroms.size();
+    if (ctx->sparse.size() != C) {
+        for (auto &c : ctx->sparse) sps_free_chrom(c);
+        ctx->sparse.assign(C, sp_sparse_chrom());
+    }
+    const sp_kparams kp = sp_make_kparams(k);
+    const unsigned end_bit = (2 * k + 1 > 64) ? 64u : (unsigned)(2 * k + 1);
+    void *scr = nullptr;
+    int rc = sp_scratch(ctx, 256, &scr);
+    if (rc) return rc;
+    unsigned long long *d_small = (unsigned long long *)scr;
+    for (size_t ci = 0; ci < C; ci++) {
+        sp_chrom &c = ctx->chroms[ci];
+        sp_sparse_chrom &o = ctx->sparse[ci];
+        const int64_t n = c.len;
+        o.n = 0;
+        o.length_sum = 0;
+        c.length_sum = 0;
+        c.n_dump = 0;
+        if (n <= 0) continue;
+        rc = sp_buf_ensure(ctx, ctx->b_sp_a, n * 8);
+        if (rc) return rc;
+        rc = sp_buf_ensure(ctx, ctx->b_sp_b, n * 8);
+        if (rc) return rc;
+        rc = sp_buf_ensure(ctx, ctx->b_sp_c, n * 4 + 64);
+        if (rc) return rc;
+        unsigned long long *A = (unsigned long long *)ctx->b_sp_a.p, *B = (unsigned long long *)ctx->b_sp_b.p;
+        uint32_t *Cn = (uint32_t *)ctx->b_sp_c.p;
+        SP_HIP(ctx, hipMemsetAsync(A, 0xff, (size_t)n * 8, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(d_small, 0, 64, ctx->stream));
+        const int64_t n_units = (n + SP_UNIT - 1) / SP_UNIT;
+        int64_t grid = (n_units + 255) / 256;
+        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        SP_LAUNCH(ctx, "sps_keygen", sps_keygen, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_nm, n_units, kp, A,
+                  d_small + 4);
+        unsigned long long nv = 0;
+        SP_HIP(ctx, hipMemcpyAsync(&nv, d_small + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // sort (sentinels, having bit 2k set, end up last)
+        size_t tmp_bytes = 0;
+        SP_HIP(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, A, B, (size_t)n, 0u, end_bit, ctx->stream));
+        rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)tmp_bytes + 256);
+        if (rc) return rc;
+        SP_HIP(ctx, rocprim::radix_sort_keys(ctx->b_sp_tmp.p, tmp_bytes, A, B, (size_t)n, 0u, end_bit, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (nv == 0) continue;
+        if (nv >= (1ULL << 32)) return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
+        // run-length encode the valid prefix: unique keys -> A, counts -> Cn, number of runs -> d_small[5]
+        tmp_bytes = 0;
+        SP_HIP(ctx, rocprim::run_length_encode(nullptr, tmp_bytes, B, (unsigned int)nv, A, Cn, d_small + 5, ctx->stream));
+        rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)tmp_bytes + 256);
+        if (rc) return rc;
+        SP_HIP(ctx, rocprim::run_length_encode(ctx->b_sp_tmp.p, tmp_bytes, B, (unsigned int)nv, A, Cn, d_small + 5,
+                                               ctx->stream));
+        unsigned long long nruns = 0;
+        SP_HIP(ctx, hipMemcpyAsync(&nruns, d_small + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = sps_ordered_select(ctx, A, Cn, (int64_t)nruns, (uint32_t)lower, o, d_small);
+        if (rc) return rc;
+        c.length_sum = o.length_sum;
+        c.n_dump = o.n;
+    }
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts) {
+    sp_sparse_chrom &o = ctx->sparse[(size_t)chrom];
+    if (o.n == 0) return SP_OK;
+    SP_HIP(ctx, hipMemcpyAsync(keys, o.d_keys, (size_t)o.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(counts, o.d_cnts, (size_t)o.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+                     const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
+                     double min_freq, double max_freq, double ratio) {
+    const int C = (int)ctx->chroms.size();
+    if (C > SPS_MAXC) return sp_fail(ctx, SP_EUNSUP, "k > 15: at most %d chromosomes supported (got %d)", SPS_MAXC, C);
+    int64_t total = 0;
+    for (auto &o : ctx->sparse) total += o.n;
+    ctx->sf_n = total;
+    ctx->n_union = ctx->n_rows = ctx->n_hist = 0;
+    if (total == 0) {
+        ctx->filtered = true;
+        return SP_OK;
+    }
+    int rc = sp_buf_ensure(ctx, ctx->b_sp_a, total * 16);   // keys | vals (unsorted)
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_b, total * 16);       // keys | vals (sorted)
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_c, total + 64);       // flags
+    if (rc) return rc;
+    unsigned long long *K0 = (unsigned long long *)ctx->b_sp_a.p, *V0 = K0 + total;
+    unsigned long long *K1 = (unsigned long long *)ctx->b_sp_b.p, *V1 = K1 + total;
+    uint8_t *flags = (uint8_t *)ctx->b_sp_c.p;
+    int64_t off = 0;
+    for (int c = 0; c < C; c++) {
+        sp_sparse_chrom &o = ctx->sparse[(size_t)c];
+        if (o.n)
+            SP_LAUNCH(ctx, "sps_concat", sps_concat, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0,
+                      (const unsigned long long *)o.d_keys, (const uint32_t *)o.d_cnts, o.n, c, K0 + off, V0 + off);
+        off += o.n;
+    }
+    const unsigned end_bit = (2 * ctx->k > 64) ? 64u : (unsigned)(2 * ctx->k);
+    size_t tmp_bytes = 0;
+    SP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, K0, K1, V0, V1, (size_t)total, 0u, end_bit, ctx->stream));
+    // parameter block + block tallies live behind the rocprim temp storage
+    const int n_units = set_off[n_sets], n_uc = unit_off[n_units];
+    const int64_t nblk = (total + SEL_SPAN - 1) / SEL_SPAN;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_set = al(tmp_bytes), o_uo = o_set + al((size_t)(n_sets + 1) * 4), o_uc = o_uo + al((size_t)(n_units + 1) * 4),
+           o_den = o_uc + al((size_t)(n_uc + 1) * 4), o_blk_r = o_den + al((size_t)n_units * 8),
+           o_blk_h = o_blk_r + al((size_t)(nblk + 1) * 8), o_small = o_blk_h + al((size_t)(nblk + 1) * 8),
+           all_b = o_small + 256;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)all_b);
+    if (rc) return rc;
+    char *T = (char *)ctx->b_sp_tmp.p;
+    SP_HIP(ctx, rocprim::radix_sort_pairs(T, tmp_bytes, K0, K1, V0, V1, (size_t)total, 0u, end_bit, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(T + o_set, set_off, (size_t)(n_sets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(T + o_uo, unit_off, (size_t)(n_units + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_uc) SP_HIP(ctx, hipMemcpyAsync(T + o_uc, unit_chrom, (size_t)n_uc * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(T + o_den, den.data(), (size_t)n_units * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(T + o_small, 0, 256, ctx->stream));
+    sps_filter_args A;
+    A.C = C;
+    A.F.n_sets = n_sets;
+    A.F.baseline = baseline;
+    A.F.set_off = (const int32_t *)(T + o_set);
+    A.F.unit_off = (const int32_t *)(T + o_uo);
+    A.F.unit_chrom = (const int32_t *)(T + o_uc);
+    A.F.unit_den = (const double *)(T + o_den);
+    A.F.min_fold = min_fold;
+    A.F.min_freq = min_freq;
+    A.F.max_freq = max_freq;
+    A.F.ratio = ratio;
+    unsigned long long *blk_r = (unsigned long long *)(T + o_blk_r), *blk_h = (unsigned long long *)(T + o_blk_h),
+                       *small = (unsigned long long *)(T + o_small);
+    SP_LAUNCH(ctx, "sps_eval", sps_eval, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, K1, V1, total, A, flags, blk_r, blk_h,
+              small);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, blk_r, nblk, small + 1);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, blk_h, nblk, small + 2);
+    unsigned long long h[3] = {0, 0, 0};
+    SP_HIP(ctx, hipMemcpyAsync(h, small, 24, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_union = (int64_t)h[0];
+    ctx->n_rows = (int64_t)h[1];
+    ctx->n_hist = (int64_t)h[2];
+    // materialise the results now (the sort buffers are reused by the next call)
+    const int64_t M = ctx->n_rows, H = ctx->n_hist;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_keys, (M + 1) * 8);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_counts, (M + 1) * (int64_t)C * 4);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_tot, (M + 1) * 8);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_hist, (H + 1) * 8);
+    if (rc) return rc;
+    if (M)
+        SP_LAUNCH(ctx, "sps_emit", sps_emit, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, K1, V1, total, C,
+                  (const uint8_t *)flags, (uint8_t)1, (const unsigned long long *)blk_r,
+                  (unsigned long long *)ctx->b_sf_keys.p, (uint32_t *)ctx->b_sf_counts.p,
+                  (unsigned long long *)ctx->b_sf_tot.p);
+    if (H)
+        SP_LAUNCH(ctx, "sps_emit_hist", sps_emit, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, K1, V1, total, C,
+                  (const uint8_t *)flags, (uint8_t)2, (const unsigned long long *)blk_h, (unsigned long long *)nullptr,
+                  (uint32_t *)nullptr, (unsigned long long *)ctx->b_sf_hist.p);
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->filtered = true;
+    return SP_OK;
+}
+
+int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot) {
+    const int C = (int)ctx->chroms.size();
+    const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
+    if (M == 0) return SP_OK;
+    if (hist) {
+        SP_HIP(ctx, hipMemcpyAsync(tot, ctx->b_sf_hist.p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SP_OK;
+    }
+    std::vector<uint32_t> tmp;
+    uint32_t *cdst = counts;
+    if (!counts && freqs) {
+        tmp.resize((size_t)M * C);
+        cdst = tmp.data();
+    }
+    if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, ctx->b_sf_keys.p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, ctx->b_sf_tot.p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (cdst) SP_HIP(ctx, hipMemcpyAsync(cdst, ctx->b_sf_counts.p, (size_t)M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (freqs)
+        for (int64_t r = 0; r < M; r++)
+            for (int c = 0; c < C; c++)   // count/length in fp64 (Jellyfish.py:647); IEEE division, same bits as the device path
+                freqs[r * C + c] = (double)cdst[r * C + c] / (double)ctx->chroms[(size_t)c].length_sum;
+    return SP_OK;
+}
+
+int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n) {
+    int64_t cap = 1024;
+    while (cap < 2 * n + 16) cap <<= 1;
+    if (cap != ctx->hcap) {
+        if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
+        if (ctx->d_hlab) hipFree(ctx->d_hlab);
+        ctx->d_hkeys = nullptr;
+        ctx->d_hlab = nullptr;
+        SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 8));
+        SP_HIP(ctx, hipMalloc(&ctx->d_hlab, (size_t)cap));
+        ctx->hcap = cap;
+    }
+    if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, (size_t)(1u << MAP_BLOOM_BITS) / 8));
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 8, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_hlab, 0, (size_t)cap, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, (size_t)(1u << MAP_BLOOM_BITS) / 8, ctx->stream));
+    if (n == 0) return SP_OK;
+    unsigned long long *d_keys = nullptr;
+    uint8_t *d_sg = nullptr;
+    SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
+    SP_HIP(ctx, hipMalloc(&d_sg, (size_t)n));
+    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
+              (unsigned long long *)ctx->d_hkeys, ctx->d_hlab, (uint64_t)(cap - 1), ctx->d_bloom);
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_keys);
+    hipFree(d_sg);
+    return SP_OK;
+}
+
+int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *d_counts, unsigned long long *d_n) {
+    if (P.n_units == 0) return SP_OK;
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    int64_t grid = n_ranges;
+    if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+              (const unsigned long long *)ctx->d_hkeys, ctx->d_hlab, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, d_counts,
+              d_n);
+    return SP_OK;
+}
+
+int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units, const int64_t *d_foff,
+                          int64_t n_feat, int S, unsigned long long *d_counts) {
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
+              n_units, d_foff, n_feat, S, (const unsigned long long *)ctx->d_hkeys, ctx->d_hlab,
+              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, d_counts);
+    return SP_OK;
+}
+
+int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
+    SP_LAUNCH(ctx, "sps_count_seen", sps_count_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
+              (const uint8_t *)ctx->d_hlab, ctx->hcap, d_n);
+    return SP_OK;
+}

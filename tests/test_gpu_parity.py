@@ -91,6 +91,76 @@ def test_count_engine2_unsupported_small_k(gpu_ctx):
         gpu_ctx.count(5, 1, 2)
 
 
+@pytest.mark.parametrize("k", [16, 17, 21, 25, 31, 32])
+def test_count_sparse_engine(gpu_ctx, k):
+    """k > 15: 64-bit keys, sort + run-length-encode engine vs the oracle."""
+    rng = np.random.RandomState(300 + k)
+    seqs = [_rand_seq(rng, n) for n in (5000, 300_001, 64, 40)]
+    rep = _rand_seq(rng, 400, 0, 0)
+    s = _rand_seq(rng, 120000)
+    for _ in range(60):
+        p = rng.randint(0, s.size - 500)
+        s[p:p + 400] = rep
+    seqs += [s, np.frombuffer(b"A" * 5000 + b"TTTAGGG" * 800, np.uint8), np.empty(0, np.uint8),
+             np.frombuffer(b"N" * 100, np.uint8)]
+    _count_both(gpu_ctx, seqs, k, 1)
+    _count_both(gpu_ctx, seqs, k, 3)
+
+
+@pytest.mark.parametrize("k", [17, 21])
+def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k):
+    """k = 17 / 21 (BASELINE config 5): matrix rows and bin counts bit-exact vs the oracle."""
+    rng = np.random.RandomState(400 + k)
+    reps = [_rand_seq(rng, 350, 0, 0) for _ in range(6)]
+    seqs = []
+    for c in range(6):
+        s = _rand_seq(rng, 40000 + 500 * c)
+        for _ in range(50):
+            r = reps[rng.randint(0, 3) + (3 if c % 2 else 0)]
+            p = rng.randint(0, s.size - 400)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    from subphaser_amd.config import sets_to_csr
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.genome_reset(len(seqs))
+        for i, s in enumerate(seqs):
+            ctx.genome_add(i, s)
+        ctx.count(k, 2)
+    assert gpu_ctx.lengths().tolist() == oracle_ctx.lengths().tolist()
+    sgs = [[[0], [1]], [[2], [3]], [[4], [5]]]
+    csr = sets_to_csr(sgs, list(range(6)))
+    res = []
+    for ctx in (gpu_ctx, oracle_ctx):
+        nu, nr, nh = ctx.filter(*csr, 2.0, 1, 10, 1e9, 1.0)
+        keys, counts, freqs, tot = ctx.filter_fetch(nr)
+        res.append((nu, nr, nh, keys, counts, freqs, tot, np.sort(ctx.filter_hist(nh))))
+    g, o = res
+    assert g[:3] == o[:3] and g[1] > 0
+    for a, b in zip(g[3:], o[3:]):
+        assert a.shape == b.shape and (a == b).all()
+    keys, counts = g[3], g[4]
+    sg = (counts[:, 1::2].sum(axis=1) > counts[:, 0::2].sum(axis=1)).astype(np.uint8)
+    gpu_ctx.labels_set(keys, sg, 2)
+    for i, s in enumerate(seqs):
+        for bin_size, chunk in ((1000, 10000), (10000, 10_000_000), (64, 0)):
+            got, n = gpu_ctx.map_bins(i, bin_size, chunk)
+            exp, hit, n2 = po.map_bins(s, k, keys, sg, 2, bin_size, chunk, nthreads=2)
+            assert (got == exp).all() and n == n2, (i, bin_size, chunk)
+    allb, nm = gpu_ctx.map_bins_all(1000, 10000)
+    assert int(nm.sum()) == sum(int(po.map_bins(s, k, keys, sg, 2, 1000, 10000)[2]) for s in seqs)
+    assert gpu_ctx.labels_hit() > 0
+    feats = [bytes(seqs[0][100:900]), bytes(seqs[1][5:2000]), b"ACGT", b""]
+    fc = gpu_ctx.map_features(feats)
+    for f, row in zip(feats, fc):
+        if len(f) == 0:
+            assert row.sum() == 0
+            continue
+        exp, _, _ = po.map_bins(f, k, keys, sg, 2, max(len(f), 1), 0)
+        assert (row == exp.sum(axis=0)).all()
+    gpu_ctx.count(15, 3, 1)      # back to the dense engine on the same context
+    assert int(gpu_ctx.lengths()[0]) == int(po.count(seqs[0], 15, 3)[1].astype(np.int64).sum())
+
+
 def test_count_edges(gpu_ctx):
     k = 15
     seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",
@@ -130,6 +200,7 @@ def test_count_rejects_bad_k(gpu_ctx):
         gpu_ctx.count(0, 1)
     with pytest.raises(ValueError):
         gpu_ctx.count(33, 1)
+    gpu_ctx.count(32, 1)         # the largest supported k
 
 
 def test_toy_dumps(gpu_ctx, golden, toy):
