@@ -42,6 +42,11 @@ def parse():
 
 def algorithmic_bytes(kernel, bases, nslots, C, S, extra):
     """SURVEY.md 8(d) per-unit figures x the units one launch processes."""
+    k = extra.get("k", 15)
+    if k > 16 and (kernel.startswith("sps_") or "radix" in kernel or "rocprim" in kernel or "run_length" in kernel):
+        return 16.25 * bases                      # 0.25 B read + 8 B key read + 4 B counter read + 4 B write per base
+    if kernel == "k5_map_sparse":
+        return 9.25 * bases + extra.get("nbins", 0) * S * 4
     if kernel.startswith("k1_") or kernel.startswith("c2_"):
         return 8.25 * bases                       # 0.25 B read + 4 B counter read + 4 B counter write per base
     if kernel == "k5_map":
@@ -176,7 +181,7 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (HIP events per launch, on the context's stream) ------
-    nslots = 1 << (2 * args.k - 1) if args.k % 2 else 1 << (2 * args.k)
+    nslots = (1 << (2 * args.k - 1) if args.k % 2 else 1 << (2 * args.k)) if args.k <= 15 else 0
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
     if dom:
@@ -186,7 +191,7 @@ def main():
         bases_per_launch = sum(gen.chroms[i]["length"] for i in my) / max(1.0, launches_per_step) \
             if launches_per_step >= n_local else sum(gen.chroms[i]["length"] for i in my)
         extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
-                     sum_dump=int(sum(a.kmer_lengths)))
+                     sum_dump=int(sum(a.kmer_lengths)), k=args.k)
         alg = algorithmic_bytes(name, bases_per_launch, nslots, C, S, extra)
         avg_s = st["ms"] / st["calls"] / 1e3
         if alg:

@@ -277,15 +277,29 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
         for (unsigned long long i = lo + threadIdx.x; i < a; i += C2_COUNT_THREADS) atomicAdd(&cnt[buf2[i]], 1u);
         const unsigned long long n4 = (hi - a) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a);
-        for (unsigned long long i = threadIdx.x; i < n4; i += C2_COUNT_THREADS) {
+        // four independent 8-byte loads in flight per lane, then the 16 LDS atomics
+        unsigned long long i = threadIdx.x;
+        for (; i + 3ULL * C2_COUNT_THREADS < n4; i += 4ULL * C2_COUNT_THREADS) {
+            uint2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = p2[i + (unsigned long long)q * C2_COUNT_THREADS];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                atomicAdd(&cnt[v[q].x & 0xffffu], 1u);
+                atomicAdd(&cnt[v[q].x >> 16], 1u);
+                atomicAdd(&cnt[v[q].y & 0xffffu], 1u);
+                atomicAdd(&cnt[v[q].y >> 16], 1u);
+            }
+        }
+        for (; i < n4; i += C2_COUNT_THREADS) {
             uint2 v = p2[i];
             atomicAdd(&cnt[v.x & 0xffffu], 1u);
             atomicAdd(&cnt[v.x >> 16], 1u);
             atomicAdd(&cnt[v.y & 0xffffu], 1u);
             atomicAdd(&cnt[v.y >> 16], 1u);
         }
-        for (unsigned long long i = a + (n4 << 2) + threadIdx.x; i < hi; i += C2_COUNT_THREADS)
-            atomicAdd(&cnt[buf2[i]], 1u);
+        for (unsigned long long t = a + (n4 << 2) + threadIdx.x; t < hi; t += C2_COUNT_THREADS)
+            atomicAdd(&cnt[buf2[t]], 1u);
         __syncthreads();
         uint4 *t4 = reinterpret_cast<uint4 *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {

@@ -97,11 +97,20 @@ k3_eval(const uint32_t *const *__restrict__ tabs, sp_filter_params P,
         const int64_t slot = gbase + lane;
         const bool in = slot < P.nslots;
         unsigned long long tot = 0;
-        for (int c = 0; c < P.C; c++) {
-            uint32_t v = in ? tabs[c][slot] : 0u;
-            v = v >= P.lower ? v : 0u;
-            mine[c * 64 + lane] = v;
-            tot += v;
+        // eight independent table loads in flight per lane (one load at a time is latency-bound:
+        // 1.8 TB/s measured; batching reaches the streaming rate)
+        for (int c0 = 0; c0 < P.C; c0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (in && c0 + j < P.C) ? tabs[c0 + j][slot] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (c0 + j < P.C) {
+                    const uint32_t x = v[j] >= P.lower ? v[j] : 0u;
+                    mine[(c0 + j) * 64 + lane] = x;
+                    tot += x;
+                }
+            }
         }
         bool is_row = false, is_hist = false;
         if (tot > 0) {

@@ -12,7 +12,12 @@
 // positions do not carry a subgenome-specific k-mer, so every position first
 // probes a hashed 2^25-bit Bloom-style bitmap that fits each XCD's 4-MiB L2 and
 // only positions that pass it touch the exact table.
+#ifndef MAP_BLOOM_BITS
 #define MAP_BLOOM_BITS 25
+#endif
+#ifndef MAP_NT
+#define MAP_NT 0
+#endif
 __host__ __device__ __forceinline__ uint32_t map_bloom_idx(uint64_t slot) {
     uint32_t x = (uint32_t)slot ^ (uint32_t)(slot >> 32);
     return (x * 0x9E3779B1u) >> (32 - MAP_BLOOM_BITS);
@@ -72,7 +77,11 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
                 const uint32_t slot = sp_slot_of32(fwd, rc, kp);
                 const uint32_t bi = map_bloom_idx(slot);
                 if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return;   // L2-resident pre-filter
+#if MAP_NT
+                const uint32_t l = __builtin_nontemporal_load(&label[slot]);   // do not let table lines evict the pre-filter from L2
+#else
                 const uint32_t l = label[slot];
+#endif
                 if (l) {
                     if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);  // idempotent "seen" mark
                     const int sg = (int)(l & 0x7fu) - 1;
