@@ -117,14 +117,14 @@ def main():
         def second_half(lab):
             return hp.map_and_enrich(lab, S)
     else:
-        def first_half():
-            return runner.count_and_filter(d_ascii)
+        def first_half(everywhere=False):
+            return runner.count_and_filter(d_ascii, host_rows_on_all_ranks=everywhere)
 
         def second_half(lab):
             return runner.map_and_enrich(lab, S)
 
     # ---- labels: the reference's unchanged Cluster step, computed once, untimed ---------------
-    r1 = first_half()
+    r1 = first_half(True) if runner is not None else first_half()
 
     class _Mat:
         pass
@@ -150,8 +150,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if runner is None:
-        hp.wall.clear()
+    (hp if runner is None else runner).wall.clear()
     ctx.prof_reset()
     ctx.prof_enable(True)
     barrier()
@@ -218,8 +217,8 @@ def main():
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "synth_s": round(t_synth, 2),
-        "host_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 2) for k_, v in hp.wall.items()}
-                                  if runner is None else None),
+        "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
+                                  for k_, v in (hp if runner is None else runner).wall.items()},
     }
     if dist is not None:
         dist.barrier()

@@ -66,6 +66,9 @@ int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
  * canonical k-mer counts, kept when count >= lower_count (`jellyfish dump -L`).
  * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter. */
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
+/* same for chromosomes [first, last) only (k <= 15): lets a multi-GPU caller ship the finished
+ * table of chromosome i over xGMI while chromosome i+1 is being counted.          */
+int sp_count_range(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last);
 /* number of slots of the dense count table for this k (2^(2k-1) for odd k, 4^k for even k) */
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
 /* use caller-owned device memory (nslots x uint32) as the count table of `chrom`, so that the
@@ -103,6 +106,9 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
  * fp64 exactly as Jellyfish.py:647 (may be NULL); tot = row sums (may be NULL) */
 int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot,
                     int64_t cap_rows);
+/* same rows written to caller-owned DEVICE buffers (any may be NULL): multi-GPU callers gather
+ * them over xGMI without a host round trip.  d_keys/d_tot: uint64 x n_rows, d_counts: uint32 x n_rows x C. */
+int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_tot, int64_t cap_rows);
 /* tot of every fold-passing k-mer (the reference's tot_freqs histogram input) */
 int sp_filter_hist(sp_ctx *ctx, uint64_t *tot, int64_t cap);
 

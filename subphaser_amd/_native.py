@@ -20,8 +20,8 @@ SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -
 SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
-    "sp_count", "sp_nslots", "sp_tables_bind", "sp_lengths", "sp_dump_size", "sp_dump",
-    "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_hist",
+    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
@@ -62,6 +62,7 @@ def load():
     L.sp_genome_len.argtypes = [vp, ci, P(i64)]
     L.sp_genome_unpack.argtypes = [vp, ci, vp, i64]
     L.sp_count.argtypes = [vp, ci, ci, ci]
+    L.sp_count_range.argtypes = [vp, ci, ci, ci, ci, ci]
     L.sp_nslots.argtypes = [vp, ci, P(i64)]
     L.sp_tables_bind.argtypes = [vp, ci, vp]
     L.sp_filter_view.argtypes = [vp, ci, vp, i64, i64, vp, ci, ci]
@@ -70,6 +71,7 @@ def load():
     L.sp_dump.argtypes = [vp, ci, vp, vp, i64, P(i64)]
     L.sp_filter.argtypes = [vp, ci, vp, vp, vp, dbl, ci, dbl, dbl, dbl, P(i64), P(i64), P(i64)]
     L.sp_filter_fetch.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.sp_filter_fetch_device.argtypes = [vp, vp, vp, vp, i64]
     L.sp_filter_hist.argtypes = [vp, vp, i64]
     L.sp_labels_set.argtypes = [vp, vp, vp, i64, ci]
     L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
@@ -205,6 +207,10 @@ class Context:
         self._ck(self.L.sp_count(self.h, int(k), int(lower_count), int(engine)))
         self.k = int(k)
 
+    def count_range(self, k, lower_count, engine, first, last):
+        self._ck(self.L.sp_count_range(self.h, int(k), int(lower_count), int(engine), int(first), int(last)))
+        self.k = int(k)
+
     def nslots(self, k):
         n = C.c_int64()
         self._ck(self.L.sp_nslots(self.h, int(k), C.byref(n)))
@@ -276,6 +282,11 @@ class Context:
             if freqs is not None:
                 freqs = freqs[o]
         return keys, counts, freqs, tot
+
+    def filter_fetch_device(self, d_keys, d_counts, d_tot, n_rows):
+        """Surviving rows into caller-owned device buffers (raw pointers or None), slot order."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        self._ck(self.L.sp_filter_fetch_device(self.h, v(d_keys), v(d_counts), v(d_tot), int(n_rows)))
 
     def filter_hist(self, n_hist):
         tot = np.empty(n_hist, np.uint64)

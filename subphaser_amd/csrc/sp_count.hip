@@ -147,13 +147,17 @@ int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
 extern "C" {
 
-int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
+static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last) {
     if (!ctx) return SP_EINVAL;
     if (k < 1 || k > 32) return sp_fail(ctx, SP_EUNSUP, "k=%d unsupported (1..32)", k);
     if (lower_count < 1) lower_count = 1;
     if (ctx->chroms.empty()) return sp_fail(ctx, SP_EINVAL, "sp_count: no chromosomes loaded");
     SP_HIP(ctx, hipSetDevice(ctx->device));
+    if (first < 0 || last > (int)ctx->chroms.size() || first > last)
+        return sp_fail(ctx, SP_EINVAL, "sp_count_range: bad chromosome range [%d, %d)", first, last);
     if (k > 15) {   // 64-bit keys: sort-based sparse engine (`engine` is ignored)
+        if (first != 0 || last != (int)ctx->chroms.size())
+            return sp_fail(ctx, SP_EUNSUP, "sp_count_range: k > 15 counts all chromosomes at once");
         for (auto &c : ctx->chroms)
             if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "a chromosome is not loaded");
         ctx->counted = false;
@@ -198,7 +202,7 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
     if (rc) return rc;
     unsigned long long *d_len = (unsigned long long *)scr;
     SP_HIP(ctx, hipMemsetAsync(d_len, 0, 2 * C * sizeof(unsigned long long), ctx->stream));
-    for (size_t ci = 0; ci < C; ci++) {
+    for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
         sp_chrom &c = ctx->chroms[ci];
         if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
         if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots * sizeof(uint32_t)));
@@ -224,12 +228,20 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
     SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 2 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t ci = 0; ci < C; ci++) {
+    for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
         ctx->chroms[ci].length_sum = (int64_t)h[2 * ci];
         ctx->chroms[ci].n_dump = (int64_t)h[2 * ci + 1];
     }
     ctx->counted = true;
     return SP_OK;
+}
+
+int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
+    return count_impl(ctx, k, lower_count, engine, 0, ctx ? (int)ctx->chroms.size() : 0);
+}
+
+int sp_count_range(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last) {
+    return count_impl(ctx, k, lower_count, engine, first, last);
 }
 
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {

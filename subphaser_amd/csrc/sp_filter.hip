@@ -463,6 +463,28 @@ int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs
     return emit_common(ctx, false, keys, counts, freqs, tot, cap_rows);
 }
 
+int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_tot, int64_t cap_rows) {
+    if (!ctx) return SP_EINVAL;
+    if (!ctx->filtered) return sp_fail(ctx, SP_EINVAL, "call sp_filter first");
+    if (ctx->sparse_mode) return sp_fail(ctx, SP_EUNSUP, "sp_filter_fetch_device: k <= 15 only");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t M = ctx->n_rows;
+    if (cap_rows < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap_rows, (long long)M);
+    if (M == 0) return SP_OK;
+    const int C = filter_C(ctx);
+    const uint32_t **d_tabs = nullptr;
+    double *d_len = nullptr;
+    int rc = upload_tabs(ctx, &d_tabs, &d_len);
+    if (rc) return rc;
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    SP_LAUNCH(ctx, "k3_emit", k3_emit, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0, d_tabs, C,
+              (uint32_t)ctx->lower, filter_nslots(ctx), filter_base(ctx), kp,
+              (const unsigned long long *)ctx->d_flag_row, (const unsigned long long *)ctx->d_blk_row, d_len,
+              (unsigned long long *)d_keys, (uint32_t *)d_counts, (double *)nullptr, (unsigned long long *)d_tot);
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
 int sp_filter_hist(sp_ctx *ctx, uint64_t *tot, int64_t cap) {
     if (!ctx || !tot) return sp_fail(ctx, SP_EINVAL, "sp_filter_hist: bad arguments");
     return emit_common(ctx, true, nullptr, nullptr, nullptr, tot, cap);

@@ -13,6 +13,8 @@ Sharding (DESIGN.md "Multi-GPU"):
 Everything that touches torch is passed in (`dist`, `torch`), so the same code runs on CPU
 tensors over gloo in the tests (tests/test_dist_gloo.py) with an oracle-backed context.
 """
+import time
+
 import numpy as np
 
 from .config import sets_to_csr
@@ -64,13 +66,21 @@ class DistHotPath:
         self.chunk_size = kw.get("chunk_size", 10_000_000)
         self.window_size = kw.get("window_size", 1_000_000)
         self.max_pval = kw.get("max_pval", 0.05)
+        self.wall = {}
+        self._pin = {}
+
+    def _t(self, name, t0):
+        t1 = time.perf_counter()
+        self.wall[name] = self.wall.get(name, 0.0) + (t1 - t0)
+        return t1
 
     # ------------------------------------------------------------------ helpers
     def _ptr(self, tensor):
         return tensor.data_ptr()
 
-    def _all_gather_rows(self, arr, dtype):
-        """all_gather of a [m, w] host array with rank-dependent m -> concatenated host array."""
+    def _all_gather_rows(self, arr, dtype, to_host=True):
+        """all_gather of a [m, w] host array with rank-dependent m -> concatenated host array
+        (None when to_host is False: the rank took part in the collective but needs no copy)."""
         t, dist = self.torch, self.dist
         arr = np.ascontiguousarray(arr)
         w = arr.shape[1] if arr.ndim == 2 else 1
@@ -84,35 +94,75 @@ class DistHotPath:
             pad[: arr.shape[0]] = t.from_numpy(arr.reshape(arr.shape[0], w)).to(self.device)
         outs = [t.zeros((mmax, w), dtype=dtype, device=self.device) for _ in range(self.world)]
         dist.all_gather(outs, pad)
+        if not to_host:
+            return None
         return np.concatenate([o[:n].cpu().numpy() for o, n in zip(outs, ms)], axis=0)
 
+    def _all_gather_dev(self, ten, m):
+        """all_gather of device tensors [m_r, w] with rank-dependent m_r -> one device tensor."""
+        t, dist = self.torch, self.dist
+        if self.world == 1:
+            return ten
+        ms = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(ms, t.tensor([m], dtype=t.int64, device=self.device))
+        ms = [int(x.item()) for x in ms]
+        mmax = max(max(ms), 1)
+        pad = t.zeros((mmax, ten.shape[1]), dtype=ten.dtype, device=self.device)
+        pad[:m] = ten
+        outs = [t.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad)
+        return t.cat([o[:n] for o, n in zip(outs, ms)], dim=0)
+
+    def _to_host(self, ten):
+        t = self.torch
+        if ten.device.type != "cuda":
+            return ten.contiguous().numpy()
+        key = (tuple(ten.shape), ten.dtype)
+        buf = self._pin.get(key)
+        if buf is None:
+            buf = t.empty(ten.shape, dtype=ten.dtype, pin_memory=True)
+            if len(self._pin) > 4:
+                self._pin.clear()
+            self._pin[key] = buf
+        buf.copy_(ten)
+        t.cuda.synchronize()
+        return buf.numpy()
+
     # ------------------------------------------------------------------ first half
-    def count_and_filter(self, d_ascii):
-        """d_ascii: list over ALL chromosomes; entries of chromosomes owned elsewhere are None."""
+    def count_and_filter(self, d_ascii, host_rows_on_all_ranks=True):
+        """d_ascii: list over ALL chromosomes; entries of chromosomes owned elsewhere are None.
+        host_rows_on_all_ranks=False: only rank 0 copies the gathered matrix to the host."""
         ctx, t, dist = self.ctx, self.torch, self.dist
         mine = self.my_chroms
+        tt = time.perf_counter()
         ctx.genome_reset(len(mine))
         for li, gi in enumerate(mine):
             ctx.tables_bind(li, self._ptr(self.tabs[li]))
             ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
-        if mine:
-            ctx.count(self.k, self.lower_count, self.engine)
-            ctx.sync()
+        ctx.sync()
+        tt = self._t("pack", tt)
+        # count chromosome i, then put its table on the wire (slot-range slice r -> rank r) while
+        # chromosome i+1 is being counted: the exchange hides behind the counting kernels
+        works = []
+        for i in range(self.max_local):
+            if i < len(mine):
+                ctx.count_range(self.k, self.lower_count, self.engine, i, i + 1)   # synchronises
+                send = self.tabs[i].view(self.world, self.chunk)
+            else:
+                if self.dummy is None:
+                    self.dummy = t.zeros((self.world, self.chunk), dtype=t.int32, device=self.device)
+                send = self.dummy
+            if self.world > 1:
+                works.append(dist.all_to_all_single(self.recv[i].view(-1), send.reshape(-1), async_op=True))
+        tt = self._t("count(+exchange issue)", tt)
         # global `lengths` (sum of dumped counts per chromosome): one small all-reduce
         lens = t.zeros(self.C, dtype=t.int64, device=self.device)
         if mine:
             lens[t.tensor(mine, device=self.device)] = t.from_numpy(ctx.lengths()).to(self.device)
         dist.all_reduce(lens)
         lengths = lens.cpu().numpy()
-        # the exchange: slot-range slices of every table to their filter rank
-        for i in range(self.max_local if self.world > 1 else 0):
-            if i < len(mine):
-                send = self.tabs[i].view(self.world, self.chunk)
-            else:
-                if self.dummy is None:
-                    self.dummy = t.zeros((self.world, self.chunk), dtype=t.int32, device=self.device)
-                send = self.dummy
-            dist.all_to_all_single(self.recv[i].view(-1), send.reshape(-1))
+        for w in works:
+            w.wait()
         ptrs = [0] * self.C
         for s, owned in enumerate(self.owned):
             for i, gi in enumerate(owned):
@@ -120,21 +170,30 @@ class DistHotPath:
                 ptrs[gi] = self._ptr(self.recv[i, s]) if self.world > 1 else self._ptr(self.tabs[i])
         if hasattr(t, "cuda") and self.device.type == "cuda":
             t.cuda.synchronize()
+        tt = self._t("lengths+exchange wait", tt)
         ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count)
         n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                              self.max_freq, self.ratio)
-        keys, counts, _, tot = ctx.filter_fetch(n_rows, want_freqs=False, sort=False)
+        # surviving rows stay on the device: gathered over xGMI, copied to the host once, where needed
+        keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
+        counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
+        ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
         ctx.filter_view(None, 0, 0, None, 0, 0)
-        # survivors of every slot range -> every rank (M x C is small)
+        tt = self._t("filter+fetch", tt)
         r = HotPathResult()
         r.kmer_lengths = lengths
-        r.keys = self._all_gather_rows(keys.astype(np.int64).reshape(-1, 1), t.int64).ravel().astype(np.uint64)
-        r.counts = self._all_gather_rows(counts.astype(np.int32), t.int32).astype(np.uint32)
+        to_host = host_rows_on_all_ranks or self.rank == 0
+        gk = self._all_gather_dev(keys_t[:n_rows].reshape(-1, 1), n_rows)
+        gc = self._all_gather_dev(counts_t[:n_rows], n_rows)
+        if to_host:
+            r.keys = self._to_host(gk).ravel().view(np.uint64)
+            r.counts = self._to_host(gc).view(np.uint32)
+            r.tot = None      # row sums: counts.sum(axis=1) on demand
         stats = t.tensor([n_union, n_rows, n_hist], dtype=t.int64, device=self.device)
         dist.all_reduce(stats)
         r.n_union, r.n_rows, r.n_hist = (int(x) for x in stats.cpu().numpy())
-        r.tot = r.counts.sum(axis=1).astype(np.uint64)
         r.freqs = None
+        tt = self._t("gather rows", tt)
         return r
 
     # ------------------------------------------------------------------ second half
@@ -142,6 +201,7 @@ class DistHotPath:
         ctx, t, dist = self.ctx, self.torch, self.dist
         mine = self.my_chroms
         r = HotPathResult()
+        tt = time.perf_counter()
         r.bins, r.n_mapped = [], 0
         rows = np.zeros((0, 2 + n_sg), np.int64)       # (chromosome, window, counts...)
         if mine:
@@ -156,6 +216,7 @@ class DistHotPath:
                 chrom = np.searchsorted(woff, nz, side="right") - 1
                 gchrom = np.asarray(mine, np.int64)[chrom]
                 rows = np.concatenate([gchrom[:, None], (nz - woff[chrom])[:, None], win[nz].astype(np.int64)], axis=1)
+        tt = self._t("map+stack", tt)
         allrows = self._all_gather_rows(rows, t.int64)
         order = np.lexsort((allrows[:, 1], allrows[:, 0]))
         allrows = allrows[order]
@@ -168,4 +229,5 @@ class DistHotPath:
         if self.rank == 0 and len(r.window_counts):
             with np.errstate(all="ignore"):
                 r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)
+        tt = self._t("gather windows+enrich", tt)
         return r

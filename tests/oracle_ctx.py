@@ -166,6 +166,23 @@ class OracleDistContext(OracleContext):
                 tab[:] = 0
                 tab[kmer.slots_of_keys(keys, k).astype(np.int64)] = cnts
 
+    def filter_fetch_device(self, d_keys, d_counts, d_tot, n_rows):
+        import ctypes
+        f = self._f
+        if n_rows == 0:
+            return
+        C_ = f.counts.shape[1]
+        if d_keys:
+            np.frombuffer((ctypes.c_uint64 * n_rows).from_address(int(d_keys)), np.uint64)[:] = f.keys
+        if d_counts:
+            np.frombuffer((ctypes.c_uint32 * (n_rows * C_)).from_address(int(d_counts)), np.uint32)[:] = f.counts.ravel()
+        if d_tot:
+            np.frombuffer((ctypes.c_uint64 * n_rows).from_address(int(d_tot)), np.uint64)[:] = f.tot
+
+    def count_range(self, k, lower_count, engine, first, last):
+        if first == 0:
+            self.count(k, lower_count, engine)      # the double counts everything on the first call
+
     def filter_view(self, ptrs, slot_base, nview, lengths, k, lower_count):
         self.view = None if ptrs is None else (list(ptrs), int(slot_base), int(nview), np.array(lengths), k, lower_count)
         if ptrs is not None:
