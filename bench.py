@@ -193,10 +193,18 @@ def main():
                      sum_dump=int(sum(a.kmer_lengths)), k=args.k)
         alg = algorithmic_bytes(name, bases_per_launch, nslots, C, S, extra)
         avg_s = st["ms"] / st["calls"] / 1e3
+        traffic = None
+        try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_wheat_pmc_traffic.json")))
+            if args.config == "wheat" and args.k == 15 and world == 1 and name in tj["kernels"]:
+                kk = tj["kernels"][name]
+                traffic = int(kk["read_bytes_per_call"] + kk["write_bytes_per_call"])
+        except (OSError, ValueError, KeyError):
+            pass
         if alg:
             ach = alg / avg_s
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
                         "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
     stages = {k_: {"calls_per_step": v["calls"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 3)}
               for k_, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
