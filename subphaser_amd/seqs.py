@@ -268,4 +268,10 @@ def _write_lines(fout, rid, starts, ends, counts):
 
 
 def _map_long_feature(ctx, seq, bin_size, k):
-    raise NotImplementedError("feature sequences longer than one bin ({} bp) are not supported yet".format(bin_size))
+    """A feature longer than one bin (rare: the reference then emits one line per 10-Mb bin of
+    the record, Seqs.py:228-236).  Bin j owns the k-mer starts [j*bin, (j+1)*bin): those are
+    exactly the k-mers of the piece seq[j*bin : (j+1)*bin + k-1], so the per-bin counts are the
+    whole-piece totals of an ordinary feature batch."""
+    nb = -(-len(seq) // bin_size)
+    pieces = [seq[j * bin_size:(j + 1) * bin_size + k - 1] for j in range(nb)]
+    return np.asarray(ctx.map_features(pieces), np.int64)

@@ -308,3 +308,20 @@ def check_pipeline_cli(ctx, golden, toy, tmp_path):
         assert len(open(str(base) + ext).read().strip().split("\n")) > 1, ext
     assert (tmpd / "split.ok").exists() and (tmpd / ("k%d_q30_f2.kmer.mat.ok" % K)).exists()
     assert (tmpd / "chromosomes" / "A1.fasta").exists()
+
+
+def check_long_feature(ctx, golden, toy, tmp_path):
+    """A feature longer than the bin size is reported per bin, like a chunk-less chromosome."""
+    cl, labels = check_output_kmers(ctx, golden, toy)
+    seq = toy["seqs"]["B1"][:12345]
+    ff = tmp_path / "long.fa"
+    ff.write_text(">B1:0-12345\n%s\n>short:1-40\n%s\n" % (seq, seq[5000:5040]))
+    buf = io.StringIO()
+    seqs.map_kmer3([str(ff)], labels, fout=buf, k=K, bin_size=1000, sg_names=cl.sg_names, chunk=False, log=False,
+                   ctx=ctx)
+    exp, _, _ = po.map_bins(seq, K, labels.keys, labels.sg_idx, len(cl.sg_names), 1000, 0)
+    lines = [l.split("\t") for l in buf.getvalue().strip().split("\n")[1:] if l.startswith("B1:")]
+    got = {int(l[1]) // 1000: [int(x) for x in l[3:]] for l in lines}
+    for b in range(13):
+        assert got.get(b, [0] * len(cl.sg_names)) == exp[b].tolist(), b
+    assert all(int(l[2]) == min(int(l[1]) + 1000, 12345) for l in lines)

@@ -61,6 +61,23 @@ def test_map_features(oracle_ctx, golden, toy, tmp_path):
     pc.check_map_features(oracle_ctx, golden, toy, tmp_path)
 
 
+def test_long_feature(oracle_ctx, golden, toy, tmp_path):
+    pc.check_long_feature(oracle_ctx, golden, toy, tmp_path)
+
+
+def test_kmeans_assignment(oracle_ctx, golden, toy):
+    """No -sg_assigned: scikit-learn KMeans on the Z-normalised matrix, as the reference does,
+    separates the two planted subgenomes of the toy genome."""
+    from subphaser_amd import cluster
+    d2 = pc.check_kmer_mat_text(oracle_ctx, golden, toy)
+    cl = cluster.Cluster(d2, n_clusters=2)
+    groups = {}
+    for c, sg in cl.d_sg.items():
+        groups.setdefault(sg, set()).add(c[0])
+    assert sorted(cl.sg_names) == ["SG1", "SG2"]
+    assert sorted(tuple(sorted(v)) for v in groups.values()) == [("A",), ("B",)]
+
+
 def test_map_dict_labels(oracle_ctx, golden, toy):
     pc.check_dict_labels(oracle_ctx, golden, toy)
 

@@ -280,6 +280,10 @@ def test_map_features(gpu_ctx, golden, toy, tmp_path):
     pc.check_map_features(gpu_ctx, golden, toy, tmp_path)
 
 
+def test_long_feature(gpu_ctx, golden, toy, tmp_path):
+    pc.check_long_feature(gpu_ctx, golden, toy, tmp_path)
+
+
 def test_map_dict_labels(gpu_ctx, golden, toy):
     pc.check_dict_labels(gpu_ctx, golden, toy)
 
@@ -388,3 +392,51 @@ def test_full_size_properties(gpu_ctx):
     got, nmap = gpu_ctx.map_bins(0, 10000, 10_000_000)
     assert nmap == int(cnts3.astype(np.int64).sum()) == int(got.sum())
     assert gpu_ctx.labels_hit() == keys3.size
+
+
+def test_wheat_sized_chromosome_properties(gpu_ctx):
+    """A chromosome of the size BASELINE.json's headline config uses (667 Mb) is far beyond what the
+    CPU oracle finishes in seconds, so the check is by size-independent properties:
+    engine 1 and engine 2 build the same table (same totals at two thresholds, identical dump of the
+    high-count k-mers); sum of counts == number of valid windows (run-length identity on a 64-Mb
+    prefix copied back); every occurrence of a labelled k-mer is mapped exactly once; windows sum to bins."""
+    n = 667_000_000
+    d = gpu_ctx.dev_alloc(n)
+    try:
+        gpu_ctx.synth_chrom(d, n, seed=3, set_id=1, sg_id=2, n_sg=3, chrom_id=5)
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.genome_add_device(0, d, n)
+        res = {}
+        for eng in (1, 2):
+            gpu_ctx.count(15, 1, eng)
+            tot1 = int(gpu_ctx.lengths()[0])
+            gpu_ctx.count(15, 200, eng)
+            tot200 = int(gpu_ctx.lengths()[0])
+            keys, cnts = gpu_ctx.dump(0)
+            res[eng] = (tot1, tot200, keys, cnts)
+        assert res[1][0] == res[2][0] and res[1][1] == res[2][1]
+        assert (res[1][2] == res[2][2]).all() and (res[1][3] == res[2][3]).all()
+        tot1, tot200, keys, cnts = res[2]
+        assert len(keys) > 1000 and int(cnts.astype(np.int64).sum()) == tot200
+        # valid-window identity: N runs of 1000 every 50 Mb, nothing else invalid in the generator
+        m = 64_000_000
+        host = gpu_ctx.dev_to_host(d, m)
+        up = host & 0xDF
+        ok = (up == 65) | (up == 67) | (up == 71) | (up == 84)
+        n_runs = (n - 1) // 50_000_000                  # runs at 50M, 100M, ... < n
+        assert int((~ok).sum()) == 1000                 # the prefix holds exactly one N run
+        expected = (n - 14) - n_runs * (1000 + 14)      # each run kills 1000 + (k-1) windows
+        assert tot1 == expected, (tot1, expected)
+        # map: label every dumped k-mer, alternate subgenomes
+        sg = (np.arange(keys.size) % 3).astype(np.uint8)
+        gpu_ctx.labels_set(keys, sg, 3)
+        slots, nm = gpu_ctx.map_bins_all(10000, 10_000_000)
+        assert int(nm[0]) == tot200 == int(slots[0].astype(np.int64).sum())
+        per_sg = [int(cnts[sg == j].astype(np.int64).sum()) for j in range(3)]
+        assert slots[0].astype(np.int64).sum(axis=0).tolist() == per_sg
+        win, woff = gpu_ctx.stack_windows(10000, 10_000_000, 1_000_000, [n])
+        assert win.sum(axis=0).tolist() == per_sg
+        assert gpu_ctx.labels_hit() == keys.size
+    finally:
+        gpu_ctx.sync()
+        gpu_ctx.dev_free(d)
