@@ -60,23 +60,64 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
 }
 
 // ---------------------------------------------------------------- c2_hist
-__global__ void __launch_bounds__(C2_HIST_THREADS)
-c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units,
-        sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine,
-        unsigned long long *__restrict__ ghist) {
+// One scan of the chromosome produces (a) the fine histogram (top B1+B2 slot bits; sizes every
+// bucket exactly) and (b) the level-1 bucket counts of every part1 tile, so that part1 needs
+// neither its own histogram pass nor global cursors: each tile's output offsets come from a
+// column scan over tiles (c2_tilescan) -- deterministic layout, no contended atomics.
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
+        sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine, int shift1, int F1, int64_t n_tiles,
+        unsigned long long *__restrict__ ghist, uint32_t *__restrict__ tile_cnt /* [F1][n_tiles] */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
+    __shared__ uint32_t th[C2_MAXF];
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
-    __syncthreads();
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units;
-         u += (int64_t)gridDim.x * blockDim.x) {
-        sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-            atomicAdd(&lh[sp_slot_of32(fwd, rc, kp) >> shift_fine], 1u);
-        });
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < F1) th[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
+        if (u < n_units)
+            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+                atomicAdd(&lh[slot >> shift_fine], 1u);
+                atomicAdd(&th[slot >> shift1], 1u);
+            });
+        __syncthreads();
+        if (threadIdx.x < F1) tile_cnt[(int64_t)threadIdx.x * n_tiles + tile] = th[threadIdx.x];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) {
         uint32_t v = lh[i];
         if (v) atomicAdd(&ghist[i], (unsigned long long)v);
+    }
+}
+
+// per level-1 bucket: exclusive scan of the tile counts over tiles (one block per bucket)
+__global__ void __launch_bounds__(256)
+c2_tilescan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, int64_t n_tiles) {
+    __shared__ uint32_t part[256];
+    const uint32_t *c = cnt + (int64_t)blockIdx.x * n_tiles;
+    uint32_t *o = off + (int64_t)blockIdx.x * n_tiles;
+    const int64_t per = (n_tiles + 255) / 256;
+    int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
+    if (hi > n_tiles) hi = n_tiles;
+    uint32_t s = 0;
+    for (int64_t i = lo; i < hi; i++) s += c[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) {
+            uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int64_t i = lo; i < hi; i++) {
+        uint32_t v = c[i];
+        o[i] = run;
+        run += v;
     }
 }
 
@@ -155,27 +196,21 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
          sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
-         unsigned long long *__restrict__ cursor1 /*F1, zeroed*/, uint32_t *__restrict__ buf1) {
+         const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, int64_t n_tiles,
+         uint32_t *__restrict__ buf1) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
     __shared__ uint32_t keys[C2_P1_KEYS];
-    const int64_t n_tiles = (n_units + C2_P1_THREADS - 1) / C2_P1_THREADS;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
-        if (threadIdx.x < F1) hist[threadIdx.x] = 0;
-        __syncthreads();
-        if (u < n_units)
-            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-                atomicAdd(&hist[sp_slot_of32(fwd, rc, kp) >> shift1], 1u);
-            });
-        __syncthreads();
-        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
         if (threadIdx.x < F1) {
-            uint32_t c = hist[threadIdx.x];
-            gbase[threadIdx.x] = off1[threadIdx.x] + (c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL);
+            const int64_t e = (int64_t)threadIdx.x * n_tiles + tile;
+            hist[threadIdx.x] = tile_cnt[e];
+            gbase[threadIdx.x] = off1[threadIdx.x] + tile_off[e];
             cur[threadIdx.x] = 0;
         }
         __syncthreads();
+        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
         if (u < n_units)
             sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
                 const uint32_t slot = sp_slot_of32(fwd, rc, kp);
@@ -193,6 +228,20 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
 }
 
 // ---------------------------------------------------------------- c2_part2
+// Software-pipelined over the tiles a block processes: the keys of tile i+1 and the global cursor
+// atomics of tile i are in flight while tile i is scanned / scattered / written (the kernel was
+// 83 % SQ_WAIT_ANY without this).
+__device__ __forceinline__ int c2_bucket_of(const unsigned long long *__restrict__ tile_start, int F1,
+                                            unsigned long long tile) {
+    int lo = 0, hi = F1;  // last b with tile_start[b] <= tile
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(C2_P2_THREADS)
 c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
@@ -201,59 +250,81 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
     __shared__ uint32_t keys[C2_TILE_KEYS];
-    __shared__ int s_bucket;
+    __shared__ int s_bucket[2];
     const unsigned long long n_tiles = tile_start[F1];
     const uint32_t mask2 = (uint32_t)F2 - 1u;
-    for (unsigned long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x == 0) {  // bucket of this tile: last b with tile_start[b] <= tile
-            int lo = 0, hi = F1;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (tile_start[mid] <= tile) lo = mid;
-                else hi = mid;
-            }
-            s_bucket = lo;
-        }
-        if (threadIdx.x < F2) hist[threadIdx.x] = 0;
-        __syncthreads();
-        const int b1 = s_bucket;
-        const unsigned long long base = off1[b1] + (tile - tile_start[b1]) * C2_TILE_KEYS;
-        const unsigned long long end = off1[b1 + 1];
-        uint32_t my[C2_P2_PER];
-        int nmine = 0;
+    unsigned long long tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if (threadIdx.x == 0) s_bucket[0] = c2_bucket_of(tile_start, F1, tile);
+    __syncthreads();
+    uint32_t nxt[C2_P2_PER];
+    int nnext = 0;
+    {
+        const int nb = s_bucket[0];
+        const unsigned long long base = off1[nb] + (tile - tile_start[nb]) * C2_TILE_KEYS, end = off1[nb + 1];
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++) {
-            unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
+            const unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
             if (idx < end) {
-                my[j] = buf1[idx];
-                atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
-                nmine = j + 1;
+                nxt[j] = buf1[idx];
+                nnext = j + 1;
             }
         }
-        __syncthreads();
+    }
+    int p = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int b1 = s_bucket[p];
+        uint32_t my[C2_P2_PER];
+#pragma unroll
+        for (int j = 0; j < C2_P2_PER; j++) my[j] = nxt[j];
+        const int nmine = nnext;
+        const unsigned long long ntile = tile + gridDim.x;
+        if (threadIdx.x < F2) hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0 && ntile < n_tiles) s_bucket[p ^ 1] = c2_bucket_of(tile_start, F1, ntile);
+        __syncthreads();  // (A) also: the previous tile's copy-out has finished reading keys/start/gbase
+#pragma unroll
+        for (int j = 0; j < C2_P2_PER; j++)
+            if (j < nmine) atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
+        __syncthreads();  // (B)
+        unsigned long long g = 0;
+        if (threadIdx.x < F2) {  // reserve the output ranges now; the result is needed only after the scan
+            const uint32_t c = hist[threadIdx.x];
+            const size_t fine = (size_t)b1 * F2 + threadIdx.x;
+            g = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+        }
+        nnext = 0;
+        if (ntile < n_tiles) {  // next tile's keys: in flight across the rest of this iteration
+            const int nb = s_bucket[p ^ 1];
+            const unsigned long long base = off1[nb] + (ntile - tile_start[nb]) * C2_TILE_KEYS, end = off1[nb + 1];
+#pragma unroll
+            for (int j = 0; j < C2_P2_PER; j++) {
+                const unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
+                if (idx < end) {
+                    nxt[j] = buf1[idx];
+                    nnext = j + 1;
+                }
+            }
+        }
         const uint32_t total = c2_scan_F(hist, start, F2, wsum);
         if (threadIdx.x < F2) {
-            uint32_t c = hist[threadIdx.x];
-            size_t fine = (size_t)b1 * F2 + threadIdx.x;
-            gbase[threadIdx.x] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+            gbase[threadIdx.x] = g;
             cur[threadIdx.x] = 0;
         }
-        __syncthreads();
+        __syncthreads();  // (C)
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++) {
             if (j < nmine) {
-                uint32_t b = (my[j] >> shift2) & mask2;
-                uint32_t pos = start[b] + atomicAdd(&cur[b], 1u);
-                keys[pos] = my[j];
+                const uint32_t b = (my[j] >> shift2) & mask2;
+                keys[start[b] + atomicAdd(&cur[b], 1u)] = my[j];
             }
         }
-        __syncthreads();
+        __syncthreads();  // (D)
         for (uint32_t i = threadIdx.x; i < total; i += C2_P2_THREADS) {
-            uint32_t s = keys[i];
-            uint32_t b = (s >> shift2) & mask2;
+            const uint32_t s = keys[i];
+            const uint32_t b = (s >> shift2) & mask2;
             buf2[gbase[b] + (i - start[b])] = (uint16_t)(s & (C2_FINE - 1));
         }
-        __syncthreads();
+        p ^= 1;
     }
 }
 
@@ -343,7 +414,11 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 8);
     size_t o_cur1 = o_tile + al((size_t)(P.F1 + 1) * 8);
     size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
-    size_t o_buf1 = o_cur2 + al(nf * 8);
+    const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
+    const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
+    size_t o_tcnt = o_cur2 + al(nf * 8);
+    size_t o_toff = o_tcnt + al((size_t)P.F1 * (size_t)n_tiles * 4);
+    size_t o_buf1 = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
     size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64);
     size_t total = o_buf2 + al((size_t)c.len * 2 + 64);
     if ((int64_t)total > ctx->ws2_bytes) {
@@ -363,26 +438,27 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     unsigned long long *tile_start = (unsigned long long *)(ws + o_tile);
     unsigned long long *cur1 = (unsigned long long *)(ws + o_cur1);
     unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
+    uint32_t *tile_cnt = (uint32_t *)(ws + o_tcnt);
+    uint32_t *tile_off = (uint32_t *)(ws + o_toff);
     uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
     // zero ghist .. cursor2 in one memset (they are contiguous)
-    SP_HIP(ctx, hipMemsetAsync(ws, 0, o_buf1, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(ws, 0, o_tcnt, ctx->stream));
 
     const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
-    const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
-    const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
     int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
     size_t sh_hist = nf * 4;
-    if (sh_hist > 64 * 1024)
+    if (sh_hist > 48 * 1024)
         hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist);
-    int64_t hist_blocks = (n_units + C2_HIST_THREADS - 1) / C2_HIST_THREADS;
-    int grid_hist = (int)(hist_blocks < (int64_t)ctx->n_cu * 2 ? hist_blocks : (int64_t)ctx->n_cu * 2);
-    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_HIST_THREADS), sh_hist, c.d_pk, c.d_nm,
-              n_units, kp32, C2_B3, (int)nf, ghist);
+    int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
+    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_nm, n_units32,
+              kp32, C2_B3, (int)nf, P.T - P.B1, P.F1, n_tiles, ghist, tile_cnt);
     SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
               off1, tile_start);
+    SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3(P.F1), dim3(256), 0, (const uint32_t *)tile_cnt, tile_off,
+              n_tiles);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_nm, n_units32,
-              kp32, P.T - P.B1, P.F1, off1, cur1, buf1);
+              kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, buf1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
     int64_t max_tiles2 = n_tiles + P.F1;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
