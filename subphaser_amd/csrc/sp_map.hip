@@ -15,12 +15,34 @@
 #ifndef MAP_BLOOM_BITS
 #define MAP_BLOOM_BITS 25
 #endif
+#ifndef MAP_BLOOM_K
+#define MAP_BLOOM_K 3
+#endif
 #ifndef MAP_NT
 #define MAP_NT 0
 #endif
-__host__ __device__ __forceinline__ uint32_t map_bloom_idx(uint64_t slot) {
-    uint32_t x = (uint32_t)slot ^ (uint32_t)(slot >> 32);
-    return (x * 0x9E3779B1u) >> (32 - MAP_BLOOM_BITS);
+// Blocked Bloom filter: one 32-bit word per key (ONE memory access per probe), two bits in it.
+// 2.2 M keys in 2^25 bits: single bit 6.5 % false positives (K5 120 ms), two bits ~2 % (109 ms),
+// three bits ~1 % (106 ms).
+struct map_bloom_probe {
+    uint32_t word, bits;
+};
+__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t slot) {
+    const uint32_t x = (uint32_t)slot ^ (uint32_t)(slot >> 32);
+    const uint32_t h = x * 0x9E3779B1u;
+    map_bloom_probe p;
+    p.word = h >> (32 - (MAP_BLOOM_BITS - 5));
+#if MAP_BLOOM_K == 3
+    const uint32_t h2 = x * 0x85EBCA6Bu;
+    p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)) | (1u << (h2 >> 27));
+#else
+    p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u));
+#endif
+    return p;
+}
+__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, uint64_t slot) {
+    const map_bloom_probe p = map_bloom(slot);
+    return (bloom[p.word] & p.bits) == p.bits;
 }
 
 __global__ void __launch_bounds__(256)
@@ -30,8 +52,8 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
     if (i >= n) return;
     const uint64_t slot = sp_slot_of_key(keys[i], kp);
     label[slot] = (uint8_t)(1u + sg[i]);
-    const uint32_t b = map_bloom_idx(slot);
-    atomicOr(&bloom[b >> 5], 1u << (b & 31));
+    const map_bloom_probe p = map_bloom(slot);
+    atomicOr(&bloom[p.word], p.bits);
 }
 
 // ----------------------------------------------------------------- K5
@@ -75,8 +97,7 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
         if (u < P.n_units) {
             sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
                 const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-                const uint32_t bi = map_bloom_idx(slot);
-                if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return;   // L2-resident pre-filter
+                if (!map_bloom_test(bloom, slot)) return;   // L2-resident pre-filter
 #if MAP_NT
                 const uint32_t l = __builtin_nontemporal_load(&label[slot]);   // do not let table lines evict the pre-filter from L2
 #else
@@ -152,8 +173,7 @@ k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp
     for (; u < n_units; u += stride) {
         sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
             const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-            const uint32_t bi = map_bloom_idx(slot);
-            if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return;
+            if (!map_bloom_test(bloom, slot)) return;
             const uint32_t l = label[slot];
             if (l) {
                 if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);

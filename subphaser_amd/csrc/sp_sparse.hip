@@ -197,15 +197,14 @@ sps_hash_insert(const unsigned long long *__restrict__ keys, const uint8_t *__re
         h = (h + 1) & mask;
     }
     hlab[h] = (uint8_t)(1u + sg[i]);
-    const uint32_t b = map_bloom_idx(key);
-    atomicOr(&bloom[b >> 5], 1u << (b & 31));
+    const map_bloom_probe p = map_bloom(key);
+    atomicOr(&bloom[p.word], p.bits);
 }
 
 __device__ __forceinline__ int sps_lookup(uint64_t key, const unsigned long long *__restrict__ hkeys,
                                           uint8_t *__restrict__ hlab, uint64_t mask,
                                           const uint32_t *__restrict__ bloom) {
-    const uint32_t bi = map_bloom_idx(key);
-    if (!((bloom[bi >> 5] >> (bi & 31)) & 1u)) return -1;
+    if (!map_bloom_test(bloom, key)) return -1;
     uint64_t h = sps_mix(key) & mask;
     for (;;) {
         const unsigned long long kk = hkeys[h];
