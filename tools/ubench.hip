@@ -42,6 +42,17 @@ __global__ void __launch_bounds__(256) k_gatherbit(const uint32_t *tab, uint64_t
     if (acc == 0xffffffffu) out[0] = acc;
 }
 
+// grouped gather: G adjacent lanes read (different words of) the same 64-B line
+__global__ void __launch_bounds__(256) k_gather_grouped(const uint32_t *tab, uint64_t mask_lines, int G, int per_thread, uint32_t *out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (int i = 0; i < per_thread; i++) {
+        uint64_t line = mix((t / G) * 1315423911ULL + i) & mask_lines;
+        acc += tab[line * 16 + (t % 16)];
+    }
+    if (acc == 0xffffffffu) out[0] = acc;
+}
+
 // LDS histogram: random increments into `bins` u32 counters, then flush (store) to global
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_ldshist(uint32_t *out, int bins, int per_thread) {
@@ -186,6 +197,19 @@ int main() {
             CK(hipEventRecord(e1));
             double ms = timeit(e0, e1);
             if (rep) printf("gather bit random over %6llu KiB bitmap: %.3f ms  %.2f G/s\n", sz >> 10, ms, n / ms / 1e6);
+        }
+    }
+    for (unsigned long long sz : {4ULL << 20, 32ULL << 20, 512ULL << 20}) {
+        for (int G : {1, 2, 4, 8, 16}) {
+            int per = 64;
+            double n = (double)blocks * threads * per;
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipEventRecord(e0));
+                k_gather_grouped<<<blocks, threads>>>((const uint32_t *)buf, sz / 64 - 1, G, per, out);
+                CK(hipEventRecord(e1));
+                double ms = timeit(e0, e1);
+                if (rep) printf("grouped gather (G=%2d lanes per 64-B line) over %4llu MiB: %.3f ms  %.2f G lanes/s  %.2f G lines/s\n", G, sz >> 20, ms, n / ms / 1e6, n / G / ms / 1e6);
+            }
         }
     }
     // LDS histogram
