@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL process group, table exchange) even with one rank")
-    ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "40")))
+    ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "300")))
     return ap.parse_args()
 
 
