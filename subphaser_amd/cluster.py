@@ -117,10 +117,15 @@ class Cluster:
         print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
         with np.errstate(invalid="ignore"):
             keep = np.flatnonzero(~(pvals > max_pval))      # `if pvalue > max_pval: continue` keeps NaN
-        kmers = kmerlib.decode_many(self.keys[keep], self.k)
-        for km, i in zip(kmers, keep.tolist()):
-            print("\t".join([km, sgs[top[i]], repr(float(pvals[i])),
-                             ",".join(repr(float(x)) for x in means[i])]), file=fout)
+        from .textio import write_chunks
+        kkeys, ktop, kp, kmeans, k = self.keys[keep], top[keep], pvals[keep], means[keep], self.k
+
+        def fmt(lo, hi):
+            kmers = kmerlib.decode_many(kkeys[lo:hi], k)
+            return "".join("\t".join([km, sgs[t], repr(p), ",".join(map(repr, mv))]) + "\n"
+                           for km, t, p, mv in zip(kmers, ktop[lo:hi].tolist(), kp[lo:hi].tolist(), kmeans[lo:hi].tolist()))
+        fout.flush() if hasattr(fout, "flush") else None
+        write_chunks(fout, len(kkeys), fmt)
         canon = kmerlib.canonical(self.keys[keep], self.k)
         return KmerLabels(canon, top[keep].astype(np.uint8), sgs, self.k)
 

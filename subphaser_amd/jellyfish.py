@@ -170,13 +170,15 @@ class JellyfishDumps:
     def write_matrix(self, d_mat, fout):
         """`.kmer.mat`: header `kmer <labels>`, rows k-mer + str(count/length)
         (Jellyfish.py:515-520; read back by Data.py:6-21)."""
+        from .textio import write_chunks
         fout.write("\t".join(["kmer"] + list(self.labels)) + "\n")
-        kmers = d_mat.kmers()
-        rows = d_mat.freqs.tolist()
-        step = 100000
-        for i in range(0, len(kmers), step):
-            fout.write("".join(km + "\t" + "\t".join(map(repr, row)) + "\n"
-                               for km, row in zip(kmers[i:i + step], rows[i:i + step])))
+        keys, freqs, k = d_mat.keys, d_mat.freqs, d_mat.k
+
+        def fmt(lo, hi):
+            kmers = kmerlib.decode_many(keys[lo:hi], k)
+            return "".join(km + "\t" + "\t".join(map(repr, row)) + "\n"
+                           for km, row in zip(kmers, freqs[lo:hi].tolist()))
+        write_chunks(fout, len(keys), fmt)
 
 
 def plot_histogram(data, outfig, step=25, xlim=99, xlabel="Kmer occurrence", ylabel="Count", vline=None):

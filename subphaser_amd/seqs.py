@@ -28,39 +28,74 @@ def _open_bytes(path):
     return open(path, "rb")
 
 
-def read_fasta(path):
-    """Yield (id, sequence bytes without newlines) for every record of a (gz) FASTA file."""
-    with _open_bytes(path) as fh:
-        data = fh.read()
-    if not data:
+def _strip_newlines(body):
+    """Sequence bytes of a FASTA record body (uint8 array view) without line breaks.
+    Fast path: fixed-width lines (every (w+1)-th byte is '\n') -> one strided copy."""
+    n = body.size
+    if n == 0:
+        return body
+    first = int(np.argmax(body == 10)) if (body[: min(n, 1 << 16)] == 10).any() else -1
+    if first > 0:
+        w = first
+        rows = n // (w + 1)
+        if rows > 0:
+            grid = body[: rows * (w + 1)].reshape(rows, w + 1)
+            if (grid[:, w] == 10).all():
+                tail = body[rows * (w + 1):]
+                head = grid[:, :w]
+                # fixed width holds for the whole prefix; check the data columns carry no stray breaks
+                if tail.size <= w + 1 and not (tail[:-1] == 10).any() if tail.size else True:
+                    t = tail[tail != 10] if tail.size else tail
+                    if not ((head <= 32).any() or (t <= 32).any()):      # no stray break/blank inside the lines
+                        return np.concatenate([head.reshape(-1), t]) if t.size else np.ascontiguousarray(head).reshape(-1)
+    keep = (body != 10) & (body != 13) & (body != 32) & (body != 9)
+    return body[keep]
+
+
+def read_fasta(path, as_array=False):
+    """Yield (id, sequence without line breaks) for every record of a (gz) FASTA file.
+    as_array=True yields uint8 numpy arrays (no extra copy for multi-GB genomes), else bytes."""
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    if magic == b"\x1f\x8b":
+        with gzip.open(path, "rb") as fh:
+            data = np.frombuffer(fh.read(), np.uint8)
+    else:
+        if os.path.getsize(path) == 0:
+            return
+        data = np.memmap(path, dtype=np.uint8, mode="r")
+    if data.size == 0:
         return
-    pos = data.find(b">")
-    while pos != -1:
-        nl = data.find(b"\n", pos)
-        if nl == -1:
-            nl = len(data)
-        header = data[pos + 1:nl].decode().split()
+    # record starts: '>' at the beginning of a line
+    starts, step = [], 1 << 28
+    for lo in range(0, int(data.size), step):
+        for i in np.flatnonzero(data[lo:lo + step] == 62).tolist():
+            i += lo
+            if i == 0 or data[i - 1] == 10:
+                starts.append(i)
+    for a, b in zip(starts, starts[1:] + [int(data.size)]):
+        rec = data[a:b]
+        nl = int(np.argmax(rec == 10)) if (rec == 10).any() else rec.size
+        header = bytes(rec[1:nl]).decode().split()
         rid = header[0] if header else ""
-        nxt = data.find(b"\n>", nl)
-        body = data[nl + 1:(nxt if nxt != -1 else len(data))]
-        yield rid, body.translate(None, b"\n\r \t")
-        pos = nxt + 1 if nxt != -1 else -1
+        seq = _strip_newlines(rec[nl + 1:])
+        yield rid, (seq if as_array else seq.tobytes())
 
 
 def write_fasta(path, rid, seq, width=60):
+    seq = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, np.uint8)
     with open(path, "wb") as f:
         f.write(b">" + rid.encode() + b"\n")
-        n = len(seq)
+        n = seq.size
         if n:
             full = (n // width) * width
             if full:
-                a = np.frombuffer(seq, np.uint8, full).reshape(-1, width)
-                b = np.empty((a.shape[0], width + 1), np.uint8)
-                b[:, :width] = a
+                b = np.empty((full // width, width + 1), np.uint8)
+                b[:, :width] = seq[:full].reshape(-1, width)
                 b[:, width] = 10
-                f.write(b.tobytes())
+                f.write(b.data)
             if n > full:
-                f.write(seq[full:] + b"\n")
+                f.write(seq[full:].tobytes() + b"\n")
 
 
 class ChromRecord:
@@ -93,8 +128,11 @@ def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", w
     else:
         d_targets2 = copy.deepcopy(d_targets)
     outfas, labels, d_size, got = [], [], {}, set()
+    from concurrent.futures import ThreadPoolExecutor
+    writer = ThreadPoolExecutor(max_workers=4) if write_files else None   # file writes overlap the parsing
+    pending = []
     for genome, prefix in zip(genomes, prefixes):
-        for old_id, seq in read_fasta(genome):
+        for old_id, seq in read_fasta(genome, as_array=True):
             new_id = "{}{}".format(prefix, old_id)
             if new_id in d_targets:
                 rid = new_id
@@ -106,11 +144,15 @@ def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", w
             rid = d_targets[rid]
             outfa = "{}{}.fasta".format(outdir, rid)
             if write_files:
-                write_fasta(outfa, rid, seq)
+                pending.append(writer.submit(write_fasta, outfa, rid, seq))
             _REG[outfa] = ChromRecord(rid, seq)
             outfas.append(outfa)
             labels.append(rid)
             d_size[rid] = len(seq)
+    for fut in pending:
+        fut.result()
+    if writer is not None:
+        writer.shutdown()
     missing = set(d_targets) - got
     if missing:
         logger.error("Chromosomes {} are not found in sequences files".format(missing))
@@ -125,7 +167,7 @@ def load_chromfile(chromfile):
         if not recs:
             raise ValueError("no FASTA record in {}".format(chromfile))
         # one record per file (Seqs.py:62-64); several records are joined with an N so no k-mer spans them
-        rec = ChromRecord(recs[0][0], b"N".join(sq for _, sq in recs))
+        rec = ChromRecord(recs[0][0], recs[0][1] if len(recs) == 1 else b"N".join(sq for _, sq in recs))
         _REG[chromfile] = rec
     return rec
 

@@ -110,7 +110,7 @@ def test_fasta_reader_and_split(tmp_path):
     assert labels == ["A", "chr2"] and d_size == {"A": 10, "chr2": 4}
     assert list(d_targets.items()) == [("A|chr1", "A"), ("chr2", "chr2")]
     assert open(files[0]).read() == ">A\nACGTacgtNN\n"
-    assert seqs.load_chromfile(files[1]).seq == b"TTTT"
+    assert bytes(seqs.load_chromfile(files[1]).seq) == b"TTTT"   # seq is bytes-like (bytes or a uint8 view of the mmap)
 
 
 def test_stat_enrich_summary(tmp_path):
