@@ -75,7 +75,8 @@ struct sp_ctx {
     int64_t n_fblocks = 0;
     // labels
     uint8_t *d_label = nullptr;  // [nslots] 0 = none, 1+sg; bit 7 = seen
-    uint32_t *d_bloom = nullptr; // 2^25-bit pre-filter over hashed slots (4 MiB: L2-resident)
+    uint32_t *d_bloom = nullptr; // L2-resident pair filter over hashed (k-1)-mers (sp_map.hip), 2^bloom_bits bits
+    int bloom_bits = 0;
     int n_sg = 0;
     int64_t n_labels = 0;
     // scratch
@@ -88,8 +89,7 @@ struct sp_ctx {
     std::vector<sp_sparse_chrom> sparse;
     sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist;
     int64_t sf_n = 0;
-    uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers
-    uint8_t *d_hlab = nullptr;
+    uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers: 16-B entries {key, label}
     int64_t hcap = 0;
     sp_buf b_map, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
     bool map_all_valid = false;

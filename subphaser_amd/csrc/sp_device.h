@@ -76,6 +76,49 @@ __device__ __forceinline__ void sp_scan_unit_t(const uint32_t *__restrict__ pk,
     }
 }
 
+// Same walk, but step(start, fwd, rc, run) is called for EVERY start of the unit (run = number of
+// valid bases ending at the k-mer's last base; the k-mer is valid iff run >= k).  Used by the
+// mapping kernel, which tests the (k-1)-mer two neighbouring k-mers share (valid iff run >= k-1).
+template <int UNIT, typename KeyT, typename KP, typename F>
+__device__ __forceinline__ void sp_scan_unit_all(const uint32_t *__restrict__ pk,
+                                                 const uint32_t *__restrict__ nm, int64_t s0,
+                                                 const KP &kp, F &&step) {
+    constexpr int MW = UNIT / 16;
+    const int64_t w0 = s0 >> 4;
+    uint32_t words[MW + 2];
+    if (MW == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + w0);
+        words[0] = v.x; words[1] = v.y; words[2] = v.z; words[3] = v.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(pk + w0);
+        words[0] = v.x; words[1] = v.y;
+    }
+    words[MW] = pk[w0 + MW];
+    words[MW + 1] = pk[w0 + MW + 1];
+    const uint64_t mlo = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+    const uint32_t mhi = (MW == 4) ? nm[(s0 >> 5) + 2] : 0u;
+    KeyT fwd = 0, rc = 0;
+    int run = 0;
+    const int k = kp.k;
+    const int total = UNIT + k - 1;
+#pragma unroll
+    for (int w = 0; w < MW + 2; w++) {
+        const uint32_t cw = words[w];
+        const uint32_t mw = (w < 4) ? (uint32_t)((mlo >> (16 * w)) & 0xffffu)
+                                    : (uint32_t)((mhi >> (16 * (w - 4))) & 0xffffu);
+        if (w * 16 >= total) break;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int b = w * 16 + j;
+            const uint32_t c = (cw >> (2 * j)) & 3u;
+            fwd = ((fwd << 2) | c) & kp.kmask;
+            rc = (rc >> 2) | ((KeyT)(3u - c) << kp.rcshift);
+            run = ((mw >> j) & 1u) ? 0 : run + 1;
+            if (b >= k - 1 && b < total) step(s0 + b - (k - 1), fwd, rc, run);
+        }
+    }
+}
+
 // 32-bit keys (k <= 16: the dense-table kernels) and 64-bit keys (k <= 32: the sparse engine)
 template <int UNIT, typename F>
 __device__ __forceinline__ void sp_scan_unit32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,

@@ -7,53 +7,105 @@
 
 // ----------------------------------------------------------------- K4
 // Two-level label lookup.  A random 1-byte gather from the 512-MiB label table
-// runs at ~54 G lookups/s on MI355X while a gather from a 4-MiB (L2-resident)
-// structure runs at ~250 G/s (profiles/r01_ubench_mi355x.txt).  Most genome
-// positions do not carry a subgenome-specific k-mer, so every position first
-// probes a hashed 2^25-bit Bloom-style bitmap that fits each XCD's 4-MiB L2 and
-// only positions that pass it touch the exact table.
-#ifndef MAP_BLOOM_BITS
-#define MAP_BLOOM_BITS 25
+// runs at ~54 G lookups/s on MI355X while a gather from an L2-resident structure
+// runs at ~250 G/s (profiles/r01_ubench_mi355x.txt).  Most genome positions do
+// not carry a subgenome-specific k-mer, so positions are first screened by a
+// blocked Bloom filter that fits each XCD's 4-MiB L2 and only positions that
+// pass it touch the exact table.
+//
+// The filter is keyed on the (k-1)-mer that two neighbouring k-mers (starts
+// 2i and 2i+1) SHARE, so ONE L2 probe screens two start positions (7 G probes
+// instead of 14 G on the wheat-like genome; K5 106 -> 84 ms at 2^25 bits, 70 ms
+// at 2^24 bits).  Every labelled k-mer inserts its prefix and its suffix
+// (k-1)-mer in canonical form: if the k-mer at s is labelled, its suffix is in
+// the filter; if the k-mer at s+1 is labelled, its prefix -- the same (k-1)-mer
+// -- is.  Size: the smallest power of two whose measured fill stays below
+// MAP_FILL_MAX, at most 2^25 bits (a 2-MiB filter leaves half of the L2 to the
+// genome stream and the table lines; 2^26 bits does not fit and is slower than
+// no growth).
+#ifndef MAP_BLOOM_MAX_BITS
+#define MAP_BLOOM_MAX_BITS 25
 #endif
-#ifndef MAP_BLOOM_K
-#define MAP_BLOOM_K 3
+#ifndef MAP_BLOOM_MIN_BITS
+#define MAP_BLOOM_MIN_BITS 12
 #endif
-#ifndef MAP_NT
-#define MAP_NT 0
+#ifndef MAP_FILL_MAX
+#define MAP_FILL_MAX 0.40
 #endif
-// Blocked Bloom filter: one 32-bit word per key (ONE memory access per probe), two bits in it.
-// 2.2 M keys in 2^25 bits: single bit 6.5 % false positives (K5 120 ms), two bits ~2 % (109 ms),
-// three bits ~1 % (106 ms).
+// Blocked Bloom filter: one 32-bit word per key (ONE memory access per probe), three bits in it.
 struct map_bloom_probe {
     uint32_t word, bits;
 };
-__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t slot) {
-    const uint32_t x = (uint32_t)slot ^ (uint32_t)(slot >> 32);
+__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t x64, int nbits) {
+    const uint32_t x = (uint32_t)x64 ^ (uint32_t)(x64 >> 32);
     const uint32_t h = x * 0x9E3779B1u;
-    map_bloom_probe p;
-    p.word = h >> (32 - (MAP_BLOOM_BITS - 5));
-#if MAP_BLOOM_K == 3
     const uint32_t h2 = x * 0x85EBCA6Bu;
+    map_bloom_probe p;
+    p.word = h >> (32 - (nbits - 5));
     p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)) | (1u << (h2 >> 27));
-#else
-    p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u));
-#endif
     return p;
 }
-__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, uint64_t slot) {
-    const map_bloom_probe p = map_bloom(slot);
+__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, int nbits, uint64_t x) {
+    const map_bloom_probe p = map_bloom(x, nbits);
     return (bloom[p.word] & p.bits) == p.bits;
+}
+
+// pair filter: prefix and suffix (k-1)-mers of every labelled canonical k-mer
+__global__ void __launch_bounds__(256)
+k4_pair_filter(const unsigned long long *__restrict__ keys, int64_t n, int k, uint32_t *__restrict__ bloom, int nbits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    uint64_t pre = 0, suf = 0;          // k = 1: the shared 0-mer is the constant 0
+    if (k > 1) {
+        const uint64_t m1mask = (k - 1 >= 32) ? ~0ULL : ((1ULL << (2 * (k - 1))) - 1ULL);
+        pre = key >> 2;
+        suf = key & m1mask;
+        const uint64_t rpre = sp_revcomp(pre, k - 1), rsuf = sp_revcomp(suf, k - 1);
+        pre = pre < rpre ? pre : rpre;
+        suf = suf < rsuf ? suf : rsuf;
+    }
+    const map_bloom_probe p = map_bloom(pre, nbits);
+    atomicOr(&bloom[p.word], p.bits);
+    const map_bloom_probe q = map_bloom(suf, nbits);
+    atomicOr(&bloom[q.word], q.bits);
+}
+
+__global__ void __launch_bounds__(256)
+k4_filter_fill(const uint32_t *__restrict__ bloom, int64_t n_words, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x)
+        c += __popc(bloom[i]);
+    unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
+// Walk one unit and call hit(start, fwd, rc) for every VALID start whose pair passes the filter.
+template <typename KeyT, typename KP, typename F>
+__device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
+                                              int64_t s0, const KP &kp, const uint32_t *__restrict__ bloom,
+                                              int nbits, F &&hit) {
+    bool pairhit = false;
+    const KeyT m1mask = (KeyT)(kp.kmask >> 2);
+    sp_scan_unit_all<SP_UNIT, KeyT>(pk, nm, s0, kp, [&](int64_t start, KeyT fwd, KeyT rc, int run) {
+        if (!(start & 1)) {   // first of the pair: screen both members through their shared (k-1)-mer
+            pairhit = false;
+            if (run >= kp.k - 1) {
+                const KeyT mf = fwd & m1mask, mr = rc >> 2;
+                pairhit = map_bloom_test(bloom, nbits, (uint64_t)(mf < mr ? mf : mr));
+            }
+        }
+        if (pairhit && run >= kp.k) hit(start, fwd, rc);
+    });
 }
 
 __global__ void __launch_bounds__(256)
 k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
-          sp_kparams kp, uint8_t *__restrict__ label, uint32_t *__restrict__ bloom) {
+          sp_kparams kp, uint8_t *__restrict__ label) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t slot = sp_slot_of_key(keys[i], kp);
-    label[slot] = (uint8_t)(1u + sg[i]);
-    const map_bloom_probe p = map_bloom(slot);
-    atomicOr(&bloom[p.word], p.bits);
+    label[sp_slot_of_key(keys[i], kp)] = (uint8_t)(1u + sg[i]);
 }
 
 // ----------------------------------------------------------------- K5
@@ -81,7 +133,7 @@ __device__ __forceinline__ int64_t map_slot(int64_t s, const sp_map_params &P, i
 
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
-       sp_map_params P, uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom,
+       sp_map_params P, uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom, int bloom_bits,
        int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
@@ -95,14 +147,9 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kpar
             __syncthreads();
         }
         if (u < P.n_units) {
-            sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+            map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
                 const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-                if (!map_bloom_test(bloom, slot)) return;   // L2-resident pre-filter
-#if MAP_NT
-                const uint32_t l = __builtin_nontemporal_load(&label[slot]);   // do not let table lines evict the pre-filter from L2
-#else
                 const uint32_t l = label[slot];
-#endif
                 if (l) {
                     if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);  // idempotent "seen" mark
                     const int sg = (int)(l & 0x7fu) - 1;
@@ -166,14 +213,13 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
             int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
-            uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom,
+            uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom, int bloom_bits,
             unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
-        sp_scan_unit32<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+        map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
             const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-            if (!map_bloom_test(bloom, slot)) return;
             const uint32_t l = label[slot];
             if (l) {
                 if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
@@ -224,6 +270,35 @@ int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_n
                           const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts);
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n);
 
+// Build the pair filter over the labelled keys (device array, canonical 2-bit keys) at the smallest
+// size whose fill stays below MAP_FILL_MAX.  Shared by the dense and the sparse label paths.
+int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n) {
+    if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, ((size_t)1 << MAP_BLOOM_MAX_BITS) / 8 + 64));   // + fill counter
+    int bits = MAP_BLOOM_MIN_BITS;
+    while (bits < MAP_BLOOM_MAX_BITS - 1 && ((int64_t)1 << bits) < 6 * n) bits++;
+    unsigned long long *d_small = (unsigned long long *)((char *)ctx->d_bloom + ((size_t)1 << MAP_BLOOM_MAX_BITS) / 8);
+    for (;;) {
+        const size_t bytes = ((size_t)1 << bits) / 8;
+        SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, bytes, ctx->stream));
+        ctx->bloom_bits = bits;
+        if (n == 0) break;
+        SP_LAUNCH(ctx, "k4_pair_filter", k4_pair_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, n,
+                  ctx->k, ctx->d_bloom, bits);
+        if (bits >= MAP_BLOOM_MAX_BITS) break;
+        SP_HIP(ctx, hipMemsetAsync(d_small, 0, 8, ctx->stream));
+        SP_LAUNCH(ctx, "k4_filter_fill", k4_filter_fill, dim3(256), dim3(256), 0, (const uint32_t *)ctx->d_bloom,
+                  (int64_t)(bytes / 4), d_small);
+        unsigned long long set = 0;
+        SP_HIP(ctx, hipMemcpyAsync(&set, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double fill = (double)set / (double)((int64_t)1 << bits);
+        if (getenv("SP_DEBUG_FILTER")) fprintf(stderr, "[sp] pair filter: 2^%d bits, fill %.3f (n=%lld)\n", bits, fill, (long long)n);
+        if (fill <= MAP_FILL_MAX) break;
+        bits++;
+    }
+    return SP_OK;
+}
+
 extern "C" {
 
 int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg) {
@@ -240,12 +315,10 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
         return sp_sparse_labels_set(ctx, keys, sg, n);
     }
     if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
-    if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, (size_t)(1u << MAP_BLOOM_BITS) / 8));
     SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, (size_t)(1u << MAP_BLOOM_BITS) / 8, ctx->stream));
     ctx->n_sg = n_sg;
     ctx->n_labels = n;
-    if (n == 0) return SP_OK;
+    if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
     unsigned long long *d_keys = nullptr;
     uint8_t *d_sg = nullptr;
     SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
@@ -254,11 +327,12 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
     SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     const sp_kparams kp = sp_make_kparams(ctx->k);
     SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
-              kp, ctx->d_label, ctx->d_bloom);
+              kp, ctx->d_label);
+    const int rcf = sp_map_filter_build(ctx, d_keys, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_keys);
     hipFree(d_sg);
-    return SP_OK;
+    return rcf;
 }
 
 int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots) {
@@ -305,7 +379,7 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
         SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                  ctx->d_label, ctx->d_bloom, d_counts, d_n);
+                  ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
     }
     unsigned long long hn = 0;
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -358,7 +432,7 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
         SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                  ctx->d_label, ctx->d_bloom, d_counts + slot_off[i] * S, d_n + i);
+                  ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
     }
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<unsigned long long> hn((size_t)C, 0);
@@ -451,7 +525,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
         SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-                  n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, d_counts);
+                  n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts);
     }
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -183,44 +183,41 @@ sps_emit(const unsigned long long *__restrict__ K, const unsigned long long *__r
 }
 
 // ------------------------------------------------------------------ labels + map
+// Open-addressing table of 16-byte entries {key, label}: a hit costs ONE cache line (key and label
+// used to live in two arrays = two L2 misses per mapped position).  label: 0 none, 1+sg, bit 7 = seen.
 __global__ void __launch_bounds__(256)
 sps_hash_insert(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
-                unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
-                uint32_t *__restrict__ bloom) {
+                unsigned long long *__restrict__ htab, uint64_t mask) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = keys[i];
     uint64_t h = sps_mix(key) & mask;
     for (;;) {
-        unsigned long long prev = atomicCAS(&hkeys[h], SPS_SENTINEL, key);
+        unsigned long long prev = atomicCAS(&htab[2 * h], SPS_SENTINEL, key);
         if (prev == SPS_SENTINEL || prev == key) break;
         h = (h + 1) & mask;
     }
-    hlab[h] = (uint8_t)(1u + sg[i]);
-    const map_bloom_probe p = map_bloom(key);
-    atomicOr(&bloom[p.word], p.bits);
+    htab[2 * h + 1] = (unsigned long long)(1u + sg[i]);
 }
 
-__device__ __forceinline__ int sps_lookup(uint64_t key, const unsigned long long *__restrict__ hkeys,
-                                          uint8_t *__restrict__ hlab, uint64_t mask,
-                                          const uint32_t *__restrict__ bloom) {
-    if (!map_bloom_test(bloom, key)) return -1;
+__device__ __forceinline__ int sps_lookup(uint64_t key, unsigned long long *__restrict__ htab, uint64_t mask) {
     uint64_t h = sps_mix(key) & mask;
     for (;;) {
-        const unsigned long long kk = hkeys[h];
-        if (kk == key) break;
-        if (kk == SPS_SENTINEL) return -1;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(htab + 2 * h);
+        if (e.x == key) {
+            const uint32_t l = (uint32_t)e.y;
+            if (!(l & 0x80u)) htab[2 * h + 1] = (unsigned long long)(l | 0x80u);   // idempotent "seen" mark
+            return (int)(l & 0x7fu) - 1;
+        }
+        if (e.x == SPS_SENTINEL) return -1;
         h = (h + 1) & mask;
     }
-    const uint32_t l = hlab[h];
-    if (!(l & 0x80u)) hlab[h] = (uint8_t)(l | 0x80u);
-    return (int)(l & 0x7fu) - 1;
 }
 
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, sp_map_params P,
-              const unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
-              const uint32_t *__restrict__ bloom, int *__restrict__ slot_counts,
+              unsigned long long *__restrict__ htab, uint64_t mask,
+              const uint32_t *__restrict__ bloom, int bloom_bits, int *__restrict__ slot_counts,
               unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
@@ -234,8 +231,8 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
             __syncthreads();
         }
         if (u < P.n_units) {
-            sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                const int sg = sps_lookup(fwd < rc ? fwd : rc, hkeys, hlab, mask, bloom);
+            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
                 if (sg < 0) return;
                 const int64_t os = map_slot(start, P, kp.k);
                 if (P.use_lds)
@@ -264,13 +261,13 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
                    const int64_t *__restrict__ foff, int64_t n_feat, int S,
-                   const unsigned long long *__restrict__ hkeys, uint8_t *__restrict__ hlab, uint64_t mask,
-                   const uint32_t *__restrict__ bloom, unsigned long long *__restrict__ counts) {
+                   unsigned long long *__restrict__ htab, uint64_t mask,
+                   const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
-        sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-            const int sg = sps_lookup(fwd < rc ? fwd : rc, hkeys, hlab, mask, bloom);
+        map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
             if (sg < 0) return;
             int64_t lo = 0, hi = n_feat;
             while (hi - lo > 1) {
@@ -284,11 +281,11 @@ k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__
 }
 
 __global__ void __launch_bounds__(256)
-sps_count_seen(const uint8_t *__restrict__ hlab, int64_t n, unsigned long long *__restrict__ out) {
+sps_count_seen(const unsigned long long *__restrict__ htab, int64_t n, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long red[16];
     unsigned long long c = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        c += (hlab[i] >> 7) & 1u;
+        c += (htab[2 * i + 1] >> 7) & 1u;
     unsigned long long t = sp_block_sum_u64(c, red);
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
@@ -304,9 +301,7 @@ void sp_sparse_release(sp_ctx *ctx) {
     for (auto &c : ctx->sparse) sps_free_chrom(c);
     ctx->sparse.clear();
     if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
-    if (ctx->d_hlab) hipFree(ctx->d_hlab);
     ctx->d_hkeys = nullptr;
-    ctx->d_hlab = nullptr;
     ctx->hcap = 0;
     sp_buf_free(ctx->b_sp_a);
     sp_buf_free(ctx->b_sp_b);
@@ -554,23 +549,21 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
     return SP_OK;
 }
 
+int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n);   // sp_map.hip
+
 int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n) {
     int64_t cap = 1024;
     while (cap < 2 * n + 16) cap <<= 1;
     if (cap != ctx->hcap) {
         if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
-        if (ctx->d_hlab) hipFree(ctx->d_hlab);
         ctx->d_hkeys = nullptr;
-        ctx->d_hlab = nullptr;
-        SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 8));
-        SP_HIP(ctx, hipMalloc(&ctx->d_hlab, (size_t)cap));
+        SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 16));
         ctx->hcap = cap;
     }
-    if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, (size_t)(1u << MAP_BLOOM_BITS) / 8));
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 8, ctx->stream));
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_hlab, 0, (size_t)cap, ctx->stream));
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, (size_t)(1u << MAP_BLOOM_BITS) / 8, ctx->stream));
-    if (n == 0) return SP_OK;
+    // {key = sentinel (all ones), label = 0}: 0xff everywhere, then the label words are written on insert
+    // and read only after a key match, so they need no clearing
+    SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 16, ctx->stream));
+    if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
     unsigned long long *d_keys = nullptr;
     uint8_t *d_sg = nullptr;
     SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
@@ -578,11 +571,12 @@ int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, i
     SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
-              (unsigned long long *)ctx->d_hkeys, ctx->d_hlab, (uint64_t)(cap - 1), ctx->d_bloom);
+              (unsigned long long *)ctx->d_hkeys, (uint64_t)(cap - 1));
+    const int rcf = sp_map_filter_build(ctx, d_keys, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(d_keys);
     hipFree(d_sg);
-    return SP_OK;
+    return rcf;
 }
 
 int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *d_counts, unsigned long long *d_n) {
@@ -592,7 +586,7 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-              (const unsigned long long *)ctx->d_hkeys, ctx->d_hlab, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, d_counts,
+              (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts,
               d_n);
     return SP_OK;
 }
@@ -603,13 +597,13 @@ int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_n
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-              n_units, d_foff, n_feat, S, (const unsigned long long *)ctx->d_hkeys, ctx->d_hlab,
-              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, d_counts);
+              n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys,
+              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts);
     return SP_OK;
 }
 
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
     SP_LAUNCH(ctx, "sps_count_seen", sps_count_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
-              (const uint8_t *)ctx->d_hlab, ctx->hcap, d_n);
+              (const unsigned long long *)ctx->d_hkeys, ctx->hcap, d_n);
     return SP_OK;
 }
