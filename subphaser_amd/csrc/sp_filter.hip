@@ -31,7 +31,7 @@ struct sp_filter_params {
 struct sp_fsets {
     int n_sets, baseline;
     const int32_t *set_off, *unit_off, *unit_chrom;
-    const double *unit_den;
+    const double *unit_den, *unit_inv;   // per-unit denominators and their reciprocals
     double min_fold, min_freq, max_freq, ratio;
 };
 
@@ -43,29 +43,78 @@ __device__ __forceinline__ void sp_filter_decide(const uint32_t *cnt, int stride
         const int u0 = F.set_off[s], nu = F.set_off[s + 1] - u0;
         if (nu == 1) continue;  // singleton ignored (Jellyfish.py:621-622)
         all++;
-        double f[F_MAXU];
-#pragma unroll
-        for (int u = 0; u < F_MAXU; u++) {
-            f[u] = 0.0;
-            if (u < nu) {
+        // descending order statistic: hi = f_(0), lo = f_(bi)   (:637-639)
+        const int bi = F.baseline < 0 ? nu + F.baseline : F.baseline;
+        double hi, lo;
+        if (bi == 1 || bi == nu - 1) {
+            // The two values the CLI allows (baseline 1 / -1) need only the running max, second max and
+            // min.  k3_eval is issue-bound on this fp64 code (16-18 ms against 8.8 ms for the table
+            // reads alone), so the set is first screened in fp32 on products with the precomputed
+            // reciprocals: fp32 moves hi and lo by a relative 1e-6 at most, so outside a 1e-5 band
+            // around the threshold the screen and the reference's fp64 quotient test agree; inside the
+            // band the quotients are formed exactly as the reference does (:630-641).
+            {
+                float m1 = -1.0f, m2 = -1.0f, mn = 3e38f;
+                for (int u = 0; u < nu; u++) {
+                    unsigned long long num = 0;
+                    for (int j = F.unit_off[u0 + u]; j < F.unit_off[u0 + u + 1]; j++)
+                        num += cnt[F.unit_chrom[j] * stride];
+                    const float x = (float)num * (float)F.unit_inv[u0 + u];
+                    if (x > m1) {
+                        m2 = m1;
+                        m1 = x;
+                    } else if (x > m2) {
+                        m2 = x;
+                    }
+                    mn = x < mn ? x : mn;
+                }
+                const float thr = (float)F.min_fold * (((bi == 1) ? m2 : mn) + 1e-20f);
+                if (m1 > thr * (1.0f + 1e-5f)) {
+                    include++;
+                    continue;
+                }
+                if (m1 < thr * (1.0f - 1e-5f)) continue;
+            }
+            double m1 = -1.0, m2 = -1.0, mn = 1e300;
+            for (int u = 0; u < nu; u++) {
                 unsigned long long num = 0;
                 for (int j = F.unit_off[u0 + u]; j < F.unit_off[u0 + u + 1]; j++)
                     num += cnt[F.unit_chrom[j] * stride];
-                f[u] = (double)num / F.unit_den[u0 + u];  // count/len or sum/sum (:630,:634)
+                const double x = (double)num / F.unit_den[u0 + u];  // count/len or sum/sum (:630,:634)
+                if (x > m1) {
+                    m2 = m1;
+                    m1 = x;
+                } else if (x > m2) {
+                    m2 = x;
+                }
+                mn = x < mn ? x : mn;
             }
-        }
-        // descending order statistic: hi = f_(0), lo = f_(bi)   (:637-639)
-        const int bi = F.baseline < 0 ? nu + F.baseline : F.baseline;
-        double hi = f[0], lo = f[0];
+            hi = m1;
+            lo = (bi == 1) ? m2 : mn;
+        } else {
+            double f[F_MAXU];
 #pragma unroll
-        for (int u = 0; u < F_MAXU; u++) {
-            if (u < nu) {
-                hi = f[u] > hi ? f[u] : hi;
-                int rank = 0;
+            for (int u = 0; u < F_MAXU; u++) {
+                f[u] = 0.0;
+                if (u < nu) {
+                    unsigned long long num = 0;
+                    for (int j = F.unit_off[u0 + u]; j < F.unit_off[u0 + u + 1]; j++)
+                        num += cnt[F.unit_chrom[j] * stride];
+                    f[u] = (double)num / F.unit_den[u0 + u];
+                }
+            }
+            hi = f[0];
+            lo = f[0];
 #pragma unroll
-                for (int v = 0; v < F_MAXU; v++)
-                    if (v < nu && (f[v] > f[u] || (f[v] == f[u] && v < u))) rank++;
-                if (rank == bi) lo = f[u];
+            for (int u = 0; u < F_MAXU; u++) {
+                if (u < nu) {
+                    hi = f[u] > hi ? f[u] : hi;
+                    int rank = 0;
+#pragma unroll
+                    for (int v = 0; v < F_MAXU; v++)
+                        if (v < nu && (f[v] > f[u] || (f[v] == f[u] && v < u))) rank++;
+                    if (rank == bi) lo = f[u];
+                }
             }
         }
         if (1.0 * hi / (lo + 1e-20) >= F.min_fold) include++;  // :640-641
@@ -121,6 +170,7 @@ k3_eval(const uint32_t *const *__restrict__ tabs, sp_filter_params P,
             F.unit_off = unit_off;
             F.unit_chrom = unit_chrom;
             F.unit_den = unit_den;
+            F.unit_inv = unit_den + set_off[P.n_sets];
             F.min_fold = P.min_fold;
             F.min_freq = P.min_freq;
             F.max_freq = P.max_freq;
@@ -315,11 +365,12 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
             return sp_fail(ctx, SP_EINVAL, "sp_filter: chromosome index %d out of range", unit_chrom[j]);
 
     if (ctx->sparse_mode) {
-        std::vector<double> den_s((size_t)n_units);
+        std::vector<double> den_s((size_t)n_units * 2);   // denominators, then their reciprocals
         for (int u = 0; u < n_units; u++) {
             int64_t d = 0;
             for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += ctx->chroms[(size_t)unit_chrom[j]].length_sum;
             den_s[(size_t)u] = (double)d;
+            den_s[(size_t)(n_units + u)] = 1.0 / (double)d;
         }
         int rcs = sp_sparse_filter(ctx, n_sets, set_off, unit_off, unit_chrom, den_s, min_fold, baseline, min_freq,
                                    max_freq, ratio);
@@ -343,14 +394,15 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     ctx->n_fblocks = nblk;
 
     // device copies of the set structure + per-unit denominators
-    std::vector<double> den((size_t)n_units);
+    std::vector<double> den((size_t)n_units * 2);   // denominators, then their reciprocals
     for (int u = 0; u < n_units; u++) {
         int64_t d = 0;
         for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += filter_len(ctx, unit_chrom[j]);
         den[(size_t)u] = (double)d;
+        den[(size_t)(n_units + u)] = 1.0 / (double)d;
     }
     size_t b_set = (size_t)(n_sets + 1) * 4, b_uo = (size_t)(n_units + 1) * 4, b_uc = (size_t)(n_uc > 0 ? n_uc : 1) * 4,
-           b_den = (size_t)n_units * 8;
+           b_den = (size_t)n_units * 16;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t tot_b = al(b_set) + al(b_uo) + al(b_uc) + al(b_den) + al(C * sizeof(void *)) + 256;
     int rcb = sp_buf_ensure(ctx, ctx->b_fpar, (int64_t)tot_b);

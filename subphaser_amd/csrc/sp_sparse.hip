@@ -463,7 +463,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     const int64_t nblk = (total + SEL_SPAN - 1) / SEL_SPAN;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_set = al(tmp_bytes), o_uo = o_set + al((size_t)(n_sets + 1) * 4), o_uc = o_uo + al((size_t)(n_units + 1) * 4),
-           o_den = o_uc + al((size_t)(n_uc + 1) * 4), o_blk_r = o_den + al((size_t)n_units * 8),
+           o_den = o_uc + al((size_t)(n_uc + 1) * 4), o_blk_r = o_den + al((size_t)n_units * 16),
            o_blk_h = o_blk_r + al((size_t)(nblk + 1) * 8), o_small = o_blk_h + al((size_t)(nblk + 1) * 8),
            all_b = o_small + 256;
     rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)all_b);
@@ -473,7 +473,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     SP_HIP(ctx, hipMemcpyAsync(T + o_set, set_off, (size_t)(n_sets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(T + o_uo, unit_off, (size_t)(n_units + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n_uc) SP_HIP(ctx, hipMemcpyAsync(T + o_uc, unit_chrom, (size_t)n_uc * 4, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(T + o_den, den.data(), (size_t)n_units * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(T + o_den, den.data(), (size_t)n_units * 16, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemsetAsync(T + o_small, 0, 256, ctx->stream));
     sps_filter_args A;
     A.C = C;
@@ -483,6 +483,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     A.F.unit_off = (const int32_t *)(T + o_uo);
     A.F.unit_chrom = (const int32_t *)(T + o_uc);
     A.F.unit_den = (const double *)(T + o_den);
+    A.F.unit_inv = A.F.unit_den + n_units;
     A.F.min_fold = min_fold;
     A.F.min_freq = min_freq;
     A.F.max_freq = max_freq;
