@@ -171,6 +171,7 @@ int sp_host_free(sp_ctx *ctx, void *h_ptr);
 int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr);
 int sp_dev_free(sp_ctx *ctx, void *d_ptr);
 int sp_dev_copy_to_host(sp_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
+int sp_dev_copy_from_host(sp_ctx *ctx, void *d_dst, const void *src, int64_t bytes);
 
 #ifdef __cplusplus
 }

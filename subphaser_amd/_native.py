@@ -25,7 +25,7 @@ SYMBOLS = [
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
-    "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host",
+    "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
 ]
 
 
@@ -90,6 +90,7 @@ def load():
     L.sp_dev_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_dev_free.argtypes = [vp, vp]
     L.sp_dev_copy_to_host.argtypes = [vp, vp, vp, i64]
+    L.sp_dev_copy_from_host.argtypes = [vp, vp, vp, i64]
     for name in SYMBOLS:
         if name not in ("sp_last_error", "sp_stream"):
             getattr(L, name).restype = ci
@@ -393,6 +394,10 @@ class Context:
         out = np.empty(nbytes, np.uint8)
         self._ck(self.L.sp_dev_copy_to_host(self.h, _p(out), C.c_void_p(ptr + offset), int(nbytes)))
         return out
+
+    def host_to_dev(self, ptr, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.L.sp_dev_copy_from_host(self.h, C.c_void_p(ptr + offset), _p(arr), int(arr.nbytes)))
 
     def synth_chrom(self, d_ptr, length, seed, set_id, sg_id, n_sg, chrom_id, exchange=0):
         self._ck(self.L.sp_synth_chrom(self.h, C.c_void_p(d_ptr), int(length), int(seed), int(set_id),

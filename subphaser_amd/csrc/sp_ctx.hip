@@ -375,4 +375,10 @@ int sp_dev_copy_to_host(sp_ctx *ctx, void *dst, const void *d_src, int64_t bytes
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }
+int sp_dev_copy_from_host(sp_ctx *ctx, void *d_dst, const void *src, int64_t bytes) {
+    if (!ctx || !d_dst || !src || bytes < 0) return sp_fail(ctx, SP_EINVAL, "sp_dev_copy_from_host: bad arguments");
+    SP_HIP(ctx, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
 }  // extern "C"

@@ -285,7 +285,7 @@ sps_count_seen(const unsigned long long *__restrict__ htab, int64_t n, unsigned 
     __shared__ unsigned long long red[16];
     unsigned long long c = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        c += (htab[2 * i + 1] >> 7) & 1u;
+        c += (htab[2 * i] != SPS_SENTINEL) ? ((htab[2 * i + 1] >> 7) & 1u) : 0u;   // empty entries are all ones
     unsigned long long t = sp_block_sum_u64(c, red);
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }

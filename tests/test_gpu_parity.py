@@ -251,6 +251,98 @@ def test_filter_vs_oracle_random(gpu_ctx, oracle_ctx):
         assert g[1] > 0
 
 
+def test_filter_near_threshold_screen(gpu_ctx):
+    """The fold test is screened in fp32 and decided in fp64 only near the threshold: hand-made count
+    tables whose fold sits within 1e-9 .. 1e-3 (relative) of min_fold on both sides, exactly on it, and
+    far from it, through the slot-range view (caller-owned tables + caller-given lengths)."""
+    from subphaser_amd import kmer as km
+    from subphaser_amd.config import sets_to_csr
+    k, lower, C = 7, 1, 6
+    n = km.dense_slots(k)
+    rng = np.random.RandomState(77)
+    base = 1_000_000_007
+    # near-equal lengths so that small integer count ratios land a hair above / below the threshold
+    lengths = np.array([base, base + 1, base + 1000, base - 3, 2 * base + 1, 2 * base - 1], np.int64)
+    tabs = np.zeros((C, n), np.uint32)
+    occ = rng.rand(C, n) < 0.5
+    tabs[occ] = rng.randint(1, 50, size=int(occ.sum())).astype(np.uint32)
+    # rows built to straddle fold == 2 and fold == 1.5: counts (2m, m), (3m, 2m), and +-1 perturbations
+    for i in range(0, n, 3):
+        m = int(rng.randint(1, 1 << 20))
+        a, b = [(2 * m, m), (2 * m + 1, m), (2 * m - 1, m), (3 * m, 2 * m), (3 * m + 1, 2 * m), (4 * m, 2 * m + 1)][(i // 3) % 6]
+        tabs[0, i], tabs[1, i] = a, b
+        tabs[2, i], tabs[3, i] = b, a
+        tabs[4, i], tabs[5, i] = 2 * a, 2 * b
+    d_tabs = []
+    for c in range(C):
+        d_tabs.append(gpu_ctx.dev_alloc(n * 4))
+        gpu_ctx.host_to_dev(d_tabs[-1], tabs[c])
+    slots = np.arange(n, dtype=np.uint64)
+    keys_all = km.keys_of_slots(slots, k)
+    dumps = []
+    for c in range(C):
+        nz = np.flatnonzero(tabs[c] >= lower)
+        kk = keys_all[nz]
+        o = np.argsort(kk, kind="stable")
+        dumps.append((kk[o], tabs[c][nz][o]))
+    gpu_ctx.genome_reset(C)
+    for c in range(C):
+        gpu_ctx.genome_add(c, b"ACGTACGTACGT")
+    gpu_ctx.count(k, lower, 1)
+    for sgs, kw in (
+        ([[[0], [1]], [[2], [3]], [[4], [5]]], dict(min_fold=2, baseline=1, min_freq=1, max_freq=1e12, ratio=1)),
+        ([[[0], [1]], [[2], [3]], [[4], [5]]], dict(min_fold=1.5, baseline=-1, min_freq=1, max_freq=1e12, ratio=0.6)),
+        ([[[0], [1], [2]], [[3], [4, 5]]], dict(min_fold=2, baseline=1, min_freq=10, max_freq=1e12, ratio=0.5)),
+        ([[[0, 4], [1, 5]], [[2], [3]]], dict(min_fold=2.0000001, baseline=-1, min_freq=1, max_freq=1e12, ratio=1)),
+    ):
+        labels = list(range(C))
+        exp = po.filter_dumps(dumps, sgs, labels, lengths=lengths, **kw)
+        gpu_ctx.filter_view(d_tabs, 0, n, lengths, k, lower)
+        try:
+            nu, nr, nh = gpu_ctx.filter(*sets_to_csr(sgs, labels), kw["min_fold"], kw["baseline"], kw["min_freq"],
+                                        kw["max_freq"], kw["ratio"])
+            keys, counts, freqs, tot = gpu_ctx.filter_fetch(nr)
+        finally:
+            gpu_ctx.filter_view(None, 0, 0, None, 0, 0)
+        assert (nu, nr, nh) == (exp.n_union, len(exp.keys), len(exp.hist)), (sgs, kw, nu, nr, nh, exp.n_union, len(exp.keys), len(exp.hist))
+        assert (keys == exp.keys).all() and (counts == exp.counts).all()
+        assert nr > 0 and nh > nr // 2
+    for d in d_tabs:
+        gpu_ctx.dev_free(d)
+
+
+def test_map_pair_filter_adversarial(gpu_ctx):
+    """The map pre-filter screens starts 2i and 2i+1 with one probe of their shared (k-1)-mer: labelled
+    k-mers at even and odd starts, next to N runs, at the chromosome ends, as isolated single hits, on
+    both strands, for odd and even k (dense) and 64-bit keys (sparse)."""
+    rng = np.random.RandomState(5)
+    for k in (2, 3, 8, 13, 15, 16, 21, 32):
+        s = _rand_seq(rng, 6000, 0.02, 0.2)
+        n_pos = s.size - k + 1
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.genome_add(0, s)
+        gpu_ctx.count(k, 1, 1)
+        keys, cnts = gpu_ctx.dump(0)
+        assert keys.size
+        # label a scattered third of the k-mers -> isolated hits at both parities, plus the first/last ones
+        sel = keys[rng.rand(keys.size) < 0.3]
+        sg = (np.arange(sel.size) % 2).astype(np.uint8)
+        gpu_ctx.labels_set(sel, sg, 2)
+        for bin_size, chunk in ((1, 0), (7, 100), (1000, 0)):
+            got, nmap = gpu_ctx.map_bins(0, bin_size, chunk)
+            exp, hit, n2 = po.map_bins(s, k, sel, sg, 2, bin_size, chunk, nthreads=2)
+            assert got.shape == exp.shape and (got == exp).all() and nmap == n2, (k, bin_size, chunk)
+        assert gpu_ctx.labels_hit() == int(hit.sum())
+        # one labelled k-mer only, then none
+        gpu_ctx.labels_set(sel[:1], sg[:1], 2)
+        got, nmap = gpu_ctx.map_bins(0, 1, 0)
+        exp, hit, n2 = po.map_bins(s, k, sel[:1], sg[:1], 2, 1, 0, nthreads=1)
+        assert (got == exp).all() and nmap == n2 and nmap >= 1
+        gpu_ctx.labels_set(sel[:0], sg[:0], 2)
+        got, nmap = gpu_ctx.map_bins(0, 1, 0)
+        assert nmap == 0 and not got.any()
+
+
 def test_filter_errors(gpu_ctx):
     rng = np.random.RandomState(2)
     gpu_ctx.genome_reset(2)
