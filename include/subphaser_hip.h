@@ -153,6 +153,27 @@ int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit);
 int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
               double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios);
 
+/* ---- multi-GPU, k > 15 ----------------------------------------------------------------------
+ * Twin of sp_tables_bind / sp_filter_view for 64-bit keys ("for k > 16 the exchange
+ * becomes key-partitioned").  After sp_count (k > 15) every local chromosome is a sorted list of
+ * (canonical key, count >= lower_count) -- what jellyfish dump holds, Jellyfish.py:697-699.
+ *   sp_sparse_sizes   n[c] = entries of local chromosome c.
+ *   sp_sparse_sample  up to n_samples evenly spaced keys of one list (to choose common splitters).
+ *   sp_sparse_split   bounds[0..n_split+1]: bounds[i+1] = first index whose key >= splitters[i];
+ *                     bounds[0] = 0, bounds[n_split+1] = n.
+ *   sp_sparse_export  copy entries [first, first+count) into caller-owned DEVICE buffers (uint64
+ *                     keys, uint32 counts); asynchronous on the context's stream (sp_sync).
+ *   sp_sparse_view    point sp_filter / sp_filter_fetch(_device) at caller-owned DEVICE lists, one per
+ *                     chromosome of the whole genome (sorted keys of ONE key range, counts >= lower),
+ *                     with the global `lengths` (Jellyfish.py:449); d_keys = NULL returns to the local
+ *                     chromosomes.  to_matrix/filter semantics are unchanged (Jellyfish.py:439-512). */
+int sp_sparse_sizes(sp_ctx *ctx, int64_t *n);
+int sp_sparse_sample(sp_ctx *ctx, int chrom, int64_t n_samples, uint64_t *keys, int64_t *n_out);
+int sp_sparse_split(sp_ctx *ctx, int chrom, const uint64_t *splitters, int n_split, int64_t *bounds);
+int sp_sparse_export(sp_ctx *ctx, int chrom, int64_t first, int64_t count, void *d_keys, void *d_counts);
+int sp_sparse_view(sp_ctx *ctx, int C, const void *const *d_keys, const void *const *d_counts, const int64_t *n,
+                   const int64_t *lengths, int k, int lower_count);
+
 /* ---- profiling: per-kernel HIP-event timing on the context's stream ------ */
 int sp_prof_enable(sp_ctx *ctx, int on);
 int sp_prof_reset(sp_ctx *ctx);

@@ -24,6 +24,7 @@ SYMBOLS = [
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
+    "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
 ]
@@ -83,6 +84,11 @@ def load():
     L.sp_host_free.argtypes = [vp, vp]
     L.sp_labels_hit.argtypes = [vp, P(i64)]
     L.sp_enrich.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
+    L.sp_sparse_sizes.argtypes = [vp, vp]
+    L.sp_sparse_sample.argtypes = [vp, ci, i64, vp, P(i64)]
+    L.sp_sparse_split.argtypes = [vp, ci, vp, ci, vp]
+    L.sp_sparse_export.argtypes = [vp, ci, i64, i64, vp, vp]
+    L.sp_sparse_view.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci]
     L.sp_prof_enable.argtypes = [vp, ci]
     L.sp_prof_reset.argtypes = [vp]
     L.sp_prof_report.argtypes = [vp, C.c_char_p, i64]
@@ -232,6 +238,44 @@ class Context:
         self._ck(self.L.sp_filter_view(self.h, len(d_ptrs), arr, int(slot_base), int(nslots_view), _p(lengths),
                                        int(k), int(lower_count)))
         self._view_C = len(d_ptrs)
+        self.k = int(k)
+
+    # -------------------------------------------------------------- multi-GPU, k > 15
+    def sparse_sizes(self):
+        out = np.zeros(self.n_chrom, np.int64)
+        if self.n_chrom:
+            self._ck(self.L.sp_sparse_sizes(self.h, _p(out)))
+        return out
+
+    def sparse_sample(self, chrom, n_samples):
+        out = np.empty(int(n_samples), np.uint64)
+        n = C.c_int64()
+        self._ck(self.L.sp_sparse_sample(self.h, int(chrom), int(n_samples), _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def sparse_split(self, chrom, splitters):
+        sp = np.ascontiguousarray(splitters, np.uint64)
+        bounds = np.zeros(sp.size + 2, np.int64)
+        self._ck(self.L.sp_sparse_split(self.h, int(chrom), _p(sp), int(sp.size), _p(bounds)))
+        return bounds
+
+    def sparse_export(self, chrom, first, count, d_keys, d_counts):
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        self._ck(self.L.sp_sparse_export(self.h, int(chrom), int(first), int(count), v(d_keys), v(d_counts)))
+
+    def sparse_view(self, d_keys, d_counts, n, lengths, k, lower_count):
+        """Point sp_filter at caller-owned device lists (one key range of every chromosome of the
+        whole genome).  d_keys=None returns to the local chromosomes."""
+        if d_keys is None:
+            self._ck(self.L.sp_sparse_view(self.h, 0, None, None, None, None, 0, 0))
+            self._view_C = None
+            return
+        ka = (C.c_void_p * len(d_keys))(*[int(p) for p in d_keys])
+        ca = (C.c_void_p * len(d_counts))(*[int(p) for p in d_counts])
+        n = np.ascontiguousarray(n, np.int64)
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        self._ck(self.L.sp_sparse_view(self.h, len(d_keys), ka, ca, _p(n), _p(lengths), int(k), int(lower_count)))
+        self._view_C = len(d_keys)
         self.k = int(k)
 
     def lengths(self):

@@ -65,6 +65,11 @@ struct sp_ctx {
     std::vector<const uint32_t *> fv_tabs;
     std::vector<int64_t> fv_lengths;
     int64_t fv_slot_base = 0, fv_nslots = 0;
+    // k > 15 twin: caller-owned sorted (key, count) lists of one KEY RANGE of every chromosome
+    bool sv_on = false;
+    std::vector<const uint64_t *> sv_keys;
+    std::vector<const uint32_t *> sv_cnts;
+    std::vector<int64_t> sv_n;
     // filter results (device)
     bool filtered = false;
     int64_t n_union = 0, n_rows = 0, n_hist = 0;

@@ -260,12 +260,14 @@ struct filter_dev {
     double *chrom_len;
 };
 
-static int filter_C(sp_ctx *ctx) { return ctx->fv_on ? (int)ctx->fv_tabs.size() : (int)ctx->chroms.size(); }
+static int filter_C(sp_ctx *ctx) {
+    return ctx->sv_on ? (int)ctx->sv_keys.size() : ctx->fv_on ? (int)ctx->fv_tabs.size() : (int)ctx->chroms.size();
+}
 static const uint32_t *filter_tab(sp_ctx *ctx, int i) {
     return ctx->fv_on ? ctx->fv_tabs[(size_t)i] : ctx->chroms[(size_t)i].d_tab;
 }
 static int64_t filter_len(sp_ctx *ctx, int i) {
-    return ctx->fv_on ? ctx->fv_lengths[(size_t)i] : ctx->chroms[(size_t)i].length_sum;
+    return (ctx->fv_on || ctx->sv_on) ? ctx->fv_lengths[(size_t)i] : ctx->chroms[(size_t)i].length_sum;
 }
 static int64_t filter_nslots(sp_ctx *ctx) { return ctx->fv_on ? ctx->fv_nslots : ctx->nslots; }
 static int64_t filter_base(sp_ctx *ctx) { return ctx->fv_on ? ctx->fv_slot_base : 0; }
@@ -336,7 +338,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
               double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist) {
     if (!ctx || !set_off || !unit_off || !unit_chrom || n_sets <= 0)
         return sp_fail(ctx, SP_EINVAL, "sp_filter: bad arguments");
-    if (!ctx->counted && !ctx->fv_on) return sp_fail(ctx, SP_EINVAL, "sp_filter: call sp_count first");
+    if (!ctx->counted && !ctx->fv_on && !ctx->sv_on) return sp_fail(ctx, SP_EINVAL, "sp_filter: call sp_count first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int C = filter_C(ctx);
     // the reference's precondition checks, same messages (Jellyfish.py:474-489)
@@ -368,7 +370,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
         std::vector<double> den_s((size_t)n_units * 2);   // denominators, then their reciprocals
         for (int u = 0; u < n_units; u++) {
             int64_t d = 0;
-            for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += ctx->chroms[(size_t)unit_chrom[j]].length_sum;
+            for (int j = unit_off[u]; j < unit_off[u + 1]; j++) d += filter_len(ctx, unit_chrom[j]);
             den_s[(size_t)u] = (double)d;
             den_s[(size_t)(n_units + u)] = 1.0 / (double)d;
         }
@@ -518,12 +520,18 @@ int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs
 int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_tot, int64_t cap_rows) {
     if (!ctx) return SP_EINVAL;
     if (!ctx->filtered) return sp_fail(ctx, SP_EINVAL, "call sp_filter first");
-    if (ctx->sparse_mode) return sp_fail(ctx, SP_EUNSUP, "sp_filter_fetch_device: k <= 15 only");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t M = ctx->n_rows;
     if (cap_rows < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap_rows, (long long)M);
     if (M == 0) return SP_OK;
     const int C = filter_C(ctx);
+    if (ctx->sparse_mode) {   // the sparse filter leaves its rows in device buffers already
+        if (d_keys) SP_HIP(ctx, hipMemcpyAsync(d_keys, ctx->b_sf_keys.p, (size_t)M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_counts) SP_HIP(ctx, hipMemcpyAsync(d_counts, ctx->b_sf_counts.p, (size_t)M * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_tot) SP_HIP(ctx, hipMemcpyAsync(d_tot, ctx->b_sf_tot.p, (size_t)M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SP_OK;
+    }
     const uint32_t **d_tabs = nullptr;
     double *d_len = nullptr;
     int rc = upload_tabs(ctx, &d_tabs, &d_len);

@@ -425,13 +425,26 @@ int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts) {
     return SP_OK;
 }
 
+// the lists the filter works on: the local chromosomes, or a caller-owned key-range view (sp_sparse_view)
+static int sps_C(sp_ctx *ctx) { return ctx->sv_on ? (int)ctx->sv_keys.size() : (int)ctx->chroms.size(); }
+static int64_t sps_n(sp_ctx *ctx, int c) { return ctx->sv_on ? ctx->sv_n[(size_t)c] : ctx->sparse[(size_t)c].n; }
+static const unsigned long long *sps_keys(sp_ctx *ctx, int c) {
+    return (const unsigned long long *)(ctx->sv_on ? ctx->sv_keys[(size_t)c] : ctx->sparse[(size_t)c].d_keys);
+}
+static const uint32_t *sps_cnts(sp_ctx *ctx, int c) {
+    return ctx->sv_on ? ctx->sv_cnts[(size_t)c] : ctx->sparse[(size_t)c].d_cnts;
+}
+static int64_t sps_len(sp_ctx *ctx, int c) {
+    return ctx->sv_on ? ctx->fv_lengths[(size_t)c] : ctx->chroms[(size_t)c].length_sum;
+}
+
 int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
                      const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
                      double min_freq, double max_freq, double ratio) {
-    const int C = (int)ctx->chroms.size();
+    const int C = sps_C(ctx);
     if (C > SPS_MAXC) return sp_fail(ctx, SP_EUNSUP, "k > 15: at most %d chromosomes supported (got %d)", SPS_MAXC, C);
     int64_t total = 0;
-    for (auto &o : ctx->sparse) total += o.n;
+    for (int c = 0; c < C; c++) total += sps_n(ctx, c);
     ctx->sf_n = total;
     ctx->n_union = ctx->n_rows = ctx->n_hist = 0;
     if (total == 0) {
@@ -449,11 +462,11 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     uint8_t *flags = (uint8_t *)ctx->b_sp_c.p;
     int64_t off = 0;
     for (int c = 0; c < C; c++) {
-        sp_sparse_chrom &o = ctx->sparse[(size_t)c];
-        if (o.n)
-            SP_LAUNCH(ctx, "sps_concat", sps_concat, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0,
-                      (const unsigned long long *)o.d_keys, (const uint32_t *)o.d_cnts, o.n, c, K0 + off, V0 + off);
-        off += o.n;
+        const int64_t n_c = sps_n(ctx, c);
+        if (n_c)
+            SP_LAUNCH(ctx, "sps_concat", sps_concat, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0,
+                      sps_keys(ctx, c), sps_cnts(ctx, c), n_c, c, K0 + off, V0 + off);
+        off += n_c;
     }
     const unsigned end_bit = (2 * ctx->k > 64) ? 64u : (unsigned)(2 * ctx->k);
     size_t tmp_bytes = 0;
@@ -525,7 +538,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
 }
 
 int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot) {
-    const int C = (int)ctx->chroms.size();
+    const int C = sps_C(ctx);
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (M == 0) return SP_OK;
     if (hist) {
@@ -546,7 +559,7 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
     if (freqs)
         for (int64_t r = 0; r < M; r++)
             for (int c = 0; c < C; c++)   // count/length in fp64 (Jellyfish.py:647); IEEE division, same bits as the device path
-                freqs[r * C + c] = (double)cdst[r * C + c] / (double)ctx->chroms[(size_t)c].length_sum;
+                freqs[r * C + c] = (double)cdst[r * C + c] / (double)sps_len(ctx, c);
     return SP_OK;
 }
 
@@ -608,3 +621,125 @@ int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
               (const unsigned long long *)ctx->d_hkeys, ctx->hcap, d_n);
     return SP_OK;
 }
+
+// ------------------------------------------------------------------ multi-GPU support (k > 15)
+// The dense path exchanges slot-range slices of the count tables; with 64-bit keys the same exchange
+// is a KEY-RANGE partition of every chromosome's sorted (key, count >= lower) list: the owner cuts its
+// lists at common splitters (sp_sparse_split), copies the pieces into the buffers handed to RCCL
+// (sp_sparse_export), and the receiver filters its key range of all chromosomes (sp_sparse_view).
+__global__ void sps_lower_bound(const unsigned long long *__restrict__ keys, int64_t n,
+                                const unsigned long long *__restrict__ q, int nq, long long *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const unsigned long long x = q[i];
+    int64_t lo = 0, hi = n;   // first index with keys[idx] >= x
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    out[i] = lo;
+}
+
+extern "C" {
+
+int sp_sparse_sizes(sp_ctx *ctx, int64_t *n) {
+    if (!ctx || !n) return sp_fail(ctx, SP_EINVAL, "sp_sparse_sizes: bad arguments");
+    if (!ctx->sparse_mode || !ctx->counted) return sp_fail(ctx, SP_EINVAL, "sp_sparse_sizes: call sp_count with k > 15 first");
+    for (size_t c = 0; c < ctx->sparse.size(); c++) n[c] = ctx->sparse[c].n;
+    return SP_OK;
+}
+
+int sp_sparse_sample(sp_ctx *ctx, int chrom, int64_t n_samples, uint64_t *keys, int64_t *n_out) {
+    if (!ctx || !keys || !n_out || n_samples < 1 || chrom < 0 || chrom >= (int)ctx->sparse.size())
+        return sp_fail(ctx, SP_EINVAL, "sp_sparse_sample: bad arguments");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const sp_sparse_chrom &o = ctx->sparse[(size_t)chrom];
+    const int64_t stride = o.n / n_samples;
+    if (stride < 1) {   // short list: all of it
+        if (o.n) SP_HIP(ctx, hipMemcpyAsync(keys, o.d_keys, (size_t)o.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        *n_out = o.n;
+    } else {            // every stride-th key of the sorted list
+        SP_HIP(ctx, hipMemcpy2DAsync(keys, 8, o.d_keys, (size_t)stride * 8, 8, (size_t)n_samples, hipMemcpyDeviceToHost,
+                                     ctx->stream));
+        *n_out = n_samples;
+    }
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int sp_sparse_split(sp_ctx *ctx, int chrom, const uint64_t *splitters, int n_split, int64_t *bounds) {
+    if (!ctx || !bounds || n_split < 0 || (n_split > 0 && !splitters) || n_split > 4096 || chrom < 0 ||
+        chrom >= (int)ctx->sparse.size())
+        return sp_fail(ctx, SP_EINVAL, "sp_sparse_split: bad arguments");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const sp_sparse_chrom &o = ctx->sparse[(size_t)chrom];
+    bounds[0] = 0;
+    bounds[n_split + 1] = o.n;
+    if (n_split == 0) return SP_OK;
+    void *scr = nullptr;
+    int rc = sp_scratch(ctx, (int64_t)n_split * 16 + 256, &scr);
+    if (rc) return rc;
+    unsigned long long *d_q = (unsigned long long *)scr;
+    long long *d_out = (long long *)(d_q + n_split);
+    SP_HIP(ctx, hipMemcpyAsync(d_q, splitters, (size_t)n_split * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_LAUNCH(ctx, "sps_lower_bound", sps_lower_bound, dim3((unsigned)((n_split + 63) / 64)), dim3(64), 0,
+              (const unsigned long long *)o.d_keys, o.n, (const unsigned long long *)d_q, n_split, d_out);
+    SP_HIP(ctx, hipMemcpyAsync(bounds + 1, d_out, (size_t)n_split * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int sp_sparse_export(sp_ctx *ctx, int chrom, int64_t first, int64_t count, void *d_keys, void *d_counts) {
+    if (!ctx || chrom < 0 || chrom >= (int)ctx->sparse.size() || first < 0 || count < 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_sparse_export: bad arguments");
+    const sp_sparse_chrom &o = ctx->sparse[(size_t)chrom];
+    if (first + count > o.n) return sp_fail(ctx, SP_EINVAL, "sp_sparse_export: range exceeds the list (%lld)", (long long)o.n);
+    if (count == 0) return SP_OK;
+    if (!d_keys || !d_counts) return sp_fail(ctx, SP_EINVAL, "sp_sparse_export: NULL destination");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipMemcpyAsync(d_keys, o.d_keys + first, (size_t)count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_counts, o.d_cnts + first, (size_t)count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return SP_OK;   // asynchronous on the context's stream: sp_sync before another stream reads the buffers
+}
+
+int sp_sparse_view(sp_ctx *ctx, int C, const void *const *d_keys, const void *const *d_counts, const int64_t *n,
+                   const int64_t *lengths, int k, int lower_count) {
+    if (!ctx) return SP_EINVAL;
+    if (!d_keys) {   // back to the local chromosomes
+        ctx->sv_on = false;
+        ctx->sv_keys.clear();
+        ctx->sv_cnts.clear();
+        ctx->sv_n.clear();
+        ctx->fv_lengths.clear();
+        ctx->filtered = false;
+        return SP_OK;
+    }
+    if (C <= 0 || !d_counts || !n || !lengths || k < 16 || k > 32)
+        return sp_fail(ctx, SP_EINVAL, "sp_sparse_view: bad arguments (k = 16..32)");
+    if (ctx->fv_on) return sp_fail(ctx, SP_EINVAL, "sp_sparse_view: a dense filter view is active");
+    if (ctx->k != 0 && ctx->k != k) return sp_fail(ctx, SP_EINVAL, "sp_sparse_view: k=%d but the context counted with k=%d", k, ctx->k);
+    for (int i = 0; i < C; i++)
+        if (n[i] < 0 || (n[i] > 0 && (!d_keys[i] || !d_counts[i])))
+            return sp_fail(ctx, SP_EINVAL, "sp_sparse_view: list %d is NULL", i);
+    ctx->sv_keys.assign((size_t)C, nullptr);
+    ctx->sv_cnts.assign((size_t)C, nullptr);
+    ctx->sv_n.assign((size_t)C, 0);
+    ctx->fv_lengths.assign((size_t)C, 0);
+    for (int i = 0; i < C; i++) {
+        ctx->sv_keys[(size_t)i] = (const uint64_t *)d_keys[i];
+        ctx->sv_cnts[(size_t)i] = (const uint32_t *)d_counts[i];
+        ctx->sv_n[(size_t)i] = n[i];
+        ctx->fv_lengths[(size_t)i] = lengths[i];
+    }
+    if (ctx->k == 0) {   // a rank that owns no chromosome still filters its key range
+        ctx->k = k;
+        ctx->sparse_mode = true;
+    }
+    ctx->lower = lower_count < 1 ? 1 : lower_count;
+    ctx->sv_on = true;
+    ctx->filtered = false;
+    return SP_OK;
+}
+
+}  // extern "C"

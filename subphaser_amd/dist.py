@@ -8,6 +8,10 @@ Sharding (DESIGN.md "Multi-GPU"):
     slots [r*n/N, (r+1)*n/N) of ALL chromosomes and filters them locally.
     With N-1 direct xGMI links per GPU an all-to-all uses every link at once; a ring
     all-reduce of the same 2-GiB tables would be bound by one link.
+    For k > 15 (64-bit keys, no dense tables) the same exchange is a KEY-RANGE partition: every
+    rank cuts the sorted (key, count) lists of its chromosomes at common splitters (quantiles of one
+    list, broadcast) and sends piece r to rank r (`all_to_all_single` with uneven splits); rank r then
+    filters its key range of all chromosomes (`sp_sparse_view`).
   * small reductions: `lengths` (all_reduce), surviving rows and window rows (all_gather).
 
 Everything that touches torch is passed in (`dist`, `torch`), so the same code runs on CPU
@@ -45,18 +49,22 @@ class DistHotPath:
         self.my_chroms = self.owned[self.rank]
         self.max_local = max(len(o) for o in self.owned)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.nslots = ctx.nslots(k)
-        if self.nslots % (64 * self.world):
-            raise ValueError("dense table of %d slots cannot be cut into %d aligned slices" % (self.nslots, self.world))
-        self.chunk = self.nslots // self.world
         self.csr = sets_to_csr(gen.sgs, self.labels)
         self.kw = kw
         t = torch
-        # count tables of the local chromosomes live in ONE torch tensor so RCCL can send them
-        self.tabs = t.zeros((max(1, len(self.my_chroms)), self.nslots), dtype=t.int32, device=self.device)
-        self.dummy = None
-        # receive side: round i, source rank s -> slice of rank s's i-th chromosome
-        self.recv = t.zeros((self.max_local, self.world, self.chunk), dtype=t.int32, device=self.device)
+        self.sparse = k > 15
+        if not self.sparse:
+            self.nslots = ctx.nslots(k)
+            if self.nslots % (64 * self.world):
+                raise ValueError("dense table of %d slots cannot be cut into %d aligned slices" % (self.nslots, self.world))
+            self.chunk = self.nslots // self.world
+            # count tables of the local chromosomes live in ONE torch tensor so RCCL can send them
+            self.tabs = t.zeros((max(1, len(self.my_chroms)), self.nslots), dtype=t.int32, device=self.device)
+            self.dummy = None
+            # receive side: round i, source rank s -> slice of rank s's i-th chromosome
+            self.recv = t.zeros((self.max_local, self.world, self.chunk), dtype=t.int32, device=self.device)
+        else:
+            self._sbuf = {}     # growth-only exchange buffers of the key-range path
         self.min_fold = kw.get("min_fold", 2.0)
         self.baseline = kw.get("baseline", 1)
         self.min_freq = kw.get("min_freq", 200)
@@ -132,6 +140,8 @@ class DistHotPath:
     def count_and_filter(self, d_ascii, host_rows_on_all_ranks=True):
         """d_ascii: list over ALL chromosomes; entries of chromosomes owned elsewhere are None.
         host_rows_on_all_ranks=False: only rank 0 copies the gathered matrix to the host."""
+        if self.sparse:
+            return self._count_and_filter_sparse(d_ascii, host_rows_on_all_ranks)
         ctx, t, dist = self.ctx, self.torch, self.dist
         mine = self.my_chroms
         tt = time.perf_counter()
@@ -180,6 +190,11 @@ class DistHotPath:
         ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
         ctx.filter_view(None, 0, 0, None, 0, 0)
         tt = self._t("filter+fetch", tt)
+        return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
+
+    def _gather_rows(self, keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt):
+        """Surviving rows of every rank's slot / key range -> one matrix (rank order = ascending range)."""
+        t, dist = self.torch, self.dist
         r = HotPathResult()
         r.kmer_lengths = lengths
         to_host = host_rows_on_all_ranks or self.rank == 0
@@ -195,6 +210,95 @@ class DistHotPath:
         r.freqs = None
         tt = self._t("gather rows", tt)
         return r
+
+    # ------------------------------------------------------------------ first half, k > 15
+    def _buf(self, name, n, dtype):
+        """growth-only device buffer (hipMalloc/hipFree of GB-sized blocks costs more than the kernels)"""
+        t = self.torch
+        b = self._sbuf.get(name)
+        if b is None or b.numel() < n:
+            b = t.empty(max(int(n * 1.1), 1), dtype=dtype, device=self.device)
+            self._sbuf[name] = b
+        return b
+
+    def _count_and_filter_sparse(self, d_ascii, host_rows_on_all_ranks=True):
+        ctx, t, dist = self.ctx, self.torch, self.dist
+        mine, W = self.my_chroms, self.world
+        tt = time.perf_counter()
+        ctx.genome_reset(len(mine))
+        for li, gi in enumerate(mine):
+            ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
+        ctx.sync()
+        tt = self._t("pack", tt)
+        if mine:
+            ctx.count(self.k, self.lower_count, self.engine)
+        tt = self._t("count", tt)
+        # common splitters: quantiles of chromosome 0's sorted key list, chosen by its owner
+        root = next(r_ for r_, o in enumerate(self.owned) if 0 in o)
+        spl = t.zeros(max(W - 1, 1), dtype=t.int64, device=self.device)
+        if W > 1:
+            if self.rank == root:
+                smp = ctx.sparse_sample(self.owned[root].index(0), 4096)
+                if smp.size:
+                    q = smp[(np.arange(1, W) * smp.size) // W]
+                    spl[:W - 1] = t.from_numpy(q.view(np.int64).copy()).to(self.device)
+            dist.broadcast(spl, src=root)
+        splitters = spl.cpu().numpy()[:W - 1].view(np.uint64) if W > 1 else np.empty(0, np.uint64)
+        bounds = [ctx.sparse_split(li, splitters) for li in range(len(mine))]
+        sz = np.zeros((self.max_local, W), np.int64)
+        for li, b in enumerate(bounds):
+            sz[li] = np.diff(b)
+        szt = t.from_numpy(sz).to(self.device)
+        if W > 1:
+            outs = [t.zeros_like(szt) for _ in range(W)]
+            dist.all_gather(outs, szt)
+            szall = np.stack([o.cpu().numpy() for o in outs])       # [source][its chromosome][destination]
+        else:
+            szall = sz[None]
+        send_counts = sz.sum(axis=0)
+        recv_counts = szall[:, :, self.rank].sum(axis=1)
+        n_send, n_recv = int(send_counts.sum()), int(recv_counts.sum())
+        keys_send, cnts_send = self._buf("ks", n_send, t.int64), self._buf("cs", n_send, t.int32)
+        off = 0
+        for d in range(W):
+            for li in range(len(mine)):
+                n = int(sz[li, d])
+                ctx.sparse_export(li, int(bounds[li][d]), n, keys_send.data_ptr() + off * 8, cnts_send.data_ptr() + off * 4)
+                off += n
+        ctx.sync()
+        tt = self._t("split+export", tt)
+        if W > 1:
+            keys_recv, cnts_recv = self._buf("kr", n_recv, t.int64), self._buf("cr", n_recv, t.int32)
+            dist.all_to_all_single(keys_recv[:n_recv], keys_send[:n_send], recv_counts.tolist(), send_counts.tolist())
+            dist.all_to_all_single(cnts_recv[:n_recv], cnts_send[:n_send], recv_counts.tolist(), send_counts.tolist())
+        else:
+            keys_recv, cnts_recv = keys_send, cnts_send
+        lens = t.zeros(self.C, dtype=t.int64, device=self.device)
+        if mine:
+            lens[t.tensor(mine, device=self.device)] = t.from_numpy(ctx.lengths()).to(self.device)
+        dist.all_reduce(lens)
+        lengths = lens.cpu().numpy()
+        if self.device.type == "cuda":
+            t.cuda.synchronize()
+        tt = self._t("exchange+lengths", tt)
+        pk, pc, ng = [0] * self.C, [0] * self.C, np.zeros(self.C, np.int64)
+        off = 0
+        for s_, owned in enumerate(self.owned):
+            for li, gi in enumerate(owned):
+                n = int(szall[s_, li, self.rank])
+                pk[gi], pc[gi], ng[gi] = keys_recv.data_ptr() + off * 8, cnts_recv.data_ptr() + off * 4, n
+                off += n
+        ctx.sparse_view(pk, pc, ng, lengths, self.k, self.lower_count)
+        try:
+            n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
+                                                 self.max_freq, self.ratio)
+            keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
+            counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
+            ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
+        finally:
+            ctx.sparse_view(None, None, None, None, 0, 0)
+        tt = self._t("filter+fetch", tt)
+        return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
 
     # ------------------------------------------------------------------ second half
     def map_and_enrich(self, kmer_labels, n_sg):

@@ -183,12 +183,59 @@ class OracleDistContext(OracleContext):
         if first == 0:
             self.count(k, lower_count, engine)      # the double counts everything on the first call
 
+    # ---- k > 15: key-range exchange of the sorted (key, count) lists
+    def sparse_sizes(self):
+        return np.array([len(d[0]) for d in self.dumps], np.int64)
+
+    def sparse_sample(self, chrom, n_samples):
+        keys = self.dumps[chrom][0]
+        stride = len(keys) // n_samples
+        return keys.copy() if stride < 1 else keys[::stride][:n_samples].copy()
+
+    def sparse_split(self, chrom, splitters):
+        keys = self.dumps[chrom][0]
+        b = np.searchsorted(keys, np.asarray(splitters, np.uint64), side="left")
+        return np.concatenate(([0], b, [len(keys)])).astype(np.int64)
+
+    def sparse_export(self, chrom, first, count, d_keys, d_counts):
+        import ctypes
+        if count == 0:
+            return
+        keys, cnts = self.dumps[chrom]
+        np.frombuffer((ctypes.c_uint64 * count).from_address(int(d_keys)), np.uint64)[:] = keys[first:first + count]
+        np.frombuffer((ctypes.c_uint32 * count).from_address(int(d_counts)), np.uint32)[:] = cnts[first:first + count]
+
+    def sparse_view(self, d_keys, d_counts, n, lengths, k, lower_count):
+        import ctypes
+        if d_keys is None:
+            self.sview = None
+            return
+        dumps = []
+        for pk, pc, m in zip(d_keys, d_counts, n):
+            m = int(m)
+            if m == 0:
+                dumps.append((np.empty(0, np.uint64), np.empty(0, np.uint32)))
+                continue
+            dumps.append((np.frombuffer((ctypes.c_uint64 * m).from_address(int(pk)), np.uint64).copy(),
+                          np.frombuffer((ctypes.c_uint32 * m).from_address(int(pc)), np.uint32).copy()))
+        self.sview = (dumps, np.array(lengths, np.int64))
+        self.k = k
+
     def filter_view(self, ptrs, slot_base, nview, lengths, k, lower_count):
         self.view = None if ptrs is None else (list(ptrs), int(slot_base), int(nview), np.array(lengths), k, lower_count)
         if ptrs is not None:
             self.k = k
 
     def filter(self, set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio):
+        sgs = []
+        for s in range(len(set_off) - 1):
+            sgs.append([[int(c) for c in unit_chrom[unit_off[u]:unit_off[u + 1]]]
+                        for u in range(set_off[s], set_off[s + 1])])
+        if getattr(self, "sview", None) is not None:
+            dumps, lengths = self.sview
+            self._f = po.filter_dumps(dumps, sgs, list(range(len(dumps))), min_fold, baseline, min_freq, max_freq,
+                                      ratio, lengths=lengths)
+            return self._f.n_union, len(self._f.keys), len(self._f.hist)
         if self.view is None:
             return super().filter(set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio)
         from subphaser_amd import kmer

@@ -20,7 +20,7 @@ class _Gen:
         self.chroms = [dict(label=l, length=len(toy["seqs"][l])) for l in self.labels]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, k=9):
     for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, out_dir):
     try:
         toy = make_toy_genome(seed=7)
         gen = _Gen(toy)
-        k, L = 9, 3        # k = 9 -> 2^17 dense slots: small enough to ship as CPU tensors
+        L = 3              # k = 9 -> 2^17 dense slots: small enough to ship as CPU tensors; k = 17 -> key-range path
         kw = dict(min_freq=30, bin_size=100, chunk_size=2000, window_size=2500)
         ctx = OracleDistContext()
         runner = DistHotPath(ctx, gen, dist, torch, k=k, lower_count=L, device=torch.device("cpu"), **kw)
@@ -59,6 +59,8 @@ def _worker(rank, world, port, out_dir):
         o = np.argsort(a.keys, kind="stable")
         assert (a.keys[o] == rk).all() and (a.counts[o] == rc).all()
         assert nr > 0
+        if k > 15:      # key ranges are ordered by rank: the gathered matrix is already in ascending key order
+            assert (a.keys[1:] > a.keys[:-1]).all()
 
         class _Mat:
             pass
@@ -90,12 +92,26 @@ def test_lpt_assign_balances():
         assert max(loads) <= sum(lens) / n * 1.15 + 1
 
 
-def test_two_rank_hot_path_over_gloo(tmp_path):
+def _spawn(tmp_path, world, k):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), k), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("ok%d" % r)).exists()
+
+
+def test_two_rank_hot_path_over_gloo(tmp_path):
+    _spawn(tmp_path, 2, 9)
+
+
+def test_two_rank_key_range_exchange_over_gloo(tmp_path):
+    """k = 17: 64-bit keys, uneven all_to_all of key-range pieces instead of table slices."""
+    _spawn(tmp_path, 2, 17)
+
+
+def test_three_rank_key_range_exchange_over_gloo(tmp_path):
+    _spawn(tmp_path, 3, 21)

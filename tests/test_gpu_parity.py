@@ -343,6 +343,82 @@ def test_map_pair_filter_adversarial(gpu_ctx):
         assert nmap == 0 and not got.any()
 
 
+def test_sparse_key_range_view(gpu_ctx, oracle_ctx):
+    """k > 15 multi-GPU building blocks through the C-ABI: cut every chromosome's sorted list at
+    common splitters, export the pieces to caller-owned device buffers, filter each key range through
+    sp_sparse_view -- the concatenated ranges must equal the one-shot filter (and the oracle's)."""
+    from subphaser_amd.config import sets_to_csr
+    rng = np.random.RandomState(19)
+    k, lower = 19, 2
+    rep = [_rand_seq(rng, 400, 0, 0) for _ in range(4)]
+    seqs = []
+    for c in range(4):
+        s = _rand_seq(rng, 20000 + 500 * c)
+        for _ in range(30):
+            r = rep[rng.randint(0, 2) + (2 if c % 2 else 0)]
+            p = rng.randint(0, s.size - 500)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    sgs = [[[0], [1]], [[2], [3]]]
+    csr = sets_to_csr(sgs, list(range(4)))
+    args = (2.0, 1, 5, 1e9, 1.0)
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.genome_reset(4)
+        for i, s in enumerate(seqs):
+            ctx.genome_add(i, s)
+        ctx.count(k, lower, 0)
+    nu, nr, nh = gpu_ctx.filter(*csr, *args)
+    keys, counts, freqs, tot = gpu_ctx.filter_fetch(nr)
+    onu, onr, onh = oracle_ctx.filter(*csr, *args)
+    okeys, ocounts, ofreqs, otot = oracle_ctx.filter_fetch(onr)
+    assert (nu, nr, nh) == (onu, onr, onh) and nr > 0
+    assert (keys == okeys).all() and (counts == ocounts).all() and (freqs == ofreqs).all()
+    lengths = gpu_ctx.lengths()
+    sizes = gpu_ctx.sparse_sizes()
+    assert sizes.tolist() == [len(oracle_ctx.dump(i)[0]) for i in range(4)]
+    smp = gpu_ctx.sparse_sample(0, 64)
+    full = oracle_ctx.dump(0)[0]
+    assert (smp == full[::len(full) // 64][:64]).all()
+    assert (gpu_ctx.sparse_sample(0, 10 ** 9) == full).all()          # short list: all of it
+    splitters = smp[[21, 42]]
+    bounds = [gpu_ctx.sparse_split(i, splitters) for i in range(4)]
+    for i in range(4):
+        kk = oracle_ctx.dump(i)[0]
+        assert bounds[i].tolist() == [0] + np.searchsorted(kk, splitters, side="left").tolist() + [len(kk)]
+    parts, tot_nu, tot_nh = [], 0, 0
+    for r in range(3):
+        bufs, pk, pc, n = [], [], [], []
+        for i in range(4):
+            lo, hi = int(bounds[i][r]), int(bounds[i][r + 1])
+            dk, dc = gpu_ctx.dev_alloc(max(hi - lo, 1) * 8), gpu_ctx.dev_alloc(max(hi - lo, 1) * 4)
+            gpu_ctx.sparse_export(i, lo, hi - lo, dk, dc)
+            bufs += [dk, dc]
+            pk.append(dk), pc.append(dc), n.append(hi - lo)
+        gpu_ctx.sync()
+        kk = gpu_ctx.dev_to_host(pk[1], n[1] * 8).view(np.uint64)
+        assert (kk == oracle_ctx.dump(1)[0][int(bounds[1][r]):int(bounds[1][r + 1])]).all()
+        gpu_ctx.sparse_view(pk, pc, n, lengths, k, lower)
+        try:
+            a, b, c_ = gpu_ctx.filter(*csr, *args)
+            parts.append(gpu_ctx.filter_fetch(b, sort=False))
+            dkeys = gpu_ctx.dev_alloc(max(b, 1) * 8)
+            gpu_ctx.filter_fetch_device(dkeys, None, None, b)
+            assert (gpu_ctx.dev_to_host(dkeys, b * 8).view(np.uint64) == parts[-1][0]).all()
+            gpu_ctx.dev_free(dkeys)
+        finally:
+            gpu_ctx.sparse_view(None, None, None, None, 0, 0)
+        tot_nu += a
+        tot_nh += c_
+        for d in bufs:
+            gpu_ctx.dev_free(d)
+    assert (tot_nu, tot_nh) == (nu, nh)
+    assert (np.concatenate([p[0] for p in parts]) == keys).all()
+    assert (np.concatenate([p[1] for p in parts]) == counts).all()
+    assert (np.concatenate([p[2] for p in parts]) == freqs).all()
+    nu2, nr2, nh2 = gpu_ctx.filter(*csr, *args)        # back on the local lists
+    assert (nu2, nr2, nh2) == (nu, nr, nh)
+
+
 def test_filter_errors(gpu_ctx):
     rng = np.random.RandomState(2)
     gpu_ctx.genome_reset(2)
