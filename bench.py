@@ -168,6 +168,13 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     gbases = gen.total_bases / (dt / args.steps) / 1e9
 
+    # sum over chromosomes of D_c = distinct k-mers with count >= L (the lines of the jellyfish dumps)
+    n_dumped = sum(ctx.dump_size(i) for i in range(len(list(my))))
+    if dist is not None and world > 1:
+        tdump = torch.tensor([n_dumped], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tdump)
+        n_dumped = int(tdump.item()) // world      # one rank's slot / key range
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -181,31 +188,55 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events per launch, on the context's stream) ------
     nslots = (1 << (2 * args.k - 1) if args.k % 2 else 1 << (2 * args.k)) if args.k <= 15 else 0
+    n_local = len(list(my))
+    local_bases = sum(gen.chroms[i]["length"] for i in my)
+    extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
+                 sum_dump=int(n_dumped), k=args.k)
+    try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_wheat_pmc_traffic.json")))["kernels"]
+        if not (args.config == "wheat" and args.k == 15 and world == 1):
+            tj = {}
+    except (OSError, ValueError, KeyError):
+        tj = {}
+
+    def price(names, label):
+        """achieved algorithmic GB/s of one kernel, or of a chain of kernels launched once per chromosome"""
+        sts = [prof[n] for n in names if n in prof]
+        if not sts:
+            return None
+        launches_per_step = max(st["calls"] for st in sts) / args.steps
+        per_launch = local_bases / launches_per_step if launches_per_step >= n_local else local_bases
+        alg = algorithmic_bytes(names[0], per_launch, nslots, C, S, extra)
+        if not alg:
+            return None
+        avg_s = sum(st["ms"] / st["calls"] for st in sts) / 1e3
+        traffic = None
+        if all(n in tj for n in names if n in prof):
+            traffic = int(sum(tj[n]["read_bytes_per_call"] + tj[n]["write_bytes_per_call"] for n in names if n in prof))
+        ach = alg / avg_s
+        return {"bound": "hbm", "kernel": label, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
+                "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
+
+    COUNT_CHAIN = [n for n in ("c2_hist", "c2_tilescan", "c2_offsets", "c2_part1", "c2_part2", "c2_count",
+                               "k1_count", "k2_lengths") if n in prof]
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
     if dom:
-        name, st = dom
-        launches_per_step = st["calls"] / args.steps
-        n_local = len(list(my))
-        bases_per_launch = sum(gen.chroms[i]["length"] for i in my) / max(1.0, launches_per_step) \
-            if launches_per_step >= n_local else sum(gen.chroms[i]["length"] for i in my)
-        extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
-                     sum_dump=int(sum(a.kmer_lengths)), k=args.k)
-        alg = algorithmic_bytes(name, bases_per_launch, nslots, C, S, extra)
-        avg_s = st["ms"] / st["calls"] / 1e3
-        traffic = None
-        try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_wheat_pmc_traffic.json")))
-            if args.config == "wheat" and args.k == 15 and world == 1 and name in tj["kernels"]:
-                kk = tj["kernels"][name]
-                traffic = int(kk["read_bytes_per_call"] + kk["write_bytes_per_call"])
-        except (OSError, ValueError, KeyError):
-            pass
-        if alg:
-            ach = alg / avg_s
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
-                        "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
+        name = dom[0]
+        if name in COUNT_CHAIN:
+            # SURVEY 8(d) prices the COUNT (8.25 B/base) as one unit; the engine spreads it over a chain of
+            # kernels launched once per chromosome, so the chain is priced together, never one link alone
+            roofline = price(COUNT_CHAIN, "count engine: " + "+".join(COUNT_CHAIN))
+        else:
+            roofline = price([name], name)
+    # the three stages of the path, each against its own SURVEY 8(d) bytes (context for the line above)
+    stage_roofline = {}
+    for label, names in (("count", COUNT_CHAIN), ("filter", ["k3_eval"]), ("map", ["k5_map"] if args.k <= 15 else ["k5_map_sparse"])):
+        pr = price(names, "+".join(names)) if names else None
+        if pr:
+            stage_roofline[label] = {"kernels": pr["kernel"], "achieved_GBps": pr["achieved"], "frac": pr["frac"],
+                                     "chain_ms": pr["avg_launch_ms"], "traffic": pr["traffic"]}
     stages = {k_: {"calls_per_step": v["calls"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 3)}
               for k_, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
@@ -224,7 +255,7 @@ def main():
                    "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "synth_s": round(t_synth, 2),
+        "roofline": roofline, "cpu_baseline": cpu, "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
                                   for k_, v in (hp if runner is None else runner).wall.items()},
     }

@@ -283,6 +283,12 @@ class Context:
         self._ck(self.L.sp_lengths(self.h, _p(out)))
         return out
 
+    def dump_size(self, chrom):
+        """number of distinct canonical k-mers with count >= lower_count (lines of the jellyfish dump)"""
+        n = C.c_int64()
+        self._ck(self.L.sp_dump_size(self.h, int(chrom), C.byref(n)))
+        return n.value
+
     def dump(self, chrom, sort=True):
         """(keys, counts) of one chromosome; canonical keys, ascending when sort=True."""
         n = C.c_int64()
