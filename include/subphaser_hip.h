@@ -74,6 +74,18 @@ int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
 /* use caller-owned device memory (nslots x uint32) as the count table of `chrom`, so that the
  * caller (e.g. a torch tensor handed to RCCL) can exchange it; NULL unbinds.  Call before sp_count. */
 int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table);
+/* wire format of a count table for the multi-GPU exchange: one byte per slot (0 = below lower_count,
+ * 1..254 = the count, 255 = see the overflow list of (uint32 slot, uint32 count) pairs).
+ *   sp_table_narrow  table of `chrom` -> d_out_u8[nslots] + overflow pairs (device, capacity `cap`);
+ *                    *n_ovf = pairs produced (SP_ENOMEM if > cap).
+ *   sp_table_widen   n bytes -> n uint32 (n % 4 == 0); asynchronous on the context's stream.
+ *   sp_table_patch   write the overflow counts whose slot lies in [slot_base, slot_base + n) into a
+ *                    widened slice; asynchronous on the context's stream.
+ * widen(narrow(t)) + patch == t with counts < lower_count zeroed, which is what sp_filter reads
+ * through sp_filter_view (the threshold is applied on read, Jellyfish.py:697 `-L`).                */
+int sp_table_narrow(sp_ctx *ctx, int chrom, void *d_out_u8, void *d_ovf, int64_t cap, int64_t *n_ovf);
+int sp_table_widen(sp_ctx *ctx, const void *d_in_u8, int64_t n, void *d_out_u32);
+int sp_table_patch(sp_ctx *ctx, void *d_tab_u32, int64_t slot_base, int64_t n, const void *d_ovf, int64_t n_ovf);
 /* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
 int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
 /* jellyfish-dump equivalent of one chromosome.  Two calls: sp_dump_size then

@@ -145,6 +145,73 @@ bool sp_engine2_supported(int64_t nslots);
 int sp_sparse_count(sp_ctx *ctx, int k, int lower);                                   // sp_sparse.hip
 int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
+// ------------------------------------------------------------------ wire format of a count table
+// Multi-GPU runs ship slot-range slices of the count tables over xGMI.  Counts that matter are
+// thresholded (>= lower_count) and almost all of them are small, so a table travels as one byte per
+// slot: 0 = below the threshold, 1..254 = the count, 255 = "look in the overflow list" (slot, count).
+// 4x less wire volume than the u32 table: at 2 and 4 GPUs the exchange is bound by ONE xGMI link per peer.
+#define KX_STAGE 2048   // overflow pairs staged in LDS before one global reservation
+__global__ void __launch_bounds__(256)
+kx_narrow(const uint32_t *__restrict__ tab, int64_t n4 /* nslots / 4 */, uint32_t lower, uint32_t *__restrict__ out,
+          uint2 *__restrict__ ovf, unsigned long long cap, unsigned long long *__restrict__ n_ovf) {
+    // counts >= 255 are appended block-wise: a few million single-address global atomics (one per entry,
+    // or even one per wave) cost more than streaming the 2-GiB table (2.1 ms against 0.6 ms)
+    __shared__ uint2 stage[KX_STAGE + 1024];
+    __shared__ uint32_t n_stage;
+    __shared__ unsigned long long g_base;
+    if (threadIdx.x == 0) n_stage = 0;
+    __syncthreads();
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(tab);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_iter = (n4 + stride - 1) / stride;
+    for (int64_t it = 0; it <= n_iter; it++) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (it < n_iter && i < n4) {
+            const uint4 v = t4[i];
+            const uint32_t a[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t c = a[j] >= lower ? a[j] : 0u;
+                if (c >= 255u) {
+                    stage[atomicAdd(&n_stage, 1u)] = make_uint2((uint32_t)(4 * i + j), c);
+                    c = 255u;
+                }
+                packed |= c << (8 * j);
+            }
+            out[i] = packed;
+        }
+        __syncthreads();
+        const uint32_t m = n_stage;
+        if (m >= KX_STAGE || (it == n_iter && m > 0)) {   // block-uniform
+            if (threadIdx.x == 0) g_base = atomicAdd(n_ovf, (unsigned long long)m);
+            __syncthreads();
+            for (uint32_t p = threadIdx.x; p < m; p += blockDim.x)
+                if (g_base + p < cap) ovf[g_base + p] = stage[p];
+            __syncthreads();
+            if (threadIdx.x == 0) n_stage = 0;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+kx_widen(const uint32_t *__restrict__ in, int64_t n4, uint4 *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = in[i];
+        out[i] = make_uint4(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u, p >> 24);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+kx_patch(uint32_t *__restrict__ tab, int64_t slot_base, int64_t n, const uint2 *__restrict__ ovf, int64_t n_ovf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ovf) return;
+    const uint2 e = ovf[i];
+    const int64_t s = (int64_t)e.x - slot_base;
+    if (s >= 0 && s < n) tab[s] = e.y;
+}
+
 extern "C" {
 
 static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last) {
@@ -265,6 +332,50 @@ int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table) {
     c.tab_external = d_table != nullptr;
     ctx->counted = false;
     return SP_OK;
+}
+
+int sp_table_narrow(sp_ctx *ctx, int chrom, void *d_out_u8, void *d_ovf, int64_t cap, int64_t *n_ovf) {
+    if (!ctx || !d_out_u8 || !n_ovf || cap < 0 || (cap > 0 && !d_ovf) || chrom < 0 || chrom >= (int)ctx->chroms.size())
+        return sp_fail(ctx, SP_EINVAL, "sp_table_narrow: bad arguments");
+    if (ctx->sparse_mode || !ctx->chroms[(size_t)chrom].d_tab || ctx->nslots <= 0)
+        return sp_fail(ctx, SP_EINVAL, "sp_table_narrow: chromosome %d has no dense count table", chrom);
+    if (ctx->nslots % 4) return sp_fail(ctx, SP_EUNSUP, "sp_table_narrow: table of %lld slots", (long long)ctx->nslots);
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    void *scr = nullptr;
+    int rc = sp_scratch(ctx, 256, &scr);
+    if (rc) return rc;
+    unsigned long long *d_n = (unsigned long long *)scr;
+    SP_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    SP_LAUNCH(ctx, "kx_narrow", kx_narrow, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
+              (const uint32_t *)ctx->chroms[(size_t)chrom].d_tab, ctx->nslots / 4, (uint32_t)ctx->lower,
+              (uint32_t *)d_out_u8, (uint2 *)d_ovf, (unsigned long long)cap, d_n);
+    unsigned long long h = 0;
+    SP_HIP(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_ovf = (int64_t)h;
+    if ((int64_t)h > cap)
+        return sp_fail(ctx, SP_ENOMEM, "sp_table_narrow: %lld counts >= 255 exceed the overflow capacity %lld",
+                       (long long)h, (long long)cap);
+    return SP_OK;
+}
+
+int sp_table_widen(sp_ctx *ctx, const void *d_in_u8, int64_t n, void *d_out_u32) {
+    if (!ctx || !d_in_u8 || !d_out_u32 || n < 0 || (n % 4)) return sp_fail(ctx, SP_EINVAL, "sp_table_widen: bad arguments (n must be a multiple of 4)");
+    if (n == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_LAUNCH(ctx, "kx_widen", kx_widen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, (const uint32_t *)d_in_u8, n / 4,
+              (uint4 *)d_out_u32);
+    return SP_OK;   // asynchronous on the context's stream
+}
+
+int sp_table_patch(sp_ctx *ctx, void *d_tab_u32, int64_t slot_base, int64_t n, const void *d_ovf, int64_t n_ovf) {
+    if (!ctx || !d_tab_u32 || slot_base < 0 || n < 0 || n_ovf < 0 || (n_ovf > 0 && !d_ovf))
+        return sp_fail(ctx, SP_EINVAL, "sp_table_patch: bad arguments");
+    if (n_ovf == 0 || n == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_LAUNCH(ctx, "kx_patch", kx_patch, dim3((unsigned)((n_ovf + 255) / 256)), dim3(256), 0, (uint32_t *)d_tab_u32,
+              slot_base, n, (const uint2 *)d_ovf, n_ovf);
+    return SP_OK;   // asynchronous on the context's stream
 }
 
 int sp_lengths(sp_ctx *ctx, int64_t *lengths) {

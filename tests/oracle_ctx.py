@@ -152,6 +152,36 @@ class OracleDistContext(OracleContext):
     def tables_bind(self, i, ptr):
         self.bound[i] = ptr
 
+    # wire format of the count tables (sp_table_narrow / widen / patch)
+    def table_narrow(self, i, d_out_u8, d_ovf, cap):
+        import ctypes
+        from subphaser_amd import kmer
+        n = kmer.dense_slots(self.k)
+        tab = self._view_i32(self.bound[i], n)
+        v = np.where(tab >= self.lower, tab, 0)
+        big = np.flatnonzero(v >= 255)
+        if big.size > cap:
+            raise MemoryError("overflow capacity")
+        out = np.frombuffer((ctypes.c_uint8 * n).from_address(int(d_out_u8)), np.uint8)
+        out[:] = np.minimum(v, 255).astype(np.uint8)
+        if big.size:
+            o = np.frombuffer((ctypes.c_uint32 * (2 * big.size)).from_address(int(d_ovf)), np.uint32).reshape(-1, 2)
+            o[:, 0] = big
+            o[:, 1] = v[big]
+        return int(big.size)
+
+    def table_widen(self, d_in_u8, n, d_out_u32):
+        import ctypes
+        src = np.frombuffer((ctypes.c_uint8 * n).from_address(int(d_in_u8)), np.uint8)
+        self._view_i32(d_out_u32, n)[:] = src
+
+    def table_patch(self, d_tab_u32, slot_base, n, d_ovf, n_ovf):
+        import ctypes
+        o = np.frombuffer((ctypes.c_uint32 * (2 * n_ovf)).from_address(int(d_ovf)), np.uint32).reshape(-1, 2)
+        s = o[:, 0].astype(np.int64) - slot_base
+        ok = (s >= 0) & (s < n)
+        self._view_i32(d_tab_u32, n)[s[ok]] = o[ok, 1]
+
     def genome_add_device(self, i, arr, n):
         self.genome_add(i, np.asarray(arr[:n], np.uint8))
 

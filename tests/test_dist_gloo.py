@@ -20,7 +20,7 @@ class _Gen:
         self.chroms = [dict(label=l, length=len(toy["seqs"][l])) for l in self.labels]
 
 
-def _worker(rank, world, port, out_dir, k=9):
+def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None):
     for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -36,12 +36,12 @@ def _worker(rank, world, port, out_dir, k=9):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        toy = make_toy_genome(seed=7)
+        toy = make_toy_genome(seed=7, **(toy_kw or {}))
         gen = _Gen(toy)
         L = 3              # k = 9 -> 2^17 dense slots: small enough to ship as CPU tensors; k = 17 -> key-range path
         kw = dict(min_freq=30, bin_size=100, chunk_size=2000, window_size=2500)
         ctx = OracleDistContext()
-        runner = DistHotPath(ctx, gen, dist, torch, k=k, lower_count=L, device=torch.device("cpu"), **kw)
+        runner = DistHotPath(ctx, gen, dist, torch, k=k, lower_count=L, device=torch.device("cpu"), **kw, **(run_kw or {}))
         ascii_ = [np.frombuffer(toy["seqs"][l].encode(), np.uint8) if i in runner.my_chroms else None
                   for i, l in enumerate(gen.labels)]
         a = runner.count_and_filter(ascii_)
@@ -92,14 +92,14 @@ def test_lpt_assign_balances():
         assert max(loads) <= sum(lens) / n * 1.15 + 1
 
 
-def _spawn(tmp_path, world, k):
+def _spawn(tmp_path, world, k, toy_kw=None, run_kw=None):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), k), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), k, toy_kw, run_kw), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / ("ok%d" % r)).exists()
 
@@ -115,3 +115,9 @@ def test_two_rank_key_range_exchange_over_gloo(tmp_path):
 
 def test_three_rank_key_range_exchange_over_gloo(tmp_path):
     _spawn(tmp_path, 3, 21)
+
+
+def test_two_rank_wire_format_overflow_over_gloo(tmp_path):
+    """k = 6 on a larger toy genome: counts >= 255 exist, so the byte wire format ships overflow pairs;
+    a 4-pair overflow buffer forces the grow-and-redo path."""
+    _spawn(tmp_path, 2, 6, dict(chrom_len=150000, copies=200), dict(ovf_cap=4))

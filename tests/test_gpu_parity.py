@@ -419,6 +419,48 @@ def test_sparse_key_range_view(gpu_ctx, oracle_ctx):
     assert (nu2, nr2, nh2) == (nu, nr, nh)
 
 
+def test_table_wire_format_roundtrip(gpu_ctx):
+    """sp_table_narrow -> sp_table_widen + sp_table_patch reproduces the thresholded count table
+    (counts >= 255 travel in the overflow list); the overflow buffer being too small is an error."""
+    rng = np.random.RandomState(8)
+    k, lower = 9, 3
+    s = _rand_seq(rng, 400000, 0.001, 0.1)
+    s[1000:61000] = ord("A")                                   # poly-A: one count far above 255
+    s[100000:160000] = np.frombuffer(b"ACGTTGCA" * 7500, np.uint8)   # 8 k-mers ~7500 times each
+    gpu_ctx.genome_reset(1)
+    gpu_ctx.genome_add(0, s)
+    gpu_ctx.count(k, lower, 1)
+    keys, cnts = gpu_ctx.dump(0)
+    from subphaser_amd import kmer as km
+    n = km.dense_slots(k)
+    expect = np.zeros(n, np.uint32)
+    expect[km.slots_of_keys(keys, k).astype(np.int64)] = cnts
+    n_big = int((expect >= 255).sum())
+    assert n_big >= 3
+    d8, d32 = gpu_ctx.dev_alloc(n), gpu_ctx.dev_alloc(n * 4)
+    dov = gpu_ctx.dev_alloc(8 * (n_big + 4))
+    with pytest.raises(MemoryError):
+        gpu_ctx.table_narrow(0, d8, dov, n_big - 1)
+    assert gpu_ctx.table_narrow(0, d8, dov, n_big + 4) == n_big
+    b = gpu_ctx.dev_to_host(d8, n)
+    assert (b == np.minimum(expect, 255)).all()
+    pairs = gpu_ctx.dev_to_host(dov, 8 * n_big).view(np.uint32).reshape(-1, 2)
+    o = np.argsort(pairs[:, 0])
+    assert (pairs[o, 0] == np.flatnonzero(expect >= 255)).all() and (pairs[o, 1] == expect[expect >= 255]).all()
+    # whole table, then a slot-range slice
+    gpu_ctx.table_widen(d8, n, d32)
+    gpu_ctx.table_patch(d32, 0, n, dov, n_big)
+    gpu_ctx.sync()
+    assert (gpu_ctx.dev_to_host(d32, n * 4).view(np.uint32) == expect).all()
+    base, m = n // 4, n // 2
+    gpu_ctx.table_widen(d8 + base, m, d32)
+    gpu_ctx.table_patch(d32, base, m, dov, n_big)
+    gpu_ctx.sync()
+    assert (gpu_ctx.dev_to_host(d32, m * 4).view(np.uint32) == expect[base:base + m]).all()
+    for d in (d8, d32, dov):
+        gpu_ctx.dev_free(d)
+
+
 def test_filter_errors(gpu_ctx):
     rng = np.random.RandomState(2)
     gpu_ctx.genome_reset(2)
