@@ -150,7 +150,9 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
 int sp_stack_windows(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
                      const int64_t *slot_off, const int64_t *win_off, int64_t *win_counts);
 /* feature mode (map_kmer3(..., chunk=False), __main__.py:509-511): n_feat
- * sequences concatenated in `ascii`, feature f = [off[f], off[f+1]).
+ * sequences lying back to back in `ascii`, feature f = [off[f], off[f+1]).
+ * Only k-mers that lie entirely inside one feature count (the kernel rejects
+ * k-mers running across a boundary; no separator copy on the host).
  * counts: n_feat x n_sg int64 (whole-feature totals).                      */
 int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,
                     int64_t *counts);

@@ -418,6 +418,16 @@ class Context:
         self._ck(self.L.sp_map_features(self.h, _p(cat), _p(off), len(arrs), _p(out)))
         return out
 
+    def map_features_cat(self, cat, off):
+        """Features lying back to back in `cat` (uint8), feature f = cat[off[f]:off[f+1]].
+        Returns int64 [n_feat, n_sg] totals."""
+        cat = np.ascontiguousarray(cat, np.uint8)
+        off = np.ascontiguousarray(off, np.int64)
+        n = off.size - 1
+        out = np.zeros((n, self.n_sg), np.int64)
+        self._ck(self.L.sp_map_features(self.h, _p(cat), _p(off), n, _p(out)))
+        return out
+
     def labels_hit(self):
         n = C.c_int64()
         self._ck(self.L.sp_labels_hit(self.h, C.byref(n)))

@@ -40,6 +40,35 @@ def read_bin_counts(inBedCount):
                        for c, (s, v) in per.items())
 
 
+def read_bin_counts_arrays(inBedCount):
+    """Array form of a `.bin.count` file: (names, code[n], starts[n], counts[n, S]); names in
+    first-appearance order, code[i] indexes names.  Fast path through the pandas C parser (files with
+    millions of feature rows); any irregular file goes through read_bin_counts."""
+    try:
+        import pandas as pd
+        df = pd.read_csv(inBedCount, sep="\t", header=None, dtype=str, keep_default_na=False, quoting=3,
+                         engine="c", compression="infer")
+        if df.shape[1] < 4:
+            raise ValueError("too few columns")
+        first = df[0].to_numpy()
+        keepm = np.array([not x.startswith("#") for x in first.tolist()], bool) if len(first) else np.zeros(0, bool)
+        df = df[keepm]
+        if (df[0].str.contains(r"\s").any()):
+            raise ValueError("whitespace inside a field")
+        starts = df[1].to_numpy().astype(np.int64)
+        df[2].to_numpy().astype(np.int64)                     # `end` must parse, like the reference's int()
+        counts = df.iloc[:, 3:].to_numpy().astype(np.int64)
+        codes, names = pd.factorize(df[0].to_numpy(), sort=False)
+        return list(names), codes.astype(np.int64), starts, counts.reshape(len(starts), -1)
+    except Exception:
+        per = read_bin_counts(inBedCount)
+        names = list(per)
+        code = np.concatenate([np.full(len(per[c][0]), i, np.int64) for i, c in enumerate(names)]) if names else np.zeros(0, np.int64)
+        starts = np.concatenate([per[c][0] for c in names]) if names else np.zeros(0, np.int64)
+        counts = np.concatenate([per[c][1] for c in names], axis=0) if names else np.zeros((0, 0), np.int64)
+        return names, code, starts, counts
+
+
 def stack_bins(starts, counts, window_size):
     """One chromosome: (window indices in first-appearance order, summed counts)."""
     window_size = int(window_size) if float(window_size).is_integer() else window_size
@@ -52,12 +81,27 @@ def stack_bins(starts, counts, window_size):
 
 
 def stack_matrix(inBedCount, window_size=100000):
-    """stack short bins: returns (coords, counts) like the reference."""
-    coords, counts = [], []
-    for chrom, (starts, vals) in read_bin_counts(inBedCount).items():
-        wins, summed = stack_bins(starts, vals, window_size)
-        for w, row in zip(wins.tolist(), summed):
-            start = int(w * window_size)
-            coords.append((chrom, start, int(start + window_size)))
-            counts.append(list(row))
-    return coords, counts
+    """stack short bins: returns (coords, counts) like the reference (Circos.py:831-842).
+    Rows: chromosomes in first-appearance order, windows of a chromosome in first-appearance order."""
+    names, code, starts, vals = read_bin_counts_arrays(inBedCount)
+    if len(starts) == 0:
+        return [], []
+    ws = int(window_size) if float(window_size).is_integer() else window_size
+    win = (starts // ws).astype(np.int64)
+    order = np.lexsort((win, code))                           # stable: ties keep file order
+    c_s, w_s = code[order], win[order]
+    newg = np.ones(len(order), bool)
+    newg[1:] = (c_s[1:] != c_s[:-1]) | (w_s[1:] != w_s[:-1])
+    gstart = np.flatnonzero(newg)
+    summed = np.add.reduceat(vals[order], gstart, axis=0)
+    first = np.minimum.reduceat(order, gstart)                # first line of each (chromosome, window)
+    g_code, g_win = c_s[gstart], w_s[gstart]
+    o2 = np.lexsort((first, g_code))                          # chromosome order, then first appearance
+    g_code, g_win, summed = g_code[o2], g_win[o2], summed[o2]
+    st = g_win * ws
+    name_arr = np.array(names, dtype=object)[g_code]
+    if isinstance(ws, int):
+        coords = list(zip(name_arr.tolist(), st.tolist(), (st + ws).tolist()))
+    else:
+        coords = [(n_, int(s_), int(s_ + ws)) for n_, s_ in zip(name_arr.tolist(), st.tolist())]
+    return coords, summed.tolist()

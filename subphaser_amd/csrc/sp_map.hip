@@ -209,7 +209,31 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
     atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
 }
 
-// feature mode: per-feature totals; feature of a start found by binary search
+// feature mode: per-feature totals.  The features lie back to back in one packed sequence (no
+// separators): a k-mer belongs to feature f iff it lies entirely inside [foff[f], foff[f+1]).  The
+// feature of a unit's first hit is found by binary search, later hits of the unit walk forward.
+struct map_feat_cursor {
+    int64_t f, next;   // current feature and foff[f + 1]; f < 0: not located yet
+};
+__device__ __forceinline__ bool map_feat_locate(map_feat_cursor &c, int64_t start, int k,
+                                                const int64_t *__restrict__ foff, int64_t n_feat) {
+    if (c.f < 0) {
+        int64_t lo = 0, hi = n_feat;   // last f with foff[f] <= start
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (foff[mid] <= start) lo = mid;
+            else hi = mid;
+        }
+        c.f = lo;
+        c.next = foff[lo + 1];
+    }
+    while (start >= c.next && c.f + 1 < n_feat) {
+        c.f++;
+        c.next = foff[c.f + 1];
+    }
+    return start + k <= c.next;        // false: the k-mer runs into the next feature
+}
+
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
             int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
@@ -218,19 +242,16 @@ k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
+        map_feat_cursor cur;
+        cur.f = -1;
+        cur.next = 0;
         map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
             const uint32_t slot = sp_slot_of32(fwd, rc, kp);
             const uint32_t l = label[slot];
-            if (l) {
+            if (l && map_feat_locate(cur, start, kp.k, foff, n_feat)) {
                 if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
                 const int sg = (int)(l & 0x7fu) - 1;
-                int64_t lo = 0, hi = n_feat;  // last f with foff[f] <= start
-                while (hi - lo > 1) {
-                    int64_t mid = (lo + hi) >> 1;
-                    if (foff[mid] <= start) lo = mid;
-                    else hi = mid;
-                }
-                atomicAdd(&counts[lo * S + sg], 1ULL);
+                atomicAdd(&counts[cur.f * S + sg], 1ULL);
             }
         });
     }
@@ -486,20 +507,15 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     memset(counts, 0, (size_t)n_feat * S * sizeof(int64_t));
     if (n_feat == 0) return SP_OK;
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    // concatenate with one invalid separator after every feature so no k-mer spans two features
-    const int64_t total = off[n_feat] + n_feat;
-    std::vector<uint8_t> buf((size_t)total);
+    // the features are uploaded as they lie in the caller's buffer (back to back); the kernel rejects
+    // k-mers that run across a feature boundary, so no separator copy is needed on the host
+    const int64_t base = off[0], total = off[n_feat] - off[0];
     std::vector<int64_t> foff((size_t)n_feat + 1);
-    int64_t w = 0;
-    for (int64_t f = 0; f < n_feat; f++) {
-        foff[(size_t)f] = w;
-        int64_t n = off[f + 1] - off[f];
-        if (n < 0) return sp_fail(ctx, SP_EINVAL, "sp_map_features: offsets must be non-decreasing");
-        memcpy(buf.data() + w, ascii + off[f], (size_t)n);
-        w += n;
-        buf[(size_t)w++] = 'N';
+    for (int64_t f = 0; f <= n_feat; f++) {
+        if (f > 0 && off[f] < off[f - 1]) return sp_fail(ctx, SP_EINVAL, "sp_map_features: offsets must be non-decreasing");
+        foff[(size_t)f] = off[f] - base;
     }
-    foff[(size_t)n_feat] = w;
+    if (total == 0) return SP_OK;
     uint8_t *d_ascii = nullptr;
     uint32_t *d_pk = nullptr, *d_nm = nullptr;
     int64_t *d_foff = nullptr;
@@ -510,7 +526,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     SP_HIP(ctx, hipMalloc(&d_nm, (size_t)nmw * 4));
     SP_HIP(ctx, hipMalloc(&d_foff, (size_t)(n_feat + 1) * 8));
     SP_HIP(ctx, hipMalloc(&d_counts, (size_t)n_feat * S * 8));
-    SP_HIP(ctx, hipMemcpyAsync(d_ascii, buf.data(), (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_ascii, ascii + base, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n_feat + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_feat * S * 8, ctx->stream));
     int64_t blocks = (nmw + 255) / 256;

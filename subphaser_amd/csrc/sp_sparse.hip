@@ -266,16 +266,14 @@ k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
+        map_feat_cursor cur;
+        cur.f = -1;
+        cur.next = 0;
         map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return;   // runs into the next feature
             const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
             if (sg < 0) return;
-            int64_t lo = 0, hi = n_feat;
-            while (hi - lo > 1) {
-                int64_t mid = (lo + hi) >> 1;
-                if (foff[mid] <= start) lo = mid;
-                else hi = mid;
-            }
-            atomicAdd(&counts[lo * S + sg], 1ULL);
+            atomicAdd(&counts[cur.f * S + sg], 1ULL);
         });
     }
 }

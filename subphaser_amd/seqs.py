@@ -82,6 +82,92 @@ def read_fasta(path, as_array=False):
         yield rid, (seq if as_array else seq.tobytes())
 
 
+_BULK_STEP = 1 << 26     # bytes per worker span of read_fasta_bulk
+
+
+def read_fasta_bulk(path):
+    """All records of a (gz) FASTA at once, for files with millions of short records (feature sets):
+    returns (ids, cat, off) -- ids list of str, cat uint8 array of all sequences back to back without
+    line breaks, off int64 [n + 1].  Pure numpy passes over the file, no per-base Python."""
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    if magic == b"\x1f\x8b":
+        with gzip.open(path, "rb") as fh:
+            data = np.frombuffer(fh.read(), np.uint8)
+    elif os.path.getsize(path) == 0:
+        data = np.empty(0, np.uint8)
+    else:
+        data = np.memmap(path, dtype=np.uint8, mode="r")
+    n = int(data.size)
+    empty = ([], np.empty(0, np.uint8), np.zeros(1, np.int64))
+    if n == 0:
+        return empty
+    from concurrent.futures import ThreadPoolExecutor
+    step = _BULK_STEP
+    spans = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+    pool = ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)), len(spans)))
+
+    def scan(span):      # positions of '>' at line starts and of line breaks (numpy releases the GIL)
+        lo, hi = span
+        d = data[lo:hi]
+        gt = np.flatnonzero(d == 62) + lo
+        if gt.size:
+            prev = np.where(gt > 0, data[np.maximum(gt - 1, 0)], 10)
+            gt = gt[prev == 10]
+        return gt, np.flatnonzero(d == 10) + lo
+    parts = list(pool.map(scan, spans))
+    starts = np.concatenate([p[0] for p in parts])
+    nl = np.concatenate([p[1] for p in parts])
+    del parts
+    if starts.size == 0:
+        pool.shutdown()
+        return empty
+    j = np.searchsorted(nl, starts)
+    hdr_end = np.full(starts.size, n, np.int64)
+    ok = j < nl.size
+    hdr_end[ok] = nl[j[ok]]
+    lens = hdr_end - starts
+    tot = int(lens.sum())
+    hdr_idx = np.repeat(starts - np.concatenate(([0], np.cumsum(lens)[:-1])), lens) + np.arange(tot)
+    first = int(starts[0])
+
+    def squeeze(span):   # sequence bytes of one span: no blanks / line breaks, no header bytes
+        lo, hi = span
+        keep = data[lo:hi] > 32
+        a_, b_ = np.searchsorted(hdr_idx, [lo, hi])
+        keep[hdr_idx[a_:b_] - lo] = False
+        if lo < first:
+            keep[:min(hi, first) - lo] = False
+        # bytes kept before every record start that falls into this span
+        ra, rb = np.searchsorted(starts, [lo, hi])
+        cs = np.add.reduceat(keep.view(np.uint8), np.concatenate(([0], starts[ra:rb] - lo)), dtype=np.int64) \
+            if rb > ra else np.array([int(keep.sum())], np.int64)
+        if rb > ra and starts[ra] == lo:      # reduceat with a repeated index returns the element itself
+            cs[0] = 0
+        return data[lo:hi][keep], cs
+    outs = list(pool.map(squeeze, spans))
+    pool.shutdown()
+    cat = np.concatenate([o[0] for o in outs])
+    # cs pieces: [tail of the record open at the span start, record 1, record 2, ...] -> per-record totals
+    rec_len = np.zeros(starts.size, np.int64)
+    r = -1
+    for (lo, hi), (_, cs) in zip(spans, outs):
+        ra, rb = np.searchsorted(starts, [lo, hi])
+        if r >= 0:
+            rec_len[r] += cs[0]
+        if rb > ra:
+            rec_len[ra:rb] += cs[1:]
+            r = rb - 1
+    off = np.zeros(starts.size + 1, np.int64)
+    off[1:] = np.cumsum(rec_len)
+    assert off[-1] == cat.size
+    ids = []
+    for a_, b_ in zip(starts.tolist(), hdr_end.tolist()):
+        h = bytes(data[a_ + 1:b_]).split()
+        ids.append(h[0].decode() if h else "")
+    return ids, cat, off
+
+
 def write_fasta(path, rid, seq, width=60):
     seq = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, np.uint8)
     with open(path, "wb") as f:
@@ -267,28 +353,36 @@ def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bi
             if log:
                 logger.info("Mapped {} kmers to chromsome {}".format(c, rid))
     else:
+        from .textio import write_chunks
         for featfile in chromfiles:
-            ids, seqs = [], []
-            for rid, seq in read_fasta(featfile):
-                ids.append(rid)
-                seqs.append(seq)
-            big = [i for i, s in enumerate(seqs) if len(s) > bin_size]
-            counts = ctx.map_features(seqs)
-            for i, rid in enumerate(ids):
-                n_seq += 1
-                if i in big:       # rare: a feature longer than one bin needs per-bin counts
-                    counts_i = _map_long_feature(ctx, seqs[i], bin_size, k)
-                    starts = np.flatnonzero(counts_i.any(axis=1)) * bin_size
-                    ends = np.minimum(starts + bin_size, len(seqs[i]))
-                    _write_lines(fout, rid, starts, ends, counts_i[counts_i.any(axis=1)])
-                    c = int(counts_i.sum())
-                else:
-                    c = int(counts[i].sum())
-                    if c:
-                        _write_lines(fout, rid, np.array([0]), np.array([min(bin_size, len(seqs[i]))]),
-                                     counts[i:i + 1])
-                mapped_num += c
-                mapped_seqs += 1 if c else 0
+            ids, cat, off = read_fasta_bulk(featfile)
+            lens = np.diff(off)
+            counts = ctx.map_features_cat(cat, off)
+            big = {}
+            for i in np.flatnonzero(lens > bin_size).tolist():   # rare: a feature longer than one bin
+                ci = _map_long_feature(ctx, cat[off[i]:off[i + 1]], bin_size, k)
+                nzb = np.flatnonzero(ci.any(axis=1))
+                big[i] = (nzb * bin_size, np.minimum(nzb * bin_size + bin_size, int(lens[i])), ci[nzb])
+                counts[i] = ci.sum(axis=0)
+            tot = counts.sum(axis=1)
+            n_seq += len(ids)
+            mapped_num += int(tot.sum())
+            mapped_seqs += int((tot > 0).sum())
+            sel = np.flatnonzero(tot > 0)
+            ends = np.minimum(bin_size, lens)
+
+            def fmt(lo, hi, sel=sel, ids=ids, ends=ends, counts=counts, big=big):
+                out = []
+                for i in sel[lo:hi].tolist():
+                    if i in big:
+                        st, en, cc = big[i]
+                        for a_, b_, row in zip(st.tolist(), en.tolist(), cc.tolist()):
+                            out.append("%s\t%d\t%d\t%s\n" % (ids[i], a_, b_, "\t".join(map(str, row))))
+                    else:
+                        out.append("%s\t0\t%d\t%s\n" % (ids[i], ends[i], "\t".join(map(str, counts[i].tolist()))))
+                return "".join(out)
+            fout.flush() if hasattr(fout, "flush") else None
+            write_chunks(fout, len(sel), fmt)
     logger.info("Processed {} sequences".format(n_seq))
     total = len(labels.keys)
     if n_seq and total:

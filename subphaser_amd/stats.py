@@ -141,32 +141,52 @@ def group_exchanges(lines, d_sg):
 _FEAT_ID = re.compile(r"(\S+?):\d+\-\d+")
 
 
-def enrich_ltr(fout, d_sg, *args, **kargs):
-    """Output LTR / custom-feature enrichments (`.ltr.enrich`, `.custom.enrich`)."""
-    total = consistent = exchange = 0
-    d_enriched, d_exchange, lines, pvalues = {}, {}, [], []
-    for res in enrich(*args, **kargs):
-        ltr, *_ = res.rowname
+def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval=0.05, ctx=None,
+               **kargs):
+    """Output LTR / custom-feature enrichments (`.ltr.enrich`, `.custom.enrich`; Stats.py:33-73).
+    Array code throughout: feature sets have millions of rows (BASELINE config 5)."""
+    from .textio import write_chunks
+    arr = np.asarray(matrix, np.int64)
+    if arr.ndim != 2:
+        arr = arr.reshape(len(matrix), -1)
+    if colnames is not None and rownames is not None:
+        assert arr.shape == (len(rownames), len(colnames)), "{} != {}".format(arr.shape, (len(rownames), len(colnames)))
+    assert len(colnames) > 1     # Stats.py:172
+    ctx = ctx or get_context()
+    n = arr.shape[0]
+    if n:
+        pvals, argmin, sig, _ = ctx.enrich(arr, max_pval, min_ratio)
+        pmin = pvals[np.arange(n), argmin]
+    else:
+        pvals, argmin, sig, pmin = np.zeros((0, arr.shape[1])), np.zeros(0, np.int64), np.zeros(0, bool), np.zeros(0)
+    sig = np.asarray(sig, bool)
+    ids = [r[0] for r in rownames]            # `ltr, *_ = res.rowname`
+    # the reference crashes (AttributeError) on ids that are not chrom:start-end
+    # (Stats.py:42-43); the evident intent is "unknown chromosome"
+    cache = {}
+    exch = []
+    for i, ltr in enumerate(ids):
         m = _FEAT_ID.match(ltr)
-        # the reference crashes (AttributeError) on ids that are not chrom:start-end
-        # (Stats.py:42-43); the evident intent is "unknown chromosome"
         chrom = m.groups()[0] if m else None
-        sg = res.key if res.sig else None
-        potential_exchange = is_exchange(d_sg.get(chrom), sg)
-        lines.append([ltr, sg, res.pval, ",".join(map(str, res.counts)), potential_exchange])
-        pvalues.append(res.pval)
-        if sg:
-            d_enriched[ltr] = sg
-        d_exchange[ltr] = potential_exchange
-        total += 1
-        exchange += potential_exchange == "yes"
-        consistent += potential_exchange == "no"
+        obs = cache.get(chrom)
+        if obs is None and chrom not in cache:
+            obs = cache[chrom] = d_sg.get(chrom)
+        exch.append(is_exchange(obs, colnames[argmin[i]] if sig[i] else None))
+    exch_a = np.array(exch, dtype=object)
+    total, exchange, consistent = n, int((exch_a == "yes").sum()), int((exch_a == "no").sum())
     if exchange > 0 and consistent > 0:
         logger.info("Consistent with subgenome assignment: {} ({:.2%}); potential exchange: {} ({:.2%})".format(
             consistent, consistent / total, exchange, exchange / total))
-    qvals = correct_pvals(pvalues)
+    qvals = correct_pvals(pmin)
     fout.write("\t".join(["#id", "subgenome", "p_value", "counts", "potential_exchange", "p_corrected"]) + "\n")
-    for line, q in zip(lines, qvals):
-        line.append(q)
-        fout.write("\t".join(map(_fmt, line)) + "\n")
+    sgcol = [colnames[m] if s_ else None for m, s_ in zip(argmin.tolist(), sig.tolist())]
+
+    def fmt(lo, hi):
+        return "".join("%s\t%s\t%s\t%s\t%s\t%s\n" % (ids[i], sgcol[i], repr(float(pmin[i])),
+                                                   ",".join(map(str, arr[i].tolist())), exch[i], repr(float(qvals[i])))
+                       for i in range(lo, hi))
+    fout.flush() if hasattr(fout, "flush") else None
+    write_chunks(fout, n, fmt)
+    d_enriched = {ltr: sg for ltr, sg in zip(ids, sgcol) if sg}
+    d_exchange = dict(zip(ids, exch))
     return d_enriched, d_exchange

@@ -122,6 +122,10 @@ class OracleContext:
             self.hit |= hit
         return out
 
+    def map_features_cat(self, cat, off):
+        cat = np.asarray(cat, np.uint8)
+        return self.map_features([cat[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)])
+
     def labels_hit(self):
         return int(self.hit.sum())
 

@@ -132,3 +132,33 @@ def test_cli_parses_reference_flags():
     assert a.k == 15 and a.min_freq == 200 and a.min_fold == 2.0 and a.lower_count == 3
     assert a.max_freq == 1e9 and a.baseline == 1 and a.ratio == 1 and a.max_pval == 0.05
     assert a.custom_features == ["te.fa"] and a.ncpu == 8
+
+
+def test_fasta_bulk_reader_matches_record_reader(tmp_path):
+    """read_fasta_bulk (feature sets with millions of records) == read_fasta, across worker-span cuts."""
+    import numpy as np
+    from subphaser_amd import seqs
+    rng = np.random.RandomState(1)
+    recs, txt = [], ["leading junk\n"]
+    for i in range(400):
+        L = int(rng.randint(0, 900))
+        w = int(rng.choice([60, 80, 10 ** 6]))
+        sq = "".join(rng.choice(list("ACGTNacgt"), L))
+        recs.append(("r%d" % i, sq.encode()))
+        txt.append(">r%d some desc\n" % i + "\n".join(sq[j:j + w] for j in range(0, L, w)) + ("\n" if L else ""))
+    txt.append(">last\r\nAC GT\r\n>empty")
+    recs += [("last", b"ACGT"), ("empty", b"")]
+    fa = tmp_path / "f.fa"
+    fa.write_text("".join(txt))
+    assert list(seqs.read_fasta(str(fa))) == recs
+    old = seqs._BULK_STEP
+    try:
+        for step in (old, 4096, 17, 1001):
+            seqs._BULK_STEP = step
+            ids, cat, off = seqs.read_fasta_bulk(str(fa))
+            assert [(i, bytes(cat[off[j]:off[j + 1]])) for j, i in enumerate(ids)] == recs, step
+    finally:
+        seqs._BULK_STEP = old
+    empty = tmp_path / "e.fa"
+    empty.write_text("")
+    assert seqs.read_fasta_bulk(str(empty))[0] == []
