@@ -143,6 +143,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower,
                      unsigned long long *d_len2);  // sp_count2.hip
 bool sp_engine2_supported(int64_t nslots);
 int sp_sparse_count(sp_ctx *ctx, int k, int lower);                                   // sp_sparse.hip
+int sp_sparse_count3(sp_ctx *ctx, int k, int lower);                                  // sp_sparse2.hip
 int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
 // ------------------------------------------------------------------ wire format of a count table
@@ -222,7 +223,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     SP_HIP(ctx, hipSetDevice(ctx->device));
     if (first < 0 || last > (int)ctx->chroms.size() || first > last)
         return sp_fail(ctx, SP_EINVAL, "sp_count_range: bad chromosome range [%d, %d)", first, last);
-    if (k > 15) {   // 64-bit keys: sort-based sparse engine (`engine` is ignored)
+    if (k > 15) {   // 64-bit keys: sparse engines (engine 1 = device-wide radix sort, otherwise the MSD partition)
         if (first != 0 || last != (int)ctx->chroms.size())
             return sp_fail(ctx, SP_EUNSUP, "sp_count_range: k > 15 counts all chromosomes at once");
         for (auto &c : ctx->chroms)
@@ -237,7 +238,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         ctx->lower = lower_count;
         ctx->nslots = 0;
         ctx->sparse_mode = true;
-        int rcs = sp_sparse_count(ctx, k, lower_count);
+        int rcs = (engine == 1) ? sp_sparse_count(ctx, k, lower_count) : sp_sparse_count3(ctx, k, lower_count);
         if (rcs) return rcs;
         ctx->counted = true;
         return SP_OK;

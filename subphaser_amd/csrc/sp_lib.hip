@@ -7,5 +7,6 @@
 #include "sp_filter.hip"
 #include "sp_map.hip"
 #include "sp_sparse.hip"
+#include "sp_sparse2.hip"
 #include "sp_enrich.hip"
 #include "sp_synth.hip"

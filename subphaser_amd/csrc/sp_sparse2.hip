@@ -1,0 +1,884 @@
+// sp_sparse2.hip -- hand-written count engine for k = 16..32 ("engine 3").
+//
+// The first sparse engine sorted every chromosome's 64-bit keys with a device-wide LSD radix sort
+// (rocPRIM, 5-6 passes x 16 B per key r+w: 480 of the 780 ms of a wheat-like pass at k = 17).  This
+// engine is the 64-bit twin of engine 2: an MSD partition that moves every key twice, in shrinking
+// form, and finishes inside LDS.
+//
+//   s3_hist1   scan the packed chromosome, histogram the top B1 key bits (LDS, F1 <= 1024 bins)
+//   s3_part1   scan again; LDS counting sort of a tile on those bits; every bucket run goes out as
+//              one burst; only the low R1 = 2k - B1 bits survive (u32 for k <= 21, else u64)
+//   s3_hist2   per level-1 bucket: histogram of the next B2 = 9 bits  -> exact fine-bucket offsets
+//   s3_part2   per level-1 bucket: LDS counting sort of 4 K-key tiles on those bits; R2 = R1 - 9
+//              bits survive (u32 for k <= 25)
+//   s3_final   one workgroup per fine bucket (2^18..2^19 of them, ~1-3 K keys): block radix sort of
+//              the residuals in registers/LDS, run-length encode, keep count >= lower_count
+//   s3_gather  ordered compaction of the kept (key, count) pairs -> the chromosome's sorted list
+//
+// Fine buckets that do not fit one workgroup (> 4096 keys: hot keys such as telomere repeats) are
+// sorted one by one with the device-wide primitive; they are rare.
+// Bytes per key (k = 21): 0.375 x 3 scans + 4 w + 4 r + 4 r + 4 w + 4 r  ~ 21 B against ~100 B.
+#include "sp_device.h"
+
+#define S3_MAXF 1024
+#define S3_P1_UNIT 32
+#define S3_P2_THREADS 512
+#define S3_P2_PER 16
+#define S3_P2_KEYS (S3_P2_THREADS * S3_P2_PER)   // keys per part2 / hist2 tile
+#define S3_SORT_THREADS 256
+#define S3_SORT_PER 8
+#define S3_SORT_CAP (S3_SORT_THREADS * S3_SORT_PER)   // keys one workgroup sorts
+
+struct s3_plan {
+    int T, B1, B2, R1, R2, F1, F2;
+    bool wide1, wide2;   // residuals after level 1 / level 2 need 64 bits
+};
+
+static s3_plan s3_make_plan(int k) {
+    s3_plan p;
+    p.T = 2 * k;
+    p.B1 = 10;   // k <= 21: the residual (2k - 10 bits) fits 32 bits
+    p.B2 = 9;
+    p.R1 = p.T - p.B1;
+    p.R2 = p.R1 - p.B2;
+    p.F1 = 1 << p.B1;
+    p.F2 = 1 << p.B2;
+    p.wide1 = p.R1 > 32;
+    p.wide2 = p.R2 > 32;
+    return p;
+}
+
+// block-wide exclusive scan of hist[0..F) (F <= 1024) -> start[]; returns the total
+template <int THREADS>
+__device__ __forceinline__ uint32_t s3_block_scan(const uint32_t *hist, uint32_t *start, int F, uint32_t *wsum) {
+    constexpr int NW = THREADS / 64;
+    const int per = (F + THREADS - 1) / THREADS;
+    const int lo = threadIdx.x * per;
+    uint32_t v = 0;
+    for (int i = 0; i < per; i++)
+        if (lo + i < F) v += hist[lo + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    uint32_t run = base + incl - v;
+    for (int i = 0; i < per; i++)
+        if (lo + i < F) {
+            start[lo + i] = run;
+            run += hist[lo + i];
+        }
+    __syncthreads();
+    return total;
+}
+
+// ---------------------------------------------------------------- s3_hist1
+__global__ void __launch_bounds__(256)
+s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 64 starts */,
+         sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ ghist) {
+    __shared__ uint32_t lh[S3_MAXF];
+    for (int i = threadIdx.x; i < F1; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x)
+        sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+            const uint64_t key = fwd < rc ? fwd : rc;
+            atomicAdd(&lh[key >> R1], 1u);
+        });
+    __syncthreads();
+    for (int i = threadIdx.x; i < F1; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&ghist[i], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------- s3_part1
+// Two scans of the tile (count, then place): the 64-bit window arithmetic is cheap next to the LDS
+// atomics, and staging raw keys would double the LDS footprint.  Output runs are reserved with one
+// global atomic per (tile, non-empty bucket); the order inside a bucket does not matter downstream.
+template <typename KR1, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
+         sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ cursor1, KR1 *__restrict__ buf1,
+         int64_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
+    KR1 *keys = reinterpret_cast<KR1 *>(s3_lds);                        // [THREADS * 32]
+    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], wsum[THREADS / 64];
+    const uint64_t rmask = (R1 >= 64) ? ~0ULL : ((1ULL << R1) - 1ULL);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
+        __syncthreads();
+        const int64_t u = tile * THREADS + threadIdx.x;
+        if (u < n_units)
+            sp_scan_unit64<S3_P1_UNIT>(pk, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+                const uint64_t key = fwd < rc ? fwd : rc;
+                atomicAdd(&hist[key >> R1], 1u);
+            });
+        __syncthreads();
+        for (int b = threadIdx.x; b < F1; b += THREADS) {
+            const uint32_t c = hist[b];
+            gbase[b] = c ? (uint32_t)atomicAdd(&cursor1[b], (unsigned long long)c) : 0u;
+        }
+        const uint32_t total = s3_block_scan<THREADS>(hist, start, F1, wsum);
+        if (threadIdx.x == 0) start[F1] = total;
+        for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;    // now the placement cursors
+        __syncthreads();
+        if (u < n_units)
+            sp_scan_unit64<S3_P1_UNIT>(pk, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+                const uint64_t key = fwd < rc ? fwd : rc;
+                const uint32_t b = (uint32_t)(key >> R1);
+                keys[start[b] + atomicAdd(&hist[b], 1u)] = (KR1)(key & rmask);
+            });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += THREADS) {
+            int lo = 0, hi = F1;   // bucket of sorted position i: last b with start[b] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (start[mid] <= i) lo = mid;
+                else hi = mid;
+            }
+            buf1[(size_t)gbase[lo] + (i - start[lo])] = keys[i];
+        }
+        __syncthreads();
+    }
+}
+
+// tile bookkeeping shared by hist2 / part2: level-1 bucket b owns keys [off1[b], off1[b+1]) of buf1 and
+// tiles [tile_start[b], tile_start[b+1]) of S3_P2_KEYS keys
+__global__ void __launch_bounds__(1024)
+s3_tiles(const unsigned long long *__restrict__ hist1_excl /* F1+1: exclusive scan */, int F1,
+         unsigned long long *__restrict__ tile_start /* F1+1 */) {
+    if (threadIdx.x == 0) {
+        unsigned long long tiles = 0;
+        for (int b = 0; b < F1; b++) {
+            tile_start[b] = tiles;
+            tiles += (hist1_excl[b + 1] - hist1_excl[b] + S3_P2_KEYS - 1) / S3_P2_KEYS;
+        }
+        tile_start[F1] = tiles;
+    }
+}
+
+__device__ __forceinline__ int s3_bucket_of(const unsigned long long *__restrict__ tile_start, int F1,
+                                            unsigned long long tile) {
+    int lo = 0, hi = F1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------- s3_hist2
+// Each block walks a contiguous range of tiles and keeps the histogram of the current level-1 bucket in
+// LDS; it is flushed when the bucket changes.
+template <typename KR1>
+__global__ void __launch_bounds__(S3_P2_THREADS)
+s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+         const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
+         unsigned long long *__restrict__ hist2 /* F1 * F2 */) {
+    __shared__ uint32_t lh[512];
+    __shared__ int s_b;
+    const unsigned long long n_tiles = tile_start[F1];
+    const unsigned long long per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    unsigned long long t0 = (unsigned long long)blockIdx.x * per, t1 = t0 + per;
+    if (t1 > n_tiles) t1 = n_tiles;
+    if (t0 >= t1) return;
+    const uint32_t mask2 = (uint32_t)F2 - 1u;
+    for (int i = threadIdx.x; i < F2; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) s_b = s3_bucket_of(tile_start, F1, t0);
+    __syncthreads();
+    int cb = s_b;
+    for (unsigned long long tile = t0; tile < t1; tile++) {
+        if (tile >= tile_start[cb + 1]) {   // block-uniform: flush and move to the bucket of this tile
+            __syncthreads();
+            for (int i = threadIdx.x; i < F2; i += blockDim.x) {
+                const uint32_t v = lh[i];
+                if (v) atomicAdd(&hist2[(size_t)cb * F2 + i], (unsigned long long)v);
+                lh[i] = 0;
+            }
+            while (tile >= tile_start[cb + 1]) cb++;
+            __syncthreads();
+        }
+        const unsigned long long base = off1[cb] + (tile - tile_start[cb]) * S3_P2_KEYS, end = off1[cb + 1];
+#pragma unroll
+        for (int j = 0; j < S3_P2_PER; j++) {
+            const unsigned long long idx = base + (unsigned long long)j * S3_P2_THREADS + threadIdx.x;
+            if (idx < end) atomicAdd(&lh[(uint32_t)(buf1[idx] >> R2) & mask2], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F2; i += blockDim.x) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&hist2[(size_t)cb * F2 + i], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------- s3_part2
+template <typename KR1, typename KR2>
+__global__ void __launch_bounds__(S3_P2_THREADS)
+s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+         const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
+         const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2,
+         KR2 *__restrict__ buf2) {
+    __shared__ uint32_t hist[512], start[512], cur[512], wsum[S3_P2_THREADS / 64];
+    __shared__ unsigned long long gbase[512];
+    __shared__ KR1 keys[S3_P2_KEYS];
+    __shared__ int s_b;
+    const unsigned long long n_tiles = tile_start[F1];
+    const uint32_t mask2 = (uint32_t)F2 - 1u;
+    const uint64_t rmask = (R2 >= 64) ? ~0ULL : ((1ULL << R2) - 1ULL);
+    for (unsigned long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) s_b = s3_bucket_of(tile_start, F1, tile);
+        for (int i = threadIdx.x; i < F2; i += S3_P2_THREADS) hist[i] = 0;
+        __syncthreads();
+        const int b1 = s_b;
+        const unsigned long long base = off1[b1] + (tile - tile_start[b1]) * S3_P2_KEYS, end = off1[b1 + 1];
+        KR1 my[S3_P2_PER];
+        int nmine = 0;
+#pragma unroll
+        for (int j = 0; j < S3_P2_PER; j++) {
+            const unsigned long long idx = base + (unsigned long long)j * S3_P2_THREADS + threadIdx.x;
+            if (idx < end) {
+                my[j] = buf1[idx];
+                nmine = j + 1;
+                atomicAdd(&hist[(uint32_t)(my[j] >> R2) & mask2], 1u);
+            }
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < F2; d += S3_P2_THREADS) {
+            const uint32_t c = hist[d];
+            const size_t fine = (size_t)b1 * F2 + d;
+            gbase[d] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+            cur[d] = 0;
+        }
+        const uint32_t total = s3_block_scan<S3_P2_THREADS>(hist, start, F2, wsum);
+#pragma unroll
+        for (int j = 0; j < S3_P2_PER; j++)
+            if (j < nmine) {
+                const uint32_t d = (uint32_t)(my[j] >> R2) & mask2;
+                keys[start[d] + atomicAdd(&cur[d], 1u)] = my[j];
+            }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += S3_P2_THREADS) {
+            const KR1 kk = keys[i];
+            const uint32_t d = (uint32_t)(kk >> R2) & mask2;
+            buf2[gbase[d] + (i - start[d])] = (KR2)((uint64_t)kk & rmask);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- s3_final
+// One workgroup per fine bucket.  <= 4096 residuals: block radix sort in registers/LDS, run-length
+// encode, keep runs >= lower.  Larger buckets are first split on their next <= 10 residual bits into a
+// scratch area (the level-1 buffer, free by now; the bucket is L2-sized, so this costs no HBM traffic) and
+// the pieces go through the same sort one after the other; a piece that is still too large is counted
+// directly in LDS when <= 13 residual bits are left (always the case for k <= 21), is a single hot key, or
+// sends the whole bucket to the device-wide fallback.  Kept (residual, count) pairs are written at the
+// bucket's own offset of the scratch arrays in ascending order, their number into kept[bucket].
+#define S3_SPLIT_BITS 8
+#define S3_DIRECT_BITS 12
+
+#define S3_SMALL_PER 8
+#define S3_SMALL_CAP (S3_SORT_THREADS * S3_SMALL_PER)   // buckets up to this size take the light kernel
+
+template <typename KR2, int PER>
+struct s3_sort_lds {
+    union {
+        typename rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER>::storage_type sort;
+        typename rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER, uint32_t>::storage_type pair_sort;
+    };
+    KR2 s[S3_SORT_THREADS * PER];
+    uint32_t heads[S3_SORT_THREADS * PER + 1];
+    uint32_t wsum[S3_SORT_THREADS / 64], cnt1[S3_SORT_THREADS], cnt2[S3_SORT_THREADS];
+};
+
+#define S3_HASH_SLOTS 2048                       // LDS hash table of the hot-key path
+#define S3_HASH_MAX (S3_HASH_SLOTS * 3 / 4)      // distinct residuals it accepts
+
+template <typename KR2>
+struct s3_final_lds {
+    union {
+        s3_sort_lds<KR2, S3_SORT_PER> q;     // also the hot-key path's (key, count) staging
+        s3_sort_lds<KR2, 4> q4;
+        s3_sort_lds<KR2, 2> q2;
+    };
+    union {
+        uint32_t direct[1 << S3_DIRECT_BITS];
+        struct {
+            KR2 key[S3_HASH_SLOTS];
+            uint32_t cnt[S3_HASH_SLOTS];
+        } hash;
+    } u;
+    uint32_t sub_cnt[1 << S3_SPLIT_BITS], sub_off[(1 << S3_SPLIT_BITS) + 1];
+    unsigned long long red[16];
+    uint32_t ones, distinct;
+};
+
+__device__ __forceinline__ uint32_t s3_hash(unsigned long long v) {
+    v ^= v >> 29;
+    v *= 0x9E3779B97F4A7C15ULL;
+    return (uint32_t)(v >> 40);
+}
+
+// sort + run-length encode + keep of one segment of <= S3_SORT_THREADS * PER residuals (all threads of the
+// block); appends at out[0...], returns the number kept; lsum accumulates the kept counts (per thread)
+template <typename KR2, int PER>
+__device__ __forceinline__ uint32_t s3_sort_segment(const KR2 *__restrict__ seg, uint32_t n, int bits, uint32_t lower,
+                                                    s3_sort_lds<KR2, PER> &L, KR2 *__restrict__ out_keys,
+                                                    uint32_t *__restrict__ out_cnts, unsigned long long &lsum) {
+    using sort_t = rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER>;
+    KR2 items[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t i = threadIdx.x * PER + j;
+        items[j] = (i < n) ? seg[i] : (KR2)~(KR2)0;   // padding sorts last (stable: after equal valid keys)
+    }
+    __syncthreads();
+    sort_t().sort(items, L.sort, 0, (unsigned)(bits > 0 ? bits : 1));
+#pragma unroll
+    for (int j = 0; j < PER; j++) L.s[threadIdx.x * PER + j] = items[j];
+    __syncthreads();
+    uint32_t nh = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t i = threadIdx.x * PER + j;
+        if (i < n && (i == 0 || L.s[i] != L.s[i - 1])) nh++;
+    }
+    L.cnt1[threadIdx.x] = nh;
+    __syncthreads();
+    const uint32_t n_runs = s3_block_scan<S3_SORT_THREADS>(L.cnt1, L.cnt2, S3_SORT_THREADS, L.wsum);
+    {
+        uint32_t r = L.cnt2[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t i = threadIdx.x * PER + j;
+            if (i < n && (i == 0 || L.s[i] != L.s[i - 1])) L.heads[r++] = i;
+        }
+        if (threadIdx.x == 0) L.heads[n_runs] = n;
+    }
+    __syncthreads();
+    const uint32_t per = (n_runs + S3_SORT_THREADS - 1) / S3_SORT_THREADS;
+    const uint32_t r0 = threadIdx.x * per, r1 = (r0 + per < n_runs) ? r0 + per : n_runs;
+    uint32_t nk = 0;
+    for (uint32_t r = r0; r < r1; r++) nk += (L.heads[r + 1] - L.heads[r]) >= lower;
+    L.cnt1[threadIdx.x] = nk;
+    __syncthreads();
+    const uint32_t n_kept = s3_block_scan<S3_SORT_THREADS>(L.cnt1, L.cnt2, S3_SORT_THREADS, L.wsum);
+    uint32_t w = L.cnt2[threadIdx.x];
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t len = L.heads[r + 1] - L.heads[r];
+        if (len >= lower) {
+            out_keys[w] = L.s[L.heads[r]];
+            out_cnts[w] = len;
+            lsum += len;
+            w++;
+        }
+    }
+    __syncthreads();
+    return n_kept;
+}
+
+// light kernel: buckets of <= 1024 residuals (4 per thread, ~14 KB of LDS: many blocks per CU)
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_final_small(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+               uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
+               unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+    // size classes: a 200-key bucket must not pay for a padded 2048-key sort
+    __shared__ union {
+        s3_sort_lds<KR2, 1> l1;
+        s3_sort_lds<KR2, 2> l2;
+        s3_sort_lds<KR2, 4> l4;
+        s3_sort_lds<KR2, S3_SMALL_PER> l8;
+    } L;
+    __shared__ unsigned long long red[16];
+    unsigned long long lsum = 0;
+    for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
+        const unsigned long long o = off_fine[bucket];
+        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        if (n64 > S3_SMALL_CAP) continue;            // the heavy kernel's
+        if (n64 == 0) {
+            if (threadIdx.x == 0) kept[bucket] = 0;
+            continue;
+        }
+        const uint32_t n = (uint32_t)n64;
+        uint32_t nk;
+        if (n <= S3_SORT_THREADS)
+            nk = s3_sort_segment<KR2, 1>(buf2 + o, n, R2, lower, L.l1, tmp_keys + o, tmp_cnts + o, lsum);
+        else if (n <= 2 * S3_SORT_THREADS)
+            nk = s3_sort_segment<KR2, 2>(buf2 + o, n, R2, lower, L.l2, tmp_keys + o, tmp_cnts + o, lsum);
+        else if (n <= 4 * S3_SORT_THREADS)
+            nk = s3_sort_segment<KR2, 4>(buf2 + o, n, R2, lower, L.l4, tmp_keys + o, tmp_cnts + o, lsum);
+        else
+            nk = s3_sort_segment<KR2, S3_SMALL_PER>(buf2 + o, n, R2, lower, L.l8, tmp_keys + o, tmp_cnts + o, lsum);
+        if (threadIdx.x == 0) kept[bucket] = nk;
+    }
+    const unsigned long long tot = sp_block_sum_u64(lsum, red);
+    if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
+}
+
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned long long *__restrict__ off_fine,
+         int64_t n_fine, int R2, uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
+         unsigned long long *__restrict__ kept, unsigned long long *__restrict__ big_list,
+         unsigned long long *__restrict__ n_big, unsigned long long big_cap, unsigned long long *__restrict__ len_sum) {
+    __shared__ s3_final_lds<KR2> L;
+    unsigned long long lsum = 0;
+    for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
+        const unsigned long long o = off_fine[bucket];
+        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        if (n64 <= S3_SMALL_CAP) continue;           // the light kernel's
+        if (n64 <= S3_SORT_CAP) {
+            const uint32_t nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
+            if (threadIdx.x == 0) kept[bucket] = nk;
+            continue;
+        }
+        bool give_up = n64 >= (1ULL << 31);
+        uint32_t w = 0;                      // kept pairs written so far (block-uniform)
+        unsigned long long bsum = 0;         // their counts; dropped if the bucket goes to the fallback
+        if (!give_up) {
+            const uint32_t n = (uint32_t)n64;
+            int sb = 1;                      // pieces of ~2 K residuals: a few sorts, not 2^10 tiny ones
+            while (sb < S3_SPLIT_BITS && (n >> sb) > S3_SORT_CAP / 2) sb++;
+            if (sb > R2) sb = R2;
+            const int rem = R2 - sb, nsub = 1 << sb;
+            const KR2 rem_mask = (rem >= (int)(8 * sizeof(KR2))) ? (KR2)~(KR2)0 : (KR2)(((KR2)1 << rem) - 1);
+            for (int i = threadIdx.x; i < nsub; i += S3_SORT_THREADS) L.sub_cnt[i] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += S3_SORT_THREADS) atomicAdd(&L.sub_cnt[(uint32_t)(buf2[o + i] >> rem)], 1u);
+            __syncthreads();
+            const uint32_t tot = s3_block_scan<S3_SORT_THREADS>(L.sub_cnt, L.sub_off, nsub, L.q.wsum);
+            if (threadIdx.x == 0) L.sub_off[nsub] = tot;
+            for (int i = threadIdx.x; i < nsub; i += S3_SORT_THREADS) L.sub_cnt[i] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += S3_SORT_THREADS) {
+                const KR2 v = buf2[o + i];
+                const uint32_t d = (uint32_t)(v >> rem);
+                scratch[o + L.sub_off[d] + atomicAdd(&L.sub_cnt[d], 1u)] = v;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int d = 0; d < nsub && !give_up; d++) {
+                const uint32_t so = L.sub_off[d], m = L.sub_off[d + 1] - so;   // block-uniform
+                if (m == 0) continue;
+                const KR2 *seg = scratch + o + so;
+                const KR2 hi = (rem >= (int)(8 * sizeof(KR2))) ? (KR2)0 : (KR2)((KR2)d << rem);
+                if (m <= S3_SORT_CAP) {
+                    // the pieces hold full residuals; sort on the remaining bits only
+                    if (m <= 2 * S3_SORT_THREADS)
+                        w += s3_sort_segment<KR2, 2>(seg, m, rem, lower, L.q2, tmp_keys + o + w, tmp_cnts + o + w, bsum);
+                    else if (m <= 4 * S3_SORT_THREADS)
+                        w += s3_sort_segment<KR2, 4>(seg, m, rem, lower, L.q4, tmp_keys + o + w, tmp_cnts + o + w, bsum);
+                    else
+                        w += s3_sort_segment<KR2, S3_SORT_PER>(seg, m, rem, lower, L.q, tmp_keys + o + w, tmp_cnts + o + w, bsum);
+                } else if (rem <= S3_DIRECT_BITS) {          // few possible values: count them all in LDS
+                    const uint32_t nv = 1u << rem;
+                    for (uint32_t i = threadIdx.x; i < nv; i += S3_SORT_THREADS) L.u.direct[i] = 0;
+                    __syncthreads();
+                    for (uint32_t i = threadIdx.x; i < m; i += S3_SORT_THREADS) atomicAdd(&L.u.direct[(uint32_t)(seg[i] & rem_mask)], 1u);
+                    __syncthreads();
+                    // ordered compaction of the values with count >= lower
+                    const uint32_t per = (nv + S3_SORT_THREADS - 1) / S3_SORT_THREADS;
+                    const uint32_t v0 = threadIdx.x * per, v1 = (v0 + per < nv) ? v0 + per : nv;
+                    uint32_t nk = 0;
+                    for (uint32_t v = v0; v < v1; v++) nk += L.u.direct[v] >= lower;
+                    L.q.cnt1[threadIdx.x] = nk;
+                    __syncthreads();
+                    const uint32_t n_kept = s3_block_scan<S3_SORT_THREADS>(L.q.cnt1, L.q.cnt2, S3_SORT_THREADS, L.q.wsum);
+                    uint32_t ww = w + L.q.cnt2[threadIdx.x];
+                    for (uint32_t v = v0; v < v1; v++) {
+                        const uint32_t c = L.u.direct[v];
+                        if (c >= lower) {
+                            tmp_keys[o + ww] = hi | (KR2)v;
+                            tmp_cnts[o + ww] = c;
+                            bsum += c;
+                            ww++;
+                        }
+                    }
+                    w += n_kept;
+                    __syncthreads();
+                } else {
+                    // hot keys (repeat families put thousands of copies of one k-mer into a bucket): count the
+                    // distinct residuals of the piece in an LDS hash table, then sort the few that are kept
+                    const KR2 EMPTY = (KR2)~(KR2)0;
+                    for (int i = threadIdx.x; i < S3_HASH_SLOTS; i += S3_SORT_THREADS) {
+                        L.u.hash.key[i] = EMPTY;
+                        L.u.hash.cnt[i] = 0;
+                    }
+                    if (threadIdx.x == 0) L.ones = L.distinct = 0;
+                    __syncthreads();
+                    for (uint32_t i = threadIdx.x; i < m; i += S3_SORT_THREADS) {
+                        const KR2 v = seg[i];
+                        if (v == EMPTY) {              // the table's empty marker: counted aside
+                            atomicAdd(&L.ones, 1u);
+                            continue;
+                        }
+                        uint32_t h = s3_hash((unsigned long long)v) & (S3_HASH_SLOTS - 1);
+                        for (int probe = 0; probe < S3_HASH_SLOTS; probe++) {
+                            const KR2 prev = atomicCAS(&L.u.hash.key[h], EMPTY, v);
+                            if (prev == EMPTY) atomicAdd(&L.distinct, 1u);
+                            if (prev == EMPTY || prev == v) {
+                                atomicAdd(&L.u.hash.cnt[h], 1u);
+                                break;
+                            }
+                            if (L.distinct > S3_HASH_MAX) break;   // too many distinct residuals: fallback
+                            h = (h + 1) & (S3_HASH_SLOTS - 1);
+                        }
+                    }
+                    __syncthreads();
+                    if (L.distinct > S3_HASH_MAX) {
+                        give_up = true;
+                    } else {
+                        // entries with count >= lower -> (q.s, q.heads) as (key, count), then sort the pairs
+                        constexpr int SPT = S3_HASH_SLOTS / S3_SORT_THREADS;
+                        uint32_t nk = 0;
+                        for (int j = 0; j < SPT; j++) nk += L.u.hash.cnt[threadIdx.x * SPT + j] >= lower;
+                        if (threadIdx.x == 0 && L.ones >= lower) nk++;
+                        L.q.cnt1[threadIdx.x] = nk;
+                        __syncthreads();
+                        const uint32_t n_kept = s3_block_scan<S3_SORT_THREADS>(L.q.cnt1, L.q.cnt2, S3_SORT_THREADS, L.q.wsum);
+                        uint32_t ww = L.q.cnt2[threadIdx.x];
+                        for (int j = 0; j < SPT; j++) {
+                            const uint32_t c = L.u.hash.cnt[threadIdx.x * SPT + j];
+                            if (c >= lower) {
+                                L.q.s[ww] = L.u.hash.key[threadIdx.x * SPT + j];
+                                L.q.heads[ww] = c;
+                                ww++;
+                            }
+                        }
+                        if (threadIdx.x == 0 && L.ones >= lower) {
+                            L.q.s[ww] = EMPTY;
+                            L.q.heads[ww] = L.ones;
+                        }
+                        __syncthreads();
+                        using psort_t = rocprim::block_radix_sort<KR2, S3_SORT_THREADS, S3_SORT_PER, uint32_t>;
+                        KR2 pk_[S3_SORT_PER];
+                        uint32_t pv_[S3_SORT_PER];
+#pragma unroll
+                        for (int j = 0; j < S3_SORT_PER; j++) {
+                            const uint32_t i = threadIdx.x * S3_SORT_PER + j;
+                            pk_[j] = (i < n_kept) ? L.q.s[i] : EMPTY;
+                            pv_[j] = (i < n_kept) ? L.q.heads[i] : 0u;
+                        }
+                        __syncthreads();
+                        psort_t().sort(pk_, pv_, L.q.pair_sort, 0, (unsigned)(R2 > 0 ? R2 : 1));
+#pragma unroll
+                        for (int j = 0; j < S3_SORT_PER; j++) {
+                            const uint32_t i = threadIdx.x * S3_SORT_PER + j;
+                            if (i < n_kept) {          // stable: real entries precede the padding
+                                tmp_keys[o + w + i] = pk_[j];
+                                tmp_cnts[o + w + i] = pv_[j];
+                                bsum += pv_[j];
+                            }
+                        }
+                        w += n_kept;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (give_up) {
+                kept[bucket] = 0;
+                const unsigned long long at = atomicAdd(n_big, 1ULL);
+                if (at < big_cap) big_list[at] = (unsigned long long)bucket;
+            } else {
+                kept[bucket] = w;
+            }
+        }
+        if (!give_up) lsum += bsum;
+    }
+    const unsigned long long tot = sp_block_sum_u64(lsum, L.red);
+    if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
+}
+
+// a bucket too large for one workgroup, after the device-wide sort + run-length encode of its residuals:
+// keep runs >= lower (single block, ordered)
+template <typename KR2>
+__global__ void __launch_bounds__(256)
+s3_big_select(const KR2 *__restrict__ uniq, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ n_runs_p,
+              uint32_t lower, unsigned long long o, int64_t bucket, KR2 *__restrict__ tmp_keys,
+              uint32_t *__restrict__ tmp_cnts, unsigned long long *__restrict__ kept,
+              unsigned long long *__restrict__ len_sum) {
+    __shared__ uint32_t lds[16];
+    __shared__ unsigned long long red[16];
+    const unsigned long long n_runs = *n_runs_p;
+    unsigned long long w = 0, lsum = 0;
+    for (unsigned long long base = 0; base < n_runs; base += 256) {
+        const unsigned long long i = base + threadIdx.x;
+        const uint32_t c = (i < n_runs) ? counts[i] : 0u;
+        const bool p = (i < n_runs) && c >= lower;
+        uint32_t tot;
+        const uint32_t my = sp_block_excl_count(p, lds, tot);
+        if (p) {
+            tmp_keys[o + w + my] = uniq[i];
+            tmp_cnts[o + w + my] = c;
+            lsum += c;
+        }
+        w += tot;
+    }
+    const unsigned long long t = sp_block_sum_u64(lsum, red);
+    if (threadIdx.x == 0) {
+        kept[bucket] = w;
+        if (t) atomicAdd(len_sum, t);
+    }
+}
+
+// ---------------------------------------------------------------- s3_gather
+template <typename KR2>
+__global__ void __launch_bounds__(256)
+s3_gather(const KR2 *__restrict__ tmp_keys, const uint32_t *__restrict__ tmp_cnts,
+          const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ kept_excl,
+          const unsigned long long *__restrict__ kept_tot, int64_t n_fine, int R2,
+          unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_cnts) {
+    // one wave per fine bucket
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t b = wave; b < n_fine; b += n_waves) {
+        const unsigned long long w0 = kept_excl[b];
+        const unsigned long long n = ((b + 1 < n_fine) ? kept_excl[b + 1] : *kept_tot) - w0;
+        const unsigned long long o = off_fine[b];
+        const unsigned long long hi = (R2 >= 64) ? 0ULL : ((unsigned long long)b << R2);
+        for (unsigned long long i = lane; i < n; i += 64) {
+            out_keys[w0 + i] = hi | (unsigned long long)tmp_keys[o + i];
+            out_cnts[w0 + i] = tmp_cnts[o + i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- multi-block exclusive scan (u64)
+// The single-block scan_excl_u64 walks 2^19 bucket counters in 0.75 ms; three of them per chromosome were
+// 10 % of the engine.  Chunk sums -> scan of <= 1024 sums -> per-chunk scan with coalesced tiles.
+__global__ void __launch_bounds__(256)
+s3_scan_sum(const unsigned long long *__restrict__ a, int64_t n, int64_t chunk, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long red[16];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    unsigned long long v = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += a[i];
+    const unsigned long long t = sp_block_sum_u64(v, red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256)
+s3_scan_apply(unsigned long long *__restrict__ a, int64_t n, int64_t chunk, const unsigned long long *__restrict__ boff) {
+    __shared__ unsigned long long wtot[4];
+    __shared__ unsigned long long carry_s;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = boff[blockIdx.x];
+    __syncthreads();
+    for (int64_t base = lo; base < hi; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned long long v = (i < hi) ? a[i] : 0ULL;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long x = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += x;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        unsigned long long pre = carry_s, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) pre += wtot[w];
+            tot += wtot[w];
+        }
+        if (i < hi) a[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+}
+
+// exclusive scan of a[0..n) in place; *total (device) receives the sum.  bsum: >= 1024 u64 of scratch.
+static int s3_scan(sp_ctx *ctx, unsigned long long *a, int64_t n, unsigned long long *total, unsigned long long *bsum) {
+    if (n <= 4096) {
+        SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, a, n, total);
+        return SP_OK;
+    }
+    int64_t nb = (n + 2047) / 2048;
+    if (nb > 1024) nb = 1024;
+    const int64_t chunk = ((n + nb - 1) / nb + 255) / 256 * 256;
+    nb = (n + chunk - 1) / chunk;
+    SP_LAUNCH(ctx, "s3_scan_sum", s3_scan_sum, dim3((unsigned)nb), dim3(256), 0, (const unsigned long long *)a, n, chunk, bsum);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, bsum, nb, total);
+    SP_LAUNCH(ctx, "s3_scan_apply", s3_scan_apply, dim3((unsigned)nb), dim3(256), 0, a, n, chunk, (const unsigned long long *)bsum);
+    return SP_OK;
+}
+
+// ================================================================== host side
+template <typename KR1, typename KR2>
+static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_plan &P, const sp_kparams &kp,
+                          int lower) {
+    const int64_t len = c.len;
+    const int64_t n_fine = (int64_t)P.F1 * P.F2;
+    // small arrays: hist1 / off1 [F1+1], cursor1 [F1], tile_start [F1+1], hist2 -> off_fine [n_fine+1],
+    // cursor2 [n_fine], kept [n_fine+1], big list, counters
+    const size_t big_cap = 1 << 16;
+    const size_t o_h1 = 0, o_c1 = o_h1 + (size_t)(P.F1 + 1) * 8, o_ts = o_c1 + (size_t)P.F1 * 8,
+                 o_of = o_ts + (size_t)(P.F1 + 1) * 8, o_c2 = o_of + (size_t)(n_fine + 1) * 8,
+                 o_kp = o_c2 + (size_t)n_fine * 8, o_big = o_kp + (size_t)(n_fine + 1) * 8,
+                 o_small = o_big + big_cap * 8, o_bsum = o_small + 256, small_bytes = o_bsum + 1024 * 8;
+    int rc = sp_buf_ensure(ctx, ctx->b_s3_small, (int64_t)small_bytes);
+    if (rc) return rc;
+    char *S = (char *)ctx->b_s3_small.p;
+    unsigned long long *d_h1 = (unsigned long long *)(S + o_h1), *d_c1 = (unsigned long long *)(S + o_c1),
+                       *d_ts = (unsigned long long *)(S + o_ts), *d_of = (unsigned long long *)(S + o_of),
+                       *d_c2 = (unsigned long long *)(S + o_c2), *d_kp = (unsigned long long *)(S + o_kp),
+                       *d_big = (unsigned long long *)(S + o_big), *d_small = (unsigned long long *)(S + o_small),
+                       *d_bsum = (unsigned long long *)(S + o_bsum);
+    // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total
+    SP_HIP(ctx, hipMemsetAsync(S, 0, small_bytes, ctx->stream));
+    const int64_t n_units64 = (len + SP_UNIT - 1) / SP_UNIT;
+    int64_t grid = (n_units64 + 255) / 256;
+    if (grid > (int64_t)ctx->n_cu * 8) grid = (int64_t)ctx->n_cu * 8;
+    SP_LAUNCH(ctx, "s3_hist1", s3_hist1, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_nm, n_units64, kp, P.R1, P.F1,
+              d_h1);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_h1, (int64_t)P.F1 + 1, d_small);
+    unsigned long long nv = 0;
+    SP_HIP(ctx, hipMemcpyAsync(&nv, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_c1, d_h1, (size_t)P.F1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out.n = 0;
+    out.length_sum = 0;
+    if (nv == 0) return SP_OK;
+    if (nv >= (1ULL << 32)) return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
+    rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)nv * (int64_t)sizeof(KR1) + 64);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_b, (int64_t)nv * (int64_t)sizeof(KR2) + 64);
+    if (rc) return rc;
+    const size_t tk_bytes = ((size_t)nv * sizeof(KR2) + 63) & ~(size_t)63;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_c, (int64_t)(tk_bytes + (size_t)nv * 4 + 64));
+    if (rc) return rc;
+    KR1 *buf1 = (KR1 *)ctx->b_sp_a.p;
+    KR2 *buf2 = (KR2 *)ctx->b_sp_b.p;
+    KR2 *tmp_keys = (KR2 *)ctx->b_sp_c.p;
+    uint32_t *tmp_cnts = (uint32_t *)((char *)ctx->b_sp_c.p + tk_bytes);
+
+    constexpr int P1T = sizeof(KR1) == 4 ? 512 : 256;
+    const int64_t n_units32 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;
+    const int64_t n_tiles1 = (n_units32 + P1T - 1) / P1T;
+    int64_t g1 = n_tiles1 < (int64_t)ctx->n_cu * 8 ? n_tiles1 : (int64_t)ctx->n_cu * 8;
+    const size_t lds1 = (size_t)P1T * S3_P1_UNIT * sizeof(KR1);
+    hipFuncSetAttribute((const void *)s3_part1<KR1, P1T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    SP_LAUNCH(ctx, "s3_part1", (s3_part1<KR1, P1T>), dim3((unsigned)g1), dim3(P1T), lds1, c.d_pk, c.d_nm, n_units32, kp,
+              P.R1, P.F1, d_c1, buf1, n_tiles1);
+    SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, P.F1, d_ts);
+    const int64_t est_tiles = (int64_t)(nv / S3_P2_KEYS) + P.F1 + 1;
+    int64_t g2 = est_tiles < (int64_t)ctx->n_cu * 8 ? est_tiles : (int64_t)ctx->n_cu * 8;
+    SP_LAUNCH(ctx, "s3_hist2", s3_hist2<KR1>, dim3((unsigned)g2), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
+              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2, d_of);
+    rc = s3_scan(ctx, d_of, n_fine + 1, d_small + 5, d_bsum);
+    if (rc) return rc;
+    int64_t g3 = est_tiles < (int64_t)ctx->n_cu * 16 ? est_tiles : (int64_t)ctx->n_cu * 16;
+    SP_LAUNCH(ctx, "s3_part2", (s3_part2<KR1, KR2>), dim3((unsigned)g3), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
+              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
+              (const unsigned long long *)d_of, d_c2, buf2);
+    int64_t g4 = n_fine < (int64_t)ctx->n_cu * 64 ? n_fine : (int64_t)ctx->n_cu * 64;
+    SP_LAUNCH(ctx, "s3_final_small", s3_final_small<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
+              (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_small + 2);
+    SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
+              (KR2 *)buf1, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
+              d_small + 1, (unsigned long long)big_cap, d_small + 2);
+    unsigned long long n_big = 0;
+    SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_big > big_cap) return sp_fail(ctx, SP_EUNSUP, "k > 15: %llu oversized k-mer buckets", n_big);
+    if (n_big) {   // hot keys: buckets beyond one workgroup, sorted one by one with the device-wide primitive
+        std::vector<unsigned long long> big((size_t)n_big), offs((size_t)n_fine + 1);
+        SP_HIP(ctx, hipMemcpy(big.data(), d_big, (size_t)n_big * 8, hipMemcpyDeviceToHost));
+        SP_HIP(ctx, hipMemcpy(offs.data(), d_of, (size_t)(n_fine + 1) * 8, hipMemcpyDeviceToHost));
+        for (unsigned long long bi = 0; bi < n_big; bi++) {
+            const int64_t b = (int64_t)big[(size_t)bi];
+            const unsigned long long o = offs[(size_t)b], n = offs[(size_t)b + 1] - o;
+            // sorted residuals -> buf1 area (free now), unique -> tmp of its own bucket range is too small for
+            // the unsorted copy, so use buf1 as scratch: [sorted n][unique n][counts n]
+            rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)(n * (2 * sizeof(KR2) + 4) + 256));
+            if (rc) return rc;
+            KR2 *srt = (KR2 *)ctx->b_sp_a.p, *unq = srt + n;
+            uint32_t *cn = (uint32_t *)(unq + n);
+            size_t tb = 0;
+            SP_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, buf2 + o, srt, (size_t)n, 0u, (unsigned)(P.R2 > 0 ? P.R2 : 1),
+                                                 ctx->stream));
+            size_t tb2 = 0;
+            SP_HIP(ctx, rocprim::run_length_encode(nullptr, tb2, srt, (unsigned int)n, unq, cn, d_small + 4, ctx->stream));
+            rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)(tb > tb2 ? tb : tb2) + 256);
+            if (rc) return rc;
+            SP_HIP(ctx, rocprim::radix_sort_keys(ctx->b_sp_tmp.p, tb, buf2 + o, srt, (size_t)n, 0u,
+                                                 (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
+            SP_HIP(ctx, rocprim::run_length_encode(ctx->b_sp_tmp.p, tb2, srt, (unsigned int)n, unq, cn, d_small + 4,
+                                                   ctx->stream));
+            SP_LAUNCH(ctx, "s3_big_select", s3_big_select<KR2>, dim3(1), dim3(256), 0, (const KR2 *)unq, (const uint32_t *)cn,
+                      (const unsigned long long *)(d_small + 4), (uint32_t)lower, o, b, tmp_keys, tmp_cnts, d_kp,
+                      d_small + 2);
+        }
+    }
+    rc = s3_scan(ctx, d_kp, n_fine, d_small + 3, d_bsum);
+    if (rc) return rc;
+    unsigned long long h[2] = {0, 0};
+    SP_HIP(ctx, hipMemcpyAsync(h, d_small + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t keep = (int64_t)h[1];
+    if (keep > out.cap) {
+        if (out.d_keys) hipFree(out.d_keys);
+        if (out.d_cnts) hipFree(out.d_cnts);
+        out.d_keys = nullptr;
+        out.d_cnts = nullptr;
+        out.cap = 0;
+        SP_HIP(ctx, hipMalloc(&out.d_keys, (size_t)(keep + 1) * 8));
+        SP_HIP(ctx, hipMalloc(&out.d_cnts, (size_t)(keep + 1) * 4));
+        out.cap = keep;
+    }
+    out.n = keep;
+    out.length_sum = (int64_t)h[0];
+    if (keep) {
+        int64_t g5 = (n_fine * 64 + 255) / 256;
+        if (g5 > (int64_t)ctx->n_cu * 32) g5 = (int64_t)ctx->n_cu * 32;
+        SP_LAUNCH(ctx, "s3_gather", s3_gather<KR2>, dim3((unsigned)g5), dim3(256), 0, (const KR2 *)tmp_keys,
+                  (const uint32_t *)tmp_cnts, (const unsigned long long *)d_of, (const unsigned long long *)d_kp,
+                  (const unsigned long long *)(d_small + 3), n_fine, P.R2, (unsigned long long *)out.d_keys, out.d_cnts);
+    }
+    return SP_OK;
+}
+
+int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
+    const size_t C = ctx->chroms.size();
+    if (ctx->sparse.size() != C) {
+        for (auto &c : ctx->sparse) sps_free_chrom(c);
+        ctx->sparse.assign(C, sp_sparse_chrom());
+    }
+    const sp_kparams kp = sp_make_kparams(k);
+    const s3_plan P = s3_make_plan(k);
+    for (size_t ci = 0; ci < C; ci++) {
+        sp_chrom &c = ctx->chroms[ci];
+        sp_sparse_chrom &o = ctx->sparse[ci];
+        o.n = 0;
+        o.length_sum = 0;
+        c.length_sum = 0;
+        c.n_dump = 0;
+        if (c.len <= 0) continue;
+        int rc;
+        if (!P.wide1) rc = s3_count_chrom<uint32_t, uint32_t>(ctx, c, o, P, kp, lower);
+        else if (!P.wide2) rc = s3_count_chrom<unsigned long long, uint32_t>(ctx, c, o, P, kp, lower);
+        else rc = s3_count_chrom<unsigned long long, unsigned long long>(ctx, c, o, P, kp, lower);
+        if (rc) return rc;
+        c.length_sum = o.length_sum;
+        c.n_dump = o.n;
+    }
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}

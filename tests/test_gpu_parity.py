@@ -91,9 +91,11 @@ def test_count_engine2_unsupported_small_k(gpu_ctx):
         gpu_ctx.count(5, 1, 2)
 
 
-@pytest.mark.parametrize("k", [16, 17, 21, 25, 31, 32])
-def test_count_sparse_engine(gpu_ctx, k):
-    """k > 15: 64-bit keys, sort + run-length-encode engine vs the oracle."""
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("k", [16, 17, 21, 22, 25, 26, 31, 32])
+def test_count_sparse_engine(gpu_ctx, k, engine):
+    """k > 15: 64-bit keys; engine 0 = MSD partition + in-LDS sort (sp_sparse2.hip), engine 1 = device-wide
+    radix sort + run-length encode (sp_sparse.hip), both vs the oracle."""
     rng = np.random.RandomState(300 + k)
     seqs = [_rand_seq(rng, n) for n in (5000, 300_001, 64, 40)]
     rep = _rand_seq(rng, 400, 0, 0)
@@ -103,8 +105,23 @@ def test_count_sparse_engine(gpu_ctx, k):
         s[p:p + 400] = rep
     seqs += [s, np.frombuffer(b"A" * 5000 + b"TTTAGGG" * 800, np.uint8), np.empty(0, np.uint8),
              np.frombuffer(b"N" * 100, np.uint8)]
-    _count_both(gpu_ctx, seqs, k, 1)
-    _count_both(gpu_ctx, seqs, k, 3)
+    _count_both(gpu_ctx, seqs, k, 1, engine)
+    _count_both(gpu_ctx, seqs, k, 3, engine)
+
+
+def test_count_sparse_engine_hot_buckets(gpu_ctx):
+    """Buckets beyond one workgroup's sort capacity (a k-mer repeated > 4096 times, and many distinct keys
+    sharing the 18-19 partition bits) take the device-wide fallback of the MSD engine."""
+    rng = np.random.RandomState(41)
+    k = 17
+    unit = _rand_seq(rng, 23, 0, 0)
+    hot = np.tile(unit, 9000)                                   # 23 distinct k-mers x 9000 copies
+    pre = _rand_seq(rng, 9, 0, 0)                               # many distinct k-mers behind one 9-base prefix
+    crowd = np.concatenate([np.concatenate([pre, _rand_seq(rng, 8, 0, 0), np.frombuffer(b"N", np.uint8)])
+                            for _ in range(12000)])
+    seqs = [np.concatenate([_rand_seq(rng, 50000), hot, _rand_seq(rng, 1000), crowd])]
+    _count_both(gpu_ctx, seqs, k, 1, 0)
+    _count_both(gpu_ctx, seqs, k, 3, 0)
 
 
 @pytest.mark.parametrize("k", [17, 21])
