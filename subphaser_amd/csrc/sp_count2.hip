@@ -436,7 +436,6 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     unsigned long long *off_fine = (unsigned long long *)(ws + o_offf);
     unsigned long long *off1 = (unsigned long long *)(ws + o_off1);
     unsigned long long *tile_start = (unsigned long long *)(ws + o_tile);
-    unsigned long long *cur1 = (unsigned long long *)(ws + o_cur1);
     unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
     uint32_t *tile_cnt = (uint32_t *)(ws + o_tcnt);
     uint32_t *tile_off = (uint32_t *)(ws + o_toff);
