@@ -34,6 +34,20 @@ struct sp_buf {
     int64_t cap = 0;
 };
 
+// temporary device allocation, released at scope exit (error returns included)
+template <typename T>
+struct sp_tmp {
+    T *p = nullptr;
+    sp_tmp() = default;
+    sp_tmp(const sp_tmp &) = delete;
+    sp_tmp &operator=(const sp_tmp &) = delete;
+    ~sp_tmp() {
+        if (p) hipFree(p);
+    }
+    hipError_t alloc(size_t n_elems) { return hipMalloc((void **)&p, (n_elems ? n_elems : 1) * sizeof(T)); }
+    operator T *() const { return p; }
+};
+
 // k > 15: per-chromosome sorted (canonical key, count >= lower_count) arrays
 struct sp_sparse_chrom {
     uint64_t *d_keys = nullptr;

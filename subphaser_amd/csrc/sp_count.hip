@@ -407,25 +407,22 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
     if (ctx->sparse_mode) return sp_sparse_dump(ctx, chrom, keys, counts);
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t nblk = (ctx->nslots + DUMP_SLOTS - 1) / DUMP_SLOTS;
-    unsigned long long *d_blk = nullptr, *d_keys = nullptr;
-    uint32_t *d_cnt = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_blk, (size_t)nblk * sizeof(unsigned long long)));
-    SP_HIP(ctx, hipMalloc(&d_keys, (size_t)c.n_dump * sizeof(unsigned long long)));
-    SP_HIP(ctx, hipMalloc(&d_cnt, (size_t)c.n_dump * sizeof(uint32_t)));
+    sp_tmp<unsigned long long> d_blk, d_keys;
+    sp_tmp<uint32_t> d_cnt;
+    SP_HIP(ctx, d_blk.alloc((size_t)nblk));
+    SP_HIP(ctx, d_keys.alloc((size_t)c.n_dump));
+    SP_HIP(ctx, d_cnt.alloc((size_t)c.n_dump));
     SP_LAUNCH(ctx, "dump_count", dump_count, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, c.d_tab,
-              ctx->nslots, (uint32_t)ctx->lower, d_blk);
-    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_blk, nblk,
+              ctx->nslots, (uint32_t)ctx->lower, d_blk.p);
+    SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_blk.p, nblk,
               (unsigned long long *)nullptr);
     SP_LAUNCH(ctx, "dump_write", dump_write, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, c.d_tab,
-              ctx->nslots, (uint32_t)ctx->lower, d_blk, kp, d_keys, d_cnt);
+              ctx->nslots, (uint32_t)ctx->lower, d_blk.p, kp, d_keys.p, d_cnt.p);
     SP_HIP(ctx, hipMemcpyAsync(keys, d_keys, (size_t)c.n_dump * sizeof(uint64_t), hipMemcpyDeviceToHost,
                               ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(counts, d_cnt, (size_t)c.n_dump * sizeof(uint32_t), hipMemcpyDeviceToHost,
                               ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_blk);
-    hipFree(d_keys);
-    hipFree(d_cnt);
     return SP_OK;
 }
 }  // extern "C"

@@ -195,30 +195,24 @@ extern "C" int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, d
     long long sum_total = 0;
     for (int j = 0; j < S; j++) sum_total += total[(size_t)j];
     const size_t nWS = (size_t)W * S;
-    long long *d_counts = nullptr, *d_total = nullptr;
-    double *d_p = nullptr, *d_q = nullptr;
-    int *d_arg = nullptr;
-    unsigned char *d_sig = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_counts, nWS * 8));
-    SP_HIP(ctx, hipMalloc(&d_total, (size_t)S * 8));
-    SP_HIP(ctx, hipMalloc(&d_p, nWS * 8));
-    SP_HIP(ctx, hipMalloc(&d_q, nWS * 8));
-    SP_HIP(ctx, hipMalloc(&d_arg, (size_t)W * 4));
-    SP_HIP(ctx, hipMalloc(&d_sig, (size_t)W));
+    sp_tmp<long long> d_counts, d_total;
+    sp_tmp<double> d_p, d_q;
+    sp_tmp<int> d_arg;
+    sp_tmp<unsigned char> d_sig;
+    SP_HIP(ctx, d_counts.alloc(nWS));
+    SP_HIP(ctx, d_total.alloc((size_t)S));
+    SP_HIP(ctx, d_p.alloc(nWS));
+    SP_HIP(ctx, d_q.alloc(nWS));
+    SP_HIP(ctx, d_arg.alloc((size_t)W));
+    SP_HIP(ctx, d_sig.alloc((size_t)W));
     SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, nWS * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_total, total.data(), (size_t)S * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_LAUNCH(ctx, "k6_enrich", k6_enrich, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, d_counts, d_total,
-              sum_total, (long long)W, S, max_pval, min_ratio, d_p, d_arg, d_sig, d_q);
+    SP_LAUNCH(ctx, "k6_enrich", k6_enrich, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, d_counts.p, d_total.p,
+              sum_total, (long long)W, S, max_pval, min_ratio, d_p.p, d_arg.p, d_sig.p, d_q.p);
     SP_HIP(ctx, hipMemcpyAsync(pvals, d_p, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(ratios, d_q, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(argmin, d_arg, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(sig, d_sig, (size_t)W, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_counts);
-    hipFree(d_total);
-    hipFree(d_p);
-    hipFree(d_q);
-    hipFree(d_arg);
-    hipFree(d_sig);
     return SP_OK;
 }

@@ -340,19 +340,17 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
     ctx->n_sg = n_sg;
     ctx->n_labels = n;
     if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
-    unsigned long long *d_keys = nullptr;
-    uint8_t *d_sg = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
-    SP_HIP(ctx, hipMalloc(&d_sg, (size_t)n));
-    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    sp_tmp<unsigned long long> d_keys;
+    sp_tmp<uint8_t> d_sg;
+    SP_HIP(ctx, d_keys.alloc((size_t)n));
+    SP_HIP(ctx, d_sg.alloc((size_t)n));
+    SP_HIP(ctx, hipMemcpyAsync(d_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg.p, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     const sp_kparams kp = sp_make_kparams(ctx->k);
-    SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
-              kp, ctx->d_label);
-    const int rcf = sp_map_filter_build(ctx, d_keys, n);
+    SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+              (const unsigned long long *)d_keys.p, (const uint8_t *)d_sg.p, n, kp, ctx->d_label);
+    const int rcf = sp_map_filter_build(ctx, d_keys.p, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_keys);
-    hipFree(d_sg);
     return rcf;
 }
 
@@ -516,40 +514,37 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
         foff[(size_t)f] = off[f] - base;
     }
     if (total == 0) return SP_OK;
-    uint8_t *d_ascii = nullptr;
-    uint32_t *d_pk = nullptr, *d_nm = nullptr;
-    int64_t *d_foff = nullptr;
-    unsigned long long *d_counts = nullptr;
+    sp_tmp<uint8_t> d_ascii;
+    sp_tmp<uint32_t> d_pk, d_nm;
+    sp_tmp<int64_t> d_foff;
+    sp_tmp<unsigned long long> d_counts;
     int64_t nmw = (total + 31) / 32 + SP_PAD_WORDS;
-    SP_HIP(ctx, hipMalloc(&d_ascii, (size_t)total));
-    SP_HIP(ctx, hipMalloc(&d_pk, (size_t)(2 * nmw) * 4));
-    SP_HIP(ctx, hipMalloc(&d_nm, (size_t)nmw * 4));
-    SP_HIP(ctx, hipMalloc(&d_foff, (size_t)(n_feat + 1) * 8));
-    SP_HIP(ctx, hipMalloc(&d_counts, (size_t)n_feat * S * 8));
+    SP_HIP(ctx, d_ascii.alloc((size_t)total));
+    SP_HIP(ctx, d_pk.alloc((size_t)(2 * nmw)));
+    SP_HIP(ctx, d_nm.alloc((size_t)nmw));
+    SP_HIP(ctx, d_foff.alloc((size_t)(n_feat + 1)));
+    SP_HIP(ctx, d_counts.alloc((size_t)n_feat * S));
     SP_HIP(ctx, hipMemcpyAsync(d_ascii, ascii + base, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_foff, foff.data(), (size_t)(n_feat + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_feat * S * 8, ctx->stream));
     int64_t blocks = (nmw + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, total, d_pk, d_nm, nmw);
+    SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, (const uint8_t *)d_ascii.p, total, d_pk.p,
+              d_nm.p, nmw);
     int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
     if (ctx->sparse_mode) {
-        int rcs = sp_sparse_feat_launch(ctx, d_pk, d_nm, n_units, d_foff, n_feat, S, d_counts);
+        int rcs = sp_sparse_feat_launch(ctx, d_pk.p, d_nm.p, n_units, d_foff.p, n_feat, S, d_counts.p);
         if (rcs) return rcs;
     } else {
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-        SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-                  n_units, d_foff, n_feat, S, ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts);
+        SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+                  (const uint32_t *)d_nm.p, kp, n_units, (const int64_t *)d_foff.p, n_feat, S, ctx->d_label,
+                  (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_counts.p);
     }
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_ascii);
-    hipFree(d_pk);
-    hipFree(d_nm);
-    hipFree(d_foff);
-    hipFree(d_counts);
     return SP_OK;
 }
 
@@ -558,19 +553,19 @@ int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
     if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
         return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long *d_n = nullptr, h = 0;
-    SP_HIP(ctx, hipMalloc(&d_n, 8));
-    SP_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    sp_tmp<unsigned long long> d_n;
+    unsigned long long h = 0;
+    SP_HIP(ctx, d_n.alloc(1));
+    SP_HIP(ctx, hipMemsetAsync(d_n.p, 0, 8, ctx->stream));
     if (ctx->sparse_mode) {
-        int rcs = sp_sparse_hit(ctx, d_n);
+        int rcs = sp_sparse_hit(ctx, d_n.p);
         if (rcs) return rcs;
     } else {
-        SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, ctx->d_label,
-                  ctx->nslots, d_n);
+        SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
+                  (const uint8_t *)ctx->d_label, ctx->nslots, d_n.p);
     }
-    SP_HIP(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(&h, d_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_n);
     *n_hit = (int64_t)h;
     return SP_OK;
 }

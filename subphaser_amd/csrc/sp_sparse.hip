@@ -577,18 +577,17 @@ int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, i
     // and read only after a key match, so they need no clearing
     SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 16, ctx->stream));
     if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
-    unsigned long long *d_keys = nullptr;
-    uint8_t *d_sg = nullptr;
-    SP_HIP(ctx, hipMalloc(&d_keys, (size_t)n * 8));
-    SP_HIP(ctx, hipMalloc(&d_sg, (size_t)n));
-    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, d_sg, n,
-              (unsigned long long *)ctx->d_hkeys, (uint64_t)(cap - 1));
-    const int rcf = sp_map_filter_build(ctx, d_keys, n);
+    sp_tmp<unsigned long long> d_keys;
+    sp_tmp<uint8_t> d_sg;
+    SP_HIP(ctx, d_keys.alloc((size_t)n));
+    SP_HIP(ctx, d_sg.alloc((size_t)n));
+    SP_HIP(ctx, hipMemcpyAsync(d_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg.p, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+              (const unsigned long long *)d_keys.p, (const uint8_t *)d_sg.p, n, (unsigned long long *)ctx->d_hkeys,
+              (uint64_t)(cap - 1));
+    const int rcf = sp_map_filter_build(ctx, d_keys.p, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_keys);
-    hipFree(d_sg);
     return rcf;
 }
 
