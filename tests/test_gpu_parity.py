@@ -667,3 +667,44 @@ def test_wheat_sized_chromosome_properties(gpu_ctx):
     finally:
         gpu_ctx.sync()
         gpu_ctx.dev_free(d)
+
+
+@pytest.mark.parametrize("k", [17, 21, 27])
+def test_wheat_sized_chromosome_properties_sparse(gpu_ctx, k):
+    """k > 15 at the headline chromosome size (667 Mb), by size-independent properties: the MSD-partition
+    engine and the device-wide radix-sort engine produce the same sorted list (same totals at two
+    thresholds, identical dump of the high-count k-mers); sum of counts == number of valid windows;
+    keys strictly ascending and canonical; every occurrence of a labelled k-mer is mapped exactly once."""
+    from subphaser_amd import kmer as km
+    n = 667_000_000
+    d = gpu_ctx.dev_alloc(n)
+    try:
+        gpu_ctx.synth_chrom(d, n, seed=3, set_id=1, sg_id=2, n_sg=3, chrom_id=5)
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.genome_add_device(0, d, n)
+        res = {}
+        for eng in (0, 1):
+            gpu_ctx.count(k, 1, eng)
+            tot1 = int(gpu_ctx.lengths()[0])
+            gpu_ctx.count(k, 200, eng)
+            tot200 = int(gpu_ctx.lengths()[0])
+            keys, cnts = gpu_ctx.dump(0, sort=False)
+            res[eng] = (tot1, tot200, keys, cnts)
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+        assert (res[0][2] == res[1][2]).all() and (res[0][3] == res[1][3]).all()
+        tot1, tot200, keys, cnts = res[0]
+        assert len(keys) > 1000 and int(cnts.astype(np.int64).sum()) == tot200 and int(cnts.min()) >= 200
+        assert (keys[1:] > keys[:-1]).all()                       # the engine itself emits ascending keys
+        assert (km.canonical(keys, k) == keys).all()
+        n_runs = (n - 1) // 50_000_000
+        assert tot1 == (n - (k - 1)) - n_runs * (1000 + (k - 1))  # each N run kills 1000 + (k-1) windows
+        sg = (np.arange(keys.size) % 3).astype(np.uint8)
+        gpu_ctx.labels_set(keys, sg, 3)
+        slots, nm = gpu_ctx.map_bins_all(10000, 10_000_000)
+        assert int(nm[0]) == tot200 == int(slots[0].astype(np.int64).sum())
+        per_sg = [int(cnts[sg == j].astype(np.int64).sum()) for j in range(3)]
+        assert slots[0].astype(np.int64).sum(axis=0).tolist() == per_sg
+        assert gpu_ctx.labels_hit() == keys.size
+    finally:
+        gpu_ctx.sync()
+        gpu_ctx.dev_free(d)
