@@ -38,7 +38,10 @@ static s3_plan s3_make_plan(int k) {
     s3_plan p;
     p.T = 2 * k;
     p.B1 = 10;   // k <= 21: the residual (2k - 10 bits) fits 32 bits
-    p.B2 = 9;
+#ifndef S3_B2
+#define S3_B2 9
+#endif
+    p.B2 = S3_B2;
     p.R1 = p.T - p.B1;
     p.R2 = p.R1 - p.B2;
     p.F1 = 1 << p.B1;
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(S3_P2_THREADS)
 s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
          unsigned long long *__restrict__ hist2 /* F1 * F2 */) {
-    __shared__ uint32_t lh[512];
+    __shared__ uint32_t lh[S3_MAXF];
     __shared__ int s_b;
     const unsigned long long n_tiles = tile_start[F1];
     const unsigned long long per = (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -231,8 +234,8 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2,
          KR2 *__restrict__ buf2) {
-    __shared__ uint32_t hist[512], start[512], cur[512], wsum[S3_P2_THREADS / 64];
-    __shared__ unsigned long long gbase[512];
+    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF], cur[S3_MAXF], wsum[S3_P2_THREADS / 64];
+    __shared__ unsigned long long gbase[S3_MAXF];
     __shared__ KR1 keys[S3_P2_KEYS];
     __shared__ int s_b;
     const unsigned long long n_tiles = tile_start[F1];
