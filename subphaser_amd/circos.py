@@ -105,3 +105,46 @@ def stack_matrix(inBedCount, window_size=100000):
     else:
         coords = [(n_, int(s_), int(s_ + ws)) for n_, s_ in zip(name_arr.tolist(), st.tolist())]
     return coords, summed.tolist()
+
+
+def abnormal(data, k=1.5, high_tile=99, low_tile=1):
+    """Upper / lower trimming cut-offs (Circos.py:973-980: the 99th / 1st percentiles)."""
+    return np.percentile(data, high_tile), np.percentile(data, low_tile)
+
+
+def stack_bed_density(inBedCount, outpre, colnames, window_size=100000, trim=True):
+    """Per-subgenome circos histogram tracks `<outpre>.<SG>.txt` from a `.bin.count` file
+    (Circos.py:777-806): windows from stack_matrix, counts capped at the column's 99th percentile,
+    lines `chrom start end value` separated by blanks.  Returns {SG: path}."""
+    import sys
+    coords, counts = stack_matrix(inBedCount, window_size=window_size)
+    colnames = list(colnames)
+    arr = np.asarray(counts, np.int64).reshape(len(coords), -1) if len(coords) else np.zeros((0, len(colnames)), np.int64)
+    assert arr.shape[0] == 0 or arr.shape[1] == len(colnames), "{} != {}".format(len(colnames), arr.shape[1])
+    d_outfiles = {key: "{}.{}.txt".format(outpre, key) for key in colnames}
+    d_upper = {}
+    if trim:
+        for j, key in enumerate(colnames):
+            upper, _ = abnormal(arr[:, j])            # the reference fails on an empty file as well
+            d_upper[key] = upper
+            print("using cutoff: upper {} for {}".format(upper, key), file=sys.stderr)
+    for j, key in enumerate(colnames):
+        with open(d_outfiles[key], "w") as fout:
+            col = arr[:, j].tolist()
+            if trim:
+                up = d_upper[key]
+                col = [min(c, up) for c in col]       # min(int, np.float64) keeps the reference's typing
+            fout.write("".join("{} {} {} {}\n".format(c[0], c[1], c[2], v) for c, v in zip(coords, col)))
+    return d_outfiles
+
+
+def out_sg_lines(sg_lines, datadir, ratio_col=6, enrich_col=7):
+    """`sg_ratio.txt` / `sg_enrich.txt` for circos from the rows enrich_bin returns (Circos.py:619-634)."""
+    ratio_file = "{}/sg_ratio.txt".format(datadir)
+    enrich_file = "{}/sg_enrich.txt".format(datadir)
+    with open(ratio_file, "w") as fr, open(enrich_file, "w") as fe:
+        for line in sg_lines:
+            chrom, start, end = line[:3]
+            for f, dat in zip((fr, fe), (line[ratio_col], line[enrich_col])):
+                f.write("\t".join(map(str, [chrom, start, end, dat])) + "\n")
+    return ratio_file, enrich_file

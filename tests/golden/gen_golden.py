@@ -296,6 +296,16 @@ def main():
                        "counts": [[int(x) for x in row] for row in counts]}
     out["G5_stack_matrix"] = g5
 
+    # G9: circos input tracks derived from the bin counts (Circos.stack_bed_density / out_sg_lines)
+    import contextlib
+    g9 = {}
+    for ws, trim in ((1000, True), (2500, True), (2500, False)):
+        with contextlib.redirect_stderr(io.StringIO()):
+            files = Circos.stack_bed_density(binfile, os.path.join(tmp, "g9_%d_%d" % (ws, trim)), sg_names,
+                                             window_size=ws, trim=trim)
+        g9["%d_%s" % (ws, "trim" if trim else "raw")] = {key: open(path).read() for key, path in files.items()}
+    out["G9_stack_bed_density"] = {"bin_count_text": g4["chunk2000_bin100"]["text"], "sg_names": sg_names, "tracks": g9}
+
     # ---------------------------------------------------------------- G6 enrichment
     g6 = {}
     coords, counts = Circos.stack_matrix(binfile, window_size=2500)

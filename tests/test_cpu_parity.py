@@ -124,3 +124,28 @@ def test_bh_hand_vector():
     from subphaser_amd.stats import correct_pvals
     assert np.allclose(po.bh_correct(p), exp, rtol=0, atol=1e-15)
     assert np.allclose(correct_pvals(p), exp, rtol=0, atol=1e-15)
+
+
+def test_circos_tracks_from_bin_counts(golden, tmp_path):
+    """G9: per-subgenome circos tracks derived from the bin counts (Circos.stack_bed_density, f-3 row):
+    byte-identical files for trimmed and untrimmed windows; sg_ratio / sg_enrich writer."""
+    import contextlib
+    import io
+    from subphaser_amd import circos
+    g = golden["G9_stack_bed_density"]
+    binfile = tmp_path / "toy.bin.count"
+    binfile.write_text(g["bin_count_text"])
+    for name, exp in g["tracks"].items():
+        ws, mode = name.split("_")
+        with contextlib.redirect_stderr(io.StringIO()):
+            files = circos.stack_bed_density(str(binfile), str(tmp_path / name), g["sg_names"], window_size=int(ws),
+                                             trim=(mode == "trim"))
+        assert sorted(files) == sorted(exp)
+        for key, path in files.items():
+            assert open(path).read() == exp[key], (name, key)
+    lines = [["chrA", 0, 2500, "SG1", 0.01, "5,6", "0.4,0.6", "1,0,0", "0.1,0.2", "no"],
+             ["chrB", 2500, 5000, None, 1.0, "0,0", "nan,nan", "0,0,1", "1.0,1.0", "none"]]
+    (tmp_path / "d").mkdir()
+    rf, ef = circos.out_sg_lines(lines, str(tmp_path / "d"))
+    assert open(rf).read() == "chrA\t0\t2500\t0.4,0.6\nchrB\t2500\t5000\tnan,nan\n"
+    assert open(ef).read() == "chrA\t0\t2500\t1,0,0\nchrB\t2500\t5000\t0,0,1\n"
