@@ -122,6 +122,17 @@ def test_count_sparse_engine_hot_buckets(gpu_ctx):
     seqs = [np.concatenate([_rand_seq(rng, 50000), hot, _rand_seq(rng, 1000), crowd])]
     _count_both(gpu_ctx, seqs, k, 1, 0)
     _count_both(gpu_ctx, seqs, k, 3, 0)
+    # k = 32: 5000 distinct k-mers (each twice) behind one 14-base prefix share all partition and split
+    # bits, so the piece exceeds the LDS hash table as well -> device-wide fallback for that bucket
+    k = 32
+    pre = np.frombuffer(b"AAAACAAAAGAAAC", np.uint8)
+    tails = [_rand_seq(rng, 18, 0, 0) for _ in range(5000)]
+    sep = np.frombuffer(b"N", np.uint8)
+    crowd = np.concatenate([np.concatenate([pre, t, sep]) for t in tails + tails])
+    seqs = [np.concatenate([_rand_seq(rng, 20000), sep, crowd, _rand_seq(rng, 3000)])]
+    _count_both(gpu_ctx, seqs, k, 1, 0)
+    _count_both(gpu_ctx, seqs, k, 2, 0)
+    _count_both(gpu_ctx, seqs, k, 3, 0)
 
 
 @pytest.mark.parametrize("k", [17, 21])
