@@ -66,20 +66,35 @@ def read_fasta(path, as_array=False):
         data = np.memmap(path, dtype=np.uint8, mode="r")
     if data.size == 0:
         return
-    # record starts: '>' at the beginning of a line
-    starts, step = [], 1 << 28
-    for lo in range(0, int(data.size), step):
-        for i in np.flatnonzero(data[lo:lo + step] == 62).tolist():
-            i += lo
-            if i == 0 or data[i - 1] == 10:
-                starts.append(i)
-    for a, b in zip(starts, starts[1:] + [int(data.size)]):
+    # record starts: '>' at the beginning of a line (numpy passes run in threads: they release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    n = int(data.size)
+    step = 1 << 26
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+
+    def find(lo):
+        hits = np.flatnonzero(data[lo:lo + step] == 62) + lo
+        return [int(i) for i in hits.tolist() if i == 0 or data[i - 1] == 10]
+
+    def one(span):
+        a, b = span
         rec = data[a:b]
-        nl = int(np.argmax(rec == 10)) if (rec == 10).any() else rec.size
+        nl = -1
+        for lo in range(0, rec.size, 1 << 16):       # header line: the first line break
+            w = np.flatnonzero(rec[lo:lo + (1 << 16)] == 10)
+            if w.size:
+                nl = lo + int(w[0])
+                break
+        if nl < 0:
+            nl = rec.size
         header = bytes(rec[1:nl]).decode().split()
-        rid = header[0] if header else ""
-        seq = _strip_newlines(rec[nl + 1:])
-        yield rid, (seq if as_array else seq.tobytes())
+        return (header[0] if header else ""), _strip_newlines(rec[nl + 1:])
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        starts = [i for part in pool.map(find, range(0, n, step)) for i in part]
+        spans = list(zip(starts, starts[1:] + [n]))
+        for rid, seq in pool.map(one, spans):
+            yield rid, (seq if as_array else seq.tobytes())
 
 
 _BULK_STEP = 1 << 26     # bytes per worker span of read_fasta_bulk
