@@ -1,6 +1,8 @@
 """GPU suite (`-m gpu`): libsubphaser_hip.so through the C-ABI vs the CPU oracle
 and the golden vectors.  Integer work is compared bit-exactly; p-values within
 the 1e-6 the north star states (they agree to ~1e-9 in practice)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -719,3 +721,13 @@ def test_wheat_sized_chromosome_properties_sparse(gpu_ctx, k):
     finally:
         gpu_ctx.sync()
         gpu_ctx.dev_free(d)
+
+
+def test_fuzz_against_oracle(gpu_ctx, oracle_ctx):
+    """150 random cases of tools/fuzz_parity.py (random genomes, k in 1..32, thresholds, engines, labels,
+    bin / chunk sizes, set structures): counts, matrix rows, bin counts, feature totals, bit-exact."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(150, 12345, gpu_ctx, oracle_ctx, verbose=False) == 0

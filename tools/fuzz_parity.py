@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the oracle (dev tool, needs a GPU):
+random genomes (N runs, lower case, homopolymers, tandem repeats, empty / shorter-than-k chromosomes),
+random k in 1..32, thresholds, engines, label sets, bin / chunk sizes and set structures.
+usage: fuzz_parity.py [iterations=200] [seed=0]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pyoracle as po
+from oracle_ctx import OracleContext
+from subphaser_amd import _native
+from subphaser_amd.config import sets_to_csr
+
+ALPHA = np.frombuffer(b"ACGTacgtNRY", np.uint8)
+
+
+def rand_chrom(rng):
+    kind = rng.randint(0, 10)
+    if kind == 0:
+        return np.empty(0, np.uint8)
+    if kind == 1:
+        return ALPHA[rng.randint(0, 4, size=rng.randint(1, 40))]
+    n = int(rng.choice([200, 3000, 20000, 70000]))
+    p = np.array([.23, .23, .23, .23, .015, .015, .015, .015, .006, .002, .002])
+    s = ALPHA[rng.choice(len(ALPHA), size=n, p=p / p.sum())].copy()
+    for _ in range(rng.randint(0, 6)):                       # repeats, homopolymers, tandem arrays, N blocks
+        a = rng.randint(0, max(1, n - 10)); m = rng.randint(1, max(2, n // 8))
+        what = rng.randint(0, 4)
+        if what == 0:
+            s[a:a + m] = ord("N")
+        elif what == 1:
+            s[a:a + m] = ALPHA[rng.randint(0, 4)]
+        elif what == 2:
+            u = ALPHA[rng.randint(0, 4, size=rng.randint(1, 30))]
+            s[a:a + m] = np.resize(u, min(m, n - a))
+        else:
+            b = rng.randint(0, max(1, n - m)); s[a:a + min(m, n - a)] = s[b:b + min(m, n - a)]
+    return s
+
+def run(iters, seed, gpu, ora, verbose=True):
+    rng = np.random.RandomState(seed)
+    bad = 0
+    for it in range(iters):
+        C = int(rng.randint(1, 6))
+        seqs = [rand_chrom(rng) for _ in range(C)]
+        k = int(rng.choice([1, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 19, 21, 24, 27, 31, 32]))
+        lower = int(rng.randint(1, 4))
+        engine = int(rng.choice([0, 1, 2])) if k <= 15 else int(rng.choice([0, 1]))
+        tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s" % (it, C, k, lower, engine, [len(s) for s in seqs])
+        try:
+            for ctx in (gpu, ora):
+                ctx.genome_reset(C)
+                for i, s in enumerate(seqs):
+                    ctx.genome_add(i, s)
+            try:
+                gpu.count(k, lower, engine)
+            except ValueError as e:
+                if engine == 2 and "engine" in str(e).lower():
+                    gpu.count(k, lower, 0)
+                else:
+                    raise
+            ora.count(k, lower)
+            assert gpu.lengths().tolist() == ora.lengths().tolist(), "lengths"
+            dumps = []
+            for i in range(C):
+                gk, gc = gpu.dump(i); ok, oc = ora.dump(i)
+                assert gk.shape == ok.shape and (gk == ok).all() and (gc == oc).all(), "dump %d" % i
+                dumps.append((gk, gc))
+            allk = np.unique(np.concatenate([d[0] for d in dumps])) if C else np.empty(0, np.uint64)
+            if allk.size:
+                sel = allk[rng.rand(allk.size) < rng.choice([0.02, 0.3, 1.0])]
+                S = int(rng.randint(1, 5))
+                sg = rng.randint(0, S, size=sel.size).astype(np.uint8)
+                for ctx in (gpu, ora):
+                    ctx.labels_set(sel, sg, S)
+                for i in range(C):
+                    bs = int(rng.choice([1, 7, 100, 10000])); ch = int(rng.choice([0, 50, 1000, 10_000_000]))
+                    g, gn = gpu.map_bins(i, bs, ch); o, on = ora.map_bins(i, bs, ch)
+                    assert g.shape == o.shape and (g == o).all() and gn == on, "map %d bin=%d chunk=%d" % (i, bs, ch)
+                assert gpu.labels_hit() == ora.labels_hit(), "labels_hit"
+                feats = [seqs[rng.randint(0, C)][a:a + int(rng.randint(0, 400))] for a in rng.randint(0, 3000, size=5)]
+                assert (gpu.map_features(feats) == ora.map_features(feats)).all(), "features"
+            if C >= 2 and all(int(l) > 0 for l in ora.lengths()):
+                perm = rng.permutation(C).tolist()
+                cut = sorted(rng.choice(range(1, C), size=min(C - 1, rng.randint(1, 3)), replace=False).tolist()) if C > 2 else [1]
+                units = [perm[a:b] for a, b in zip([0] + cut, cut + [C])]
+                sgs = [[u for u in units]] if len(units) >= 2 else [[[perm[0]], perm[1:]]]
+                args = (float(rng.choice([1.0, 1.5, 2.0, 3.0])), int(rng.choice([1, -1])), float(rng.choice([1, 3, 20])), 1e9,
+                        float(rng.choice([0.5, 1.0])))
+                csr = sets_to_csr(sgs, list(range(C)))
+                res = []
+                for ctx in (gpu, ora):
+                    try:
+                        nu, nr, nh = ctx.filter(*csr, *args)
+                        kk, cc, ff, tt = ctx.filter_fetch(nr)
+                        res.append((nu, nr, nh, kk, cc, ff, tt, np.sort(ctx.filter_hist(nh))))
+                    except ValueError as e:
+                        res.append(("err", str(e)[:40]))
+                if res[0][0] == "err" or res[1][0] == "err":
+                    assert res[0][0] == res[1][0], "filter error mismatch %s %s" % (res[0], res[1])
+                else:
+                    assert res[0][:3] == res[1][:3], "filter counts %s %s" % (res[0][:3], res[1][:3])
+                    for a, b in zip(res[0][3:], res[1][3:]):
+                        assert a.shape == b.shape and (a == b).all(), "filter rows"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", tag, "->", e)
+            if bad >= 5:
+                break
+    if verbose:
+        print("fuzz: %d iterations, %d mismatches" % (it + 1, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    sys.exit(1 if run(n_it, sd, _native.Context(0), OracleContext(nthreads=4)) else 0)
