@@ -34,6 +34,21 @@ __device__ __forceinline__ uint32_t sp_slot_of32(uint32_t fwd, uint32_t rc, cons
     return fwd < rc ? fwd : rc;
 }
 
+// bit b of the result is set iff an invalid base lies in the window of `w` bases that ENDS at base b
+// (bases b-w+1 .. b) -- the validity of every window of a unit from a handful of shifts instead of a
+// run counter updated at every base (3 VALU instructions per base in the scan-bound kernels)
+__device__ __forceinline__ unsigned __int128 sp_bad_windows(unsigned __int128 m, int w) {
+    if (w <= 0) return 0;
+    unsigned __int128 e = m;
+    int have = 1;
+    while (have * 2 <= w) {
+        e |= e << have;
+        have *= 2;
+    }
+    if (have < w) e |= e << (w - have);
+    return e;
+}
+
 // UNIT consecutive k-mer START positions [s0, s0+UNIT), s0 a multiple of UNIT (UNIT = 32 or 64),
 // emit(start, fwd, rc) for every start whose k bases are all valid.
 template <int UNIT, typename KeyT, typename KP, typename F>
@@ -55,14 +70,16 @@ __device__ __forceinline__ void sp_scan_unit_t(const uint32_t *__restrict__ pk,
     const uint64_t mlo = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     const uint32_t mhi = (MW == 4) ? nm[(s0 >> 5) + 2] : 0u;
     KeyT fwd = 0, rc = 0;
-    int run = 0;
     const int k = kp.k;
     const int total = UNIT + k - 1;  // bases to consume (k - 1 <= 31 halo bases: two extra words)
+    // emit mask: bit b set iff the k-mer ENDING at base b starts inside the unit and has no invalid base
+    const unsigned __int128 m128 = (unsigned __int128)mlo | ((unsigned __int128)mhi << 64);
+    const unsigned __int128 range = ((((unsigned __int128)1 << total) - 1) >> (k - 1)) << (k - 1);
+    const unsigned __int128 em = ~sp_bad_windows(m128, k) & range;
+    const uint64_t em_lo = (uint64_t)em, em_hi = (uint64_t)(em >> 64);
 #pragma unroll
     for (int w = 0; w < MW + 2; w++) {
         const uint32_t cw = words[w];
-        const uint32_t mw = (w < 4) ? (uint32_t)((mlo >> (16 * w)) & 0xffffu)
-                                    : (uint32_t)((mhi >> (16 * (w - 4))) & 0xffffu);
         if (w * 16 >= total) break;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -70,15 +87,14 @@ __device__ __forceinline__ void sp_scan_unit_t(const uint32_t *__restrict__ pk,
             const uint32_t c = (cw >> (2 * j)) & 3u;
             fwd = ((fwd << 2) | c) & kp.kmask;
             rc = (rc >> 2) | ((KeyT)(3u - c) << kp.rcshift);
-            run = ((mw >> j) & 1u) ? 0 : run + 1;
-            if (run >= k && b < total) emit(s0 + b - (k - 1), fwd, rc);
+            if (((b < 64 ? em_lo >> b : em_hi >> (b - 64)) & 1ULL)) emit(s0 + b - (k - 1), fwd, rc);
         }
     }
 }
 
-// Same walk, but step(start, fwd, rc, run) is called for EVERY start of the unit (run = number of
-// valid bases ending at the k-mer's last base; the k-mer is valid iff run >= k).  Used by the
-// mapping kernel, which tests the (k-1)-mer two neighbouring k-mers share (valid iff run >= k-1).
+// Same walk, but step(start, fwd, rc, valid_k, valid_k1) is called for EVERY start of the unit:
+// valid_k = the k-mer is valid, valid_k1 = the (k-1)-mer ending at the same base is valid (the
+// mapping kernel tests the (k-1)-mer two neighbouring k-mers share).
 template <int UNIT, typename KeyT, typename KP, typename F>
 __device__ __forceinline__ void sp_scan_unit_all(const uint32_t *__restrict__ pk,
                                                  const uint32_t *__restrict__ nm, int64_t s0,
@@ -98,14 +114,15 @@ __device__ __forceinline__ void sp_scan_unit_all(const uint32_t *__restrict__ pk
     const uint64_t mlo = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     const uint32_t mhi = (MW == 4) ? nm[(s0 >> 5) + 2] : 0u;
     KeyT fwd = 0, rc = 0;
-    int run = 0;
     const int k = kp.k;
     const int total = UNIT + k - 1;
+    const unsigned __int128 m128 = (unsigned __int128)mlo | ((unsigned __int128)mhi << 64);
+    const unsigned __int128 ok_k = ~sp_bad_windows(m128, k), ok_k1 = ~sp_bad_windows(m128, k - 1);
+    const uint64_t k_lo = (uint64_t)ok_k, k_hi = (uint64_t)(ok_k >> 64);
+    const uint64_t k1_lo = (uint64_t)ok_k1, k1_hi = (uint64_t)(ok_k1 >> 64);
 #pragma unroll
     for (int w = 0; w < MW + 2; w++) {
         const uint32_t cw = words[w];
-        const uint32_t mw = (w < 4) ? (uint32_t)((mlo >> (16 * w)) & 0xffffu)
-                                    : (uint32_t)((mhi >> (16 * (w - 4))) & 0xffffu);
         if (w * 16 >= total) break;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -113,8 +130,9 @@ __device__ __forceinline__ void sp_scan_unit_all(const uint32_t *__restrict__ pk
             const uint32_t c = (cw >> (2 * j)) & 3u;
             fwd = ((fwd << 2) | c) & kp.kmask;
             rc = (rc >> 2) | ((KeyT)(3u - c) << kp.rcshift);
-            run = ((mw >> j) & 1u) ? 0 : run + 1;
-            if (b >= k - 1 && b < total) step(s0 + b - (k - 1), fwd, rc, run);
+            if (b >= k - 1 && b < total)
+                step(s0 + b - (k - 1), fwd, rc, (bool)((b < 64 ? k_lo >> b : k_hi >> (b - 64)) & 1ULL),
+                     (bool)((b < 64 ? k1_lo >> b : k1_hi >> (b - 64)) & 1ULL));
         }
     }
 }

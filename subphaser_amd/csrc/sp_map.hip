@@ -88,15 +88,15 @@ __device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, c
                                               int nbits, F &&hit) {
     bool pairhit = false;
     const KeyT m1mask = (KeyT)(kp.kmask >> 2);
-    sp_scan_unit_all<SP_UNIT, KeyT>(pk, nm, s0, kp, [&](int64_t start, KeyT fwd, KeyT rc, int run) {
+    sp_scan_unit_all<SP_UNIT, KeyT>(pk, nm, s0, kp, [&](int64_t start, KeyT fwd, KeyT rc, bool valid_k, bool valid_k1) {
         if (!(start & 1)) {   // first of the pair: screen both members through their shared (k-1)-mer
             pairhit = false;
-            if (run >= kp.k - 1) {
+            if (valid_k1) {
                 const KeyT mf = fwd & m1mask, mr = rc >> 2;
                 pairhit = map_bloom_test(bloom, nbits, (uint64_t)(mf < mr ? mf : mr));
             }
         }
-        if (pairhit && run >= kp.k) hit(start, fwd, rc);
+        if (pairhit && valid_k) hit(start, fwd, rc);
     });
 }
 
