@@ -75,12 +75,17 @@ c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_
         if (threadIdx.x < F1) th[threadIdx.x] = 0;
         __syncthreads();
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
-        if (u < n_units)
-            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-                atomicAdd(&lh[slot >> shift_fine], 1u);
-                atomicAdd(&th[slot >> shift1], 1u);
-            });
+        if (u < n_units) {
+            auto scan = [&](auto parity) {
+                sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+                    const uint32_t slot = sp_slot_of32_t<decltype(parity)::value>(fwd, rc, kp);
+                    atomicAdd(&lh[slot >> shift_fine], 1u);
+                    atomicAdd(&th[slot >> shift1], 1u);
+                });
+            };
+            if (kp.odd) scan(sp_odd_tag{});
+            else scan(sp_even_tag{});
+        }
         __syncthreads();
         if (threadIdx.x < F1) tile_cnt[(int64_t)threadIdx.x * n_tiles + tile] = th[threadIdx.x];
     }
@@ -211,12 +216,17 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
         }
         __syncthreads();
         const uint32_t total = c2_scan_F(hist, start, F1, wsum);
-        if (u < n_units)
-            sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-                const uint32_t b = slot >> shift1;
-                keys[start[b] + atomicAdd(&cur[b], 1u)] = slot;
-            });
+        if (u < n_units) {
+            auto scan = [&](auto parity) {
+                sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
+                    const uint32_t slot = sp_slot_of32_t<decltype(parity)::value>(fwd, rc, kp);
+                    const uint32_t b = slot >> shift1;
+                    keys[start[b] + atomicAdd(&cur[b], 1u)] = slot;
+                });
+            };
+            if (kp.odd) scan(sp_odd_tag{});
+            else scan(sp_even_tag{});
+        }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
             const uint32_t s = keys[i];

@@ -49,6 +49,20 @@ __device__ __forceinline__ unsigned __int128 sp_bad_windows(unsigned __int128 m,
     return e;
 }
 
+// compile-time twin of sp_slot_of32: the kernels branch once per unit on the (uniform) parity of k instead of
+// computing both forms and selecting at every k-mer
+template <bool ODD>
+__device__ __forceinline__ uint32_t sp_slot_of32_t(uint32_t fwd, uint32_t rc, const sp_kparams32 &p) {
+    if (ODD) {
+        const uint32_t rep = ((fwd >> p.k) & 1u) ? rc : fwd;
+        const uint32_t lowmask = (1u << p.k) - 1u;
+        return (rep & lowmask) | ((rep >> (p.k + 1)) << p.k);
+    }
+    return fwd < rc ? fwd : rc;
+}
+struct sp_odd_tag { static constexpr bool value = true; };
+struct sp_even_tag { static constexpr bool value = false; };
+
 // UNIT consecutive k-mer START positions [s0, s0+UNIT), s0 a multiple of UNIT (UNIT = 32 or 64),
 // emit(start, fwd, rc) for every start whose k bases are all valid.
 template <int UNIT, typename KeyT, typename KP, typename F>
