@@ -112,8 +112,13 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
 // One block-iteration covers MAP_UNITS_PER_BLOCK units of 64 starts.  Hits are
 // accumulated in an LDS histogram over the (few) output slots the range
 // touches and flushed with one global atomic per non-zero entry.
-#define MAP_BLOCK 256
-#define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // 16384 starts
+#ifndef MAP_GRID_MULT
+#define MAP_GRID_MULT 16
+#endif
+#ifndef MAP_BLOCK
+#define MAP_BLOCK 768   // measured: 256 -> 70.5 ms, 512 -> 68.3, 768 -> 66.2, 1024 -> 73.8 (640 / 896: 76-79)
+#endif
+#define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // starts per block iteration
 #define MAP_LDS_ENTRIES 4096
 
 struct sp_map_params {
@@ -396,7 +401,7 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
-        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
         SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
                   ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
     }
@@ -449,7 +454,7 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
         }
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
-        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
         SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
                   ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
     }
@@ -538,7 +543,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     } else {
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
-        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
         SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
                   (const uint32_t *)d_nm.p, kp, n_units, (const int64_t *)d_foff.p, n_feat, S, ctx->d_label,
                   (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_counts.p);
