@@ -119,7 +119,9 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
 #define MAP_BLOCK 768   // measured: 256 -> 70.5 ms, 512 -> 68.3, 768 -> 66.2, 1024 -> 73.8 (640 / 896: 76-79)
 #endif
 #define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // starts per block iteration
+#ifndef MAP_LDS_ENTRIES
 #define MAP_LDS_ENTRIES 4096
+#endif
 
 struct sp_map_params {
     int64_t n_units;
