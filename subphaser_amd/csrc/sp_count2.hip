@@ -27,10 +27,11 @@
 #define C2_P1_UNIT 32
 #define C2_P1_KEYS (C2_P1_THREADS * C2_P1_UNIT)   // starts (<= keys) per part1 tile
 #ifndef C2_P2_THREADS
-#define C2_P2_THREADS 512             // part2: 512 threads x 8 keys (4 K-key tiles: 4 blocks per CU, measured best)
+#define C2_P2_THREADS 768             // part2: 768 threads x 12 keys (9 K-key tiles; with the software pipeline:
+                                      // 512 x 8 -> 1.37 ms per 667-Mb chromosome, 768 x 10 -> 1.28, 768 x 12 -> 1.22, 768 x 16 -> 1.24)
 #endif
 #ifndef C2_P2_PER
-#define C2_P2_PER 8
+#define C2_P2_PER 12
 #endif
 #define C2_TILE_KEYS (C2_P2_THREADS * C2_P2_PER)  // keys per part2 tile
 #define C2_HIST_THREADS 512
@@ -339,7 +340,9 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
 }
 
 // ---------------------------------------------------------------- c2_count
+#ifndef C2_COUNT_THREADS
 #define C2_COUNT_THREADS 1024
+#endif
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict__ off_fine,
          int64_t n_fine, uint32_t lower, uint32_t *__restrict__ tab,
