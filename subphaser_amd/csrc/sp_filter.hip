@@ -12,9 +12,14 @@
 // surviving rows, in ascending slot order, so the output is deterministic.
 #include "sp_device.h"
 
+#ifndef F_BLOCK
 #define F_BLOCK 256
+#endif
+#ifndef F_GROUPS_PER_WAVE
 #define F_GROUPS_PER_WAVE 64
-#define F_SLOTS_PER_BLOCK (4 * F_GROUPS_PER_WAVE * 64)  // 16384
+#endif
+#define F_WAVES (F_BLOCK / 64)
+#define F_SLOTS_PER_BLOCK (F_WAVES * F_GROUPS_PER_WAVE * 64)  // 16384
 #define F_MAXU 8
 
 struct sp_filter_params {
@@ -208,7 +213,7 @@ k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t
         const unsigned long long *__restrict__ blk_off, const double *__restrict__ chrom_len,
         unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
         double *__restrict__ freqs, unsigned long long *__restrict__ tots) {
-    __shared__ unsigned long long wave_cnt[4];
+    __shared__ unsigned long long wave_cnt[F_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t blk_base = (int64_t)blockIdx.x * F_SLOTS_PER_BLOCK;
     const int64_t g0 = (blk_base >> 6) + (int64_t)wave * F_GROUPS_PER_WAVE;
@@ -442,7 +447,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     P.max_freq = max_freq;
     P.ratio = ratio;
     P.nslots = nslots;
-    size_t shmem = (size_t)4 * C * 64 * sizeof(uint32_t);
+    size_t shmem = (size_t)F_WAVES * C * 64 * sizeof(uint32_t);
     if (shmem > 150 * 1024)
         return sp_fail(ctx, SP_EUNSUP, "sp_filter: %d chromosomes exceed the LDS staging budget", C);
     if (shmem > 64 * 1024)
