@@ -22,8 +22,12 @@
 
 #define S3_MAXF 1024
 #define S3_P1_UNIT 32
+#ifndef S3_P2_THREADS
 #define S3_P2_THREADS 512
+#endif
+#ifndef S3_P2_PER
 #define S3_P2_PER 16
+#endif
 #define S3_P2_KEYS (S3_P2_THREADS * S3_P2_PER)   // keys per part2 / hist2 tile
 #define S3_SORT_THREADS 256
 #define S3_SORT_PER 8
