@@ -731,3 +731,58 @@ def test_fuzz_against_oracle(gpu_ctx, oracle_ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(150, 12345, gpu_ctx, oracle_ctx, verbose=False) == 0
+
+
+@pytest.mark.parametrize("k", [15, 17, 22])
+def test_medium_scale_count_filter_map_vs_oracle(gpu_ctx, oracle_ctx, k):
+    """Three 6-Mb chromosomes with planted repeat families, default engines (k = 15: engine 2 counts, pair
+    filter sized from the label set, 768-thread map blocks, several block iterations per kernel; k = 17 / 22:
+    MSD-partition engine with u32 / u64 residuals, sort-join filter, hash-table map): dumps, matrix rows and
+    bin counts bit-exact against the oracle."""
+    from subphaser_amd.config import sets_to_csr
+    rng = np.random.RandomState(2024)
+    lower = 3
+    fams = [[_rand_seq(rng, 600, 0, 0) for _ in range(8)] for _ in range(2)]
+    seqs = []
+    for c in range(3):
+        s = _rand_seq(rng, 6_000_000 + 4099 * c, 0.0005, 0.1)
+        lib = fams[c % 2]
+        for _ in range(1500):
+            r = lib[rng.randint(0, len(lib))].copy()
+            mut = rng.rand(r.size) < 0.02
+            r[mut] = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, int(mut.sum()))]
+            p = rng.randint(0, s.size - 700)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.genome_reset(3)
+        for i, s in enumerate(seqs):
+            ctx.genome_add(i, s)
+        ctx.count(k, lower, 0)
+    assert gpu_ctx.lengths().tolist() == oracle_ctx.lengths().tolist()
+    for i in range(3):
+        gk, gc = gpu_ctx.dump(i)
+        ok, oc = oracle_ctx.dump(i)
+        assert gk.shape == ok.shape and (gk == ok).all() and (gc == oc).all(), i
+    csr = sets_to_csr([[[0], [1], [2]]], [0, 1, 2])
+    res = []
+    for ctx in (gpu_ctx, oracle_ctx):
+        nu, nr, nh = ctx.filter(*csr, 2.0, 1, 50, 1e9, 1.0)
+        res.append((nu, nr, nh) + tuple(ctx.filter_fetch(nr)))
+    assert res[0][:3] == res[1][:3] and res[0][1] > 100
+    for a, b in zip(res[0][3:], res[1][3:]):
+        assert (a == b).all()
+    keys = res[0][3]
+    sg = (np.arange(keys.size) % 2).astype(np.uint8)
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.labels_set(keys, sg, 2)
+    for i in range(3):
+        for bs, ch in ((10000, 10_000_000), (10000, 1_000_000), (333, 50_000)):
+            g, gn = gpu_ctx.map_bins(i, bs, ch)
+            o, on = oracle_ctx.map_bins(i, bs, ch)
+            assert g.shape == o.shape and (g == o).all() and gn == on, (i, bs, ch)
+    allb, nm = gpu_ctx.map_bins_all(10000, 10_000_000)
+    for i in range(3):
+        o, on = oracle_ctx.map_bins(i, 10000, 10_000_000)
+        assert (allb[i] == o).all() and int(nm[i]) == on
+    assert gpu_ctx.labels_hit() == oracle_ctx.labels_hit()
