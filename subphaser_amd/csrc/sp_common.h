@@ -106,7 +106,7 @@ struct sp_ctx {
     // sparse engine (k = 16..32)
     bool sparse_mode = false;
     std::vector<sp_sparse_chrom> sparse;
-    sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist, b_s3_small;
+    sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist, b_s3_small, b_slots;
     int64_t sf_n = 0;
     uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers: 16-B entries {key, label}
     int64_t hcap = 0;

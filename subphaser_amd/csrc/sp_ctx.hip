@@ -140,6 +140,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_emit);
+    sp_buf_free(ctx->b_slots);
     sp_buf_free(ctx->b_fpar);
     sp_buf_free(ctx->b_win);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

@@ -207,12 +207,11 @@ k3_eval(const uint32_t *const *__restrict__ tabs, sp_filter_params P,
 // scan defined in sp_count.hip
 __global__ void scan_excl_u64(unsigned long long *a, int64_t n, unsigned long long *total);
 
+// Pass B, step 1: ordered list of the surviving slots (bitmap walk only; the table gathers of a row used to
+// run on the one lane that owned its slot -- one active lane per wave at 0.4 % density)
 __global__ void __launch_bounds__(F_BLOCK)
-k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t nslots,
-        int64_t slot_base, sp_kparams kp, const unsigned long long *__restrict__ bm,
-        const unsigned long long *__restrict__ blk_off, const double *__restrict__ chrom_len,
-        unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
-        double *__restrict__ freqs, unsigned long long *__restrict__ tots) {
+k3_emit_slots(int64_t nslots, const unsigned long long *__restrict__ bm, const unsigned long long *__restrict__ blk_off,
+              uint32_t *__restrict__ slots) {
     __shared__ unsigned long long wave_cnt[F_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t blk_base = (int64_t)blockIdx.x * F_SLOTS_PER_BLOCK;
@@ -231,22 +230,31 @@ k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t
         if (g0 + g >= ngroups) break;
         const unsigned long long bits = bm[g0 + g];
         if (bits == 0) continue;
-        if ((bits >> lane) & 1ULL) {
-            const unsigned long long r = off + __popcll(bits & ((1ULL << lane) - 1ULL));
-            const int64_t slot = ((g0 + g) << 6) + lane;
-            unsigned long long tot = 0;
-            for (int c = 0; c < C; c++) {
-                uint32_t v = tabs[c][slot];
-                v = v >= lower ? v : 0u;
-                tot += v;
-                if (counts) counts[r * C + c] = v;
-                if (freqs) freqs[r * C + c] = (double)v / chrom_len[c];  // :647
-            }
-            if (keys) keys[r] = sp_key_of_slot((uint64_t)(slot_base + slot), kp);
-            if (tots) tots[r] = tot;
-        }
+        if ((bits >> lane) & 1ULL)
+            slots[off + __popcll(bits & ((1ULL << lane) - 1ULL))] = (uint32_t)(((g0 + g) << 6) + lane);
         off += __popcll(bits);
     }
+}
+
+// Pass B, step 2: one thread per surviving row gathers its C counts (independent loads, every lane busy)
+__global__ void __launch_bounds__(256)
+k3_emit(const uint32_t *const *__restrict__ tabs, int C, uint32_t lower, int64_t M, int64_t slot_base, sp_kparams kp,
+        const uint32_t *__restrict__ slots, const double *__restrict__ chrom_len,
+        unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
+        double *__restrict__ freqs, unsigned long long *__restrict__ tots) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const int64_t slot = slots[r];
+    unsigned long long tot = 0;
+    for (int c = 0; c < C; c++) {
+        uint32_t v = tabs[c][slot];
+        v = v >= lower ? v : 0u;
+        tot += v;
+        if (counts) counts[r * C + c] = v;
+        if (freqs) freqs[r * C + c] = (double)v / chrom_len[c];  // :647
+    }
+    if (keys) keys[r] = sp_key_of_slot((uint64_t)(slot_base + slot), kp);
+    if (tots) tots[r] = tot;
 }
 
 static void free_filter_buffers(sp_ctx *ctx) {
@@ -503,11 +511,15 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
         if (freqs) { d_freqs = (double *)q; q += al((size_t)M * C * 8); }
     }
     const sp_kparams kp = sp_make_kparams(ctx->k);
-    SP_LAUNCH(ctx, hist ? "k3_emit_hist" : "k3_emit", k3_emit, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0,
-              d_tabs, C, (uint32_t)ctx->lower, filter_nslots(ctx), filter_base(ctx), kp,
+    rc = sp_buf_ensure(ctx, ctx->b_slots, M * 4 + 64);
+    if (rc) return rc;
+    uint32_t *d_slots = (uint32_t *)ctx->b_slots.p;
+    SP_LAUNCH(ctx, "k3_emit_slots", k3_emit_slots, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0, filter_nslots(ctx),
               (const unsigned long long *)(hist ? ctx->d_flag_hist : ctx->d_flag_row),
-              (const unsigned long long *)(hist ? ctx->d_blk_hist : ctx->d_blk_row), d_len, d_keys, d_counts,
-              d_freqs, d_tot);
+              (const unsigned long long *)(hist ? ctx->d_blk_hist : ctx->d_blk_row), d_slots);
+    SP_LAUNCH(ctx, hist ? "k3_emit_hist" : "k3_emit", k3_emit, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_tabs, C,
+              (uint32_t)ctx->lower, M, filter_base(ctx), kp, (const uint32_t *)d_slots, (const double *)d_len, d_keys,
+              d_counts, d_freqs, d_tot);
     if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, d_keys, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, d_tot, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (counts) SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,10 +554,14 @@ int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_to
     int rc = upload_tabs(ctx, &d_tabs, &d_len);
     if (rc) return rc;
     const sp_kparams kp = sp_make_kparams(ctx->k);
-    SP_LAUNCH(ctx, "k3_emit", k3_emit, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0, d_tabs, C,
-              (uint32_t)ctx->lower, filter_nslots(ctx), filter_base(ctx), kp,
-              (const unsigned long long *)ctx->d_flag_row, (const unsigned long long *)ctx->d_blk_row, d_len,
-              (unsigned long long *)d_keys, (uint32_t *)d_counts, (double *)nullptr, (unsigned long long *)d_tot);
+    rc = sp_buf_ensure(ctx, ctx->b_slots, M * 4 + 64);
+    if (rc) return rc;
+    uint32_t *d_slots = (uint32_t *)ctx->b_slots.p;
+    SP_LAUNCH(ctx, "k3_emit_slots", k3_emit_slots, dim3((unsigned)ctx->n_fblocks), dim3(F_BLOCK), 0, filter_nslots(ctx),
+              (const unsigned long long *)ctx->d_flag_row, (const unsigned long long *)ctx->d_blk_row, d_slots);
+    SP_LAUNCH(ctx, "k3_emit", k3_emit, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_tabs, C, (uint32_t)ctx->lower, M,
+              filter_base(ctx), kp, (const uint32_t *)d_slots, (const double *)d_len, (unsigned long long *)d_keys,
+              (uint32_t *)d_counts, (double *)nullptr, (unsigned long long *)d_tot);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }
