@@ -157,16 +157,22 @@ c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int
         off_fine[i] = run;
         run += ghist[i];
     }
-    __syncthreads();
     __threadfence_block();
+    __syncthreads();
+    // level-1 offsets and tile starts: one thread per bucket, then a short serial prefix over <= 256 counts in LDS
+    __shared__ unsigned long long tcount[C2_MAXF];
+    if (threadIdx.x < F1) {
+        const int b = threadIdx.x;
+        const unsigned long long o = off_fine[(size_t)b * F2], e = off_fine[(size_t)(b + 1) * F2];
+        off1[b] = o;
+        tcount[b] = (e - o + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long tiles = 0;
         for (int b = 0; b < F1; b++) {
-            unsigned long long o = off_fine[(size_t)b * F2];
-            unsigned long long e = off_fine[(size_t)(b + 1) * F2];
-            off1[b] = o;
             tile_start[b] = tiles;
-            tiles += (e - o + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+            tiles += tcount[b];
         }
         off1[F1] = off_fine[n_fine];
         tile_start[F1] = tiles;
