@@ -360,7 +360,7 @@ class DistHotPath:
         order = np.lexsort((allrows[:, 1], allrows[:, 0]))
         allrows = allrows[order]
         ws = self.window_size
-        r.coords = [(self.labels[c], w * ws, w * ws + ws) for c, w in zip(allrows[:, 0].tolist(), allrows[:, 1].tolist())]
+        r.coord_chrom, r.coord_win, r.coord_labels, r.coord_ws = allrows[:, 0], allrows[:, 1], self.labels, ws
         r.window_counts = np.ascontiguousarray(allrows[:, 2:])
         nm = t.tensor([r.n_mapped], dtype=t.int64, device=self.device)
         dist.all_reduce(nm)
