@@ -776,7 +776,10 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     KR2 *tmp_keys = (KR2 *)ctx->b_sp_c.p;
     uint32_t *tmp_cnts = (uint32_t *)((char *)ctx->b_sp_c.p + tk_bytes);
 
-    constexpr int P1T = sizeof(KR1) == 4 ? 512 : 256;
+#ifndef S3_P1T32
+#define S3_P1T32 512
+#endif
+    constexpr int P1T = sizeof(KR1) == 4 ? S3_P1T32 : 256;
     const int64_t n_units32 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;
     const int64_t n_tiles1 = (n_units32 + P1T - 1) / P1T;
     int64_t g1 = n_tiles1 < (int64_t)ctx->n_cu * 8 ? n_tiles1 : (int64_t)ctx->n_cu * 8;
