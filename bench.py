@@ -65,7 +65,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
+        # RCCL rendezvous on the loopback address) and hand over to them
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch
     if not torch.cuda.is_available():
@@ -255,7 +266,7 @@ def main():
                    "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu, "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
+        "roofline": roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
                                   for k_, v in (hp if runner is None else runner).wall.items()},
     }
@@ -277,9 +288,12 @@ def main():
 
 def cpu_baseline(ctx, gen, d_ascii, kmer_labels, args):
     """Oracle (C port of the same path) on the host cores over the first `cpu_sample_mb` Mb of
-    every chromosome of the first homoeologous set.  Reported, never the target."""
+    every chromosome of the first homoeologous set.  Reported, never the target.  The oracle's results
+    are not thrown away: the HIP path then redoes the same sample and dumps, matrix rows and bin counts
+    must be identical (`verified`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    from subphaser_amd.config import sets_to_csr
     cores = len(os.sched_getaffinity(0))
     n = int(args.cpu_sample_mb * 1e6)
     first = gen.sgs[0]
@@ -287,23 +301,49 @@ def cpu_baseline(ctx, gen, d_ascii, kmer_labels, args):
     idx = [gen.labels.index(l) for l in labs]
     seqs = [ctx.dev_to_host(d_ascii[i], min(n, gen.chroms[i]["length"])) for i in idx]
     bases = sum(len(s) for s in seqs)
+    fkw = (2.0, 1, 200 * bases / gen.total_bases, 1e9, 1.0)
     t0 = time.perf_counter()
     dumps = [po.count(s, args.k, 3, nthreads=cores) for s in seqs]
     t_count = time.perf_counter() - t0
     try:
-        po.filter_dumps(dumps, [first], labs, 2.0, 1, 200 * bases / gen.total_bases, 1e9, 1.0)
+        filt = po.filter_dumps(dumps, [first], labs, *fkw)
     except ValueError:
-        pass
+        filt = None
     t_filter = time.perf_counter() - t0 - t_count
     S = gen.S
-    for s in seqs:
-        po.map_bins(s, args.k, kmer_labels.keys, kmer_labels.sg_idx, S, 10000, 10_000_000, nthreads=cores)
+    obins = [po.map_bins(s, args.k, kmer_labels.keys, kmer_labels.sg_idx, S, 10000, 10_000_000, nthreads=cores)
+             for s in seqs]
     t_map = time.perf_counter() - t0 - t_count - t_filter
     total = time.perf_counter() - t0
+    # ---- the same sample through the HIP path (untimed): bit-exact or the bench fails ---------------
+    ctx.genome_reset(len(seqs))
+    for i, s in enumerate(seqs):
+        ctx.genome_add(i, s)
+    ctx.count(args.k, 3, args.engine)
+    checked = {"dump_kmers": 0, "matrix_rows": 0, "bins": 0}
+    for i, (ok, oc) in enumerate(dumps):
+        gk, gc = ctx.dump(i)
+        if gk.shape != ok.shape or not (gk == ok).all() or not (gc == oc).all():
+            raise SystemExit("VERIFY FAILED: dump of sample chromosome %d differs from the oracle" % i)
+        checked["dump_kmers"] += int(gk.size)
+    if filt is not None:
+        nu, nr, nh = ctx.filter(*sets_to_csr([first], labs), *fkw)
+        gkeys, gcounts, _, gtot = ctx.filter_fetch(nr, want_freqs=False, sort=True)
+        if (nu, nr, nh) != (filt.n_union, len(filt.keys), len(filt.hist)) or not (gkeys == filt.keys).all() \
+                or not (gcounts == filt.counts).all() or not (gtot == filt.tot).all():
+            raise SystemExit("VERIFY FAILED: matrix / filter rows of the sample differ from the oracle")
+        checked["matrix_rows"] = int(nr)
+    ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, S)
+    for i, ob in enumerate(obins):
+        gb, gn = ctx.map_bins(i, 10000, 10_000_000)
+        if gb.shape != ob[0].shape or not (gb == ob[0]).all() or gn != ob[2]:
+            raise SystemExit("VERIFY FAILED: bin counts of sample chromosome %d differ from the oracle" % i)
+        checked["bins"] += int(gb.shape[0])
     return {"value": round(bases / total / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
             "sample": "first %.0f Mb of each of the %d chromosomes of homoeologous set 1 (%.1f Mbases): "
                       "oracle count %.2fs + matrix/filter %.2fs + map %.2fs"
-                      % (args.cpu_sample_mb, len(seqs), bases / 1e6, t_count, t_filter, t_map)}
+                      % (args.cpu_sample_mb, len(seqs), bases / 1e6, t_count, t_filter, t_map),
+            "verified": True, "verified_items": checked}
 
 
 if __name__ == "__main__":

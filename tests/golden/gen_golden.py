@@ -44,6 +44,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import pyoracle as po  # noqa: E402
 from toygenome import make_toy_genome  # noqa: E402
 
@@ -393,6 +394,135 @@ def main():
         out["G6_hypergeom_mp"] = vec
     except ImportError:
         pass
+
+
+    # ---------------------------------------------------------------- G10 BASELINE shapes
+    # 21 chromosomes / 7 sets x 3 (wheat), 20 / 10 x 2 (peanut), 13 comma-grouped (Arabidopsis suecica):
+    # the whole path of the reference on toys with those structures (Jellyfish.py:439-512, Cluster.py:151-194,
+    # Seqs.py:74-119, Circos.py:831-842, Stats.py:75-118)
+    import hashlib
+    from toygenome import make_shape_genome
+
+    def sha(txt):
+        return hashlib.sha256(txt.encode()).hexdigest()
+
+    captured = []
+    Jellyfish.plot_histogram = lambda data, outfig, **kw: captured.append(sorted(int(x) for x in data))
+    g10 = {}
+    for shape in ("wheat", "peanut", "ara"):
+        tg = make_shape_genome(shape)
+        sdir = os.path.join(tmp, "shape_" + shape)
+        os.makedirs(sdir)
+        s_chromfiles, s_dumpfiles = [], []
+        for lab in tg["labels"]:
+            cf = os.path.join(sdir, lab + ".fasta")
+            with open(cf, "w") as f:
+                f.write(">%s\n%s\n" % (lab, tg["seqs"][lab]))
+            s_chromfiles.append(cf)
+            keys, cnts = po.count_bruteforce(tg["seqs"][lab], k, L)
+            df = "%s_%d.fa" % (cf, k)
+            write_dump(df, keys, cnts, k)
+            s_dumpfiles.append(df)
+        ent = {"seed": 11, "cases": {}}
+        for cname, kw in {"q20_f2": dict(min_freq=20, max_freq=1e9, min_fold=2, baseline=1, ratio=1),
+                          "q10_f3_last_r06": dict(min_freq=10, max_freq=500, min_fold=3, baseline=-1, ratio=0.6)}.items():
+            jd = Jellyfish.JellyfishDumps(s_dumpfiles, tg["labels"], ncpu=2, method="map", chunksize=None)
+            d_mat = jd.to_matrix()
+            del captured[:]
+            d2 = jd.filter(d_mat, jd.lengths, tg["sgs"], outfig=os.path.join(tmp, "h.png"), **kw)
+            rows = sorted(d2.items())
+            rows_txt = "\n".join("\t".join([km] + [repr(float(x)) for x in fr]) for km, fr in rows)
+            case = {"kw": kw, "n_union": len(d_mat), "lengths": [int(x) for x in jd.lengths], "n_rows": len(rows),
+                    "rows_sha256": sha(rows_txt), "rows_head": rows_txt.split("\n")[:5],
+                    "hist_n": len(captured[0]), "hist_sum": int(sum(captured[0])),
+                    "hist_sha256": sha(",".join(map(str, captured[0])))}
+            ent["cases"][cname] = case
+            if cname != "q20_f2":
+                continue
+            buf = io.StringIO()
+            jd.write_matrix(dict(rows), buf)
+            case["kmer_mat_sha256"] = sha(buf.getvalue())
+            matfile = os.path.join(sdir, "x.kmer.mat")
+            open(matfile, "w").write(buf.getvalue())
+            cl = Cluster(matfile, n_clusters=tg["n_sg"], sg_prefix="SG", sg_assigned=tg["sg_assigned"], bootstrap=False)
+            buf = io.StringIO()
+            s_dk = cl.output_kmers(buf, max_pval=0.05, ncpu=2, test_method="ttest_ind")
+            sig_lines = sorted(buf.getvalue().strip().split("\n")[1:])
+            case["sg_names"], case["d_sg"] = cl.sg_names, dict(cl.d_sg)
+            case["n_dkmers"] = len(s_dk)
+            case["sig_kmers_sha256"] = sha("\n".join("\t".join(l.split("\t")[:2]) for l in sig_lines))
+            buf = io.StringIO()
+            Seqs.map_kmer3(s_chromfiles, s_dk, fout=buf, k=k, sg_names=cl.sg_names, ncpu=2, method="map",
+                           window_size=4000, bin_size=500, chunk=True)
+            case["bin_count_text"] = buf.getvalue()
+            binf = os.path.join(sdir, "x.bin.count")
+            open(binf, "w").write(buf.getvalue())
+            coords, counts = Circos.stack_matrix(binf, window_size=2000)
+            case["window_size"] = 2000
+            case["coords"] = [[c, int(s), int(e)] for c, s, e in coords]
+            case["counts"] = [[int(x) for x in row] for row in counts]
+            f1, f2 = io.StringIO(), io.StringIO()
+            Stats.enrich_bin(f1, f2, dict(cl.d_sg), counts, colnames=cl.sg_names, rownames=coords, max_pval=0.05, ncpu=2)
+            case["enrich_text"], case["group_text"] = f1.getvalue(), f2.getvalue()
+        g10[shape] = ent
+    out["G10_shapes"] = g10
+
+    # ---------------------------------------------------------------- G11 Seqs.split_genomes (Seqs.py:27-71)
+    gdir = os.path.join(tmp, "split")
+    os.makedirs(gdir)
+    ga, gb = os.path.join(gdir, "gA.fa"), os.path.join(gdir, "gB.fa")
+    open(ga, "w").write(">chr1 first genome\nACGTACGTAC\nGGGTTTNNAC\n>chr2\nTTTTGGGGCC\n>scaf9\nAC\n")
+    open(gb, "w").write(">chr1 second genome\nCCCCAAAATT\n>chr3\nGATTACAGAT\nTACA\n>chr2\nAAAA\n")
+    g11 = {"genomes": {"gA.fa": open(ga).read(), "gB.fa": open(gb).read()}, "cases": {}}
+    split_cases = {
+        "plain": dict(prefixes=["", ""], targets=["chr1", "chr3"]),
+        "rename": dict(prefixes=["", ""], targets=["A1|chr2", "chr3", "X|scaf9"]),
+        "prefixed": dict(prefixes=["a-", "b-"], targets=["a-chr1", "b-chr1", "B3|b-chr3", "a-chr2"]),
+        "missing": dict(prefixes=["", ""], targets=["chr1", "nothere", "N|alsonot"]),
+        "d_targets_given": dict(prefixes=["a-", "b-"], targets=["a-chr1", "b-chr3"],
+                                d_targets={"a-chr1": "a-chr1", "b-chr3": "b-chr3"}),
+        "d_targets_extra": dict(prefixes=["a-", "b-"], targets=["a-chr1", "Q|b-chr2"], d_targets={"a-chr1": "a-chr1"}),
+    }
+    from collections import OrderedDict as _OD
+    for cname, c in split_cases.items():
+        od = os.path.join(gdir, cname) + "/"
+        os.makedirs(od)
+        dt = _OD(c["d_targets"]) if "d_targets" in c else None
+        outfas, labs, dt2, dsz = Seqs.split_genomes([ga, gb], c["prefixes"], c["targets"], od, d_targets=dt, sep="|")
+        g11["cases"][cname] = {"prefixes": c["prefixes"], "targets": c["targets"], "d_targets": c.get("d_targets"),
+                               "files": [os.path.basename(x) for x in outfas], "labels": labs,
+                               "d_targets2": sorted(dt2.items()), "d_size": dsz,
+                               "seqs": {os.path.basename(x): "".join(open(x).read().split("\n")[1:]) for x in outfas}}
+    out["G11_split_genomes"] = g11
+
+    # ---------------------------------------------------------------- G12 stat_enrich.main (stat_enrich.py:4-37)
+    tsv = os.path.join(tmp, "e4.tsv")
+    sys.argv = [sys.argv[0], tsv]      # the script binds sys.argv[1] as a default argument at import time
+    from subphaser import stat_enrich as ref_stat
+    txt = ("#id\tsubgenome\tp_value\tcounts\n"
+           "LTR-1\tSG1\t0.01\t5,1\nLTR-2\tSG1\t0.01\t7,0\nLTR-3\tSG2\t0.01\t0,9\nGENE-1\tSG2\t0.5\t1,1\n"
+           "GENE-2\tSG2\t0.4\t2,3\nDNA-7\tSG1\t0.04\t11,2\n")
+    open(tsv, "w").write(txt)
+    buf = io.StringIO()
+    ref_stat.main(tsv, buf)
+    out["G12_stat_enrich"] = {"input": txt, "output": buf.getvalue()}
+
+    # ---------------------------------------------------------------- G13 our jellyfish-format dumps through
+    # the reference's own parser (Jellyfish.py:46-98, 439-460): KmerDump.write_text -> JellyfishDumps.to_matrix
+    from oracle_ctx import OracleContext
+    from subphaser_amd import jellyfish as our_jf, seqs as our_seqs
+    octx = OracleContext()
+    rt_files = []
+    for lab in labels[:3]:
+        path = os.path.join(tmp, "rt_%s.fasta" % lab)
+        our_seqs._REG[path] = our_seqs.ChromRecord(lab, seqs[lab].encode())
+        rt_files.append(path)
+    rt_dumps = our_jf.run_jellyfish_dumps(rt_files, k=k, lower_count=L, ctx=octx, write_dumps=True)
+    jd = Jellyfish.JellyfishDumps([str(d) for d in rt_dumps], labels[:3], ncpu=2, method="map", chunksize=None)
+    d_mat = jd.to_matrix()
+    out["G13_dump_roundtrip"] = {"labels": labels[:3], "text_sha256": [sha(open(str(d)).read()) for d in rt_dumps],
+                                 "ref_lengths": [int(x) for x in jd.lengths], "ref_n_union": len(d_mat),
+                                 "ok_files": [os.path.exists(str(d) + ".ok") for d in rt_dumps]}
 
     dst = os.path.join(HERE, "golden.json.gz")
     with gzip.open(dst, "wt") as f:

@@ -325,3 +325,118 @@ def check_long_feature(ctx, golden, toy, tmp_path):
     for b in range(13):
         assert got.get(b, [0] * len(cl.sg_names)) == exp[b].tolist(), b
     assert all(int(l[2]) == min(int(l[1]) + 1000, 12345) for l in lines)
+
+
+# ------------------------------------------------------------------ G10: BASELINE chromosome/set structures
+def _sha(txt):
+    import hashlib
+    return hashlib.sha256(txt.encode()).hexdigest()
+
+
+def check_shape(ctx, golden, shape, engine=0):
+    """Whole path on a toy with the structure of the wheat (21 / 7 x 3), peanut (20 / 10 x 2) or
+    Arabidopsis suecica (13, comma-grouped units) config, against what the imported reference produced."""
+    from toygenome import make_shape_genome
+    tg = make_shape_genome(shape)
+    ent = golden["G10_shapes"][shape]
+    files = []
+    for lab in tg["labels"]:
+        path = "/virtual/shape_%s/%s.fasta" % (shape, lab)
+        if path not in seqs._REG:
+            seqs._REG[path] = seqs.ChromRecord(lab, tg["seqs"][lab].encode())
+        files.append(path)
+    dumps = jellyfish.run_jellyfish_dumps(files, k=K, lower_count=L, ctx=ctx, engine=engine)
+    for cname, case in ent["cases"].items():
+        jd = jellyfish.JellyfishDumps(dumps, tg["labels"])
+        d_mat = jd.to_matrix()
+        assert jd.lengths == case["lengths"], (shape, cname)
+        d2 = jd.filter(d_mat, jd.lengths, tg["sgs"], outfig="h.png", **case["kw"])
+        assert len(d_mat) == case["n_union"], (shape, cname)
+        assert len(d2) == case["n_rows"], (shape, cname)
+        rows = ["\t".join([km] + [repr(float(x)) for x in fr]) for km, fr in d2.items()]
+        assert rows[:5] == case["rows_head"], (shape, cname)
+        assert _sha("\n".join(rows)) == case["rows_sha256"], (shape, cname)
+        hist = np.sort(jd.hist_tot()).astype(np.int64)
+        assert len(hist) == case["hist_n"] and int(hist.sum()) == case["hist_sum"], (shape, cname)
+        assert _sha(",".join(map(str, hist.tolist()))) == case["hist_sha256"], (shape, cname)
+        if "kmer_mat_sha256" not in case:
+            continue
+        buf = io.StringIO()
+        jd.write_matrix(d2, buf)
+        assert _sha(buf.getvalue()) == case["kmer_mat_sha256"], shape
+        cl = cluster.Cluster(d2, n_clusters=tg["n_sg"], sg_prefix="SG", sg_assigned=tg["sg_assigned"])
+        assert cl.sg_names == case["sg_names"] and dict(cl.d_sg) == case["d_sg"], shape
+        buf = io.StringIO()
+        labels = cl.output_kmers(buf, max_pval=0.05)
+        assert len(labels) == case["n_dkmers"], shape
+        sig = sorted(buf.getvalue().strip().split("\n")[1:])
+        assert _sha("\n".join("\t".join(l.split("\t")[:2]) for l in sig)) == case["sig_kmers_sha256"], shape
+        buf = io.StringIO()
+        seqs.map_kmer3(files, labels, fout=buf, k=K, sg_names=cl.sg_names, ctx=ctx, window_size=4000, bin_size=500,
+                       chunk=True)
+        assert buf.getvalue() == case["bin_count_text"], shape
+        # array fast path (what bench.py times) against the reference's stack_matrix + enrich_bin
+        from subphaser_amd.hotpath import HotPath
+        lens = [len(tg["seqs"][lab]) for lab in tg["labels"]]
+        hp = HotPath(ctx, tg["labels"], lens, tg["sgs"], k=K, lower_count=L, bin_size=500, chunk_size=4000,
+                     window_size=case["window_size"])
+        r = hp.map_and_enrich(labels, len(cl.sg_names))
+        assert [[c, s, e] for c, s, e in r.coords] == case["coords"], shape
+        assert r.window_counts.tolist() == case["counts"], shape
+        f1, f2 = io.StringIO(), io.StringIO()
+        stats.enrich_bin(f1, f2, dict(cl.d_sg), r.window_counts.tolist(), colnames=cl.sg_names, rownames=r.coords,
+                         max_pval=0.05, ctx=ctx)
+        _cmp_enrich_text(f1.getvalue(), case["enrich_text"], {4, 10}, {8})
+        assert f2.getvalue() == case["group_text"], shape
+
+
+# ------------------------------------------------------------------ G11 / G12 / G13 host rows pinned by the reference
+def check_split_genomes(golden, tmp_path):
+    """Seqs.split_genomes (Seqs.py:27-71): `new|old` renames, label prefixes, d_targets, missing ids."""
+    from collections import OrderedDict
+    g = golden["G11_split_genomes"]
+    paths = []
+    for name, txt in sorted(g["genomes"].items()):
+        p = tmp_path / name
+        p.write_text(txt)
+        paths.append(str(p))
+    for cname, c in g["cases"].items():
+        od = str(tmp_path / cname) + "/"
+        (tmp_path / cname).mkdir()
+        dt = OrderedDict(c["d_targets"]) if c["d_targets"] else None
+        outfas, labs, dt2, dsz = seqs.split_genomes(paths, c["prefixes"], c["targets"], od, d_targets=dt, sep="|")
+        assert [x[len(od):] for x in outfas] == c["files"], cname
+        assert labs == c["labels"], cname
+        assert sorted([list(kv) for kv in dt2.items()]) == c["d_targets2"], cname
+        assert dsz == c["d_size"], cname
+        for f in outfas:
+            assert "".join(open(f).read().split("\n")[1:]) == c["seqs"][f[len(od):]], (cname, f)
+            assert open(f).read().split("\n")[0] == ">" + f[len(od):-len(".fasta")], (cname, f)
+
+
+def check_stat_enrich(golden, tmp_path):
+    from subphaser_amd.stat_enrich import summarize
+    g = golden["G12_stat_enrich"]
+    p = tmp_path / "e4.tsv"
+    p.write_text(g["input"])
+    buf = io.StringIO()
+    summarize(str(p), buf)
+    assert buf.getvalue() == g["output"]
+
+
+def check_dump_roundtrip(ctx, golden, toy, tmp_path):
+    """KmerDump.write_text writes the text the reference's own dump parser was fed when the fixture was
+    generated (it parsed `ref_lengths` / `ref_n_union` out of exactly these bytes, Jellyfish.py:46-98,439-460)."""
+    g = golden["G13_dump_roundtrip"]
+    files = []
+    for lab in g["labels"]:
+        path = str(tmp_path / ("rt_%s.fasta" % lab))
+        seqs._REG[path] = seqs.ChromRecord(lab, toy["seqs"][lab].encode())
+        files.append(path)
+    dumps = jellyfish.run_jellyfish_dumps(files, k=K, lower_count=L, ctx=ctx, write_dumps=True)
+    for d, exp in zip(dumps, g["text_sha256"]):
+        assert _sha(open(str(d)).read()) == exp
+        assert (tmp_path / (str(d).split("/")[-1] + ".ok")).exists()
+    jd = jellyfish.JellyfishDumps(dumps, g["labels"])
+    assert len(jd.to_matrix()) == g["ref_n_union"]
+    assert jd.lengths == g["ref_lengths"]

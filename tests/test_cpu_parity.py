@@ -90,6 +90,23 @@ def test_pipeline_cli(oracle_ctx, golden, toy, tmp_path):
     pc.check_pipeline_cli(oracle_ctx, golden, toy, tmp_path)
 
 
+@pytest.mark.parametrize("shape", ["wheat", "peanut", "ara"])
+def test_baseline_shapes(oracle_ctx, golden, shape):
+    pc.check_shape(oracle_ctx, golden, shape)
+
+
+def test_split_genomes_reference_cases(golden, tmp_path):
+    pc.check_split_genomes(golden, tmp_path)
+
+
+def test_stat_enrich_reference_output(golden, tmp_path):
+    pc.check_stat_enrich(golden, tmp_path)
+
+
+def test_dump_roundtrip(oracle_ctx, golden, toy, tmp_path):
+    pc.check_dump_roundtrip(oracle_ctx, golden, toy, tmp_path)
+
+
 def test_stack_matrix(golden, tmp_path):
     pc.check_stack_matrix(golden, tmp_path)
 

@@ -508,6 +508,17 @@ def test_filter_errors(gpu_ctx):
         gpu_ctx.filter(*csr1, 2, 1, 1, 1e9, 1)
 
 
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("shape", ["wheat", "peanut", "ara"])
+def test_baseline_shapes(gpu_ctx, golden, shape, engine):
+    """21 / 7 x 3, 20 / 10 x 2 and 13 comma-grouped chromosomes against reference-generated fixtures (G10)."""
+    pc.check_shape(gpu_ctx, golden, shape, engine=engine)
+
+
+def test_dump_roundtrip(gpu_ctx, golden, toy, tmp_path):
+    pc.check_dump_roundtrip(gpu_ctx, golden, toy, tmp_path)
+
+
 def test_kmer_mat_text(gpu_ctx, golden, toy):
     pc.check_kmer_mat_text(gpu_ctx, golden, toy)
 
@@ -786,3 +797,62 @@ def test_medium_scale_count_filter_map_vs_oracle(gpu_ctx, oracle_ctx, k):
         o, on = oracle_ctx.map_bins(i, 10000, 10_000_000)
         assert (allb[i] == o).all() and int(nm[i]) == on
     assert gpu_ctx.labels_hit() == oracle_ctx.labels_hit()
+
+
+@pytest.mark.parametrize("config,scale", [("wheat", 0.003), ("peanut", 0.012), ("ara", 0.08)])
+def test_synth_baseline_shapes_vs_oracle(gpu_ctx, config, scale):
+    """bench.py's own generator at the BASELINE chromosome / set structures (21 / 7 x 3, 20 / 10 x 2, 13
+    comma-grouped), scaled down until the oracle finishes in seconds: HotPath on the HIP context against the
+    oracle step by step -- lengths, (n_union, n_rows, n_hist), matrix rows, bins, windows, p-values, calls."""
+    from oracle_ctx import OracleContext
+    from subphaser_amd import cluster
+    from subphaser_amd.hotpath import HotPath
+    from subphaser_amd.synth import SynthGenome
+    gen = SynthGenome(config, scale)
+    C, S = len(gen.chroms), gen.S
+    ptrs, host = [], []
+    try:
+        for c in gen.chroms:
+            p = gpu_ctx.dev_alloc(c["length"])
+            gpu_ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], S, c["chrom_id"], c["exchange"])
+            ptrs.append(p)
+        gpu_ctx.sync()
+        host = [gpu_ctx.dev_to_host(p, c["length"]) for p, c in zip(ptrs, gen.chroms)]
+        lens = [c["length"] for c in gen.chroms]
+        kw = dict(k=15, lower_count=3, min_freq=20, bin_size=10000, chunk_size=10_000_000, window_size=250_000)
+        hp = HotPath(gpu_ctx, gen.labels, lens, gen.sgs, **kw)
+        a = hp.count_and_filter(ptrs, sort=True)
+    finally:
+        gpu_ctx.sync()
+        for p in ptrs:
+            gpu_ctx.dev_free(p)
+    octx = OracleContext(nthreads=min(32, len(os.sched_getaffinity(0))))
+    octx.genome_reset(C)
+    for i, s in enumerate(host):
+        octx.genome_add(i, s)
+    octx.count(15, 3)
+    assert a.kmer_lengths.tolist() == octx.lengths().tolist()
+    ho = HotPath(octx, gen.labels, lens, gen.sgs, **kw)
+    nu, nr, nh = octx.filter(*ho.csr, ho.min_fold, ho.baseline, ho.min_freq, ho.max_freq, ho.ratio)
+    assert (a.n_union, a.n_rows, a.n_hist) == (nu, nr, nh) and nr > 50, (a.n_union, a.n_rows, a.n_hist, nu, nr, nh)
+    okeys, ocounts, ofreqs, otot = octx.filter_fetch(nr)
+    assert (a.keys == okeys).all() and (a.counts == ocounts).all() and (a.tot == otot).all()
+
+    class _Mat:
+        pass
+    mat = _Mat()
+    mat.labels, mat.keys, mat.k = gen.labels, a.keys, 15
+    mat.freqs = a.counts.astype(np.float64) / np.asarray(a.kmer_lengths, np.float64)
+    assert (mat.freqs == ofreqs).all()
+    cl = cluster.Cluster(mat, n_clusters=S, sg_assigned=gen.sg_assigned)
+    labels = cl.output_kmers(open(os.devnull, "w"), max_pval=0.05)
+    assert len(labels.keys) > 20
+    b = hp.map_and_enrich(labels, S)
+    o = ho.map_and_enrich(labels, S)
+    assert b.n_mapped == o.n_mapped and b.n_mapped > 0
+    for x, y in zip(b.bins, o.bins):
+        assert x.shape == y.shape and (x == y).all()
+    assert b.coords == o.coords and (b.window_counts == o.window_counts).all() and len(b.window_counts) > C
+    assert (b.argmin == o.argmin).all() and (b.sig == o.sig).all() and b.sig.any()
+    assert np.allclose(b.pvals, o.pvals, rtol=1e-6, atol=1e-6)      # north star: p-values within 1e-6
+    assert (b.ratios == o.ratios).all() or np.allclose(b.ratios, o.ratios, rtol=1e-15, atol=0, equal_nan=True)

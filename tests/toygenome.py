@@ -80,3 +80,57 @@ def make_toy_genome(seed=7, n_sets=3, chrom_len=40000, copies=25):
     feats.append(("weird_id_without_coords", seqs["B2"][100:900]))
     return {"labels": labels, "seqs": seqs, "sgs": sgs, "sgs3": sgs3, "sgs_grouped": sgs_grouped,
             "sg_assigned": sg_assigned, "features": feats}
+
+
+# ---------------------------------------------------------------------------------------------
+# Toys with the chromosome / set STRUCTURE of the three BASELINE genomes (the filter's set loop,
+# its 8-wide table batching and the comma-grouped units depend on the shape, not on the size):
+#   wheat   21 chromosomes, 7 config lines x 3 single-chromosome units   (example_data/wheat_sg.config)
+#   peanut  20 chromosomes, 10 lines x 2 units                            (example_data/peanut_sg.config)
+#   ara     13 chromosomes, 3 lines with comma-joined units, 5 + 8        (example_data/Arabidopsis_suecica_sg.config)
+SHAPES = {
+    "wheat": dict(letters="ABD", layout=[[["Chr%d%s" % (h, g)] for g in "ABD"] for h in range(1, 8)]),
+    "peanut": dict(letters="AB", layout=[[["Arahy.%02d" % h], ["Arahy.%02d" % (h + 10)]] for h in range(1, 11)]),
+    "ara": dict(letters="AB", layout=[[["c1"], ["c6", "c7"]], [["c2", "c3"], ["c9", "c8", "c10"]],
+                                      [["c4", "c5"], ["c13", "c11", "c12"]]]),
+}
+
+
+def make_shape_genome(shape, seed=11, chrom_len=9000, copies=9):
+    cfg = SHAPES[shape]
+    rng = np.random.RandomState(seed)
+    S = len(cfg["letters"])
+    lib = [[_rand_seq(rng, rng.randint(120, 360)) for _ in range(5)] for _ in range(S)]
+    shared = [_rand_seq(rng, rng.randint(120, 360)) for _ in range(3)]
+    seqs, sg_of = {}, {}
+    for set_id, units in enumerate(cfg["layout"]):
+        backbone = _rand_seq(rng, chrom_len + rng.randint(-1500, 1500))
+        for sg_id, unit in enumerate(units):
+            for lab in unit:
+                s = _mutate(rng, backbone, 0.08)[: chrom_len + rng.randint(-1200, 1200)]
+                n = s.size
+                for fam in lib[sg_id]:
+                    for _ in range(copies):
+                        pos = rng.randint(50, n - 400)
+                        el = _mutate(rng, fam, rng.uniform(0, 0.05))
+                        s[pos:pos + el.size] = el[: n - pos]
+                for fam in shared:
+                    for _ in range(copies // 2):
+                        pos = rng.randint(50, n - 400)
+                        el = _mutate(rng, fam, rng.uniform(0, 0.05))
+                        s[pos:pos + el.size] = el[: n - pos]
+                tel = np.frombuffer(b"TTTAGGG" * 12, dtype=np.uint8)
+                s[: tel.size] = tel
+                txt = bytearray(s.tobytes())
+                p = rng.randint(0, n - 200)
+                txt[p:p + 150] = bytes(txt[p:p + 150]).lower()
+                p = rng.randint(100, n - 100)
+                txt[p:p + 7] = b"NNNNNNN"
+                seqs[lab] = txt.decode()
+                sg_of[lab] = "SG%d" % (sg_id + 1)
+    if shape == "ara":
+        labels = sorted(seqs, key=lambda x: int(x[1:]))
+    else:
+        labels = [lab for units in cfg["layout"] for unit in units for lab in unit]
+    return {"labels": labels, "seqs": seqs, "sgs": cfg["layout"], "sg_assigned": {l: sg_of[l] for l in labels},
+            "n_sg": S}
