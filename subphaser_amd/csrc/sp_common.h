@@ -20,6 +20,7 @@ struct sp_chrom {
     int64_t nw = 0;      // 16-base words actually covering len
     int64_t cap_mw = 0;  // capacity of d_pk/d_nm in mask words (buffers are reused across sp_genome_reset)
     uint32_t *d_pk = nullptr;  // 2-bit codes, base i at bits 2*(i%16) of word i/16; padded with SP_PAD_WORDS
+    uint32_t *d_pm = nullptr;  // the same codes MSB-first (base i at bits 30 - 2*(i%16)); lives behind d_pk in one allocation
     uint32_t *d_nm = nullptr;  // invalid mask, base i at bit (i%32) of word i/32; padding marked invalid
     uint32_t *d_tab = nullptr; // dense count table [nslots] (valid after sp_count)
     int64_t length_sum = 0;    // sum of counts >= lower_count
@@ -94,6 +95,9 @@ struct sp_ctx {
     int64_t n_fblocks = 0;
     // labels
     uint8_t *d_label = nullptr;  // [nslots] 0 = none, 1+sg; bit 7 = seen
+    sp_buf b_ptab, b_labkeys;    // pair table (sp_map.hip: 4^(k-1) x u32) and the labelled keys it was built from
+    int map_engine = 0;          // 0 = pair table (S <= 7), 1 = label table
+    bool labels_ready = false;
     uint32_t *d_bloom = nullptr; // L2-resident pair filter over hashed (k-1)-mers (sp_map.hip), 2^bloom_bits bits
     int bloom_bits = 0;
     int n_sg = 0;

@@ -234,6 +234,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             hipFree(ctx->d_label);
             ctx->d_label = nullptr;
         }
+        if (ctx->k != k) ctx->labels_ready = false;
         ctx->k = k;
         ctx->lower = lower_count;
         ctx->nslots = 0;
@@ -258,6 +259,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             hipFree(ctx->d_label);
             ctx->d_label = nullptr;
         }
+        ctx->labels_ready = false;
     }
     ctx->k = k;
     ctx->lower = lower_count;

@@ -66,7 +66,8 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
 // neither its own histogram pass nor global cursors: each tile's output offsets come from a
 // column scan over tiles (c2_tilescan) -- deterministic layout, no contended atomics.
 __global__ void __launch_bounds__(C2_P1_THREADS)
-c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
+c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+        int64_t n_units /* of 32 starts */,
         sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine, int shift1, int F1, int64_t n_tiles,
         unsigned long long *__restrict__ ghist, uint32_t *__restrict__ tile_cnt /* [F1][n_tiles] */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
@@ -78,8 +79,7 @@ c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
         if (u < n_units) {
             auto scan = [&](auto parity) {
-                sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-                    const uint32_t slot = sp_slot_of32_t<decltype(parity)::value>(fwd, rc, kp);
+                sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp, [&](uint32_t slot) {
                     atomicAdd(&lh[slot >> shift_fine], 1u);
                     atomicAdd(&th[slot >> shift1], 1u);
                 });
@@ -206,7 +206,8 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 
 // ---------------------------------------------------------------- c2_part1
 __global__ void __launch_bounds__(C2_P1_THREADS)
-c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
+c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+         int64_t n_units /* of 32 starts */,
          sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
          const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, int64_t n_tiles,
          uint32_t *__restrict__ buf1) {
@@ -225,8 +226,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
         const uint32_t total = c2_scan_F(hist, start, F1, wsum);
         if (u < n_units) {
             auto scan = [&](auto parity) {
-                sp_scan_unit32<C2_P1_UNIT>(pk, nm, u * C2_P1_UNIT, kp, [&](int64_t, uint32_t fwd, uint32_t rc) {
-                    const uint32_t slot = sp_slot_of32_t<decltype(parity)::value>(fwd, rc, kp);
+                sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp, [&](uint32_t slot) {
                     const uint32_t b = slot >> shift1;
                     keys[start[b] + atomicAdd(&cur[b], 1u)] = slot;
                 });
@@ -469,13 +469,13 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     if (sh_hist > 48 * 1024)
         hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist);
     int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
-    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_nm, n_units32,
+    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_pm, c.d_nm, n_units32,
               kp32, C2_B3, (int)nf, P.T - P.B1, P.F1, n_tiles, ghist, tile_cnt);
     SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
               off1, tile_start);
     SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3(P.F1), dim3(256), 0, (const uint32_t *)tile_cnt, tile_off,
               n_tiles);
-    SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_nm, n_units32,
+    SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
               kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, buf1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
     int64_t max_tiles2 = n_tiles + P.F1;

@@ -139,6 +139,8 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
     sp_buf_free(ctx->b_map);
+    sp_buf_free(ctx->b_ptab);
+    sp_buf_free(ctx->b_labkeys);
     sp_buf_free(ctx->b_emit);
     sp_buf_free(ctx->b_slots);
     sp_buf_free(ctx->b_fpar);
@@ -188,14 +190,14 @@ __device__ __forceinline__ void pack_byte(uint32_t b, uint32_t &code, uint32_t &
 }
 
 __global__ void __launch_bounds__(256)
-k0_pack(const uint8_t *__restrict__ ascii, int64_t len, uint32_t *__restrict__ pk,
+k0_pack(const uint8_t *__restrict__ ascii, int64_t len, uint32_t *__restrict__ pk, uint32_t *__restrict__ pm,
         uint32_t *__restrict__ nm, int64_t n_mask_words) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool aligned = (((uintptr_t)ascii) & 15) == 0;
     for (; t < n_mask_words; t += stride) {
         int64_t base = t * 32;
-        uint32_t w0 = 0, w1 = 0, m = 0;
+        uint32_t w0 = 0, w1 = 0, m = 0, r0 = 0, r1 = 0;   // r*: MSB-first twins
         if (base + 32 <= len && aligned) {
             const uint4 *p = reinterpret_cast<const uint4 *>(ascii + base);
             uint4 a = p[0], b = p[1];
@@ -208,8 +210,8 @@ k0_pack(const uint8_t *__restrict__ ascii, int64_t len, uint32_t *__restrict__ p
                     pack_byte((v[q] >> (8 * j)) & 0xffu, c, iv);
                     c &= iv - 1u;  // invalid bases pack as code 0
                     int i = q * 4 + j;
-                    if (i < 16) w0 |= c << (2 * i);
-                    else w1 |= c << (2 * (i - 16));
+                    if (i < 16) { w0 |= c << (2 * i); r0 |= c << (30 - 2 * i); }
+                    else { w1 |= c << (2 * (i - 16)); r1 |= c << (30 - 2 * (i - 16)); }
                     m |= iv << i;
                 }
             }
@@ -218,13 +220,13 @@ k0_pack(const uint8_t *__restrict__ ascii, int64_t len, uint32_t *__restrict__ p
                 uint32_t c = 0, iv = 1;
                 if (base + i < len) pack_byte(ascii[base + i], c, iv);
                 if (iv) c = 0;
-                if (i < 16) w0 |= c << (2 * i);
-                else w1 |= c << (2 * (i - 16));
+                if (i < 16) { w0 |= c << (2 * i); r0 |= c << (30 - 2 * i); }
+                else { w1 |= c << (2 * (i - 16)); r1 |= c << (30 - 2 * (i - 16)); }
                 m |= iv << i;
             }
         }
-        pk[2 * t] = w0;
-        pk[2 * t + 1] = w1;
+        *reinterpret_cast<uint2 *>(pk + 2 * t) = make_uint2(w0, w1);
+        *reinterpret_cast<uint2 *>(pm + 2 * t) = make_uint2(r0, r1);
         nm[t] = m;
     }
 }
@@ -251,9 +253,10 @@ static int genome_add_impl(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64
     if (nmw > c.cap_mw) {
         if (c.d_pk) hipFree(c.d_pk);
         if (c.d_nm) hipFree(c.d_nm);
-        c.d_pk = c.d_nm = nullptr;
+        c.d_pk = c.d_pm = c.d_nm = nullptr;
         c.cap_mw = 0;
-        SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(2 * nmw) * sizeof(uint32_t)));
+        SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(4 * nmw) * sizeof(uint32_t)));   // LSB-first | MSB-first
+        c.d_pm = c.d_pk + 2 * nmw;
         SP_HIP(ctx, hipMalloc(&c.d_nm, (size_t)nmw * sizeof(uint32_t)));
         c.cap_mw = nmw;
     }
@@ -261,7 +264,7 @@ static int genome_add_impl(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64
     if (blocks > 8LL * ctx->n_cu * 8) blocks = 8LL * ctx->n_cu * 8;
     if (blocks < 1) blocks = 1;
     SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, len, c.d_pk,
-              c.d_nm, nmw);
+              c.d_pm, c.d_nm, nmw);
     ctx->counted = false;
     return SP_OK;
 }

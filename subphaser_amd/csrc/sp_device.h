@@ -163,6 +163,91 @@ __device__ __forceinline__ void sp_scan_unit64(const uint32_t *__restrict__ pk, 
     sp_scan_unit_t<UNIT, uint64_t>(pk, nm, s0, kp, emit);
 }
 
+// ------------------------------------------------------------------ direct-window scan (k <= 15/16)
+// The rolling scan above spends ~40 VALU instructions per k-mer (two shift/or chains per base, the
+// run mask test and an exec-mask branch per emitted k-mer).  The dense-table kernels are bound by
+// exactly that, so they read the genome from TWO packed streams instead:
+//   pk  LSB-first  (base i at bits 2*(i%16))      -- also what the 64-bit engines use
+//   pm  MSB-first  (base i at bits 30 - 2*(i%16))
+// A 16-base window starting at ANY base is one v_alignbit_b32 per stream.  From the MSB-first window V
+// the forward k-mer in key order (first base most significant) is V >> (32 - 2k); from the LSB-first
+// window W its reverse complement in key order is ~W & kmask (complementing reverses nothing: the last
+// base of the k-mer already sits in the most significant used bits).  ~6 instructions for both strands.
+#define SP_UNIT32 32
+
+// bit j of the result: the w bases s0+j .. s0+j+w-1 are all valid (w <= 32; s0 a multiple of 32).
+// `shift1`: answer for windows starting one base later (s0+j+1 ..), used for the shared (k-1)-mer.
+__device__ __forceinline__ uint64_t sp_bad_starts64(const uint32_t *__restrict__ nm, int64_t s0, int w) {
+    const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+    if (w <= 0) return 0;
+    uint64_t e = inv;
+    int have = 1;
+    while (have * 2 <= w) {
+        e |= e >> have;
+        have *= 2;
+    }
+    if (have < w) e |= e >> (w - have);
+    return e;   // bit j: an invalid base in [s0+j, s0+j+w)
+}
+
+struct sp_words32 {
+    uint32_t l[3], m[3];
+};
+__device__ __forceinline__ sp_words32 sp_load_words32(const uint32_t *__restrict__ pk,
+                                                      const uint32_t *__restrict__ pm, int64_t s0) {
+    const int64_t w0 = s0 >> 4;   // even: 8-byte aligned
+    sp_words32 r;
+    const uint2 a = *reinterpret_cast<const uint2 *>(pk + w0);
+    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0);
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = pk[w0 + 2];
+    r.m[0] = b.x; r.m[1] = b.y; r.m[2] = pm[w0 + 2];
+    return r;
+}
+// 16-base windows starting at base s0 + J (J a compile-time constant after unrolling)
+template <int J>
+__device__ __forceinline__ uint32_t sp_win_lsb(const sp_words32 &x) {
+    constexpr int q = J >> 4, r = J & 15;
+    if (r == 0) return x.l[q];
+    return __builtin_amdgcn_alignbit(x.l[q + 1], x.l[q], 2 * r);
+}
+template <int J>
+__device__ __forceinline__ uint32_t sp_win_msb(const sp_words32 &x) {
+    constexpr int q = J >> 4, r = J & 15;
+    if (r == 0) return x.m[q];
+    return __builtin_amdgcn_alignbit(x.m[q], x.m[q + 1], 32 - 2 * r);
+}
+
+template <int J, int STEP, typename F>
+struct sp_win_loop {
+    static __device__ __forceinline__ void run(const sp_words32 &x, F &f) {
+        f(J, sp_win_msb<J>(x), sp_win_lsb<J>(x));
+        sp_win_loop<J + STEP, STEP, F>::run(x, f);
+    }
+};
+template <int STEP, typename F>
+struct sp_win_loop<32, STEP, F> {
+    static __device__ __forceinline__ void run(const sp_words32 &, F &) {}
+};
+
+// emit(slot) for every valid k-mer start of the unit [s0, s0+32); k <= 15 (dense-table kernels)
+template <bool ODD, typename F>
+__device__ __forceinline__ void sp_scan32_slots(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                const uint32_t *__restrict__ nm, int64_t s0,
+                                                const sp_kparams32 &kp, F &&emit) {
+    const uint32_t ok = ~(uint32_t)sp_bad_starts64(nm, s0, kp.k);
+    const sp_words32 x = sp_load_words32(pk, pm, s0);
+    const int sh = 32 - 2 * kp.k;
+    if (__all(ok == 0xffffffffu)) {   // wave-uniform: no N / chromosome end in any lane's unit
+        auto f = [&](int, uint32_t V, uint32_t W) { emit(sp_slot_of32_t<ODD>(V >> sh, ~W & kp.kmask, kp)); };
+        sp_win_loop<0, 1, decltype(f)>::run(x, f);
+    } else {
+        auto f = [&](int j, uint32_t V, uint32_t W) {
+            if ((ok >> j) & 1u) emit(sp_slot_of32_t<ODD>(V >> sh, ~W & kp.kmask, kp));
+        };
+        sp_win_loop<0, 1, decltype(f)>::run(x, f);
+    }
+}
+
 // wave-level inclusive/exclusive helpers (64 lanes)
 __device__ __forceinline__ int sp_lane() { return threadIdx.x & 63; }
 

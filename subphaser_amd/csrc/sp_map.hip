@@ -108,6 +108,115 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
     label[sp_slot_of_key(keys[i], kp)] = (uint8_t)(1u + sg[i]);
 }
 
+// ----------------------------------------------------------------- K4b: exact PAIR table
+// The exact lookup that follows the filter used to be one random byte gather per candidate START from
+// the 2^(2k-1)-byte label table -- an L2 miss each (54 G/s on this chip), 2.7 G of them on the wheat-like
+// genome.  The pair table is keyed like the filter, on the canonical (k-1)-mer x two neighbouring starts
+// share, and its 32-bit entry answers BOTH of them: eight 4-bit fields
+//     field b     (b = 0..3)  label of the k-mer  b + x   ("L": x extended to the left by base b)
+//     field 4 + b             label of the k-mer  x + b   ("R")
+// in the orientation in which x is canonical; a field is (1 + SG) in its low three bits (0 = not a
+// subgenome-specific k-mer) and a "seen" flag in bit 3.  One gather per candidate PAIR instead of one per
+// candidate start: labelled k-mers come in runs (repeat copies), so almost every candidate pair carries
+// two hits.  4^(k-1) entries (1 GiB at k = 15); S <= 7 (the label-table path below stays for S > 7).
+#define MAP_PAIR_MAX_SG 7
+
+struct map_pair_loc {
+    uint32_t idx;   // canonical (k-1)-mer
+    int field;
+};
+// where the k-mer `o` (any orientation; k >= 1) lives when it is looked up through its prefix / suffix (k-1)-mer
+__host__ __device__ __forceinline__ map_pair_loc map_pair_loc_prefix(uint64_t o, int k) {
+    map_pair_loc r;
+    const uint32_t b = (uint32_t)(o & 3ULL);
+    if (k == 1) { r.idx = 0; r.field = 4 + (int)b; return r; }
+    const uint64_t p = o >> 2, pc = sp_revcomp(p, k - 1);
+    if (p <= pc) { r.idx = (uint32_t)p; r.field = 4 + (int)b; }       // x + b
+    else { r.idx = (uint32_t)pc; r.field = 3 - (int)b; }              // rc: comp(b) + rc(x)
+    return r;
+}
+__host__ __device__ __forceinline__ map_pair_loc map_pair_loc_suffix(uint64_t o, int k) {
+    map_pair_loc r;
+    const uint32_t b = (uint32_t)(o >> (2 * (k - 1))) & 3u;
+    if (k == 1) { r.idx = 0; r.field = (int)b; return r; }
+    const uint64_t m1mask = (1ULL << (2 * (k - 1))) - 1ULL;
+    const uint64_t x = o & m1mask, xc = sp_revcomp(x, k - 1);
+    if (x <= xc) { r.idx = (uint32_t)x; r.field = (int)b; }           // b + x
+    else { r.idx = (uint32_t)xc; r.field = 7 - (int)b; }              // rc: rc(x) + comp(b)
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k4_pair_table(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n, int k,
+              uint32_t *__restrict__ ptab) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const uint32_t l = 1u + sg[i];
+    // a strand pair has ONE prefix location and ONE suffix location (both orientations lead to the same
+    // two fields); palindromic x is handled by the <= in map_pair_loc_* and the same <= in the lookup
+    const map_pair_loc a = map_pair_loc_prefix(key, k), b = map_pair_loc_suffix(key, k);
+    atomicOr(&ptab[a.idx], l << (4 * a.field));
+    atomicOr(&ptab[b.idx], l << (4 * b.field));
+    const uint64_t r = sp_revcomp(key, k);
+    const map_pair_loc c = map_pair_loc_prefix(r, k), d = map_pair_loc_suffix(r, k);
+    atomicOr(&ptab[c.idx], l << (4 * c.field));
+    atomicOr(&ptab[d.idx], l << (4 * d.field));
+}
+
+__global__ void __launch_bounds__(256)
+k4_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, const uint32_t *__restrict__ ptab,
+             unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i], r = sp_revcomp(key, k);
+        const map_pair_loc a = map_pair_loc_prefix(key, k), b = map_pair_loc_suffix(key, k);
+        const map_pair_loc e = map_pair_loc_prefix(r, k), f = map_pair_loc_suffix(r, k);
+        const uint32_t seen = ((ptab[a.idx] >> (4 * a.field)) | (ptab[b.idx] >> (4 * b.field)) |
+                               (ptab[e.idx] >> (4 * e.field)) | (ptab[f.idx] >> (4 * f.field))) & 8u;
+        c += seen ? 1 : 0;
+    }
+    unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
+// Walk the 32 starts [s0, s0+32) pair by pair: ONE filter probe per pair, ONE pair-table gather per
+// candidate pair; hit(start, sg) for every valid start that carries a labelled k-mer.  k <= 15.
+template <typename F>
+__device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
+                                                const uint32_t *__restrict__ bloom, int nbits,
+                                                uint32_t *__restrict__ ptab, F &&hit) {
+    const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
+    const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+    const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
+    const uint32_t ok_x = ~(uint32_t)(bad_k1 >> 1);                    // (k-1)-mer starting at s0+j+1
+    if (__all((ok_x & 0x55555555u) == 0)) return;
+    const sp_words32 x = sp_load_words32(pk, pm, s0);
+    const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
+    const uint32_t m1mask = kp.kmask >> 2;
+    auto f = [&](int j, uint32_t V, uint32_t W) {
+        const uint32_t xf = (V >> sh) & m1mask;          // shared (k-1)-mer, forward, key order
+        const uint32_t xr = (~W >> 2) & m1mask;          // its reverse complement
+        const uint32_t canon = xf < xr ? xf : xr;
+        if (!((ok_x >> j) & 1u) || !map_bloom_test(bloom, nbits, (uint64_t)canon)) return;
+        const uint32_t e = ptab[canon];
+        if (!(e & 0x77777777u)) return;
+        const bool fwd = xf <= xr;
+        const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
+        const int f0 = fwd ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
+        const int f1 = fwd ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
+        const uint32_t v0 = ((ok_k >> j) & 1u) ? (e >> (4 * f0)) & 15u : 0u;
+        const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e >> (4 * f1)) & 15u : 0u;
+        uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
+        if ((v0 & 7u) && hit(s0 + j, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
+        if ((v1 & 7u) && hit(s0 + j + 1, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
+        if (mark) atomicOr(&ptab[canon], mark);           // "seen": first touch only
+    };
+    sp_win_loop<0, 2, decltype(f)>::run(x, f);
+}
+
 // ----------------------------------------------------------------- K5
 // One block-iteration covers MAP_UNITS_PER_BLOCK units of 64 starts.  Hits are
 // accumulated in an LDS histogram over the (few) output slots the range
@@ -138,8 +247,69 @@ __device__ __forceinline__ int64_t map_slot(int64_t s, const sp_map_params &P, i
     return s / P.bin_size + chunk;
 }
 
+// first start after `s` whose output slot differs from map_slot(s) (next bin or next chunk boundary)
+__device__ __forceinline__ int64_t map_slot_end(int64_t s, const sp_map_params &P, int k) {
+    int64_t e = (s / P.bin_size + 1) * P.bin_size;
+    if (P.chunk_size > 0) {
+        const int64_t chunk = (s >= P.chunk_size - (k - 1)) ? (s + (k - 1)) / P.chunk_size : 0;
+        const int64_t c = (chunk + 1) * P.chunk_size - (k - 1);
+        e = c < e ? c : e;
+    }
+    return e;
+}
+
+// K5, pair-table engine (S <= 7): one block-iteration covers MAP_BLOCK units of 64 starts
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
+k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+       sp_kparams32 kp, sp_map_params P, uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom,
+       int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
+    __shared__ int hist[MAP_LDS_ENTRIES];
+    __shared__ unsigned long long red[16];
+    unsigned long long mapped = 0;
+    const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const int64_t u = r * MAP_BLOCK + threadIdx.x;
+        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k);
+        if (P.use_lds) {
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        if (u < P.n_units) {
+            int64_t cur_end = -1, cur_os = 0;   // starts are visited in ascending order: [.., cur_end) -> cur_os
+            auto hit = [&](int64_t start, int sg) {
+                if (start >= cur_end) {
+                    cur_os = map_slot(start, P, kp.k);
+                    cur_end = map_slot_end(start, P, kp.k);
+                }
+                if (P.use_lds)
+                    atomicAdd(&hist[(cur_os - slot_lo) * P.S + sg], 1);
+                else if (cur_os < P.nslots)
+                    atomicAdd(&slot_counts[cur_os * P.S + sg], 1);
+                mapped++;
+                return true;
+            };
+            map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+        }
+        if (P.use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
+                int v = hist[i];
+                if (v) {
+                    int64_t os = slot_lo + i / P.S;
+                    if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + (i % P.S)], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long t = sp_block_sum_u64(mapped, red);
+    if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
+}
+
+// K5, label-table engine (any S <= 126; the rolling scan + one byte gather per candidate start)
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
        sp_map_params P, uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom, int bloom_bits,
        int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
@@ -242,7 +412,28 @@ __device__ __forceinline__ bool map_feat_locate(map_feat_cursor &c, int64_t star
 }
 
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
+k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+            sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
+            uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
+            unsigned long long *__restrict__ counts) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        map_feat_cursor cur;
+        cur.f = -1;
+        cur.next = 0;
+        auto hit = [&](int64_t start, int sg) {
+            if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return false;
+            atomicAdd(&counts[cur.f * S + sg], 1ULL);
+            return true;
+        };
+        map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+        map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+    }
+}
+
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_feat_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp,
             int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
             uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom, int bloom_bits,
             unsigned long long *__restrict__ counts) {
@@ -283,7 +474,7 @@ k4_count_seen(const uint8_t *__restrict__ label, int64_t nslots, unsigned long l
 }
 
 // pack kernel from sp_ctx.hip
-__global__ void k0_pack(const uint8_t *ascii, int64_t len, uint32_t *pk, uint32_t *nm, int64_t n_mask_words);
+__global__ void k0_pack(const uint8_t *ascii, int64_t len, uint32_t *pk, uint32_t *pm, uint32_t *nm, int64_t n_mask_words);
 
 static int64_t map_nslots_host(int64_t len, int64_t bin_size, int64_t chunk_size, int k) {
     int64_t L = len > 0 ? len : 1;
@@ -342,22 +533,39 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
         ctx->n_labels = n;
         return sp_sparse_labels_set(ctx, keys, sg, n);
     }
-    if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
+    const char *eng = getenv("SP_MAP_ENGINE");
+    ctx->map_engine = (n_sg > MAP_PAIR_MAX_SG || (eng && eng[0] == '1')) ? 1 : 0;
     ctx->n_sg = n_sg;
     ctx->n_labels = n;
-    if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
-    sp_tmp<unsigned long long> d_keys;
-    sp_tmp<uint8_t> d_sg;
-    SP_HIP(ctx, d_keys.alloc((size_t)n));
-    SP_HIP(ctx, d_sg.alloc((size_t)n));
-    SP_HIP(ctx, hipMemcpyAsync(d_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_sg.p, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    const sp_kparams kp = sp_make_kparams(ctx->k);
-    SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-              (const unsigned long long *)d_keys.p, (const uint8_t *)d_sg.p, n, kp, ctx->d_label);
-    const int rcf = sp_map_filter_build(ctx, d_keys.p, n);
+    ctx->labels_ready = false;
+    int rcb = sp_buf_ensure(ctx, ctx->b_labkeys, (n > 0 ? n : 1) * 9);
+    if (rcb) return rcb;
+    unsigned long long *d_keys = (unsigned long long *)ctx->b_labkeys.p;
+    uint8_t *d_sg = (uint8_t *)(d_keys + (n > 0 ? n : 1));
+    if (n > 0) {
+        SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (ctx->map_engine == 0) {
+        const int64_t entries = 1LL << (2 * (ctx->k - 1));
+        rcb = sp_buf_ensure(ctx, ctx->b_ptab, entries * 4);
+        if (rcb) return rcb;
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_ptab.p, 0, (size_t)entries * 4, ctx->stream));
+        if (n > 0)
+            SP_LAUNCH(ctx, "k4_pair_table", k4_pair_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                      (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, (uint32_t *)ctx->b_ptab.p);
+    } else {
+        if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
+        SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
+        if (n > 0) {
+            const sp_kparams kp = sp_make_kparams(ctx->k);
+            SP_LAUNCH(ctx, "k4_labels", k4_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                      (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, kp, ctx->d_label);
+        }
+    }
+    const int rcf = sp_map_filter_build(ctx, n > 0 ? d_keys : nullptr, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rcf == SP_OK) ctx->labels_ready = true;
     return rcf;
 }
 
@@ -373,7 +581,7 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
     if (!ctx || !slot_counts || chrom < 0 || chrom >= (int)ctx->chroms.size() || bin_size < 1 ||
         chunk_size < 0)
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins: bad arguments");
-    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+    if (!(ctx->sparse_mode ? ctx->d_hkeys != nullptr : ctx->labels_ready))
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_chrom &c = ctx->chroms[(size_t)chrom];
@@ -404,8 +612,12 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                  ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
+        if (ctx->map_engine == 0)
+            SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
+                      (uint32_t *)ctx->b_ptab.p, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
+        else
+            SP_LAUNCH(ctx, "k5_map_lab", k5_map_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+                      ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
     }
     unsigned long long hn = 0;
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -419,7 +631,7 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
                     int32_t *slot_counts, int64_t *n_mapped) {
     if (!ctx || !slot_off || !slot_counts || bin_size < 1 || chunk_size < 0)
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: bad arguments");
-    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+    if (!(ctx->sparse_mode ? ctx->d_hkeys != nullptr : ctx->labels_ready))
         return sp_fail(ctx, SP_EINVAL, "sp_map_bins_all: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int C = (int)ctx->chroms.size();
@@ -457,8 +669,12 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                  ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
+        if (ctx->map_engine == 0)
+            SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
+                      (uint32_t *)ctx->b_ptab.p, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
+        else
+            SP_LAUNCH(ctx, "k5_map_lab", k5_map_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+                      ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
     }
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<unsigned long long> hn((size_t)C, 0);
@@ -506,7 +722,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
                     int64_t *counts) {
     if (!ctx || !off || !counts || n_feat < 0 || (n_feat > 0 && off[n_feat] > 0 && !ascii))
         return sp_fail(ctx, SP_EINVAL, "sp_map_features: bad arguments");
-    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+    if (!(ctx->sparse_mode ? ctx->d_hkeys != nullptr : ctx->labels_ready))
         return sp_fail(ctx, SP_EINVAL, "sp_map_features: call sp_labels_set first");
     const int S = ctx->n_sg;
     memset(counts, 0, (size_t)n_feat * S * sizeof(int64_t));
@@ -527,7 +743,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     sp_tmp<unsigned long long> d_counts;
     int64_t nmw = (total + 31) / 32 + SP_PAD_WORDS;
     SP_HIP(ctx, d_ascii.alloc((size_t)total));
-    SP_HIP(ctx, d_pk.alloc((size_t)(2 * nmw)));
+    SP_HIP(ctx, d_pk.alloc((size_t)(4 * nmw)));   // LSB-first | MSB-first
     SP_HIP(ctx, d_nm.alloc((size_t)nmw));
     SP_HIP(ctx, d_foff.alloc((size_t)(n_feat + 1)));
     SP_HIP(ctx, d_counts.alloc((size_t)n_feat * S));
@@ -537,7 +753,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
     int64_t blocks = (nmw + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, (const uint8_t *)d_ascii.p, total, d_pk.p,
-              d_nm.p, nmw);
+              d_pk.p + 2 * nmw, d_nm.p, nmw);
     int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
     if (ctx->sparse_mode) {
         int rcs = sp_sparse_feat_launch(ctx, d_pk.p, d_nm.p, n_units, d_foff.p, n_feat, S, d_counts.p);
@@ -546,9 +762,15 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
-                  (const uint32_t *)d_nm.p, kp, n_units, (const int64_t *)d_foff.p, n_feat, S, ctx->d_label,
-                  (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_counts.p);
+        if (ctx->map_engine == 0)
+            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+                      (const uint32_t *)(d_pk.p + 2 * nmw), (const uint32_t *)d_nm.p, kp, n_units,
+                      (const int64_t *)d_foff.p, n_feat, S, (uint32_t *)ctx->b_ptab.p, (const uint32_t *)ctx->d_bloom,
+                      ctx->bloom_bits, d_counts.p);
+        else
+            SP_LAUNCH(ctx, "k5_map_feat_lab", k5_map_feat_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0,
+                      (const uint32_t *)d_pk.p, (const uint32_t *)d_nm.p, kp, n_units, (const int64_t *)d_foff.p, n_feat,
+                      S, ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_counts.p);
     }
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -557,7 +779,7 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
 
 int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
     if (!ctx || !n_hit) return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: bad arguments");
-    if (!(ctx->sparse_mode ? (void *)ctx->d_hkeys : (void *)ctx->d_label))
+    if (!(ctx->sparse_mode ? ctx->d_hkeys != nullptr : ctx->labels_ready))
         return sp_fail(ctx, SP_EINVAL, "sp_labels_hit: call sp_labels_set first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_tmp<unsigned long long> d_n;
@@ -568,8 +790,15 @@ int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
         int rcs = sp_sparse_hit(ctx, d_n.p);
         if (rcs) return rcs;
     } else {
-        SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
-                  (const uint8_t *)ctx->d_label, ctx->nslots, d_n.p);
+        if (ctx->map_engine == 0) {
+            if (ctx->n_labels > 0)
+                SP_LAUNCH(ctx, "k4_pair_seen", k4_pair_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
+                          (const unsigned long long *)ctx->b_labkeys.p, ctx->n_labels, ctx->k,
+                          (const uint32_t *)ctx->b_ptab.p, d_n.p);
+        } else {
+            SP_LAUNCH(ctx, "k4_count_seen", k4_count_seen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
+                      (const uint8_t *)ctx->d_label, ctx->nslots, d_n.p);
+        }
     }
     SP_HIP(ctx, hipMemcpyAsync(&h, d_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
