@@ -71,21 +71,19 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
 int sp_count_range(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last);
 /* number of slots of the dense count table for this k (2^(2k-1) for odd k, 4^k for even k) */
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
-/* use caller-owned device memory (nslots x uint32) as the count table of `chrom`, so that the
- * caller (e.g. a torch tensor handed to RCCL) can exchange it; NULL unbinds.  Call before sp_count. */
+/* Count tables (k <= 15) are BYTE tables: one byte per dense slot holding the RAW count, saturated --
+ * 0..254 = the count, 255 = "the count is >= 255: see the chromosome's overflow list" of
+ * (uint32 slot, uint32 count) pairs, ascending slot.  lower_count (`jellyfish dump -L`,
+ * Jellyfish.py:697) is applied wherever a table is read, so lengths, dumps and the matrix all see
+ * m[key][c] = count if count >= lower_count else 0.  A byte table is also the multi-GPU wire format:
+ * slot-range slices travel over xGMI as they are (a quarter of a u32 table).
+ *   sp_tables_bind    use caller-owned device memory (nslots bytes, 16-byte aligned) as the table of
+ *                     `chrom`, so that the caller (e.g. a torch tensor handed to RCCL) can exchange it;
+ *                     NULL unbinds.  Call before sp_count.
+ *   sp_table_overflow copy the overflow pairs of `chrom` into caller-owned DEVICE memory (capacity `cap`
+ *                     pairs; d_pairs = NULL only queries *n_pairs); asynchronous on the context's stream. */
 int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table);
-/* wire format of a count table for the multi-GPU exchange: one byte per slot (0 = below lower_count,
- * 1..254 = the count, 255 = see the overflow list of (uint32 slot, uint32 count) pairs).
- *   sp_table_narrow  table of `chrom` -> d_out_u8[nslots] + overflow pairs (device, capacity `cap`);
- *                    *n_ovf = pairs produced (SP_ENOMEM if > cap).
- *   sp_table_widen   n bytes -> n uint32 (n % 4 == 0); asynchronous on the context's stream.
- *   sp_table_patch   write the overflow counts whose slot lies in [slot_base, slot_base + n) into a
- *                    widened slice; asynchronous on the context's stream.
- * widen(narrow(t)) + patch == t with counts < lower_count zeroed, which is what sp_filter reads
- * through sp_filter_view (the threshold is applied on read, Jellyfish.py:697 `-L`).                */
-int sp_table_narrow(sp_ctx *ctx, int chrom, void *d_out_u8, void *d_ovf, int64_t cap, int64_t *n_ovf);
-int sp_table_widen(sp_ctx *ctx, const void *d_in_u8, int64_t n, void *d_out_u32);
-int sp_table_patch(sp_ctx *ctx, void *d_tab_u32, int64_t slot_base, int64_t n, const void *d_ovf, int64_t n_ovf);
+int sp_table_overflow(sp_ctx *ctx, int chrom, void *d_pairs, int64_t cap, int64_t *n_pairs);
 /* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
 int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
 /* jellyfish-dump equivalent of one chromosome.  Two calls: sp_dump_size then
@@ -104,11 +102,14 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
  * sp_lengths).  Outputs: n_union = len(d_mat), n_rows = differential k-mers,
  * n_hist = len(tot_freqs) (fold-passing k-mers, in or out of the freq range). */
 /* Multi-GPU: make sp_filter / sp_filter_fetch work on a slot-range VIEW instead of the local
- * tables: C device pointers, each to nslots_view uint32 counts of slots [slot_base,
+ * tables: C device pointers (16-byte aligned), each to the nslots_view table bytes of slots [slot_base,
  * slot_base + nslots_view) of one chromosome (all chromosomes of the genome, gathered from their
- * owner ranks), plus the global `lengths`.  d_tabs = NULL returns to the local tables.       */
+ * owner ranks), the chromosomes' overflow lists (d_ovf[c]: n_ovf[c] pairs with ABSOLUTE slots,
+ * ascending; may cover more than the slot range; d_ovf = NULL: none) and the global `lengths`.
+ * d_tabs = NULL returns to the local tables.                                                   */
 int sp_filter_view(sp_ctx *ctx, int C, const void *const *d_tabs, int64_t slot_base,
-                   int64_t nslots_view, const int64_t *lengths, int k, int lower_count);
+                   int64_t nslots_view, const int64_t *lengths, int k, int lower_count,
+                   const void *const *d_ovf, const int64_t *n_ovf);
 int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
               const int32_t *unit_chrom, double min_fold, int baseline, double min_freq,
               double max_freq, double ratio, int64_t *n_union, int64_t *n_rows, int64_t *n_hist);

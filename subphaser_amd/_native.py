@@ -20,7 +20,7 @@ SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -
 SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
-    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_narrow", "sp_table_widen", "sp_table_patch", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
     "sp_enrich",
@@ -66,10 +66,8 @@ def load():
     L.sp_count_range.argtypes = [vp, ci, ci, ci, ci, ci]
     L.sp_nslots.argtypes = [vp, ci, P(i64)]
     L.sp_tables_bind.argtypes = [vp, ci, vp]
-    L.sp_table_narrow.argtypes = [vp, ci, vp, vp, i64, P(i64)]
-    L.sp_table_widen.argtypes = [vp, vp, i64, vp]
-    L.sp_table_patch.argtypes = [vp, vp, i64, i64, vp, i64]
-    L.sp_filter_view.argtypes = [vp, ci, vp, i64, i64, vp, ci, ci]
+    L.sp_table_overflow.argtypes = [vp, ci, vp, i64, P(i64)]
+    L.sp_filter_view.argtypes = [vp, ci, vp, i64, i64, vp, ci, ci, vp, vp]
     L.sp_lengths.argtypes = [vp, vp]
     L.sp_dump_size.argtypes = [vp, ci, P(i64)]
     L.sp_dump.argtypes = [vp, ci, vp, vp, i64, P(i64)]
@@ -229,31 +227,30 @@ class Context:
     def tables_bind(self, chrom, d_ptr):
         self._ck(self.L.sp_tables_bind(self.h, int(chrom), C.c_void_p(int(d_ptr)) if d_ptr else None))
 
-    def table_narrow(self, chrom, d_out_u8, d_ovf, cap):
-        """count table of `chrom` -> one byte per slot + overflow (slot, count) pairs; returns their number"""
+    def table_overflow(self, chrom, d_pairs=None, cap=0):
+        """Overflow pairs (uint32 slot, uint32 raw count >= 255; ascending slot) of the byte table of `chrom`:
+        their number; with d_pairs (device pointer, capacity `cap` pairs) they are copied there (async)."""
         n = C.c_int64()
-        self._ck(self.L.sp_table_narrow(self.h, int(chrom), C.c_void_p(int(d_out_u8)),
-                                        C.c_void_p(int(d_ovf)) if d_ovf else None, int(cap), C.byref(n)))
+        self._ck(self.L.sp_table_overflow(self.h, int(chrom), C.c_void_p(int(d_pairs)) if d_pairs else None, int(cap),
+                                          C.byref(n)))
         return n.value
 
-    def table_widen(self, d_in_u8, n, d_out_u32):
-        self._ck(self.L.sp_table_widen(self.h, C.c_void_p(int(d_in_u8)), int(n), C.c_void_p(int(d_out_u32))))
-
-    def table_patch(self, d_tab_u32, slot_base, n, d_ovf, n_ovf):
-        self._ck(self.L.sp_table_patch(self.h, C.c_void_p(int(d_tab_u32)), int(slot_base), int(n),
-                                       C.c_void_p(int(d_ovf)) if d_ovf else None, int(n_ovf)))
-
-    def filter_view(self, d_ptrs, slot_base, nslots_view, lengths, k, lower_count):
-        """Point sp_filter at slot-range slices (device pointers, one per chromosome of the whole
-        genome).  d_ptrs=None returns to the local tables."""
+    def filter_view(self, d_ptrs, slot_base, nslots_view, lengths, k, lower_count, d_ovf=None, n_ovf=None):
+        """Point sp_filter at slot-range slices of byte tables (device pointers, one per chromosome of the
+        whole genome) + their overflow lists (device pointers / pair counts).  d_ptrs=None returns to the
+        local tables."""
         if d_ptrs is None:
-            self._ck(self.L.sp_filter_view(self.h, 0, None, 0, 0, None, 0, 0))
+            self._ck(self.L.sp_filter_view(self.h, 0, None, 0, 0, None, 0, 0, None, None))
             self._view_C = None
             return
         arr = (C.c_void_p * len(d_ptrs))(*[int(p) for p in d_ptrs])
         lengths = np.ascontiguousarray(lengths, np.int64)
+        oarr, narr = None, None
+        if d_ovf is not None:
+            oarr = (C.c_void_p * len(d_ptrs))(*[int(p) if p else None for p in d_ovf])
+            narr = _p(np.ascontiguousarray(n_ovf, np.int64))
         self._ck(self.L.sp_filter_view(self.h, len(d_ptrs), arr, int(slot_base), int(nslots_view), _p(lengths),
-                                       int(k), int(lower_count)))
+                                       int(k), int(lower_count), oarr, narr))
         self._view_C = len(d_ptrs)
         self.k = int(k)
 

@@ -22,7 +22,10 @@ struct sp_chrom {
     uint32_t *d_pk = nullptr;  // 2-bit codes, base i at bits 2*(i%16) of word i/16; padded with SP_PAD_WORDS
     uint32_t *d_pm = nullptr;  // the same codes MSB-first (base i at bits 30 - 2*(i%16)); lives behind d_pk in one allocation
     uint32_t *d_nm = nullptr;  // invalid mask, base i at bit (i%32) of word i/32; padding marked invalid
-    uint32_t *d_tab = nullptr; // dense count table [nslots] (valid after sp_count)
+    uint8_t *d_tab = nullptr;  // dense RAW count table [nslots], one byte per slot: 0..254 = the count,
+                               // 255 = the count is >= 255 and lives in the overflow list (valid after sp_count)
+    uint2 *d_ovf = nullptr;    // overflow list: (slot, raw count >= 255), ascending slot
+    int64_t n_ovf = 0, cap_ovf = 0;
     int64_t length_sum = 0;    // sum of counts >= lower_count
     int64_t n_dump = 0;        // number of k-mers with count >= lower_count
 };
@@ -56,6 +59,14 @@ struct sp_sparse_chrom {
     int64_t n = 0, cap = 0, length_sum = 0;
 };
 
+// what the filter / emit / dump kernels read: one chromosome's byte table (or a slot-range slice of it,
+// already offset so that index = slot - slot_base) and its overflow list (absolute slots)
+struct sp_tabref {
+    const uint8_t *tab;
+    const uint2 *ovf;
+    int64_t n_ovf;
+};
+
 struct sp_prof_entry {
     std::string name;
     hipEvent_t e0, e1;
@@ -77,7 +88,7 @@ struct sp_ctx {
     // filter view: which tables / slot range sp_filter works on (default: the local chromosomes,
     // all slots).  Multi-GPU runs point it at slot-range slices gathered from every rank.
     bool fv_on = false;
-    std::vector<const uint32_t *> fv_tabs;
+    std::vector<sp_tabref> fv_tabs;
     std::vector<int64_t> fv_lengths;
     int64_t fv_slot_base = 0, fv_nslots = 0;
     // k > 15 twin: caller-owned sorted (key, count) lists of one KEY RANGE of every chromosome
@@ -107,6 +118,7 @@ struct sp_ctx {
     int64_t scratch_bytes = 0;
     void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
     int64_t ws2_bytes = 0;
+    sp_buf b_tab32, b_ovfw;      // engine 1: u32 scratch table; overflow staging (unordered pairs + per-bucket index)
     // sparse engine (k = 16..32)
     bool sparse_mode = false;
     std::vector<sp_sparse_chrom> sparse;
@@ -114,6 +126,8 @@ struct sp_ctx {
     int64_t sf_n = 0;
     uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers: 16-B entries {key, label}
     int64_t hcap = 0;
+    sp_buf b_fq;      // global slow queue of the filter
+    sp_buf b_fflat;   // flat set tables of the filter (sp_filter.hip)
     sp_buf b_map, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
     bool map_all_valid = false;
     // profiling

@@ -32,32 +32,104 @@ k1_count_atomic(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm
     }
 }
 
-// ----------------------------------------------------------------- K2
-// lengths[c] = sum of counts >= lower (Jellyfish.py:97,449) and the number of
-// such k-mers (the dump size).  Pure streaming read of the table.
+// ----------------------------------------------------------------- K2 (engine 1) + byte table
+// Engine 1 counts into a u32 scratch table; this pass turns it into the byte table every consumer
+// reads (raw count saturated at 255 + overflow pairs), fused with lengths[c] = sum of counts >= lower
+// (Jellyfish.py:97,449) and the dump size.  One block per bucket of 2^15 slots, same overflow-segment
+// protocol as c2_count (sp_count2.hip).
 __global__ void __launch_bounds__(256)
-k2_lengths(const uint32_t *__restrict__ tab, int64_t nslots, uint32_t lower,
-           unsigned long long *__restrict__ out /*[0]=sum,[1]=n*/) {
+k1_narrow(const uint32_t *__restrict__ tab32, int64_t nslots, uint32_t lower, uint8_t *__restrict__ tab,
+          unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[2]=overflow cursor*/, uint2 *__restrict__ ovf_tmp,
+          unsigned long long ovf_cap, uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt,
+          int64_t n_buckets) {
     __shared__ unsigned long long red[16];
-    const int64_t n4 = nslots >> 2;
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(tab);
+    __shared__ uint32_t s_nov, s_rank;
+    __shared__ unsigned long long s_base;
     unsigned long long s = 0, n = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        uint4 v = t4[i];
-        if (v.x >= lower) { s += v.x; n++; }
-        if (v.y >= lower) { s += v.y; n++; }
-        if (v.z >= lower) { s += v.z; n++; }
-        if (v.w >= lower) { s += v.w; n++; }
+    for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        if (threadIdx.x == 0) s_nov = s_rank = 0;
+        __syncthreads();
+        const int64_t lo = b << SP_OVF_SHIFT;
+        int64_t hi = lo + (1LL << SP_OVF_SHIFT);
+        if (hi > nslots) hi = nslots;
+        uint32_t my_ov = 0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint32_t v = tab32[i];
+            if (v >= lower) { s += v; n++; }
+            my_ov += v >= 255u;
+            tab[i] = (uint8_t)(v < 255u ? v : 255u);
+        }
+        if (my_ov) atomicAdd(&s_nov, my_ov);
+        __syncthreads();
+        const uint32_t nov = s_nov;
+        if (nov) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&out3[2], (unsigned long long)nov);
+            __syncthreads();
+            const unsigned long long base = s_base;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const uint32_t v = tab32[i];
+                if (v >= 255u) {
+                    const unsigned long long pos = base + atomicAdd(&s_rank, 1u);
+                    if (pos < ovf_cap) ovf_tmp[pos] = make_uint2((uint32_t)i, v);
+                }
+            }
+            if (threadIdx.x == 0) seg_base[b] = (uint32_t)base;
+        }
+        if (threadIdx.x == 0) seg_cnt[b] = nov;
+        __syncthreads();
     }
-    if (blockIdx.x == 0)  // tail when nslots is not a multiple of 4 (tiny k)
-        for (int64_t i = (n4 << 2) + threadIdx.x; i < nslots; i += blockDim.x)
-            if (tab[i] >= lower) { s += tab[i]; n++; }
     unsigned long long ts = sp_block_sum_u64(s, red);
     unsigned long long tn = sp_block_sum_u64(n, red);
     if (threadIdx.x == 0) {
-        if (ts) atomicAdd(&out[0], ts);
-        if (tn) atomicAdd(&out[1], tn);
+        if (ts) atomicAdd(&out3[0], ts);
+        if (tn) atomicAdd(&out3[1], tn);
+    }
+}
+
+// ----------------------------------------------------------------- overflow list: segments -> sorted list
+// exclusive scan of the per-bucket overflow counts (n <= 2^16 buckets; single block)
+__global__ void __launch_bounds__(1024)
+ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/) {
+    __shared__ uint32_t part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+    uint32_t s = 0;
+    for (int64_t i = lo; i < hi; i++) s += seg_cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        seg_off[n] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int64_t i = lo; i < hi; i++) {
+        seg_off[i] = run;
+        run += seg_cnt[i];
+    }
+}
+// one wave per bucket: its (few) pairs are ranked by slot and written to their final place
+__global__ void __launch_bounds__(256)
+ovf_place(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+          const uint32_t *__restrict__ seg_off, int64_t n_buckets, uint2 *__restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_buckets) return;
+    const uint32_t m = seg_cnt[b];
+    if (!m) return;
+    const uint2 *src = tmp + seg_base[b];
+    uint2 *dst = out + seg_off[b];
+    for (uint32_t j = threadIdx.x & 63; j < m; j += 64) {
+        const uint2 e = src[j];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < m; i++) rank += src[i].x < e.x;
+        dst[rank] = e;
     }
 }
 
@@ -67,14 +139,13 @@ k2_lengths(const uint32_t *__restrict__ tab, int64_t nslots, uint32_t lower,
 #define DUMP_SLOTS (DUMP_PER_THREAD * DUMP_BLOCK)
 
 __global__ void __launch_bounds__(DUMP_BLOCK)
-dump_count(const uint32_t *__restrict__ tab, int64_t nslots, uint32_t lower,
-           unsigned long long *__restrict__ blk) {
+dump_count(sp_tabref T, int64_t nslots, uint32_t lower, unsigned long long *__restrict__ blk) {
     __shared__ unsigned long long red[16];
     int64_t base = (int64_t)blockIdx.x * DUMP_SLOTS;
     unsigned long long n = 0;
     for (int j = 0; j < DUMP_PER_THREAD; j++) {
         int64_t i = base + (int64_t)j * DUMP_BLOCK + threadIdx.x;
-        if (i < nslots && tab[i] >= lower) n++;
+        if (i < nslots && sp_tab_count(T, i, 0) >= lower) n++;
     }
     unsigned long long t = sp_block_sum_u64(n, red);
     if (threadIdx.x == 0) blk[blockIdx.x] = t;
@@ -111,7 +182,7 @@ scan_excl_u64(unsigned long long *__restrict__ a, int64_t n, unsigned long long 
 }
 
 __global__ void __launch_bounds__(DUMP_BLOCK)
-dump_write(const uint32_t *__restrict__ tab, int64_t nslots, uint32_t lower,
+dump_write(sp_tabref T, int64_t nslots, uint32_t lower,
            const unsigned long long *__restrict__ blk, sp_kparams kp,
            unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts) {
     __shared__ uint32_t lds[16];
@@ -119,7 +190,7 @@ dump_write(const uint32_t *__restrict__ tab, int64_t nslots, uint32_t lower,
     unsigned long long off = blk[blockIdx.x];
     for (int j = 0; j < DUMP_PER_THREAD; j++) {
         int64_t i = base + (int64_t)j * DUMP_BLOCK + threadIdx.x;
-        uint32_t c = (i < nslots) ? tab[i] : 0u;
+        uint32_t c = (i < nslots) ? sp_tab_count(T, i, 0) : 0u;
         bool p = (i < nslots) && c >= lower;
         uint32_t tot;
         uint32_t my = sp_block_excl_count(p, lds, tot);
@@ -146,71 +217,13 @@ int sp_sparse_count(sp_ctx *ctx, int k, int lower);                             
 int sp_sparse_count3(sp_ctx *ctx, int k, int lower);                                  // sp_sparse2.hip
 int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
-// ------------------------------------------------------------------ wire format of a count table
-// Multi-GPU runs ship slot-range slices of the count tables over xGMI.  Counts that matter are
-// thresholded (>= lower_count) and almost all of them are small, so a table travels as one byte per
-// slot: 0 = below the threshold, 1..254 = the count, 255 = "look in the overflow list" (slot, count).
-// 4x less wire volume than the u32 table: at 2 and 4 GPUs the exchange is bound by ONE xGMI link per peer.
-#define KX_STAGE 2048   // overflow pairs staged in LDS before one global reservation
-__global__ void __launch_bounds__(256)
-kx_narrow(const uint32_t *__restrict__ tab, int64_t n4 /* nslots / 4 */, uint32_t lower, uint32_t *__restrict__ out,
-          uint2 *__restrict__ ovf, unsigned long long cap, unsigned long long *__restrict__ n_ovf) {
-    // counts >= 255 are appended block-wise: a few million single-address global atomics (one per entry,
-    // or even one per wave) cost more than streaming the 2-GiB table (2.1 ms against 0.6 ms)
-    __shared__ uint2 stage[KX_STAGE + 1024];
-    __shared__ uint32_t n_stage;
-    __shared__ unsigned long long g_base;
-    if (threadIdx.x == 0) n_stage = 0;
-    __syncthreads();
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(tab);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n_iter = (n4 + stride - 1) / stride;
-    for (int64_t it = 0; it <= n_iter; it++) {
-        const int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (it < n_iter && i < n4) {
-            const uint4 v = t4[i];
-            const uint32_t a[4] = {v.x, v.y, v.z, v.w};
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t c = a[j] >= lower ? a[j] : 0u;
-                if (c >= 255u) {
-                    stage[atomicAdd(&n_stage, 1u)] = make_uint2((uint32_t)(4 * i + j), c);
-                    c = 255u;
-                }
-                packed |= c << (8 * j);
-            }
-            out[i] = packed;
-        }
-        __syncthreads();
-        const uint32_t m = n_stage;
-        if (m >= KX_STAGE || (it == n_iter && m > 0)) {   // block-uniform
-            if (threadIdx.x == 0) g_base = atomicAdd(n_ovf, (unsigned long long)m);
-            __syncthreads();
-            for (uint32_t p = threadIdx.x; p < m; p += blockDim.x)
-                if (g_base + p < cap) ovf[g_base + p] = stage[p];
-            __syncthreads();
-            if (threadIdx.x == 0) n_stage = 0;
-            __syncthreads();
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-kx_widen(const uint32_t *__restrict__ in, int64_t n4, uint4 *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t p = in[i];
-        out[i] = make_uint4(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u, p >> 24);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-kx_patch(uint32_t *__restrict__ tab, int64_t slot_base, int64_t n, const uint2 *__restrict__ ovf, int64_t n_ovf) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_ovf) return;
-    const uint2 e = ovf[i];
-    const int64_t s = (int64_t)e.x - slot_base;
-    if (s >= 0 && s < n) tab[s] = e.y;
+// Lay the overflow segments a counting kernel left behind out in bucket order (= ascending slot order).
+int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
+                    uint32_t *seg_off, int64_t n_buckets) {
+    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
+    SP_LAUNCH(ctx, "ovf_place", ovf_place, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base, seg_cnt,
+              (const uint32_t *)seg_off, n_buckets, c.d_ovf);
+    return SP_OK;
 }
 
 extern "C" {
@@ -268,39 +281,66 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     ctx->filtered = false;
     const size_t C = ctx->chroms.size();
     void *scr = nullptr;
-    int rc = sp_scratch(ctx, (int64_t)(2 * C * sizeof(unsigned long long)), &scr);
+    int rc = sp_scratch(ctx, (int64_t)(3 * C * sizeof(unsigned long long)), &scr);
     if (rc) return rc;
-    unsigned long long *d_len = (unsigned long long *)scr;
-    SP_HIP(ctx, hipMemsetAsync(d_len, 0, 2 * C * sizeof(unsigned long long), ctx->stream));
+    unsigned long long *d_len = (unsigned long long *)scr;   // per chromosome: sum, n (counts >= lower), overflow pairs
+    SP_HIP(ctx, hipMemsetAsync(d_len, 0, 3 * C * sizeof(unsigned long long), ctx->stream));
     for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
         sp_chrom &c = ctx->chroms[ci];
         if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
-        if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots * sizeof(uint32_t)));
+        if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots));
+        // every overflow pair accounts for >= 255 k-mer occurrences
+        const int64_t need_ovf = c.len / 255 + 16;
+        if (need_ovf > c.cap_ovf) {
+            if (c.d_ovf) {
+                SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                hipFree(c.d_ovf);
+                c.d_ovf = nullptr;
+            }
+            SP_HIP(ctx, hipMalloc(&c.d_ovf, (size_t)need_ovf * sizeof(uint2)));
+            c.cap_ovf = need_ovf;
+        }
         int eng = engine;
         if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
         if (eng == 2) {
-            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 2 * ci);
+            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 3 * ci);
             if (rc) return rc;
             continue;
         }
-        SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)nslots * sizeof(uint32_t), ctx->stream));
+        // engine 1: global atomics into a u32 scratch table, then one pass to the byte table
+        const int64_t n_buckets = (nslots + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT;
+        rc = sp_buf_ensure(ctx, ctx->b_tab32, nslots * 4);
+        if (rc) return rc;
+        rc = sp_buf_ensure(ctx, ctx->b_ovfw, need_ovf * 8 + (3 * n_buckets + 1) * 4 + 256);
+        if (rc) return rc;
+        uint32_t *tab32 = (uint32_t *)ctx->b_tab32.p;
+        uint2 *ovf_tmp = (uint2 *)ctx->b_ovfw.p;
+        uint32_t *seg_base = (uint32_t *)(ovf_tmp + need_ovf), *seg_cnt = seg_base + n_buckets, *seg_off = seg_cnt + n_buckets;
+        SP_HIP(ctx, hipMemsetAsync(tab32, 0, (size_t)nslots * sizeof(uint32_t), ctx->stream));
         int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
         if (n_units > 0) {
             int grid = grid_for(ctx, n_units, 256, 16);
             SP_LAUNCH(ctx, "k1_count_atomic", k1_count_atomic, dim3(grid), dim3(256), 0, c.d_pk, c.d_nm,
-                      n_units, sp_make_kparams32(k), c.d_tab);
+                      n_units, sp_make_kparams32(k), tab32);
         }
-        int grid2 = grid_for(ctx, nslots / 4, 256, 16);
-        SP_LAUNCH(ctx, "k2_lengths", k2_lengths, dim3(grid2), dim3(256), 0, c.d_tab, nslots,
-                  (uint32_t)lower_count, d_len + 2 * ci);
+        int grid2 = (int)(n_buckets < (int64_t)ctx->n_cu * 8 ? n_buckets : (int64_t)ctx->n_cu * 8);
+        SP_LAUNCH(ctx, "k1_narrow", k1_narrow, dim3(grid2), dim3(256), 0, (const uint32_t *)tab32, nslots,
+                  (uint32_t)lower_count, c.d_tab, d_len + 3 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
+                  n_buckets);
+        rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets);
+        if (rc) return rc;
     }
-    std::vector<unsigned long long> h(2 * C);
-    SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 2 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    std::vector<unsigned long long> h(3 * C);
+    SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 3 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
-        ctx->chroms[ci].length_sum = (int64_t)h[2 * ci];
-        ctx->chroms[ci].n_dump = (int64_t)h[2 * ci + 1];
+        ctx->chroms[ci].length_sum = (int64_t)h[3 * ci];
+        ctx->chroms[ci].n_dump = (int64_t)h[3 * ci + 1];
+        ctx->chroms[ci].n_ovf = (int64_t)h[3 * ci + 2];
+        if (ctx->chroms[ci].n_ovf > ctx->chroms[ci].cap_ovf)
+            return sp_fail(ctx, SP_ESTATE, "overflow list of chromosome %zu: %lld pairs exceed the capacity %lld", ci,
+                           (long long)ctx->chroms[ci].n_ovf, (long long)ctx->chroms[ci].cap_ovf);
     }
     ctx->counted = true;
     return SP_OK;
@@ -324,60 +364,29 @@ int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {
 int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table) {
     if (!ctx || chrom < 0 || chrom >= (int)ctx->chroms.size())
         return sp_fail(ctx, SP_EINVAL, "sp_tables_bind: bad arguments");
-    if (ctx->sparse_mode && d_table) return sp_fail(ctx, SP_EUNSUP, "sp_tables_bind: dense tables exist for k <= 15 only");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_chrom &c = ctx->chroms[(size_t)chrom];
     if (c.d_tab && !c.tab_external) {
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hipFree(c.d_tab);
     }
-    c.d_tab = (uint32_t *)d_table;
+    c.d_tab = (uint8_t *)d_table;
     c.tab_external = d_table != nullptr;
     ctx->counted = false;
     return SP_OK;
 }
 
-int sp_table_narrow(sp_ctx *ctx, int chrom, void *d_out_u8, void *d_ovf, int64_t cap, int64_t *n_ovf) {
-    if (!ctx || !d_out_u8 || !n_ovf || cap < 0 || (cap > 0 && !d_ovf) || chrom < 0 || chrom >= (int)ctx->chroms.size())
-        return sp_fail(ctx, SP_EINVAL, "sp_table_narrow: bad arguments");
-    if (ctx->sparse_mode || !ctx->chroms[(size_t)chrom].d_tab || ctx->nslots <= 0)
-        return sp_fail(ctx, SP_EINVAL, "sp_table_narrow: chromosome %d has no dense count table", chrom);
-    if (ctx->nslots % 4) return sp_fail(ctx, SP_EUNSUP, "sp_table_narrow: table of %lld slots", (long long)ctx->nslots);
+int sp_table_overflow(sp_ctx *ctx, int chrom, void *d_pairs, int64_t cap, int64_t *n_pairs) {
+    if (!ctx || !n_pairs || cap < 0 || chrom < 0 || chrom >= (int)ctx->chroms.size())
+        return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: bad arguments");
+    if (ctx->sparse_mode || !ctx->counted) return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: call sp_count (k <= 15) first");
+    sp_chrom &c = ctx->chroms[(size_t)chrom];
+    *n_pairs = c.n_ovf;
+    if (!d_pairs) return SP_OK;   // size query
+    if (cap < c.n_ovf) return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: capacity %lld < %lld", (long long)cap, (long long)c.n_ovf);
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    void *scr = nullptr;
-    int rc = sp_scratch(ctx, 256, &scr);
-    if (rc) return rc;
-    unsigned long long *d_n = (unsigned long long *)scr;
-    SP_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
-    SP_LAUNCH(ctx, "kx_narrow", kx_narrow, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
-              (const uint32_t *)ctx->chroms[(size_t)chrom].d_tab, ctx->nslots / 4, (uint32_t)ctx->lower,
-              (uint32_t *)d_out_u8, (uint2 *)d_ovf, (unsigned long long)cap, d_n);
-    unsigned long long h = 0;
-    SP_HIP(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *n_ovf = (int64_t)h;
-    if ((int64_t)h > cap)
-        return sp_fail(ctx, SP_ENOMEM, "sp_table_narrow: %lld counts >= 255 exceed the overflow capacity %lld",
-                       (long long)h, (long long)cap);
-    return SP_OK;
-}
-
-int sp_table_widen(sp_ctx *ctx, const void *d_in_u8, int64_t n, void *d_out_u32) {
-    if (!ctx || !d_in_u8 || !d_out_u32 || n < 0 || (n % 4)) return sp_fail(ctx, SP_EINVAL, "sp_table_widen: bad arguments (n must be a multiple of 4)");
-    if (n == 0) return SP_OK;
-    SP_HIP(ctx, hipSetDevice(ctx->device));
-    SP_LAUNCH(ctx, "kx_widen", kx_widen, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, (const uint32_t *)d_in_u8, n / 4,
-              (uint4 *)d_out_u32);
-    return SP_OK;   // asynchronous on the context's stream
-}
-
-int sp_table_patch(sp_ctx *ctx, void *d_tab_u32, int64_t slot_base, int64_t n, const void *d_ovf, int64_t n_ovf) {
-    if (!ctx || !d_tab_u32 || slot_base < 0 || n < 0 || n_ovf < 0 || (n_ovf > 0 && !d_ovf))
-        return sp_fail(ctx, SP_EINVAL, "sp_table_patch: bad arguments");
-    if (n_ovf == 0 || n == 0) return SP_OK;
-    SP_HIP(ctx, hipSetDevice(ctx->device));
-    SP_LAUNCH(ctx, "kx_patch", kx_patch, dim3((unsigned)((n_ovf + 255) / 256)), dim3(256), 0, (uint32_t *)d_tab_u32,
-              slot_base, n, (const uint2 *)d_ovf, n_ovf);
+    if (c.n_ovf)
+        SP_HIP(ctx, hipMemcpyAsync(d_pairs, c.d_ovf, (size_t)c.n_ovf * sizeof(uint2), hipMemcpyDeviceToDevice, ctx->stream));
     return SP_OK;   // asynchronous on the context's stream
 }
 
@@ -414,11 +423,15 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
     SP_HIP(ctx, d_blk.alloc((size_t)nblk));
     SP_HIP(ctx, d_keys.alloc((size_t)c.n_dump));
     SP_HIP(ctx, d_cnt.alloc((size_t)c.n_dump));
-    SP_LAUNCH(ctx, "dump_count", dump_count, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, c.d_tab,
+    sp_tabref T;
+    T.tab = c.d_tab;
+    T.ovf = c.d_ovf;
+    T.n_ovf = c.n_ovf;
+    SP_LAUNCH(ctx, "dump_count", dump_count, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, T,
               ctx->nslots, (uint32_t)ctx->lower, d_blk.p);
     SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_blk.p, nblk,
               (unsigned long long *)nullptr);
-    SP_LAUNCH(ctx, "dump_write", dump_write, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, c.d_tab,
+    SP_LAUNCH(ctx, "dump_write", dump_write, dim3((unsigned)nblk), dim3(DUMP_BLOCK), 0, T,
               ctx->nslots, (uint32_t)ctx->lower, d_blk.p, kp, d_keys.p, d_cnt.p);
     SP_HIP(ctx, hipMemcpyAsync(keys, d_keys, (size_t)c.n_dump * sizeof(uint64_t), hipMemcpyDeviceToHost,
                               ctx->stream));

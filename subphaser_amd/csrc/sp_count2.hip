@@ -205,30 +205,34 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 }
 
 // ---------------------------------------------------------------- c2_part1
+// LDS traffic per key: one returning atomic (rank inside its bucket run; the run starts come from the
+// tile counts c2_hist left behind), one LDS write, and in the copy-out one key read + ONE table read
+// (delta[b] = global base of the run - its LDS start, so that out index = delta[b] + i).
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
          int64_t n_units /* of 32 starts */,
          sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
          const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, int64_t n_tiles,
          uint32_t *__restrict__ buf1) {
-    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
-    __shared__ unsigned long long gbase[C2_MAXF];
+    __shared__ uint32_t hist[C2_MAXF], cur[C2_MAXF], wsum[4];
+    __shared__ unsigned long long delta[C2_MAXF];
     __shared__ uint32_t keys[C2_P1_KEYS];
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
+        unsigned long long gb = 0;
         if (threadIdx.x < F1) {
             const int64_t e = (int64_t)threadIdx.x * n_tiles + tile;
             hist[threadIdx.x] = tile_cnt[e];
-            gbase[threadIdx.x] = off1[threadIdx.x] + tile_off[e];
-            cur[threadIdx.x] = 0;
+            gb = off1[threadIdx.x] + tile_off[e];
         }
         __syncthreads();
-        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
+        const uint32_t total = c2_scan_F(hist, cur, F1, wsum);   // cur[b] = LDS start of run b (then the cursor)
+        if (threadIdx.x < F1) delta[threadIdx.x] = gb - cur[threadIdx.x];
+        __syncthreads();
         if (u < n_units) {
             auto scan = [&](auto parity) {
                 sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp, [&](uint32_t slot) {
-                    const uint32_t b = slot >> shift1;
-                    keys[start[b] + atomicAdd(&cur[b], 1u)] = slot;
+                    keys[atomicAdd(&cur[slot >> shift1], 1u)] = slot;
                 });
             };
             if (kp.odd) scan(sp_odd_tag{});
@@ -237,8 +241,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
             const uint32_t s = keys[i];
-            const uint32_t b = s >> shift1;
-            buf1[gbase[b] + (i - start[b])] = s;
+            buf1[delta[s >> shift1] + i] = s;
         }
         __syncthreads();
     }
@@ -264,7 +267,7 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
          uint16_t *__restrict__ buf2) {
-    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], cur[C2_MAXF], wsum[4];
+    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
     __shared__ uint32_t keys[C2_TILE_KEYS];
     __shared__ int s_bucket[2];
@@ -299,9 +302,10 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
         if (threadIdx.x < F2) hist[threadIdx.x] = 0;
         if (threadIdx.x == 0 && ntile < n_tiles) s_bucket[p ^ 1] = c2_bucket_of(tile_start, F1, ntile);
         __syncthreads();  // (A) also: the previous tile's copy-out has finished reading keys/start/gbase
+        uint32_t rank[C2_P2_PER];   // position of the key inside its bucket run = what the counting atomic returns
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++)
-            if (j < nmine) atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
+            if (j < nmine) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
         __syncthreads();  // (B)
         unsigned long long g = 0;
         if (threadIdx.x < F2) {  // reserve the output ranges now; the result is needed only after the scan
@@ -323,42 +327,46 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
             }
         }
         const uint32_t total = c2_scan_F(hist, start, F2, wsum);
-        if (threadIdx.x < F2) {
-            gbase[threadIdx.x] = g;
-            cur[threadIdx.x] = 0;
-        }
+        if (threadIdx.x < F2) gbase[threadIdx.x] = g - start[threadIdx.x];   // out index = gbase[b] + LDS index
         __syncthreads();  // (C)
 #pragma unroll
-        for (int j = 0; j < C2_P2_PER; j++) {
-            if (j < nmine) {
-                const uint32_t b = (my[j] >> shift2) & mask2;
-                keys[start[b] + atomicAdd(&cur[b], 1u)] = my[j];
-            }
-        }
+        for (int j = 0; j < C2_P2_PER; j++)
+            if (j < nmine) keys[start[(my[j] >> shift2) & mask2] + rank[j]] = my[j];
         __syncthreads();  // (D)
         for (uint32_t i = threadIdx.x; i < total; i += C2_P2_THREADS) {
             const uint32_t s = keys[i];
-            const uint32_t b = (s >> shift2) & mask2;
-            buf2[gbase[b] + (i - start[b])] = (uint16_t)(s & (C2_FINE - 1));
+            buf2[gbase[(s >> shift2) & mask2] + i] = (uint16_t)(s & (C2_FINE - 1));
         }
         p ^= 1;
     }
 }
 
 // ---------------------------------------------------------------- c2_count
+// One workgroup per fine bucket: u32 counters in LDS, then ONE byte per slot goes to HBM (raw count,
+// saturated at 255) -- a quarter of the u32 table the filter used to stream 21 times.  Counts >= 255 are
+// rare; they are appended to an overflow list: the block reserves a contiguous segment for its bucket
+// (one global atomic per bucket that has any) and records (segment base, count) per bucket, so that
+// sp_ovf_finalize can lay the segments out in bucket order = ascending slot order without a device-wide sort.
 #ifndef C2_COUNT_THREADS
 #define C2_COUNT_THREADS 1024
 #endif
+#define C2_STAGE 1024   // overflow pairs staged in LDS per bucket (8 KiB next to the 128 KiB of counters)
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict__ off_fine,
-         int64_t n_fine, uint32_t lower, uint32_t *__restrict__ tab,
-         unsigned long long *__restrict__ out2 /*[0]=sum,[1]=n*/) {
+         int64_t n_fine, uint32_t lower, uint8_t *__restrict__ tab,
+         unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[2]=overflow cursor*/,
+         uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap, uint32_t *__restrict__ seg_base,
+         uint32_t *__restrict__ seg_cnt) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE
     __shared__ unsigned long long red[16];
+    __shared__ uint32_t s_nov, s_rank;
+    __shared__ unsigned long long s_base;
+    __shared__ uint2 stage[C2_STAGE];
     unsigned long long s = 0, n = 0;
     for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
         uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) s_nov = s_rank = 0;
         __syncthreads();
         const unsigned long long lo = off_fine[fb], hi = off_fine[fb + 1];
         // 8-byte aligned body: four u16 keys per load
@@ -391,24 +399,59 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
         for (unsigned long long t = a + (n4 << 2) + threadIdx.x; t < hi; t += C2_COUNT_THREADS)
             atomicAdd(&cnt[buf2[t]], 1u);
         __syncthreads();
-        uint4 *t4 = reinterpret_cast<uint4 *>(tab + fb * C2_FINE);
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
-            uint4 v = c4[i];
-            t4[i] = v;
-            if (v.x >= lower) { s += v.x; n++; }
-            if (v.y >= lower) { s += v.y; n++; }
-            if (v.z >= lower) { s += v.z; n++; }
-            if (v.w >= lower) { s += v.w; n++; }
+            const uint4 v = c4[i];
+            const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c = a4[j];
+                if (c >= lower) { s += c; n++; }
+                if (c >= 255u) {   // rare: staged in LDS; a bucket with more than C2_STAGE of them re-scans its counters
+                    const uint32_t pos = atomicAdd(&s_nov, 1u);
+                    if (pos < C2_STAGE) stage[pos] = make_uint2((uint32_t)(fb * C2_FINE + 4 * i + j), c);
+                }
+                packed |= (c < 255u ? c : 255u) << (8 * j);
+            }
+            t32[i] = packed;
         }
+        __syncthreads();
+        const uint32_t nov = s_nov;   // block-uniform
+        if (nov) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&out3[2], (unsigned long long)nov);
+            __syncthreads();
+            const unsigned long long base = s_base;
+            if (nov <= C2_STAGE) {
+                for (uint32_t p = threadIdx.x; p < nov; p += C2_COUNT_THREADS)
+                    if (base + p < ovf_cap) ovf_tmp[base + p] = stage[p];
+            } else {
+                for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
+                    const uint4 v = c4[i];
+                    const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (a4[j] >= 255u) {
+                            const unsigned long long pos = base + atomicAdd(&s_rank, 1u);
+                            if (pos < ovf_cap) ovf_tmp[pos] = make_uint2((uint32_t)(fb * C2_FINE + 4 * i + j), a4[j]);
+                        }
+                }
+            }
+            if (threadIdx.x == 0) seg_base[fb] = (uint32_t)base;
+        }
+        if (threadIdx.x == 0) seg_cnt[fb] = nov;
         __syncthreads();
     }
     unsigned long long ts = sp_block_sum_u64(s, red);
     unsigned long long tn = sp_block_sum_u64(n, red);
     if (threadIdx.x == 0) {
-        if (ts) atomicAdd(&out2[0], ts);
-        if (tn) atomicAdd(&out2[1], tn);
+        if (ts) atomicAdd(&out3[0], ts);
+        if (tn) atomicAdd(&out3[1], tn);
     }
 }
+
+int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
+                    uint32_t *seg_off, int64_t n_buckets);   // sp_count.hip
 
 bool sp_engine2_supported(int64_t nslots) {
     c2_plan p;
@@ -421,7 +464,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
         return sp_fail(ctx, SP_EUNSUP, "count engine 2 needs a dense table of 2^17..2^31 slots (k=%d)", kp.k);
     const int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
     if (n_units == 0) {
-        SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots * 4, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots, ctx->stream));
+        c.n_ovf = 0;
         return SP_OK;
     }
     // workspace: ghist | off_fine | off1 | tile_start | cursor1 | cursor2 | buf1 (u32 x len) | buf2 (u16 x len)
@@ -439,7 +483,11 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_toff = o_tcnt + al((size_t)P.F1 * (size_t)n_tiles * 4);
     size_t o_buf1 = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
     size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64);
-    size_t total = o_buf2 + al((size_t)c.len * 2 + 64);
+    size_t o_segb = o_buf2 + al((size_t)c.len * 2 + 64);          // overflow segments: base, count, offsets per fine bucket
+    size_t o_segc = o_segb + al(nf * 4);
+    size_t o_sego = o_segc + al(nf * 4);
+    size_t total = o_sego + al((nf + 1) * 4);
+    // the unordered overflow pairs live in buf1 (u32 keys of level 1: dead once part2 has run)
     if ((int64_t)total > ctx->ws2_bytes) {
         if (ctx->d_ws2) {
             SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -460,6 +508,9 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     uint32_t *tile_off = (uint32_t *)(ws + o_toff);
     uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
+    uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
+    uint2 *ovf_tmp = (uint2 *)buf1;
+    const unsigned long long ovf_cap = (unsigned long long)c.len / 2 + 8;   // pairs that fit in buf1 (>= len/255 + 16)
     // zero ghist .. cursor2 in one memset (they are contiguous)
     SP_HIP(ctx, hipMemsetAsync(ws, 0, o_tcnt, ctx->stream));
 
@@ -485,6 +536,6 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4);
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
     SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, off_fine,
-              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len2);
-    return SP_OK;
+              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len2, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+    return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf);
 }

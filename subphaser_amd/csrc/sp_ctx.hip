@@ -113,6 +113,7 @@ static void free_chrom(sp_chrom &c) {
     if (c.d_pk) hipFree(c.d_pk);
     if (c.d_nm) hipFree(c.d_nm);
     if (c.d_tab && !c.tab_external) hipFree(c.d_tab);
+    if (c.d_ovf) hipFree(c.d_ovf);
     c = sp_chrom();
 }
 
@@ -140,10 +141,14 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_ptab);
+    sp_buf_free(ctx->b_tab32);
+    sp_buf_free(ctx->b_ovfw);
     sp_buf_free(ctx->b_labkeys);
     sp_buf_free(ctx->b_emit);
     sp_buf_free(ctx->b_slots);
     sp_buf_free(ctx->b_fpar);
+    sp_buf_free(ctx->b_fflat);
+    sp_buf_free(ctx->b_fq);
     sp_buf_free(ctx->b_win);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -168,6 +173,7 @@ int sp_genome_reset(sp_ctx *ctx, int n_chrom) {
             c.nw = 0;
             c.length_sum = 0;
             c.n_dump = 0;
+            c.n_ovf = 0;
         }
     } else {
         for (auto &c : ctx->chroms) free_chrom(c);

@@ -248,6 +248,25 @@ __device__ __forceinline__ void sp_scan32_slots(const uint32_t *__restrict__ pk,
     }
 }
 
+// ------------------------------------------------------------------ byte tables
+// raw count of `slot` (absolute) given its table byte: bytes below 255 are exact, 255 defers to the
+// chromosome's overflow list (ascending slots; binary search -- counts >= 255 are rare)
+__device__ __forceinline__ uint32_t sp_ovf_lookup(const uint2 *__restrict__ ovf, int64_t n, uint32_t slot) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ovf[mid].x < slot) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < n && ovf[lo].x == slot) ? ovf[lo].y : 255u;
+}
+__device__ __forceinline__ uint32_t sp_tab_count(const sp_tabref &t, int64_t local, int64_t slot_base) {
+    const uint32_t b = t.tab[local];
+    return b < 255u ? b : sp_ovf_lookup(t.ovf, t.n_ovf, (uint32_t)(slot_base + local));
+}
+// overflow lists are produced bucket by bucket (2^15 consecutive slots), see sp_count2.hip / sp_count.hip
+#define SP_OVF_SHIFT 15
+
 // wave-level inclusive/exclusive helpers (64 lanes)
 __device__ __forceinline__ int sp_lane() { return threadIdx.x & 63; }
 

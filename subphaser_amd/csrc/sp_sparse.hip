@@ -134,7 +134,7 @@ sps_eval(const unsigned long long *__restrict__ K, const unsigned long long *__r
                 tot += (uint32_t)v;
             }
             bool is_row, is_hist;
-            sp_filter_decide(row, 1, tot, A.F, is_row, is_hist);
+            sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tot, A.F, is_row, is_hist);
             fl = 4 | (is_row ? 1 : 0) | (is_hist ? 2 : 0);
             nuni++;
             nrow += is_row;
@@ -490,6 +490,8 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     sps_filter_args A;
     A.C = C;
     A.F.n_sets = n_sets;
+    A.F.n_multi = 0;
+    for (int st = 0; st < n_sets; st++) A.F.n_multi += (set_off[st + 1] - set_off[st]) > 1;
     A.F.baseline = baseline;
     A.F.set_off = (const int32_t *)(T + o_set);
     A.F.unit_off = (const int32_t *)(T + o_uo);

@@ -58,19 +58,14 @@ class DistHotPath:
             if self.nslots % (64 * self.world):
                 raise ValueError("dense table of %d slots cannot be cut into %d aligned slices" % (self.nslots, self.world))
             self.chunk = self.nslots // self.world
-            # count tables of the local chromosomes live in ONE torch tensor so RCCL can send them
-            self.tabs = t.zeros((max(1, len(self.my_chroms)), self.nslots), dtype=t.int32, device=self.device)
-            # wire format: one byte per slot (+ overflow pairs for counts >= 255), see sp_table_narrow
+            # byte count tables of the local chromosomes live in ONE torch tensor: the table IS the wire format
+            # (one byte per slot + a short overflow list for counts >= 255), so RCCL sends slices of it as they are
             nl = max(1, len(self.my_chroms))
-            self.send8 = t.zeros((nl, self.world, self.chunk), dtype=t.uint8, device=self.device)
+            self.tabs = t.zeros((nl, self.world, self.chunk), dtype=t.uint8, device=self.device)
             self.dummy8 = None
-            # receive side: round i, source rank s -> byte slice of rank s's i-th chromosome, widened into
-            # the uint32 slices (one per chromosome of the whole genome) the filter reads
-            self.recv8 = self.send8 if self.world == 1 else \
+            # receive side: round i, source rank s -> byte slice of rank s's i-th chromosome; the filter reads them in place
+            self.recv8 = self.tabs if self.world == 1 else \
                 t.zeros((self.max_local, self.world, self.chunk), dtype=t.uint8, device=self.device)
-            self.recv32 = t.zeros((self.C, self.chunk), dtype=t.int32, device=self.device)
-            self.ovf_cap = int(kw.get("ovf_cap", 1 << 22))
-            self.ovf = t.zeros((nl, self.ovf_cap, 2), dtype=t.int32, device=self.device)
         else:
             self._sbuf = {}     # growth-only exchange buffers of the key-range path
         self.min_fold = kw.get("min_fold", 2.0)
@@ -159,22 +154,14 @@ class DistHotPath:
             ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
         ctx.sync()
         tt = self._t("pack", tt)
-        # count chromosome i, narrow its table to the wire format and put it on the wire (slot-range slice
-        # r -> rank r) while chromosome i+1 is being counted: the exchange hides behind the counting kernels
+        # count chromosome i and put its byte table on the wire (slot-range slice r -> rank r) while
+        # chromosome i+1 is being counted: the exchange hides behind the counting kernels
         works, n_ovf = [], np.zeros(self.max_local, np.int64)
         for i in range(self.max_local):
             if i < len(mine):
                 ctx.count_range(self.k, self.lower_count, self.engine, i, i + 1)   # synchronises
-                while True:
-                    try:
-                        n_ovf[i] = ctx.table_narrow(i, self._ptr(self.send8[i]), self._ptr(self.ovf[i]), self.ovf_cap)
-                        break
-                    except MemoryError:      # more counts >= 255 than planned for: grow the overflow lists
-                        self.ovf_cap *= 4
-                        self.ovf = t.zeros((max(1, len(mine)), self.ovf_cap, 2), dtype=t.int32, device=self.device)
-                        for j in range(i):   # lists of the chromosomes already narrowed live in the old buffer
-                            n_ovf[j] = ctx.table_narrow(j, self._ptr(self.send8[j]), self._ptr(self.ovf[j]), self.ovf_cap)
-                send = self.send8[i]
+                n_ovf[i] = ctx.table_overflow(i)
+                send = self.tabs[i]
             else:
                 if self.dummy8 is None:
                     self.dummy8 = t.zeros((self.world, self.chunk), dtype=t.uint8, device=self.device)
@@ -189,8 +176,14 @@ class DistHotPath:
         dist.all_reduce(lens)
         lengths = lens.cpu().numpy()
         # overflow pairs of every chromosome to every rank (small: counts >= 255 are rare)
-        local = [self.ovf[i, :int(n_ovf[i])] for i in range(len(mine))]
-        mine_ovf = t.cat(local, dim=0) if local else t.zeros((0, 2), dtype=t.int32, device=self.device)
+        mine_ovf = t.zeros((max(int(n_ovf.sum()), 1), 2), dtype=t.int32, device=self.device)
+        off = 0
+        for i in range(len(mine)):
+            if n_ovf[i]:
+                ctx.table_overflow(i, mine_ovf.data_ptr() + off * 8, int(n_ovf[i]))
+            off += int(n_ovf[i])
+        ctx.sync()
+        mine_ovf = mine_ovf[:int(n_ovf.sum())]
         novf_t = t.from_numpy(n_ovf).to(self.device)
         if self.world > 1:
             outs = [t.zeros_like(novf_t) for _ in range(self.world)]
@@ -204,19 +197,15 @@ class DistHotPath:
         if hasattr(t, "cuda") and self.device.type == "cuda":
             t.cuda.synchronize()
         tt = self._t("lengths+exchange wait", tt)
-        ptrs, off = [0] * self.C, 0
+        ptrs, optrs, ons, off = [0] * self.C, [0] * self.C, np.zeros(self.C, np.int64), 0
         for s, owned in enumerate(self.owned):
             for i, gi in enumerate(owned):
-                dst = self._ptr(self.recv32[gi])
-                ctx.table_widen(self._ptr(self.recv8[i, s]), self.chunk, dst)
+                ptrs[gi] = self._ptr(self.recv8[i, s])
                 n = int(novf_all[s, i])
-                if n:
-                    ctx.table_patch(dst, self.rank * self.chunk, self.chunk, all_ovf.data_ptr() + off * 8, n)
+                optrs[gi], ons[gi] = (all_ovf.data_ptr() + off * 8 if n else 0), n
                 off += n
-                ptrs[gi] = dst
             off += int(novf_all[s, len(owned):].sum())
-        tt = self._t("widen", tt)
-        ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count)
+        ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count, optrs, ons)
         n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                              self.max_freq, self.ratio)
         # surviving rows stay on the device: gathered over xGMI, copied to the host once, where needed

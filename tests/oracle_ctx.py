@@ -149,42 +149,22 @@ class OracleDistContext(OracleContext):
         return kmer.dense_slots(k)
 
     @staticmethod
-    def _view_i32(ptr, n):
+    def _view_u8(ptr, n):
         import ctypes
-        return np.frombuffer((ctypes.c_uint32 * n).from_address(int(ptr)), dtype=np.uint32)
+        return np.frombuffer((ctypes.c_uint8 * n).from_address(int(ptr)), dtype=np.uint8)
 
     def tables_bind(self, i, ptr):
         self.bound[i] = ptr
 
-    # wire format of the count tables (sp_table_narrow / widen / patch)
-    def table_narrow(self, i, d_out_u8, d_ovf, cap):
+    # byte tables (raw count saturated at 255 + overflow pairs): what sp_count leaves in bound memory
+    def table_overflow(self, i, d_pairs=None, cap=0):
         import ctypes
-        from subphaser_amd import kmer
-        n = kmer.dense_slots(self.k)
-        tab = self._view_i32(self.bound[i], n)
-        v = np.where(tab >= self.lower, tab, 0)
-        big = np.flatnonzero(v >= 255)
-        if big.size > cap:
-            raise MemoryError("overflow capacity")
-        out = np.frombuffer((ctypes.c_uint8 * n).from_address(int(d_out_u8)), np.uint8)
-        out[:] = np.minimum(v, 255).astype(np.uint8)
-        if big.size:
-            o = np.frombuffer((ctypes.c_uint32 * (2 * big.size)).from_address(int(d_ovf)), np.uint32).reshape(-1, 2)
-            o[:, 0] = big
-            o[:, 1] = v[big]
-        return int(big.size)
-
-    def table_widen(self, d_in_u8, n, d_out_u32):
-        import ctypes
-        src = np.frombuffer((ctypes.c_uint8 * n).from_address(int(d_in_u8)), np.uint8)
-        self._view_i32(d_out_u32, n)[:] = src
-
-    def table_patch(self, d_tab_u32, slot_base, n, d_ovf, n_ovf):
-        import ctypes
-        o = np.frombuffer((ctypes.c_uint32 * (2 * n_ovf)).from_address(int(d_ovf)), np.uint32).reshape(-1, 2)
-        s = o[:, 0].astype(np.int64) - slot_base
-        ok = (s >= 0) & (s < n)
-        self._view_i32(d_tab_u32, n)[s[ok]] = o[ok, 1]
+        ov = self.ovf.get(i, np.zeros((0, 2), np.uint32))
+        if d_pairs and len(ov):
+            assert cap >= len(ov)
+            o = np.frombuffer((ctypes.c_uint32 * (2 * len(ov))).from_address(int(d_pairs)), np.uint32).reshape(-1, 2)
+            o[:] = ov
+        return int(len(ov))
 
     def genome_add_device(self, i, arr, n):
         self.genome_add(i, np.asarray(arr[:n], np.uint8))
@@ -193,12 +173,18 @@ class OracleDistContext(OracleContext):
         from subphaser_amd import kmer
         super().count(k, lower_count, engine)
         n = kmer.dense_slots(k)
+        self.ovf = {}
         for i, s in enumerate(self.seqs):
             if i in self.bound:
                 keys, cnts = po.count(s, k, 1, self.nthreads)     # raw counts, threshold applied on read
-                tab = self._view_i32(self.bound[i], n)
+                tab = self._view_u8(self.bound[i], n)
                 tab[:] = 0
-                tab[kmer.slots_of_keys(keys, k).astype(np.int64)] = cnts
+                slots = kmer.slots_of_keys(keys, k).astype(np.int64)
+                tab[slots] = np.minimum(cnts, 255).astype(np.uint8)
+                big = np.flatnonzero(cnts >= 255)
+                o = np.argsort(slots[big], kind="stable")
+                self.ovf[i] = np.stack([slots[big][o].astype(np.uint32), cnts[big][o].astype(np.uint32)], axis=1) \
+                    if big.size else np.zeros((0, 2), np.uint32)
 
     def filter_fetch_device(self, d_keys, d_counts, d_tot, n_rows):
         import ctypes
@@ -255,8 +241,10 @@ class OracleDistContext(OracleContext):
         self.sview = (dumps, np.array(lengths, np.int64))
         self.k = k
 
-    def filter_view(self, ptrs, slot_base, nview, lengths, k, lower_count):
-        self.view = None if ptrs is None else (list(ptrs), int(slot_base), int(nview), np.array(lengths), k, lower_count)
+    def filter_view(self, ptrs, slot_base, nview, lengths, k, lower_count, d_ovf=None, n_ovf=None):
+        self.view = None if ptrs is None else (list(ptrs), int(slot_base), int(nview), np.array(lengths), k, lower_count,
+                                               list(d_ovf) if d_ovf is not None else None,
+                                               list(n_ovf) if n_ovf is not None else None)
         if ptrs is not None:
             self.k = k
 
@@ -273,10 +261,19 @@ class OracleDistContext(OracleContext):
         if self.view is None:
             return super().filter(set_off, unit_off, unit_chrom, min_fold, baseline, min_freq, max_freq, ratio)
         from subphaser_amd import kmer
-        ptrs, base, nview, lengths, k, L = self.view
+        import ctypes
+        ptrs, base, nview, lengths, k, L, d_ovf, n_ovf = self.view
         dumps = []
-        for p in ptrs:
-            arr = self._view_i32(p, nview)
+        for ci, p in enumerate(ptrs):
+            arr = self._view_u8(p, nview).astype(np.uint32)
+            if d_ovf is not None and n_ovf[ci]:
+                o = np.frombuffer((ctypes.c_uint32 * (2 * int(n_ovf[ci]))).from_address(int(d_ovf[ci])),
+                                  np.uint32).reshape(-1, 2)
+                loc = o[:, 0].astype(np.int64) - base
+                ok = (loc >= 0) & (loc < nview)
+                assert (arr[loc[ok]] == 255).all()
+                arr[loc[ok]] = o[ok, 1]
+            assert not (arr == 255).any() or d_ovf is not None
             idx = np.flatnonzero(arr >= L)
             keys = kmer.keys_of_slots((idx + base).astype(np.uint64), k)
             o = np.argsort(keys, kind="stable")

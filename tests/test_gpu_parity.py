@@ -303,10 +303,16 @@ def test_filter_near_threshold_screen(gpu_ctx):
         tabs[0, i], tabs[1, i] = a, b
         tabs[2, i], tabs[3, i] = b, a
         tabs[4, i], tabs[5, i] = 2 * a, 2 * b
-    d_tabs = []
+    d_tabs, d_ovf, n_ovf = [], [], []     # byte tables + overflow pairs (most counts here are >= 255)
     for c in range(C):
-        d_tabs.append(gpu_ctx.dev_alloc(n * 4))
-        gpu_ctx.host_to_dev(d_tabs[-1], tabs[c])
+        d_tabs.append(gpu_ctx.dev_alloc(n))
+        gpu_ctx.host_to_dev(d_tabs[-1], np.minimum(tabs[c], 255).astype(np.uint8))
+        big = np.flatnonzero(tabs[c] >= 255)
+        pairs = np.stack([big.astype(np.uint32), tabs[c][big]], axis=1).astype(np.uint32)
+        d_ovf.append(gpu_ctx.dev_alloc(max(8 * len(big), 8)))
+        if len(big):
+            gpu_ctx.host_to_dev(d_ovf[-1], np.ascontiguousarray(pairs))
+        n_ovf.append(len(big))
     slots = np.arange(n, dtype=np.uint64)
     keys_all = km.keys_of_slots(slots, k)
     dumps = []
@@ -327,7 +333,7 @@ def test_filter_near_threshold_screen(gpu_ctx):
     ):
         labels = list(range(C))
         exp = po.filter_dumps(dumps, sgs, labels, lengths=lengths, **kw)
-        gpu_ctx.filter_view(d_tabs, 0, n, lengths, k, lower)
+        gpu_ctx.filter_view(d_tabs, 0, n, lengths, k, lower, d_ovf, n_ovf)
         try:
             nu, nr, nh = gpu_ctx.filter(*sets_to_csr(sgs, labels), kw["min_fold"], kw["baseline"], kw["min_freq"],
                                         kw["max_freq"], kw["ratio"])
@@ -337,7 +343,7 @@ def test_filter_near_threshold_screen(gpu_ctx):
         assert (nu, nr, nh) == (exp.n_union, len(exp.keys), len(exp.hist)), (sgs, kw, nu, nr, nh, exp.n_union, len(exp.keys), len(exp.hist))
         assert (keys == exp.keys).all() and (counts == exp.counts).all()
         assert nr > 0 and nh > nr // 2
-    for d in d_tabs:
+    for d in d_tabs + d_ovf:
         gpu_ctx.dev_free(d)
 
 
@@ -449,46 +455,47 @@ def test_sparse_key_range_view(gpu_ctx, oracle_ctx):
     assert (nu2, nr2, nh2) == (nu, nr, nh)
 
 
-def test_table_wire_format_roundtrip(gpu_ctx):
-    """sp_table_narrow -> sp_table_widen + sp_table_patch reproduces the thresholded count table
-    (counts >= 255 travel in the overflow list); the overflow buffer being too small is an error."""
-    rng = np.random.RandomState(8)
-    k, lower = 9, 3
-    s = _rand_seq(rng, 400000, 0.001, 0.1)
+@pytest.mark.parametrize("engine", [1, 2])
+def test_byte_table_and_overflow_list(gpu_ctx, engine):
+    """The count table is one byte per slot (raw count saturated at 255) + an overflow list of
+    (slot, count) pairs in ascending slot order; this is also what travels between GPUs.  Both engines,
+    a caller-bound table (sp_tables_bind), hot keys far above 255 and many buckets with overflow."""
+    rng = np.random.RandomState(9)
+    k, lower = 11, 3
+    s = _rand_seq(rng, 5_000_000, 0.001, 0.1)
     s[1000:61000] = ord("A")                                   # poly-A: one count far above 255
     s[100000:160000] = np.frombuffer(b"ACGTTGCA" * 7500, np.uint8)   # 8 k-mers ~7500 times each
-    gpu_ctx.genome_reset(1)
-    gpu_ctx.genome_add(0, s)
-    gpu_ctx.count(k, lower, 1)
-    keys, cnts = gpu_ctx.dump(0)
+    fam = _rand_seq(rng, 3000, 0, 0)
+    for p in rng.randint(200000, 4_900_000, size=400):         # a repeat family: ~3000 slots with counts ~400
+        s[p:p + 3000] = fam
     from subphaser_amd import kmer as km
     n = km.dense_slots(k)
-    expect = np.zeros(n, np.uint32)
-    expect[km.slots_of_keys(keys, k).astype(np.int64)] = cnts
-    n_big = int((expect >= 255).sum())
-    assert n_big >= 3
-    d8, d32 = gpu_ctx.dev_alloc(n), gpu_ctx.dev_alloc(n * 4)
-    dov = gpu_ctx.dev_alloc(8 * (n_big + 4))
-    with pytest.raises(MemoryError):
-        gpu_ctx.table_narrow(0, d8, dov, n_big - 1)
-    assert gpu_ctx.table_narrow(0, d8, dov, n_big + 4) == n_big
-    b = gpu_ctx.dev_to_host(d8, n)
-    assert (b == np.minimum(expect, 255)).all()
-    pairs = gpu_ctx.dev_to_host(dov, 8 * n_big).view(np.uint32).reshape(-1, 2)
-    o = np.argsort(pairs[:, 0])
-    assert (pairs[o, 0] == np.flatnonzero(expect >= 255)).all() and (pairs[o, 1] == expect[expect >= 255]).all()
-    # whole table, then a slot-range slice
-    gpu_ctx.table_widen(d8, n, d32)
-    gpu_ctx.table_patch(d32, 0, n, dov, n_big)
-    gpu_ctx.sync()
-    assert (gpu_ctx.dev_to_host(d32, n * 4).view(np.uint32) == expect).all()
-    base, m = n // 4, n // 2
-    gpu_ctx.table_widen(d8 + base, m, d32)
-    gpu_ctx.table_patch(d32, base, m, dov, n_big)
-    gpu_ctx.sync()
-    assert (gpu_ctx.dev_to_host(d32, m * 4).view(np.uint32) == expect[base:base + m]).all()
-    for d in (d8, d32, dov):
-        gpu_ctx.dev_free(d)
+    d8 = gpu_ctx.dev_alloc(n)
+    try:
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.tables_bind(0, d8)
+        gpu_ctx.genome_add(0, s)
+        gpu_ctx.count(k, lower, engine)
+        okeys, ocnts = po.count(s, k, 1, nthreads=4)           # raw counts
+        expect = np.zeros(n, np.uint32)
+        expect[km.slots_of_keys(okeys, k).astype(np.int64)] = ocnts
+        n_big = int((expect >= 255).sum())
+        assert n_big >= 1000
+        assert (gpu_ctx.dev_to_host(d8, n) == np.minimum(expect, 255)).all()
+        assert gpu_ctx.table_overflow(0) == n_big
+        dov = gpu_ctx.dev_alloc(8 * n_big)
+        gpu_ctx.table_overflow(0, dov, n_big)
+        gpu_ctx.sync()
+        pairs = gpu_ctx.dev_to_host(dov, 8 * n_big).view(np.uint32).reshape(-1, 2)
+        gpu_ctx.dev_free(dov)
+        assert (pairs[:, 0] == np.flatnonzero(expect >= 255)).all()      # ascending slots, no sort needed
+        assert (pairs[:, 1] == expect[expect >= 255]).all()
+        keys, cnts = gpu_ctx.dump(0)                                     # threshold applied on read
+        assert (keys == okeys[ocnts >= lower]).all() and (cnts == ocnts[ocnts >= lower]).all()
+        assert int(gpu_ctx.lengths()[0]) == int(ocnts[ocnts >= lower].astype(np.int64).sum())
+    finally:
+        gpu_ctx.tables_bind(0, None)
+        gpu_ctx.dev_free(d8)
 
 
 def test_filter_errors(gpu_ctx):

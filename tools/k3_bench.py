@@ -15,6 +15,7 @@ for i, c in enumerate(gen.chroms):
     ctx.genome_add_device(i, p, c["length"])
     ctx.dev_free(p)
 ctx.count(15, 3, 0)
+print('overflow pairs per chromosome:', [ctx.table_overflow(i) for i in range(len(gen.chroms))])
 csr = sets_to_csr(gen.sgs, gen.labels)
 ctx.prof_enable(True)
 for _ in range(3):

@@ -15,7 +15,7 @@ def main(db, out=sys.stdout):
     out.write("| kernel | calls | total_ms | avg_us | min_us | max_us | pct | vgpr | sgpr | lds_B | wg | grid_x |\n")
     out.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
     for n, c, s, a, mn, mx, vg, sg, lds, wg, gx in rows:
-        name = n.split("(")[0]
+        name = n.split("(")[0].replace("void ", "").split("<")[0]
         out.write("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.2f | %s | %s | %s | %s | %s |\n"
                   % (name, c, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / total, vg, sg, lds, wg, gx))
 
