@@ -107,15 +107,16 @@ def main():
     # ---- synthetic genome straight into HBM (untimed) ----------------------------------------
     t0 = time.perf_counter()
     d_ascii = []
-    my = range(C) if runner is None else runner.my_chroms
-    for i in range(C):
-        if i in my:
-            c = gen.chroms[i]
-            p = ctx.dev_alloc(c["length"])
-            ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], S, c["chrom_id"], c["exchange"])
-            d_ascii.append(p)
-        else:
-            d_ascii.append(None)
+    if runner is None:
+        pieces = [dict(chrom=i, start=0, end=c["length"], stop=c["length"]) for i, c in enumerate(gen.chroms)]
+    else:
+        pieces = runner.local_pieces     # contiguous slices of the concatenated genome (k-1 halo inside a chromosome)
+    for pc in pieces:
+        c = gen.chroms[pc["chrom"]]
+        n = pc["stop"] - pc["start"]
+        p = ctx.dev_alloc(max(n, 1))
+        ctx.synth_chrom_range(p, c["length"], pc["start"], n, gen.seed, c["set_id"], c["sg_id"], S, c["chrom_id"], c["exchange"])
+        d_ascii.append(p)
     ctx.sync()
     t_synth = time.perf_counter() - t0
 
@@ -180,7 +181,7 @@ def main():
     gbases = gen.total_bases / (dt / args.steps) / 1e9
 
     # sum over chromosomes of D_c = distinct k-mers with count >= L (the lines of the jellyfish dumps)
-    n_dumped = sum(ctx.dump_size(i) for i in range(len(list(my))))
+    n_dumped = sum(ctx.dump_size(i) for i in range(len(pieces)))
     if dist is not None and world > 1:
         tdump = torch.tensor([n_dumped], dtype=torch.int64, device="cuda")
         dist.all_reduce(tdump)
@@ -199,8 +200,8 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events per launch, on the context's stream) ------
     nslots = (1 << (2 * args.k - 1) if args.k % 2 else 1 << (2 * args.k)) if args.k <= 15 else 0
-    n_local = len(list(my))
-    local_bases = sum(gen.chroms[i]["length"] for i in my)
+    n_local = len(pieces)
+    local_bases = sum(pc["stop"] - pc["start"] for pc in pieces)
     extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
                  sum_dump=int(n_dumped), k=args.k)
     try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
@@ -265,7 +266,7 @@ def main():
                                "q=200 f=2, 10-kb bins, 1-Mb windows" % (args.config, C, gen.total_bases / 1e9, args.k),
                    "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
-                   "mapped_positions": int(b.n_mapped), "parallelism": "chromosome-sharded x%d" % world},
+                   "mapped_positions": int(b.n_mapped), "parallelism": ("single GPU" if world == 1 else "genome-position-sharded count/map + slot-range-sharded filter x%d" % world)},
         "roofline": roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
                                   for k_, v in (hp if runner is None else runner).wall.items()},

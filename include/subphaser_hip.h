@@ -84,6 +84,20 @@ int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
  *                     pairs; d_pairs = NULL only queries *n_pairs); asynchronous on the context's stream. */
 int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table);
 int sp_table_overflow(sp_ctx *ctx, int chrom, void *d_pairs, int64_t cap, int64_t *n_pairs);
+/* Multi-GPU, a chromosome counted in pieces by several ranks (the reference cuts chromosomes into 10-Mb
+ * chunks with a k-1 overlap for the same purpose, Seqs.py:121-139): byte slices of the same slot range
+ * [slot_base, slot_base + n) are added up exactly on the rank that filters that range.
+ *   sp_table_merge    dst += src (device byte slices, dst may be read and written in place).  A slot whose sum
+ *                     reaches 255 or whose summands were saturated becomes 255 and its exact sum (looked up in
+ *                     the two overflow lists, absolute slots) goes to d_out_ovf -- a NEW list of the slots of this
+ *                     range only, ascending (capacity `cap` pairs; SP_ENOMEM with *n_out = the number needed).
+ *   sp_table_lengths  sum and number of the counts >= lower_count of a slice (the chromosome's contribution of this
+ *                     slot range to `lengths`, Jellyfish.py:97,449, and to the dump size).                         */
+int sp_table_merge(sp_ctx *ctx, void *d_dst_u8, const void *d_dst_ovf, int64_t n_dst_ovf, const void *d_src_u8,
+                   const void *d_src_ovf, int64_t n_src_ovf, int64_t slot_base, int64_t n, void *d_out_ovf, int64_t cap,
+                   int64_t *n_out);
+int sp_table_lengths(sp_ctx *ctx, const void *d_tab_u8, const void *d_ovf, int64_t n_ovf, int64_t slot_base, int64_t n,
+                     int lower_count, int64_t *sum, int64_t *n_dump);
 /* lengths[c] = sum of the dumped counts of chromosome c (Jellyfish.py:97,449) */
 int sp_lengths(sp_ctx *ctx, int64_t *lengths /*C*/);
 /* jellyfish-dump equivalent of one chromosome.  Two calls: sp_dump_size then
@@ -150,6 +164,12 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
  * at least len/window_size + 2 each; win_counts: total x n_sg int64 (overwritten).          */
 int sp_stack_windows(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
                      const int64_t *slot_off, const int64_t *win_off, int64_t *win_counts);
+/* same into a caller-owned DEVICE table (total x n_sg uint64, ACCUMULATED: clear it first), for callers that
+ * hold pieces of chromosomes: seg_start[i] = position of local chromosome i's base 0 inside the chromosome it is
+ * a piece of (NULL = 0), win_off[i] = first window row of THAT chromosome.  Several ranks' tables add up
+ * (all-reduce) to the whole-genome window table.                                                        */
+int sp_stack_windows_dev(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
+                         const int64_t *slot_off, const int64_t *win_off, const int64_t *seg_start, void *d_win);
 /* feature mode (map_kmer3(..., chunk=False), __main__.py:509-511): n_feat
  * sequences lying back to back in `ascii`, feature f = [off[f], off[f+1]).
  * Only k-mers that lie entirely inside one feature count (the kernel rejects
@@ -167,6 +187,15 @@ int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit);
  * Outputs (host): pvals W x S; argmin W; sig W; ratios W x S.              */
 int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
               double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios);
+/* counts in DEVICE memory (column totals are reduced on the device) */
+int sp_enrich_dev(sp_ctx *ctx, const void *d_counts, int64_t W, int S, double max_pval, double min_ratio,
+                  double *pvals, int32_t *argmin, uint8_t *sig, double *ratios);
+/* sp_stack_windows + sp_enrich fused on the device (Circos.stack_matrix -> Stats.enrich without the text and
+ * host round trips): every window row of win_off (empty rows included -- they change no total) is tested;
+ * outputs are host arrays of win_off[C] rows.                                                            */
+int sp_stack_enrich(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size, const int64_t *slot_off,
+                    const int64_t *win_off, double max_pval, double min_ratio, int64_t *win_counts, double *pvals,
+                    int32_t *argmin, uint8_t *sig, double *ratios);
 
 /* ---- multi-GPU, k > 15 ----------------------------------------------------------------------
  * Twin of sp_tables_bind / sp_filter_view for 64-bit keys ("for k > 16 the exchange
@@ -199,6 +228,9 @@ int sp_prof_report(sp_ctx *ctx, char *buf, int64_t cap);
  * Deterministic synthetic chromosome written as ASCII into a device buffer. */
 int sp_synth_chrom(sp_ctx *ctx, uint8_t *d_out, int64_t len, uint64_t seed, int set_id,
                    int sg_id, int n_sg, int chrom_id, int exchange);
+/* positions [start, start + n) of the same chromosome (every base is a pure function of its position) */
+int sp_synth_chrom_range(sp_ctx *ctx, uint8_t *d_out, int64_t len, int64_t start, int64_t n, uint64_t seed, int set_id,
+                         int sg_id, int n_sg, int chrom_id, int exchange);
 /* page-locked host memory: device->host copies into it run at PCIe speed; plain
  * (pageable) buffers are accepted everywhere but copy several times slower.     */
 int sp_host_alloc(sp_ctx *ctx, int64_t bytes, void **h_ptr);

@@ -20,13 +20,13 @@ SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -
 SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
-    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_device", "sp_filter_hist",
-    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_map_features", "sp_labels_hit",
-    "sp_enrich",
+    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_labels_hit",
+    "sp_enrich", "sp_enrich_dev",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
-    "sp_synth_chrom", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
+    "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
 ]
 
 
@@ -67,6 +67,8 @@ def load():
     L.sp_nslots.argtypes = [vp, ci, P(i64)]
     L.sp_tables_bind.argtypes = [vp, ci, vp]
     L.sp_table_overflow.argtypes = [vp, ci, vp, i64, P(i64)]
+    L.sp_table_merge.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i64, vp, i64, P(i64)]
+    L.sp_table_lengths.argtypes = [vp, vp, vp, i64, i64, i64, ci, P(i64), P(i64)]
     L.sp_filter_view.argtypes = [vp, ci, vp, i64, i64, vp, ci, ci, vp, vp]
     L.sp_lengths.argtypes = [vp, vp]
     L.sp_dump_size.argtypes = [vp, ci, P(i64)]
@@ -80,11 +82,14 @@ def load():
     L.sp_map_bins.argtypes = [vp, ci, i64, i64, vp, i64, P(i64)]
     L.sp_map_bins_all.argtypes = [vp, i64, i64, vp, vp, vp]
     L.sp_stack_windows.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+    L.sp_stack_windows_dev.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
+    L.sp_stack_enrich.argtypes = [vp, i64, i64, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
     L.sp_map_features.argtypes = [vp, vp, vp, i64, vp]
     L.sp_host_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_host_free.argtypes = [vp, vp]
     L.sp_labels_hit.argtypes = [vp, P(i64)]
     L.sp_enrich.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
+    L.sp_enrich_dev.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
     L.sp_sparse_sizes.argtypes = [vp, vp]
     L.sp_sparse_sample.argtypes = [vp, ci, i64, vp, P(i64)]
     L.sp_sparse_split.argtypes = [vp, ci, vp, ci, vp]
@@ -94,6 +99,7 @@ def load():
     L.sp_prof_reset.argtypes = [vp]
     L.sp_prof_report.argtypes = [vp, C.c_char_p, i64]
     L.sp_synth_chrom.argtypes = [vp, vp, i64, C.c_uint64, ci, ci, ci, ci, ci]
+    L.sp_synth_chrom_range.argtypes = [vp, vp, i64, i64, i64, C.c_uint64, ci, ci, ci, ci, ci]
     L.sp_dev_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_dev_free.argtypes = [vp, vp]
     L.sp_dev_copy_to_host.argtypes = [vp, vp, vp, i64]
@@ -234,6 +240,23 @@ class Context:
         self._ck(self.L.sp_table_overflow(self.h, int(chrom), C.c_void_p(int(d_pairs)) if d_pairs else None, int(cap),
                                           C.byref(n)))
         return n.value
+
+    def table_merge(self, d_dst, d_dst_ovf, n_dst_ovf, d_src, d_src_ovf, n_src_ovf, slot_base, n, d_out_ovf, cap):
+        """dst += src over the byte slices of slots [slot_base, slot_base + n) (device pointers); returns the
+        number of pairs of the merged overflow list written to d_out_ovf (MemoryError: capacity too small)."""
+        m = C.c_int64()
+        self._ck(self.L.sp_table_merge(self.h, C.c_void_p(int(d_dst)), C.c_void_p(int(d_dst_ovf)) if n_dst_ovf else None,
+                                       int(n_dst_ovf), C.c_void_p(int(d_src)),
+                                       C.c_void_p(int(d_src_ovf)) if n_src_ovf else None, int(n_src_ovf), int(slot_base),
+                                       int(n), C.c_void_p(int(d_out_ovf)) if cap else None, int(cap), C.byref(m)))
+        return m.value
+
+    def table_lengths(self, d_tab, d_ovf, n_ovf, slot_base, n, lower_count):
+        """(sum, number) of the counts >= lower_count of a byte slice."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.L.sp_table_lengths(self.h, C.c_void_p(int(d_tab)), C.c_void_p(int(d_ovf)) if n_ovf else None,
+                                         int(n_ovf), int(slot_base), int(n), int(lower_count), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def filter_view(self, d_ptrs, slot_base, nslots_view, lengths, k, lower_count, d_ovf=None, n_ovf=None):
         """Point sp_filter at slot-range slices of byte tables (device pointers, one per chromosome of the
@@ -403,6 +426,44 @@ class Context:
                                          _p(woff), _p(win)))
         return win, woff
 
+    def stack_windows_dev(self, bin_size, chunk_size, window_size, win_off, seg_start, d_win):
+        """Window counts of the last map_bins_all accumulated into a DEVICE table (d_win: int64 [total, n_sg],
+        cleared by the caller).  win_off[i] = first window row of the chromosome local chromosome i is (a piece
+        of), seg_start[i] = position of its base 0 inside that chromosome."""
+        out, off = self.last_map
+        win_off = np.ascontiguousarray(win_off, np.int64)
+        seg = np.ascontiguousarray(seg_start, np.int64) if seg_start is not None else None
+        self._ck(self.L.sp_stack_windows_dev(self.h, int(bin_size), int(chunk_size), int(window_size), _p(off),
+                                             _p(win_off), _p(seg) if seg is not None else None, C.c_void_p(int(d_win))))
+
+    def stack_enrich(self, bin_size, chunk_size, window_size, lengths, max_pval=0.05, min_ratio=0.5):
+        """stack_windows + enrich fused on the device.  Returns (win int64 [W, S], win_off [C+1], pvals, argmin,
+        sig, ratios) over EVERY window row (empty rows included)."""
+        out, off = self.last_map
+        woff = np.zeros(self.n_chrom + 1, np.int64)
+        for i, n in enumerate(lengths):
+            woff[i + 1] = woff[i] + (int(n) + int(window_size) - 1) // int(window_size) + 1
+        W, S = int(woff[-1]), self.n_sg
+        win = self.pinned_empty("win_all", (W, S), np.int64)
+        pvals = self.pinned_empty("enr_p", (W, S), np.float64)
+        ratios = self.pinned_empty("enr_q", (W, S), np.float64)
+        argmin = self.pinned_empty("enr_a", (W,), np.int32)
+        sig = self.pinned_empty("enr_s", (W,), np.uint8)
+        self._ck(self.L.sp_stack_enrich(self.h, int(bin_size), int(chunk_size), int(window_size), _p(off), _p(woff),
+                                        float(max_pval), float(min_ratio), _p(win), _p(pvals), _p(argmin), _p(sig),
+                                        _p(ratios)))
+        return win, woff, pvals, argmin, sig, ratios
+
+    def enrich_dev(self, d_counts, W, S, max_pval=0.05, min_ratio=0.5):
+        """enrich() for a window table that already lives in device memory (int64 [W, S])."""
+        pvals = np.empty((W, S), np.float64)
+        ratios = np.empty((W, S), np.float64)
+        argmin = np.empty(W, np.int32)
+        sig = np.empty(W, np.uint8)
+        self._ck(self.L.sp_enrich_dev(self.h, C.c_void_p(int(d_counts)), int(W), int(S), float(max_pval),
+                                      float(min_ratio), _p(pvals), _p(argmin), _p(sig), _p(ratios)))
+        return pvals, argmin, sig.astype(bool), ratios
+
     def map_features(self, seqs):
         """seqs: list of str/bytes.  Returns int64 [n_feat, n_sg] totals."""
         arrs = [as_ascii(s) for s in seqs]
@@ -472,6 +533,10 @@ class Context:
     def host_to_dev(self, ptr, arr, offset=0):
         arr = np.ascontiguousarray(arr)
         self._ck(self.L.sp_dev_copy_from_host(self.h, C.c_void_p(ptr + offset), _p(arr), int(arr.nbytes)))
+
+    def synth_chrom_range(self, d_ptr, length, start, n, seed, set_id, sg_id, n_sg, chrom_id, exchange=0):
+        self._ck(self.L.sp_synth_chrom_range(self.h, C.c_void_p(d_ptr), int(length), int(start), int(n), int(seed),
+                                             int(set_id), int(sg_id), int(n_sg), int(chrom_id), int(exchange)))
 
     def synth_chrom(self, d_ptr, length, seed, set_id, sg_id, n_sg, chrom_id, exchange=0):
         self._ck(self.L.sp_synth_chrom(self.h, C.c_void_p(d_ptr), int(length), int(seed), int(set_id),

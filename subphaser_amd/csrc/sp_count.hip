@@ -217,13 +217,86 @@ int sp_sparse_count(sp_ctx *ctx, int k, int lower);                             
 int sp_sparse_count3(sp_ctx *ctx, int k, int lower);                                  // sp_sparse2.hip
 int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts);
 
+// ----------------------------------------------------------------- merging two byte tables (multi-GPU)
+// A chromosome whose bases were counted by two ranks arrives at the rank that filters a slot range as two
+// byte slices.  dst += src over n slots, exactly: a slot whose sum reaches 255 -- or whose summands were
+// already saturated -- is written as 255 and its exact sum (overflow-list look-ups for saturated summands)
+// goes to the merged overflow list, through the same per-bucket segment protocol as the counting kernels.
+__global__ void __launch_bounds__(256)
+kx_merge(uint8_t *dst /* may alias A.tab */, sp_tabref A, sp_tabref B, int64_t slot_base, int64_t n,
+         unsigned long long *__restrict__ cursor, uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap,
+         uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt, int64_t n_buckets) {
+    __shared__ uint32_t s_nov, s_rank;
+    __shared__ unsigned long long s_base;
+    for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        if (threadIdx.x == 0) s_nov = s_rank = 0;
+        __syncthreads();
+        const int64_t lo = b << SP_OVF_SHIFT;
+        int64_t hi = lo + (1LL << SP_OVF_SHIFT);
+        if (hi > n) hi = n;
+        uint32_t my_ov = 0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint32_t x = A.tab[i], y = B.tab[i];
+            my_ov += (x == 255u || y == 255u || x + y >= 255u);
+        }
+        if (my_ov) atomicAdd(&s_nov, my_ov);
+        __syncthreads();
+        const uint32_t nov = s_nov;
+        if (nov && threadIdx.x == 0) s_base = atomicAdd(cursor, (unsigned long long)nov);
+        __syncthreads();
+        const unsigned long long base = s_base;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint32_t x = A.tab[i], y = B.tab[i];
+            if (x == 255u || y == 255u || x + y >= 255u) {
+                const uint32_t slot = (uint32_t)(slot_base + i);
+                const uint32_t ex = (x < 255u ? x : sp_ovf_lookup(A.ovf, A.n_ovf, slot)) +
+                                    (y < 255u ? y : sp_ovf_lookup(B.ovf, B.n_ovf, slot));
+                const unsigned long long pos = base + atomicAdd(&s_rank, 1u);
+                if (pos < ovf_cap) ovf_tmp[pos] = make_uint2(slot, ex);
+                dst[i] = 255;
+            } else {
+                dst[i] = (uint8_t)(x + y);
+            }
+        }
+        if (threadIdx.x == 0) {
+            seg_cnt[b] = nov;
+            if (nov) seg_base[b] = (uint32_t)base;
+        }
+        __syncthreads();
+    }
+}
+
+// sum and number of the counts >= lower of a byte slice (+ the overflow pairs that fall into it)
+__global__ void __launch_bounds__(256)
+kx_lengths(sp_tabref T, int64_t slot_base, int64_t n, uint32_t lower, unsigned long long *__restrict__ out2) {
+    __shared__ unsigned long long red[16];
+    unsigned long long s = 0, c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = T.tab[i];
+        if (v < 255u && v >= lower) { s += v; c++; }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.n_ovf; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 e = T.ovf[i];
+        if ((int64_t)e.x >= slot_base && (int64_t)e.x < slot_base + n && e.y >= lower) { s += e.y; c++; }
+    }
+    const unsigned long long ts = sp_block_sum_u64(s, red), tc = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0) {
+        if (ts) atomicAdd(&out2[0], ts);
+        if (tc) atomicAdd(&out2[1], tc);
+    }
+}
+
 // Lay the overflow segments a counting kernel left behind out in bucket order (= ascending slot order).
-int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
-                    uint32_t *seg_off, int64_t n_buckets) {
+static int ovf_finalize_to(sp_ctx *ctx, uint2 *out, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
+                           uint32_t *seg_off, int64_t n_buckets) {
     SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
     SP_LAUNCH(ctx, "ovf_place", ovf_place, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base, seg_cnt,
-              (const uint32_t *)seg_off, n_buckets, c.d_ovf);
+              (const uint32_t *)seg_off, n_buckets, out);
     return SP_OK;
+}
+int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
+                    uint32_t *seg_off, int64_t n_buckets) {
+    return ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets);
 }
 
 extern "C" {
@@ -388,6 +461,63 @@ int sp_table_overflow(sp_ctx *ctx, int chrom, void *d_pairs, int64_t cap, int64_
     if (c.n_ovf)
         SP_HIP(ctx, hipMemcpyAsync(d_pairs, c.d_ovf, (size_t)c.n_ovf * sizeof(uint2), hipMemcpyDeviceToDevice, ctx->stream));
     return SP_OK;   // asynchronous on the context's stream
+}
+
+int sp_table_merge(sp_ctx *ctx, void *d_dst_u8, const void *d_dst_ovf, int64_t n_dst_ovf, const void *d_src_u8,
+                   const void *d_src_ovf, int64_t n_src_ovf, int64_t slot_base, int64_t n, void *d_out_ovf, int64_t cap,
+                   int64_t *n_out) {
+    if (!ctx || !d_dst_u8 || !d_src_u8 || !n_out || n < 0 || slot_base < 0 || cap < 0 || n_dst_ovf < 0 || n_src_ovf < 0 ||
+        (n_dst_ovf > 0 && !d_dst_ovf) || (n_src_ovf > 0 && !d_src_ovf) || (cap > 0 && !d_out_ovf) ||
+        (d_out_ovf && (d_out_ovf == d_dst_ovf || d_out_ovf == d_src_ovf)))
+        return sp_fail(ctx, SP_EINVAL, "sp_table_merge: bad arguments");
+    *n_out = 0;
+    if (n == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n_buckets = (n + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT;
+    int rc = sp_buf_ensure(ctx, ctx->b_ovfw, (cap + 1) * 8 + (3 * n_buckets + 1) * 4 + 256);
+    if (rc) return rc;
+    unsigned long long *d_cur = (unsigned long long *)ctx->b_ovfw.p;
+    uint2 *tmp = (uint2 *)(d_cur + 1);
+    uint32_t *seg_base = (uint32_t *)(tmp + cap), *seg_cnt = seg_base + n_buckets, *seg_off = seg_cnt + n_buckets;
+    SP_HIP(ctx, hipMemsetAsync(d_cur, 0, 8, ctx->stream));
+    sp_tabref A, B;
+    A.tab = (const uint8_t *)d_dst_u8; A.ovf = (const uint2 *)d_dst_ovf; A.n_ovf = n_dst_ovf;
+    B.tab = (const uint8_t *)d_src_u8; B.ovf = (const uint2 *)d_src_ovf; B.n_ovf = n_src_ovf;
+    int grid = (int)(n_buckets < (int64_t)ctx->n_cu * 8 ? n_buckets : (int64_t)ctx->n_cu * 8);
+    SP_LAUNCH(ctx, "kx_merge", kx_merge, dim3(grid), dim3(256), 0, (uint8_t *)d_dst_u8, A, B, slot_base, n, d_cur, tmp,
+              (unsigned long long)cap, seg_base, seg_cnt, n_buckets);
+    unsigned long long h = 0;
+    SP_HIP(ctx, hipMemcpyAsync(&h, d_cur, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = (int64_t)h;
+    if ((int64_t)h > cap)
+        return sp_fail(ctx, SP_ENOMEM, "sp_table_merge: %lld overflow pairs exceed the capacity %lld (the tables are now "
+                       "inconsistent: merge again from fresh inputs)", (long long)h, (long long)cap);
+    if (h) return ovf_finalize_to(ctx, (uint2 *)d_out_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets);
+    return SP_OK;
+}
+
+int sp_table_lengths(sp_ctx *ctx, const void *d_tab_u8, const void *d_ovf, int64_t n_ovf, int64_t slot_base, int64_t n,
+                     int lower_count, int64_t *sum, int64_t *n_dump) {
+    if (!ctx || !d_tab_u8 || !sum || !n_dump || n < 0 || n_ovf < 0 || (n_ovf > 0 && !d_ovf))
+        return sp_fail(ctx, SP_EINVAL, "sp_table_lengths: bad arguments");
+    *sum = *n_dump = 0;
+    if (n == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    void *scr = nullptr;
+    int rc = sp_scratch(ctx, 256, &scr);
+    if (rc) return rc;
+    unsigned long long *d2 = (unsigned long long *)scr, h[2] = {0, 0};
+    SP_HIP(ctx, hipMemsetAsync(d2, 0, 16, ctx->stream));
+    sp_tabref T;
+    T.tab = (const uint8_t *)d_tab_u8; T.ovf = (const uint2 *)d_ovf; T.n_ovf = n_ovf;
+    SP_LAUNCH(ctx, "kx_lengths", kx_lengths, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0, T, slot_base, n,
+              (uint32_t)(lower_count < 1 ? 1 : lower_count), d2);
+    SP_HIP(ctx, hipMemcpyAsync(h, d2, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *sum = (int64_t)h[0];
+    *n_dump = (int64_t)h[1];
+    return SP_OK;
 }
 
 int sp_lengths(sp_ctx *ctx, int64_t *lengths) {

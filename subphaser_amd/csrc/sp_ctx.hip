@@ -149,6 +149,8 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_fpar);
     sp_buf_free(ctx->b_fflat);
     sp_buf_free(ctx->b_fq);
+    sp_buf_free(ctx->b_wtab);
+    sp_buf_free(ctx->b_enr);
     sp_buf_free(ctx->b_win);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -138,11 +138,12 @@ __device__ __forceinline__ double d_np_sum(const double *a, int n) {
 }
 
 __global__ void __launch_bounds__(64)
-k6_enrich(const long long *__restrict__ counts, const long long *__restrict__ total, long long sum_total,
+k6_enrich(const long long *__restrict__ counts, const long long *__restrict__ total /* S column sums, then their sum */,
           long long W, int S, double max_pval, double min_ratio, double *__restrict__ pvals,
           int *__restrict__ argmin, unsigned char *__restrict__ sig, double *__restrict__ ratios) {
     long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
+    const long long sum_total = total[S];
     const long long *row = counts + w * S;
     double *p = pvals + w * S;
     double *q = ratios + w * S;
@@ -181,38 +182,67 @@ k6_enrich(const long long *__restrict__ counts, const long long *__restrict__ to
     sig[w] = sg ? 1 : 0;
 }
 
-extern "C" int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
-                         double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios) {
-    if (!ctx || W < 0 || (W > 0 && (!counts || !pvals || !argmin || !sig || !ratios)))
+// column sums of the window table (Stats.py:142) + their sum, on the device
+__global__ void __launch_bounds__(256)
+k6_totals(const long long *__restrict__ counts, long long W, int S, long long *__restrict__ total /* S + 1 */) {
+    __shared__ unsigned long long acc[SP_ENRICH_MAXS + 1];
+    if (threadIdx.x <= S) acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = 0; j < S; j++) {
+        unsigned long long s = 0;
+        for (long long w = threadIdx.x; w < W; w += blockDim.x) s += (unsigned long long)counts[w * S + j];
+        if (s) atomicAdd(&acc[j], s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int j = 0; j < S; j++) {
+            total[j] = (long long)acc[j];
+            t += acc[j];
+        }
+        total[S] = (long long)t;
+    }
+}
+
+extern "C" int sp_enrich_dev(sp_ctx *ctx, const void *d_counts, int64_t W, int S, double max_pval, double min_ratio,
+                             double *pvals, int32_t *argmin, uint8_t *sig, double *ratios) {
+    if (!ctx || W < 0 || (W > 0 && (!d_counts || !pvals || !argmin || !sig || !ratios)))
         return sp_fail(ctx, SP_EINVAL, "sp_enrich: bad arguments");
     if (S < 2) return sp_fail(ctx, SP_ESTATE, "sp_enrich: at least 2 subgenome columns required (Stats.py:172)");
     if (S > SP_ENRICH_MAXS) return sp_fail(ctx, SP_EUNSUP, "sp_enrich: S=%d > %d", S, SP_ENRICH_MAXS);
     if (W == 0) return SP_OK;
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<long long> total((size_t)S, 0);
-    for (int64_t w = 0; w < W; w++)
-        for (int j = 0; j < S; j++) total[(size_t)j] += counts[w * S + j];
-    long long sum_total = 0;
-    for (int j = 0; j < S; j++) sum_total += total[(size_t)j];
     const size_t nWS = (size_t)W * S;
-    sp_tmp<long long> d_counts, d_total;
-    sp_tmp<double> d_p, d_q;
-    sp_tmp<int> d_arg;
-    sp_tmp<unsigned char> d_sig;
-    SP_HIP(ctx, d_counts.alloc(nWS));
-    SP_HIP(ctx, d_total.alloc((size_t)S));
-    SP_HIP(ctx, d_p.alloc(nWS));
-    SP_HIP(ctx, d_q.alloc(nWS));
-    SP_HIP(ctx, d_arg.alloc((size_t)W));
-    SP_HIP(ctx, d_sig.alloc((size_t)W));
-    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, nWS * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_total, total.data(), (size_t)S * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_LAUNCH(ctx, "k6_enrich", k6_enrich, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, d_counts.p, d_total.p,
-              sum_total, (long long)W, S, max_pval, min_ratio, d_p.p, d_arg.p, d_sig.p, d_q.p);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // one growth-only buffer: totals | p | ratios | argmin | sig   (no per-call hipMalloc)
+    int rc = sp_buf_ensure(ctx, ctx->b_enr, (int64_t)(al((size_t)(S + 1) * 8) + 2 * al(nWS * 8) + al((size_t)W * 4) + al((size_t)W)));
+    if (rc) return rc;
+    char *q = (char *)ctx->b_enr.p;
+    long long *d_total = (long long *)q; q += al((size_t)(S + 1) * 8);
+    double *d_p = (double *)q; q += al(nWS * 8);
+    double *d_q = (double *)q; q += al(nWS * 8);
+    int *d_arg = (int *)q; q += al((size_t)W * 4);
+    unsigned char *d_sig = (unsigned char *)q;
+    SP_LAUNCH(ctx, "k6_totals", k6_totals, dim3(1), dim3(256), 0, (const long long *)d_counts, (long long)W, S, d_total);
+    SP_LAUNCH(ctx, "k6_enrich", k6_enrich, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (const long long *)d_counts,
+              (const long long *)d_total, (long long)W, S, max_pval, min_ratio, d_p, d_arg, d_sig, d_q);
     SP_HIP(ctx, hipMemcpyAsync(pvals, d_p, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(ratios, d_q, nWS * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(argmin, d_arg, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(sig, d_sig, (size_t)W, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
+}
+
+extern "C" int sp_enrich(sp_ctx *ctx, const int64_t *counts, int64_t W, int S, double max_pval,
+                         double min_ratio, double *pvals, int32_t *argmin, uint8_t *sig, double *ratios) {
+    if (!ctx || W < 0 || (W > 0 && (!counts || !pvals || !argmin || !sig || !ratios)))
+        return sp_fail(ctx, SP_EINVAL, "sp_enrich: bad arguments");
+    if (W == 0 || S < 2 || S > SP_ENRICH_MAXS) return sp_enrich_dev(ctx, counts, W, S, max_pval, min_ratio, pvals, argmin, sig, ratios);
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nWS = (size_t)W * S;
+    int rc = sp_buf_ensure(ctx, ctx->b_wtab, (int64_t)nWS * 8 + 64);
+    if (rc) return rc;
+    SP_HIP(ctx, hipMemcpyAsync(ctx->b_wtab.p, counts, nWS * 8, hipMemcpyHostToDevice, ctx->stream));
+    return sp_enrich_dev(ctx, ctx->b_wtab.p, W, S, max_pval, min_ratio, pvals, argmin, sig, ratios);
 }

@@ -360,8 +360,9 @@ k5_map_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_
 // land in the same window.
 __global__ void __launch_bounds__(256)
 k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
-         const long long *__restrict__ slot_off, const long long *__restrict__ win_off, int64_t bin_size,
-         int64_t chunk_size, int64_t window_size, int k, unsigned long long *__restrict__ win_counts) {
+         const long long *__restrict__ slot_off, const long long *__restrict__ win_off,
+         const long long *__restrict__ seg_start /* position of local base 0 inside its chromosome, or NULL */,
+         int64_t bin_size, int64_t chunk_size, int64_t window_size, int k, unsigned long long *__restrict__ win_counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_slots * S) return;
     const int v = slot_counts[i];
@@ -382,7 +383,7 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
         while ((((chunk + 1) * chunk_size - (k - 1)) / bin_size + (chunk + 1)) <= slot) chunk++;
         while (chunk > 0 && ((chunk * chunk_size - (k - 1)) / bin_size + chunk) > slot) chunk--;
     }
-    const int64_t win = (slot - chunk) * bin_size / window_size;
+    const int64_t win = ((seg_start ? seg_start[lo] : 0) + (slot - chunk) * bin_size) / window_size;
     atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
 }
 
@@ -686,36 +687,89 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
     return SP_OK;
 }
 
+// window stack into a DEVICE table (accumulated: the caller clears it).  Entry i of slot_off / win_off /
+// seg_start describes local chromosome (or chromosome segment) i: its slots in the table sp_map_bins_all left
+// behind, the first window row of the chromosome it belongs to, and where its base 0 lies in that chromosome.
+int sp_stack_windows_dev(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size, const int64_t *slot_off,
+                         const int64_t *win_off, const int64_t *seg_start, void *d_win) {
+    if (!ctx || !slot_off || !win_off || !d_win || bin_size < 1 || chunk_size < 0 || window_size < 1)
+        return sp_fail(ctx, SP_EINVAL, "sp_stack_windows_dev: bad arguments");
+    if (!ctx->map_all_valid) return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: call sp_map_bins_all first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    const int C = (int)ctx->chroms.size();
+    const int S = ctx->n_sg;
+    const int64_t total_slots = slot_off[C];
+    int rcb = sp_buf_ensure(ctx, ctx->b_win, (int64_t)(24 * (size_t)(C + 1)));
+    if (rcb) return rcb;
+    long long *d_soff = (long long *)ctx->b_win.p;
+    long long *d_woff = d_soff + (C + 1), *d_seg = d_woff + (C + 1);
+    SP_HIP(ctx, hipMemcpyAsync(d_soff, slot_off, 8 * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_woff, win_off, 8 * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
+    if (seg_start) SP_HIP(ctx, hipMemcpyAsync(d_seg, seg_start, 8 * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
+    if (total_slots > 0)
+        SP_LAUNCH(ctx, "k5_stack", k5_stack, dim3((unsigned)((total_slots * S + 255) / 256)), dim3(256), 0,
+                  (const int *)ctx->b_map.p, total_slots, S, C, d_soff, d_woff, seg_start ? d_seg : (long long *)nullptr,
+                  bin_size, chunk_size, window_size, ctx->k, (unsigned long long *)d_win);
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // slot_off / win_off are the caller's
+    return SP_OK;
+}
+
+static int stack_check(sp_ctx *ctx, int64_t window_size, const int64_t *win_off) {
+    const int C = (int)ctx->chroms.size();
+    for (int i = 0; i < C; i++) {
+        int64_t need = (ctx->chroms[(size_t)i].len + window_size - 1) / window_size + 1;
+        if (win_off[i + 1] - win_off[i] < need)
+            return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: chromosome %d needs %lld windows", i, (long long)need);
+    }
+    return SP_OK;
+}
+
 int sp_stack_windows(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size,
                      const int64_t *slot_off, const int64_t *win_off, int64_t *win_counts) {
     if (!ctx || !slot_off || !win_off || !win_counts || bin_size < 1 || chunk_size < 0 || window_size < 1)
         return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: bad arguments");
     if (!ctx->map_all_valid) return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: call sp_map_bins_all first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = stack_check(ctx, window_size, win_off);
+    if (rc) return rc;
     const int C = (int)ctx->chroms.size();
-    const int S = ctx->n_sg;
-    for (int i = 0; i < C; i++) {
-        int64_t need = (ctx->chroms[(size_t)i].len + window_size - 1) / window_size + 1;
-        if (win_off[i + 1] - win_off[i] < need)
-            return sp_fail(ctx, SP_EINVAL, "sp_stack_windows: chromosome %d needs %lld windows", i, (long long)need);
-    }
-    const int64_t total_slots = slot_off[C], total_win = win_off[C];
-    const size_t wbytes = (size_t)total_win * S * 8;
-    int rcb = sp_buf_ensure(ctx, ctx->b_win, (int64_t)(wbytes + 16 * (size_t)(C + 1)));
-    if (rcb) return rcb;
-    unsigned long long *d_win = (unsigned long long *)ctx->b_win.p;
-    long long *d_soff = (long long *)((char *)d_win + wbytes);
-    long long *d_woff = d_soff + (C + 1);
-    SP_HIP(ctx, hipMemsetAsync(d_win, 0, wbytes, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_soff, slot_off, 8 * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_woff, win_off, 8 * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (total_slots > 0)
-        SP_LAUNCH(ctx, "k5_stack", k5_stack, dim3((unsigned)((total_slots * S + 255) / 256)), dim3(256), 0,
-                  (const int *)ctx->b_map.p, total_slots, S, C, d_soff, d_woff, bin_size, chunk_size, window_size,
-                  ctx->k, d_win);
-    SP_HIP(ctx, hipMemcpyAsync(win_counts, d_win, wbytes, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t wbytes = (size_t)win_off[C] * ctx->n_sg * 8;
+    rc = sp_buf_ensure(ctx, ctx->b_wtab, (int64_t)wbytes + 64);
+    if (rc) return rc;
+    SP_HIP(ctx, hipMemsetAsync(ctx->b_wtab.p, 0, wbytes, ctx->stream));
+    rc = sp_stack_windows_dev(ctx, bin_size, chunk_size, window_size, slot_off, win_off, nullptr, ctx->b_wtab.p);
+    if (rc) return rc;
+    SP_HIP(ctx, hipMemcpyAsync(win_counts, ctx->b_wtab.p, wbytes, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
+}
+
+int sp_enrich_dev(sp_ctx *ctx, const void *d_counts, int64_t W, int S, double max_pval, double min_ratio, double *pvals,
+                  int32_t *argmin, uint8_t *sig, double *ratios);   // sp_enrich.hip
+
+// map -> stack -> enrich without leaving the device: the window table is built in HBM, the column totals are
+// reduced there, every window row (empty ones included: they change no total) is tested, and the table and the
+// decisions come back in one go.  The caller keeps the rows that have any count (Circos.py:734-742).
+int sp_stack_enrich(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t window_size, const int64_t *slot_off,
+                    const int64_t *win_off, double max_pval, double min_ratio, int64_t *win_counts, double *pvals,
+                    int32_t *argmin, uint8_t *sig, double *ratios) {
+    if (!ctx || !slot_off || !win_off || !win_counts || !pvals || !argmin || !sig || !ratios || bin_size < 1 ||
+        chunk_size < 0 || window_size < 1)
+        return sp_fail(ctx, SP_EINVAL, "sp_stack_enrich: bad arguments");
+    if (!ctx->map_all_valid) return sp_fail(ctx, SP_EINVAL, "sp_stack_enrich: call sp_map_bins_all first");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = stack_check(ctx, window_size, win_off);
+    if (rc) return rc;
+    const int C = (int)ctx->chroms.size();
+    const int64_t W = win_off[C];
+    const size_t wbytes = (size_t)W * ctx->n_sg * 8;
+    rc = sp_buf_ensure(ctx, ctx->b_wtab, (int64_t)wbytes + 64);
+    if (rc) return rc;
+    SP_HIP(ctx, hipMemsetAsync(ctx->b_wtab.p, 0, wbytes, ctx->stream));
+    rc = sp_stack_windows_dev(ctx, bin_size, chunk_size, window_size, slot_off, win_off, nullptr, ctx->b_wtab.p);
+    if (rc) return rc;
+    SP_HIP(ctx, hipMemcpyAsync(win_counts, ctx->b_wtab.p, wbytes, hipMemcpyDeviceToHost, ctx->stream));
+    return sp_enrich_dev(ctx, ctx->b_wtab.p, W, ctx->n_sg, max_pval, min_ratio, pvals, argmin, sig, ratios);
 }
 
 int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,

@@ -26,7 +26,8 @@ __host__ __device__ inline uint64_t synth_h(uint64_t seed, uint64_t stream, uint
 #define SYN_FAMILIES 200
 
 struct sp_synth_params {
-    int64_t len;
+    int64_t len;       // length of the whole chromosome
+    int64_t start, n;  // positions [start, start + n) are written to out[0 .. n)
     uint64_t seed;
     int set_id, sg_id, n_sg, chrom_id, exchange;
 };
@@ -72,40 +73,50 @@ __global__ void __launch_bounds__(256)
 synth_fill(uint8_t *__restrict__ out, sp_synth_params P) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n16 = (P.len + 15) / 16;
+    const int64_t n16 = (P.n + 15) / 16;
     const bool aligned = (((uintptr_t)out) & 15) == 0;
     for (; t < n16; t += stride) {
         int64_t p0 = t * 16;
-        if (aligned && p0 + 16 <= P.len) {
+        if (aligned && p0 + 16 <= P.n) {
             uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t v = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) v |= (uint32_t)synth_base(p0 + q * 4 + j, P) << (8 * j);
+                for (int j = 0; j < 4; j++) v |= (uint32_t)synth_base(P.start + p0 + q * 4 + j, P) << (8 * j);
                 w[q] = v;
             }
             *reinterpret_cast<uint4 *>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
         } else {
-            for (int j = 0; j < 16 && p0 + j < P.len; j++) out[p0 + j] = synth_base(p0 + j, P);
+            for (int j = 0; j < 16 && p0 + j < P.n; j++) out[p0 + j] = synth_base(P.start + p0 + j, P);
         }
     }
 }
 
-extern "C" int sp_synth_chrom(sp_ctx *ctx, uint8_t *d_out, int64_t len, uint64_t seed, int set_id,
-                              int sg_id, int n_sg, int chrom_id, int exchange) {
-    if (!ctx || !d_out || len <= 0 || n_sg < 1) return sp_fail(ctx, SP_EINVAL, "sp_synth_chrom: bad arguments");
+extern "C" int sp_synth_chrom_range(sp_ctx *ctx, uint8_t *d_out, int64_t len, int64_t start, int64_t n, uint64_t seed,
+                                    int set_id, int sg_id, int n_sg, int chrom_id, int exchange) {
+    if (!ctx || !d_out || len <= 0 || n_sg < 1 || start < 0 || n < 0 || start + n > len)
+        return sp_fail(ctx, SP_EINVAL, "sp_synth_chrom_range: bad arguments");
+    if (n == 0) return SP_OK;
     SP_HIP(ctx, hipSetDevice(ctx->device));
     sp_synth_params P;
     P.len = len;
+    P.start = start;
+    P.n = n;
     P.seed = seed;
     P.set_id = set_id;
     P.sg_id = sg_id;
     P.n_sg = n_sg;
     P.chrom_id = chrom_id;
     P.exchange = exchange;
-    int64_t blocks = ((len + 15) / 16 + 255) / 256;
+    int64_t blocks = ((n + 15) / 16 + 255) / 256;
     if (blocks > (int64_t)ctx->n_cu * 32) blocks = (int64_t)ctx->n_cu * 32;
     SP_LAUNCH(ctx, "synth_fill", synth_fill, dim3((unsigned)blocks), dim3(256), 0, d_out, P);
     return SP_OK;
+}
+
+extern "C" int sp_synth_chrom(sp_ctx *ctx, uint8_t *d_out, int64_t len, uint64_t seed, int set_id,
+                              int sg_id, int n_sg, int chrom_id, int exchange) {
+    if (len <= 0) return sp_fail(ctx, SP_EINVAL, "sp_synth_chrom: bad arguments");
+    return sp_synth_chrom_range(ctx, d_out, len, 0, len, seed, set_id, sg_id, n_sg, chrom_id, exchange);
 }

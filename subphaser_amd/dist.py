@@ -1,13 +1,20 @@
 """Multi-GPU hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
-Sharding (DESIGN.md "Multi-GPU"):
-  * K0-K2 (pack, count) and K5 (bin map): by CHROMOSOME, longest-processing-time assignment.
+Sharding (DESIGN.md "Multi-GPU"), k <= 15:
+  * K0-K2 (pack, count) and K5 (bin map): by GENOME POSITION.  The concatenated genome is cut into N
+    contiguous slices of equal size; a cut inside a chromosome lies on a multiple of the 10-Mb chunk size
+    and the left piece carries a k-1 base halo -- the reference's own chunking rule (Seqs.py:121-139), so
+    every k-mer start is counted and mapped exactly once.  Perfect balance for any chromosome count
+    (21 wheat chromosomes on 8 GPUs would otherwise leave 3 chromosomes on the busiest rank).
   * K3 (matrix + differential filter): by dense-table SLOT RANGE.  The one real exchange step of
-    the path: every rank sends slice r of each of its count tables to rank r
-    (`all_to_all_single`, one round per locally-owned chromosome), so rank r holds
-    slots [r*n/N, (r+1)*n/N) of ALL chromosomes and filters them locally.
-    With N-1 direct xGMI links per GPU an all-to-all uses every link at once; a ring
-    all-reduce of the same 2-GiB tables would be bound by one link.
+    the path: every rank sends slice r of each of its byte count tables to rank r
+    (`all_to_all_single`, one round per local piece), so rank r holds slots [r*n/N, (r+1)*n/N) of ALL
+    pieces; pieces of one chromosome are added up exactly (`sp_table_merge`) and the range is filtered
+    locally.  With N-1 direct xGMI links per GPU an all-to-all uses every link at once; a ring
+    all-reduce of the same tables would be bound by one link.
+  * windows: every rank stacks its pieces into a whole-genome window table on the device, one all-reduce
+    (a few hundred KB) adds them up, and every rank then holds all windows and tests them (the Fisher
+    stage is 40 us of kernel time: computing it everywhere is cheaper than gathering results).
     For k > 15 (64-bit keys, no dense tables) the same exchange is a KEY-RANGE partition: every
     rank cuts the sorted (key, count) lists of its chromosomes at common splitters (quantiles of one
     list, broadcast) and sends piece r to rank r (`all_to_all_single` with uneven splits); rank r then
@@ -37,6 +44,34 @@ def lpt_assign(lengths, n_ranks):
     return [sorted(o) for o in owned]
 
 
+def plan_pieces(lengths, n_ranks, align):
+    """Cut the concatenated genome into n_ranks contiguous slices of (almost) equal size.  A cut inside a
+    chromosome is moved to the nearest multiple of `align` (the map stage's chunk size: the slot and window
+    numbering of a piece is then the chromosome's numbering plus a constant).  Returns, per rank, a list of
+    (chromosome, start, end): the rank owns the k-mer STARTS in [start, end)."""
+    total = sum(lengths)
+    offs = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    cuts = [0]
+    for r in range(1, n_ranks):
+        g = total * r // n_ranks
+        c = int(np.searchsorted(offs, g, side="right") - 1)
+        c = min(c, len(lengths) - 1)
+        p = int(g - offs[c])
+        p = int(round(p / align)) * align if align > 0 else p
+        p = min(max(p, 0), int(lengths[c]))
+        cuts.append(max(int(offs[c]) + p, cuts[-1]))
+    cuts.append(total)
+    out = []
+    for r in range(n_ranks):
+        a, b, pieces = cuts[r], cuts[r + 1], []
+        for c, n in enumerate(lengths):
+            lo, hi = max(a, int(offs[c])), min(b, int(offs[c + 1]))
+            if hi > lo:
+                pieces.append((c, lo - int(offs[c]), hi - int(offs[c])))
+        out.append(pieces)
+    return out
+
+
 class DistHotPath:
     def __init__(self, ctx, gen, dist, torch, k=15, lower_count=3, engine=0, device=None, **kw):
         self.ctx, self.gen, self.dist, self.torch = ctx, gen, dist, torch
@@ -45,25 +80,38 @@ class DistHotPath:
         self.labels = gen.labels
         self.lengths_bp = [c["length"] for c in gen.chroms]
         self.C = len(self.labels)
-        self.owned = lpt_assign(self.lengths_bp, self.world)
-        self.my_chroms = self.owned[self.rank]
-        self.max_local = max(len(o) for o in self.owned)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.csr = sets_to_csr(gen.sgs, self.labels)
         self.kw = kw
+        self.bin_size = kw.get("bin_size", 10000)
+        self.chunk_size = kw.get("chunk_size", 10_000_000)
+        self.window_size = kw.get("window_size", 1_000_000)
         t = torch
         self.sparse = k > 15
+        if self.sparse:
+            # k > 15: whole chromosomes per rank (longest-processing-time assignment)
+            self.owned = lpt_assign(self.lengths_bp, self.world)
+            self.pieces = [[(c, 0, self.lengths_bp[c]) for c in o] for o in self.owned]
+        else:
+            self.pieces = plan_pieces(self.lengths_bp, self.world, self.chunk_size if self.chunk_size > 0 else self.bin_size)
+            self.owned = [sorted({c for c, _, _ in p}) for p in self.pieces]
+        self.my_chroms = self.owned[self.rank]
+        self.max_local = max(len(p) for p in self.pieces)
+        # what the caller hands to count_and_filter, in this order: bases [start, stop) of chromosome `chrom`
+        # (stop = end + k - 1 inside a chromosome: the halo that lets the piece see its last k-mer starts)
+        self.local_pieces = [dict(chrom=c, start=a, end=b, stop=min(b + k - 1, self.lengths_bp[c]) if b < self.lengths_bp[c] else b)
+                             for c, a, b in self.pieces[self.rank]]
         if not self.sparse:
             self.nslots = ctx.nslots(k)
-            if self.nslots % (64 * self.world):
-                raise ValueError("dense table of %d slots cannot be cut into %d aligned slices" % (self.nslots, self.world))
-            self.chunk = self.nslots // self.world
-            # byte count tables of the local chromosomes live in ONE torch tensor: the table IS the wire format
+            # slot range of rank r: [r * chunk, min((r + 1) * chunk, nslots)); 64-slot aligned, the last one may be short
+            self.chunk = (self.nslots + 64 * self.world - 1) // (64 * self.world) * 64
+            self.nview = max(0, min(self.chunk, self.nslots - self.rank * self.chunk))
+            # byte count tables of the local pieces live in ONE torch tensor: the table IS the wire format
             # (one byte per slot + a short overflow list for counts >= 255), so RCCL sends slices of it as they are
-            nl = max(1, len(self.my_chroms))
+            nl = max(1, len(self.local_pieces))
             self.tabs = t.zeros((nl, self.world, self.chunk), dtype=t.uint8, device=self.device)
             self.dummy8 = None
-            # receive side: round i, source rank s -> byte slice of rank s's i-th chromosome; the filter reads them in place
+            # receive side: round i, source rank s -> byte slice of rank s's i-th piece; the filter reads them in place
             self.recv8 = self.tabs if self.world == 1 else \
                 t.zeros((self.max_local, self.world, self.chunk), dtype=t.uint8, device=self.device)
         else:
@@ -73,9 +121,6 @@ class DistHotPath:
         self.min_freq = kw.get("min_freq", 200)
         self.max_freq = kw.get("max_freq", 1e9)
         self.ratio = kw.get("ratio", 1.0)
-        self.bin_size = kw.get("bin_size", 10000)
-        self.chunk_size = kw.get("chunk_size", 10_000_000)
-        self.window_size = kw.get("window_size", 1_000_000)
         self.max_pval = kw.get("max_pval", 0.05)
         self.wall = {}
         self._pin = {}
@@ -140,22 +185,22 @@ class DistHotPath:
         return buf.numpy()
 
     # ------------------------------------------------------------------ first half
-    def count_and_filter(self, d_ascii, host_rows_on_all_ranks=True):
-        """d_ascii: list over ALL chromosomes; entries of chromosomes owned elsewhere are None.
-        host_rows_on_all_ranks=False: only rank 0 copies the gathered matrix to the host."""
+    def count_and_filter(self, d_pieces, host_rows_on_all_ranks=True):
+        """d_pieces: device pointers (or arrays, for a CPU context) of the ASCII bases of `self.local_pieces`,
+        in that order.  host_rows_on_all_ranks=False: only rank 0 copies the gathered matrix to the host."""
         if self.sparse:
-            return self._count_and_filter_sparse(d_ascii, host_rows_on_all_ranks)
+            return self._count_and_filter_sparse(d_pieces, host_rows_on_all_ranks)
         ctx, t, dist = self.ctx, self.torch, self.dist
-        mine = self.my_chroms
+        mine = self.local_pieces
         tt = time.perf_counter()
         ctx.genome_reset(len(mine))
-        for li, gi in enumerate(mine):
+        for li, pc in enumerate(mine):
             ctx.tables_bind(li, self._ptr(self.tabs[li]))
-            ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
+            ctx.genome_add_device(li, d_pieces[li], pc["stop"] - pc["start"])
         ctx.sync()
         tt = self._t("pack", tt)
-        # count chromosome i and put its byte table on the wire (slot-range slice r -> rank r) while
-        # chromosome i+1 is being counted: the exchange hides behind the counting kernels
+        # count piece i and put its byte table on the wire (slot-range slice r -> rank r) while piece i+1 is
+        # being counted: the exchange hides behind the counting kernels
         works, n_ovf = [], np.zeros(self.max_local, np.int64)
         for i in range(self.max_local):
             if i < len(mine):
@@ -169,13 +214,7 @@ class DistHotPath:
             if self.world > 1:
                 works.append(dist.all_to_all_single(self.recv8[i].view(-1), send.reshape(-1), async_op=True))
         tt = self._t("count(+exchange issue)", tt)
-        # global `lengths` (sum of dumped counts per chromosome): one small all-reduce
-        lens = t.zeros(self.C, dtype=t.int64, device=self.device)
-        if mine:
-            lens[t.tensor(mine, device=self.device)] = t.from_numpy(ctx.lengths()).to(self.device)
-        dist.all_reduce(lens)
-        lengths = lens.cpu().numpy()
-        # overflow pairs of every chromosome to every rank (small: counts >= 255 are rare)
+        # overflow pairs of every piece to every rank (small: counts >= 255 are rare)
         mine_ovf = t.zeros((max(int(n_ovf.sum()), 1), 2), dtype=t.int32, device=self.device)
         off = 0
         for i in range(len(mine)):
@@ -188,7 +227,7 @@ class DistHotPath:
         if self.world > 1:
             outs = [t.zeros_like(novf_t) for _ in range(self.world)]
             dist.all_gather(outs, novf_t)
-            novf_all = np.stack([o.cpu().numpy() for o in outs])      # [rank][its i-th chromosome]
+            novf_all = np.stack([o.cpu().numpy() for o in outs])      # [rank][its i-th piece]
         else:
             novf_all = n_ovf[None]
         all_ovf = self._all_gather_dev(mine_ovf, int(n_ovf.sum()))
@@ -196,23 +235,55 @@ class DistHotPath:
             w.wait()
         if hasattr(t, "cuda") and self.device.type == "cuda":
             t.cuda.synchronize()
-        tt = self._t("lengths+exchange wait", tt)
-        ptrs, optrs, ons, off = [0] * self.C, [0] * self.C, np.zeros(self.C, np.int64), 0
-        for s, owned in enumerate(self.owned):
-            for i, gi in enumerate(owned):
-                ptrs[gi] = self._ptr(self.recv8[i, s])
-                n = int(novf_all[s, i])
-                optrs[gi], ons[gi] = (all_ovf.data_ptr() + off * 8 if n else 0), n
+        tt = self._t("exchange wait", tt)
+        # one byte slice + overflow list per CHROMOSOME: pieces of a chromosome counted on different ranks add up
+        ptrs, optrs, ons = [0] * self.C, [0] * self.C, np.zeros(self.C, np.int64)
+        split = np.zeros(self.C, bool)
+        self._merged = []      # keeps the merged overflow lists alive until the filter has run
+        base, off = self.rank * self.chunk, 0
+        for s_, pieces in enumerate(self.pieces):
+            for i, (gi, a, b) in enumerate(pieces):
+                n = int(novf_all[s_, i])
+                src, src_ovf = self._ptr(self.recv8[i, s_]), (all_ovf.data_ptr() + off * 8 if n else 0)
                 off += n
-            off += int(novf_all[s, len(owned):].sum())
-        ctx.filter_view(ptrs, self.rank * self.chunk, self.chunk, lengths, self.k, self.lower_count, optrs, ons)
-        n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
-                                             self.max_freq, self.ratio)
+                if not ptrs[gi]:
+                    ptrs[gi], optrs[gi], ons[gi] = src, src_ovf, n
+                    continue
+                split[gi] = True
+                cap = int(ons[gi]) + n + self.lengths_bp[gi] // 255 + 16
+                merged = t.zeros((cap, 2), dtype=t.int32, device=self.device)
+                m = ctx.table_merge(ptrs[gi], optrs[gi], int(ons[gi]), src, src_ovf, n, base, self.nview,
+                                    merged.data_ptr(), cap) if self.nview else 0
+                self._merged.append(merged)
+                optrs[gi], ons[gi] = (merged.data_ptr() if m else 0), m
+            off += int(novf_all[s_, len(pieces):].sum())
+        # global `lengths` (sum of the dumped counts per chromosome, Jellyfish.py:97,449): the owner of a whole
+        # chromosome knows it from counting; a split chromosome's is summed over the slot ranges after merging
+        lens = t.zeros(self.C, dtype=t.int64, device=self.device)
+        local = ctx.lengths() if mine else np.zeros(0, np.int64)
+        lens_h = np.zeros(self.C, np.int64)
+        for li, pc in enumerate(mine):
+            if not split[pc["chrom"]]:
+                lens_h[pc["chrom"]] = local[li]
+        for gi in np.flatnonzero(split):
+            if self.nview:
+                lens_h[gi] = ctx.table_lengths(ptrs[gi], optrs[gi], int(ons[gi]), base, self.nview, self.lower_count)[0]
+        lens += t.from_numpy(lens_h).to(self.device)
+        dist.all_reduce(lens)
+        lengths = lens.cpu().numpy()
+        tt = self._t("merge+lengths", tt)
+        n_union = n_rows = n_hist = 0
+        if self.nview:
+            ctx.filter_view(ptrs, base, self.nview, lengths, self.k, self.lower_count, optrs, ons)
+            n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
+                                                 self.max_freq, self.ratio)
         # surviving rows stay on the device: gathered over xGMI, copied to the host once, where needed
         keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
         counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
-        ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
-        ctx.filter_view(None, 0, 0, None, 0, 0)
+        if self.nview:
+            ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
+            ctx.filter_view(None, 0, 0, None, 0, 0)
+        self._merged = []
         tt = self._t("filter+fetch", tt)
         return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
 
@@ -245,13 +316,13 @@ class DistHotPath:
             self._sbuf[name] = b
         return b
 
-    def _count_and_filter_sparse(self, d_ascii, host_rows_on_all_ranks=True):
+    def _count_and_filter_sparse(self, d_pieces, host_rows_on_all_ranks=True):
         ctx, t, dist = self.ctx, self.torch, self.dist
         mine, W = self.my_chroms, self.world
         tt = time.perf_counter()
         ctx.genome_reset(len(mine))
         for li, gi in enumerate(mine):
-            ctx.genome_add_device(li, d_ascii[gi], self.lengths_bp[gi])
+            ctx.genome_add_device(li, d_pieces[li], self.lengths_bp[gi])
         ctx.sync()
         tt = self._t("pack", tt)
         if mine:
@@ -325,37 +396,67 @@ class DistHotPath:
         return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
 
     # ------------------------------------------------------------------ second half
-    def map_and_enrich(self, kmer_labels, n_sg):
+    def map_and_enrich(self, kmer_labels, n_sg, gather_bins=False):
+        """K4-K6 over the local pieces.  Every rank ends up with all windows and their tests; `r.bins` holds the
+        LOCAL pieces' slot counts (gather_bins=True: rank 0 gets the whole-chromosome slot arrays instead)."""
         ctx, t, dist = self.ctx, self.torch, self.dist
-        mine = self.my_chroms
+        mine = self.local_pieces
         r = HotPathResult()
         tt = time.perf_counter()
+        ws, S = int(self.window_size), n_sg
+        woff = np.zeros(self.C + 1, np.int64)      # whole-genome window rows, as the single-GPU path lays them out
+        for c, n in enumerate(self.lengths_bp):
+            woff[c + 1] = woff[c] + (int(n) + ws - 1) // ws + 1
+        win_t = t.zeros((int(woff[-1]), S), dtype=t.int64, device=self.device)
         r.bins, r.n_mapped = [], 0
-        rows = np.zeros((0, 2 + n_sg), np.int64)       # (chromosome, window, counts...)
         if mine:
             ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
             all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
             r.bins = all_slots
             r.n_mapped = int(n_mapped.sum())
-            win, woff = ctx.stack_windows(self.bin_size, self.chunk_size, self.window_size,
-                                          [self.lengths_bp[i] for i in mine])
-            nz = np.flatnonzero(win.any(axis=1))
-            if nz.size:
-                chrom = np.searchsorted(woff, nz, side="right") - 1
-                gchrom = np.asarray(mine, np.int64)[chrom]
-                rows = np.concatenate([gchrom[:, None], (nz - woff[chrom])[:, None], win[nz].astype(np.int64)], axis=1)
+            ctx.stack_windows_dev(self.bin_size, self.chunk_size, ws, [woff[pc["chrom"]] for pc in mine],
+                                  [pc["start"] for pc in mine], win_t.data_ptr())
         tt = self._t("map+stack", tt)
-        allrows = self._all_gather_rows(rows, t.int64)
-        order = np.lexsort((allrows[:, 1], allrows[:, 0]))
-        allrows = allrows[order]
-        ws = self.window_size
-        r.coord_chrom, r.coord_win, r.coord_labels, r.coord_ws = allrows[:, 0], allrows[:, 1], self.labels, ws
-        r.window_counts = np.ascontiguousarray(allrows[:, 2:])
+        if self.world > 1:
+            dist.all_reduce(win_t)
         nm = t.tensor([r.n_mapped], dtype=t.int64, device=self.device)
         dist.all_reduce(nm)
         r.n_mapped = int(nm.item())
-        if self.rank == 0 and len(r.window_counts):
-            with np.errstate(all="ignore"):
-                r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)
-        tt = self._t("gather windows+enrich", tt)
+        win = win_t.cpu().numpy()
+        with np.errstate(all="ignore"):
+            pvals, argmin, sig, ratios = ctx.enrich_dev(win_t.data_ptr(), win.shape[0], S, self.max_pval, 0.5) \
+                if win.shape[0] else (np.zeros((0, S)), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros((0, S)))
+        nz = np.flatnonzero(win.any(axis=1))
+        chrom = np.searchsorted(woff, nz, side="right") - 1
+        r.coord_chrom, r.coord_win, r.coord_labels, r.coord_ws = chrom, nz - woff[chrom], self.labels, ws
+        r.window_counts = np.ascontiguousarray(win[nz])
+        r.pvals, r.argmin, r.sig, r.ratios = pvals[nz], argmin[nz], np.asarray(sig[nz], bool), ratios[nz]
+        tt = self._t("windows all-reduce+enrich", tt)
+        if gather_bins:
+            r.bins = self._gather_bins(r.bins, S)
         return r
+
+    def _gather_bins(self, local_bins, S):
+        """Whole-chromosome slot arrays on rank 0 (the `.subgenome.bin.count` lines): a piece that starts at a
+        multiple of the chunk size numbers its slots like the chromosome does, shifted by a constant."""
+        t = self.torch
+        rows = []
+        for pc, arr in zip(self.local_pieces, local_bins):
+            shift = pc["start"] // self.bin_size + (pc["start"] // self.chunk_size if self.chunk_size > 0 else 0)
+            nzr = np.flatnonzero(np.asarray(arr).any(axis=1))
+            if nzr.size:
+                rows.append(np.concatenate([np.full((nzr.size, 1), pc["chrom"], np.int64), (nzr + shift)[:, None],
+                                            np.asarray(arr)[nzr].astype(np.int64)], axis=1))
+        rows = np.concatenate(rows, axis=0) if rows else np.zeros((0, 2 + S), np.int64)
+        allrows = self._all_gather_rows(rows, t.int64, to_host=self.rank == 0)
+        if self.rank != 0:
+            return None
+        out = []
+        for c, n in enumerate(self.lengths_bp):
+            L = max(int(n), 1)
+            ns = (L + self.bin_size - 1) // self.bin_size + ((L + self.k - 1) // self.chunk_size + 1 if self.chunk_size > 0 else 1)
+            a = np.zeros((ns, S), np.int32)
+            sel = allrows[allrows[:, 0] == c]
+            np.add.at(a, sel[:, 1], sel[:, 2:].astype(np.int32))
+            out.append(a)
+        return out

@@ -80,6 +80,7 @@ class HotPath:
 
     # ---- second half: K4..K6 -----------------------------------------------
     def map_and_enrich(self, kmer_labels, n_sg):
+        """K4 labels -> K5 bin map -> window stack -> K6 enrichment."""
         ctx = self.ctx
         t = time.perf_counter()
         ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
@@ -89,17 +90,14 @@ class HotPath:
         t = self._t("map_bins", t)
         r.n_mapped = int(n_mapped.sum())
         r.bins = all_slots
-        # window stack on the device (Circos.stack_matrix semantics), then only the non-empty windows
-        win, woff = ctx.stack_windows(self.bin_size, self.chunk_size, self.window_size, self.lengths)
+        # window stack + Fisher on the device (Circos.stack_matrix -> Stats.enrich semantics) in one call: the window
+        # table never leaves HBM between the two; only the non-empty windows are rows (Circos.py:734-742)
+        win, woff, pvals, argmin, sig, ratios = ctx.stack_enrich(self.bin_size, self.chunk_size, self.window_size,
+                                                                 self.lengths, self.max_pval, 0.5)
         nz = np.flatnonzero(win.any(axis=1))
-        rows = [win[nz].astype(np.int64)]
         chrom = np.searchsorted(woff, nz, side="right") - 1
-        w = nz - woff[chrom]
-        r.coord_chrom, r.coord_win, r.coord_labels, r.coord_ws = chrom, w, self.labels, self.window_size
-        r.window_counts = np.concatenate(rows) if rows else np.zeros((0, n_sg), np.int64)
-        t = self._t("stack", t)
-        if len(r.window_counts):
-            with np.errstate(all="ignore"):
-                r.pvals, r.argmin, r.sig, r.ratios = ctx.enrich(r.window_counts, self.max_pval, 0.5)
+        r.coord_chrom, r.coord_win, r.coord_labels, r.coord_ws = chrom, nz - woff[chrom], self.labels, self.window_size
+        r.window_counts = win[nz].astype(np.int64)
+        r.pvals, r.argmin, r.sig, r.ratios = pvals[nz], argmin[nz], sig[nz].astype(bool), ratios[nz]
         t = self._t("enrich", t)
         return r

@@ -111,6 +111,17 @@ class OracleContext:
                 win[woff[c] + (local - chunk) * bin_size // window_size] += row
         return win, woff
 
+    def stack_enrich(self, bin_size, chunk_size, window_size, lengths, max_pval=0.05, min_ratio=0.5):
+        win, woff = self.stack_windows(bin_size, chunk_size, window_size, lengths)
+        W, S = win.shape
+        pvals, ratios = np.ones((W, S)), np.full((W, S), np.nan)
+        argmin, sig = np.zeros(W, np.int32), np.zeros(W, bool)
+        nz = np.flatnonzero(win.any(axis=1))
+        if nz.size:     # empty windows change no column total: testing the non-empty rows alone is the same thing
+            with np.errstate(all="ignore"):
+                pvals[nz], argmin[nz], sig[nz], ratios[nz] = self.enrich(win[nz])
+        return win, woff, pvals, argmin, sig, ratios
+
     def map_features(self, seqs):
         out = np.zeros((len(seqs), self.n_sg), np.int64)
         for f, s in enumerate(seqs):
@@ -165,6 +176,74 @@ class OracleDistContext(OracleContext):
             o = np.frombuffer((ctypes.c_uint32 * (2 * len(ov))).from_address(int(d_pairs)), np.uint32).reshape(-1, 2)
             o[:] = ov
         return int(len(ov))
+
+    @staticmethod
+    def _pairs(ptr, n):
+        import ctypes
+        if not n:
+            return np.zeros((0, 2), np.uint32)
+        return np.frombuffer((ctypes.c_uint32 * (2 * int(n))).from_address(int(ptr)), np.uint32).reshape(-1, 2)
+
+    def _decode(self, d_tab, d_ovf, n_ovf, slot_base, n):
+        """exact raw counts of a byte slice"""
+        arr = self._view_u8(d_tab, n).astype(np.uint32)
+        o = self._pairs(d_ovf, n_ovf)
+        loc = o[:, 0].astype(np.int64) - slot_base
+        ok = (loc >= 0) & (loc < n)
+        assert (arr[loc[ok]] == 255).all()
+        arr[loc[ok]] = o[ok, 1]
+        assert int((arr == 255).sum()) == int((o[ok, 1] == 255).sum())    # every saturated byte has its pair
+        return arr
+
+    def table_merge(self, d_dst, d_dst_ovf, n_dst_ovf, d_src, d_src_ovf, n_src_ovf, slot_base, n, d_out_ovf, cap):
+        tot = self._decode(d_dst, d_dst_ovf, n_dst_ovf, slot_base, n) + self._decode(d_src, d_src_ovf, n_src_ovf, slot_base, n)
+        self._view_u8(d_dst, n)[:] = np.minimum(tot, 255).astype(np.uint8)
+        big = np.flatnonzero(tot >= 255)
+        if big.size > cap:
+            raise MemoryError("overflow capacity")
+        if big.size:
+            o = self._pairs(d_out_ovf, big.size)
+            o[:, 0] = big + slot_base
+            o[:, 1] = tot[big]
+        return int(big.size)
+
+    def table_lengths(self, d_tab, d_ovf, n_ovf, slot_base, n, lower_count):
+        arr = self._decode(d_tab, d_ovf, n_ovf, slot_base, n).astype(np.int64)
+        keep = arr >= max(1, lower_count)
+        return int(arr[keep].sum()), int(keep.sum())
+
+    def stack_windows_dev(self, bin_size, chunk_size, window_size, win_off, seg_start, d_win):
+        import ctypes
+        big, off = self.last_map
+        S = self.n_sg
+        tot_rows = None
+        for c in range(self.n_chrom):
+            for slot in range(int(off[c]), int(off[c + 1])):
+                row = big[slot]
+                if not row.any():
+                    continue
+                local = slot - int(off[c])
+                chunk = 0
+                if chunk_size:
+                    j = 1
+                    while (j * chunk_size - (self.k - 1)) // bin_size + j <= local:
+                        chunk = j
+                        j += 1
+                pos = (int(seg_start[c]) if seg_start is not None else 0) + (local - chunk) * bin_size
+                w = int(win_off[c]) + pos // window_size
+                dst = np.frombuffer((ctypes.c_int64 * S).from_address(int(d_win) + 8 * S * w), np.int64)
+                dst += row
+
+    def enrich_dev(self, d_counts, W, S, max_pval=0.05, min_ratio=0.5):
+        import ctypes
+        win = np.frombuffer((ctypes.c_int64 * (W * S)).from_address(int(d_counts)), np.int64).reshape(W, S)
+        pvals, ratios = np.ones((W, S)), np.full((W, S), np.nan)
+        argmin, sig = np.zeros(W, np.int32), np.zeros(W, bool)
+        nz = np.flatnonzero(win.any(axis=1))
+        if nz.size:
+            with np.errstate(all="ignore"):
+                pvals[nz], argmin[nz], sig[nz], ratios[nz] = self.enrich(win[nz].copy())
+        return pvals, argmin, sig, ratios
 
     def genome_add_device(self, i, arr, n):
         self.genome_add(i, np.asarray(arr[:n], np.uint8))

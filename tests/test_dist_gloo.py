@@ -1,6 +1,7 @@
-"""Multi-GPU path on CPU: world_size 2 over gloo, oracle-backed contexts.  Checks that the
-chromosome-sharded count + slot-range-sharded filter (all_to_all of table slices) + sharded map
-reproduce the single-process result exactly."""
+"""Multi-GPU path on CPU: world_size 2 / 3 / 8 over gloo, oracle-backed contexts.  Checks that the
+position-sharded count (chromosomes cut into pieces with a k-1 halo) + slot-range-sharded filter
+(all_to_all of byte-table slices, exact merge of the pieces of one chromosome) + position-sharded map
++ all-reduced window table reproduce the single-process result exactly."""
 import os
 import sys
 
@@ -20,7 +21,7 @@ class _Gen:
         self.chroms = [dict(label=l, length=len(toy["seqs"][l])) for l in self.labels]
 
 
-def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None):
+def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None, shape=None):
     for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,20 +31,25 @@ def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None):
     from subphaser_amd import cluster
     from subphaser_amd.dist import DistHotPath
     from subphaser_amd.hotpath import HotPath
-    from toygenome import make_toy_genome
+    from toygenome import make_shape_genome, make_toy_genome
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        toy = make_toy_genome(seed=7, **(toy_kw or {}))
+        toy = make_shape_genome(shape) if shape else make_toy_genome(seed=7, **(toy_kw or {}))
+        n_sg = toy.get("n_sg", 2)
         gen = _Gen(toy)
         L = 3              # k = 9 -> 2^17 dense slots: small enough to ship as CPU tensors; k = 17 -> key-range path
         kw = dict(min_freq=30, bin_size=100, chunk_size=2000, window_size=2500)
         ctx = OracleDistContext()
         runner = DistHotPath(ctx, gen, dist, torch, k=k, lower_count=L, device=torch.device("cpu"), **kw, **(run_kw or {}))
-        ascii_ = [np.frombuffer(toy["seqs"][l].encode(), np.uint8) if i in runner.my_chroms else None
-                  for i, l in enumerate(gen.labels)]
+        ascii_ = [np.frombuffer(toy["seqs"][gen.labels[pc["chrom"]]].encode(), np.uint8)[pc["start"]:pc["stop"]]
+                  for pc in runner.local_pieces]
+        if not runner.sparse and world > 1:     # pieces are cut inside chromosomes and cover every start exactly once
+            allp = [p for r_ in runner.pieces for p in r_]
+            assert sum(b_ - a_ for _, a_, b_ in allp) == sum(c["length"] for c in gen.chroms)
+            assert len(allp) > len({c for c, _, _ in allp}) or world > len(gen.chroms)
         a = runner.count_and_filter(ascii_)
         # single-process reference on the same genome
         ref = OracleContext()
@@ -67,16 +73,18 @@ def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None):
         mat = _Mat()
         mat.labels, mat.keys, mat.k = gen.labels, rk, k
         mat.freqs = rc.astype(np.float64) / ref.lengths().astype(np.float64)
-        cl = cluster.Cluster(mat, n_clusters=2, sg_assigned=toy["sg_assigned"])
+        cl = cluster.Cluster(mat, n_clusters=n_sg, sg_assigned=toy["sg_assigned"])
         labels = cl.output_kmers(open(os.devnull, "w"), max_pval=0.05)
-        b = runner.map_and_enrich(labels, 2)
-        rb = hp.map_and_enrich(labels, 2)
-        assert b.coords == rb.coords
+        b = runner.map_and_enrich(labels, n_sg, gather_bins=True)
+        rb = hp.map_and_enrich(labels, n_sg)
+        assert b.coords == rb.coords and len(rb.coords) > 0
         assert (b.window_counts == rb.window_counts).all()
         assert b.n_mapped == rb.n_mapped
+        assert np.allclose(b.pvals, rb.pvals, rtol=0, atol=0)      # every rank holds every window and its test
+        assert (b.sig == rb.sig).all() and (b.argmin == rb.argmin).all()
         if rank == 0:
-            assert np.allclose(b.pvals, rb.pvals, rtol=0, atol=0)
-            assert (b.sig == rb.sig).all()
+            for x, y in zip(b.bins, rb.bins):
+                assert x.shape == y.shape and (x == y).all()
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -92,14 +100,14 @@ def test_lpt_assign_balances():
         assert max(loads) <= sum(lens) / n * 1.15 + 1
 
 
-def _spawn(tmp_path, world, k, toy_kw=None, run_kw=None):
+def _spawn(tmp_path, world, k, toy_kw=None, run_kw=None, shape=None):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), k, toy_kw, run_kw), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), k, toy_kw, run_kw, shape), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / ("ok%d" % r)).exists()
 
@@ -117,7 +125,17 @@ def test_three_rank_key_range_exchange_over_gloo(tmp_path):
     _spawn(tmp_path, 3, 21)
 
 
-def test_two_rank_wire_format_overflow_over_gloo(tmp_path):
-    """k = 6 on a larger toy genome: counts >= 255 exist, so the byte wire format ships overflow pairs;
-    a 4-pair overflow buffer forces the grow-and-redo path."""
-    _spawn(tmp_path, 2, 6, dict(chrom_len=150000, copies=200), dict(ovf_cap=4))
+def test_three_rank_hot_path_over_gloo(tmp_path):
+    """three ranks, six chromosomes: two chromosomes are cut, their pieces' tables are merged at the filter"""
+    _spawn(tmp_path, 3, 9)
+
+
+def test_two_rank_overflow_lists_over_gloo(tmp_path):
+    """k = 6 on a larger toy genome: counts >= 255 exist, so the byte tables travel with overflow pairs and the
+    merge of the cut chromosome's two pieces has to add saturated bytes exactly."""
+    _spawn(tmp_path, 2, 6, dict(chrom_len=150000, copies=200))
+
+
+def test_eight_rank_wheat_shape_over_gloo(tmp_path):
+    """21 chromosomes / 7 sets x 3 (the wheat structure) on 8 ranks: seven chromosomes are cut"""
+    _spawn(tmp_path, 8, 9, shape="wheat")
