@@ -188,6 +188,9 @@ def main():
         n_dumped = int(tdump.item()) // world      # one rank's slot / key range
 
     if rank != 0:
+        if runner is not None:
+            a = b = None
+            runner.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -271,6 +274,9 @@ def main():
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
                                   for k_, v in (hp if runner is None else runner).wall.items()},
     }
+    if runner is not None:
+        a = b = None
+        runner.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

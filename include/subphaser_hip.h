@@ -235,6 +235,10 @@ int sp_synth_chrom_range(sp_ctx *ctx, uint8_t *d_out, int64_t len, int64_t start
  * (pageable) buffers are accepted everywhere but copy several times slower.     */
 int sp_host_alloc(sp_ctx *ctx, int64_t bytes, void **h_ptr);
 int sp_host_free(sp_ctx *ctx, void *h_ptr);
+/* page-lock memory the caller already owns (e.g. a POSIX shared-memory segment the ranks of one node
+ * assemble the matrix in: every rank copies ITS rows over ITS PCIe link); undone by sp_host_unregister */
+int sp_host_register(sp_ctx *ctx, void *h_ptr, int64_t bytes);
+int sp_host_unregister(sp_ctx *ctx, void *h_ptr);
 /* device memory helpers so a non-torch caller can stage buffers */
 int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr);
 int sp_dev_free(sp_ctx *ctx, void *d_ptr);

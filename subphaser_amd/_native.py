@@ -26,7 +26,7 @@ SYMBOLS = [
     "sp_enrich", "sp_enrich_dev",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
-    "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
+    "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_host_register", "sp_host_unregister", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
 ]
 
 
@@ -103,6 +103,8 @@ def load():
     L.sp_dev_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_dev_free.argtypes = [vp, vp]
     L.sp_dev_copy_to_host.argtypes = [vp, vp, vp, i64]
+    L.sp_host_register.argtypes = [vp, vp, i64]
+    L.sp_host_unregister.argtypes = [vp, vp]
     L.sp_dev_copy_from_host.argtypes = [vp, vp, vp, i64]
     for name in SYMBOLS:
         if name not in ("sp_last_error", "sp_stream"):
@@ -529,6 +531,17 @@ class Context:
         out = np.empty(nbytes, np.uint8)
         self._ck(self.L.sp_dev_copy_to_host(self.h, _p(out), C.c_void_p(ptr + offset), int(nbytes)))
         return out
+
+    def host_register(self, h_ptr, nbytes):
+        self._ck(self.L.sp_host_register(self.h, C.c_void_p(int(h_ptr)), int(nbytes)))
+
+    def host_unregister(self, h_ptr):
+        self._ck(self.L.sp_host_unregister(self.h, C.c_void_p(int(h_ptr))))
+
+    def dev_to_host_ptr(self, h_ptr, d_ptr, nbytes):
+        """device -> host copy into memory given by ADDRESS (e.g. a registered shared-memory segment)"""
+        if nbytes:
+            self._ck(self.L.sp_dev_copy_to_host(self.h, C.c_void_p(int(h_ptr)), C.c_void_p(int(d_ptr)), int(nbytes)))
 
     def host_to_dev(self, ptr, arr, offset=0):
         arr = np.ascontiguousarray(arr)

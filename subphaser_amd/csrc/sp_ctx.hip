@@ -369,6 +369,17 @@ int sp_host_free(sp_ctx *ctx, void *h_ptr) {
     SP_HIP(ctx, hipHostFree(h_ptr));
     return SP_OK;
 }
+int sp_host_register(sp_ctx *ctx, void *h_ptr, int64_t bytes) {
+    if (!ctx || !h_ptr || bytes <= 0) return sp_fail(ctx, SP_EINVAL, "sp_host_register: bad arguments");
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    SP_HIP(ctx, hipHostRegister(h_ptr, (size_t)bytes, hipHostRegisterPortable));
+    return SP_OK;
+}
+int sp_host_unregister(sp_ctx *ctx, void *h_ptr) {
+    if (!ctx || !h_ptr) return SP_EINVAL;
+    SP_HIP(ctx, hipHostUnregister(h_ptr));
+    return SP_OK;
+}
 int sp_dev_alloc(sp_ctx *ctx, int64_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr || bytes < 0) return sp_fail(ctx, SP_EINVAL, "sp_dev_alloc: bad arguments");
     SP_HIP(ctx, hipSetDevice(ctx->device));

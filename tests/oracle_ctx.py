@@ -245,6 +245,17 @@ class OracleDistContext(OracleContext):
                 pvals[nz], argmin[nz], sig[nz], ratios[nz] = self.enrich(win[nz].copy())
         return pvals, argmin, sig, ratios
 
+    def host_register(self, h_ptr, nbytes):
+        pass
+
+    def host_unregister(self, h_ptr):
+        pass
+
+    def dev_to_host_ptr(self, h_ptr, d_ptr, nbytes):
+        import ctypes
+        if nbytes:
+            ctypes.memmove(int(h_ptr), int(d_ptr), int(nbytes))
+
     def genome_add_device(self, i, arr, n):
         self.genome_add(i, np.asarray(arr[:n], np.uint8))
 

@@ -51,6 +51,12 @@ def _worker(rank, world, port, out_dir, k=9, toy_kw=None, run_kw=None, shape=Non
             assert sum(b_ - a_ for _, a_, b_ in allp) == sum(c["length"] for c in gen.chroms)
             assert len(allp) > len({c for c, _, _ in allp}) or world > len(gen.chroms)
         a = runner.count_and_filter(ascii_)
+        if (run_kw or {}).get("shared_rows"):     # the bench path: rank 0 reads the matrix from the shared segment
+            a0 = runner.count_and_filter(ascii_, host_rows_on_all_ranks=False)
+            if rank == 0:
+                assert (a0.keys == a.keys).all() and (a0.counts == a.counts).all()
+            a0 = None
+            runner.close()
         # single-process reference on the same genome
         ref = OracleContext()
         ref.genome_reset(len(gen.labels))
@@ -126,8 +132,9 @@ def test_three_rank_key_range_exchange_over_gloo(tmp_path):
 
 
 def test_three_rank_hot_path_over_gloo(tmp_path):
-    """three ranks, six chromosomes: two chromosomes are cut, their pieces' tables are merged at the filter"""
-    _spawn(tmp_path, 3, 9)
+    """three ranks, six chromosomes: two chromosomes are cut, their pieces' tables are merged at the filter;
+    the matrix is also assembled in the shared host segment (every rank writes its own rows)"""
+    _spawn(tmp_path, 3, 9, run_kw=dict(shared_rows=True))
 
 
 def test_two_rank_overflow_lists_over_gloo(tmp_path):

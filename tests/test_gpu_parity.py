@@ -863,3 +863,27 @@ def test_synth_baseline_shapes_vs_oracle(gpu_ctx, config, scale):
     assert (b.argmin == o.argmin).all() and (b.sig == o.sig).all() and b.sig.any()
     assert np.allclose(b.pvals, o.pvals, rtol=1e-6, atol=1e-6)      # north star: p-values within 1e-6
     assert (b.ratios == o.ratios).all() or np.allclose(b.ratios, o.ratios, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def test_shared_host_segment_copy(gpu_ctx):
+    """The multi-GPU matrix hand-over: a POSIX shared-memory segment is page-locked (sp_host_register) and the
+    device rows are copied straight into it at a row offset (what every rank does with its own rows)."""
+    import ctypes
+    from multiprocessing import shared_memory
+    rng = np.random.RandomState(3)
+    rows = rng.randint(0, 1 << 31, size=(5000, 21)).astype(np.uint32)
+    d = gpu_ctx.dev_alloc(rows.nbytes)
+    shm = shared_memory.SharedMemory(create=True, size=4 * rows.nbytes)
+    try:
+        gpu_ctx.host_to_dev(d, rows)
+        addr = ctypes.addressof(ctypes.c_char.from_buffer(shm.buf))
+        gpu_ctx.host_register(addr, 4 * rows.nbytes)
+        gpu_ctx.dev_to_host_ptr(addr + rows.nbytes, d, rows.nbytes)
+        got = np.frombuffer(shm.buf, np.uint32, rows.size, rows.nbytes).reshape(rows.shape).copy()
+        gpu_ctx.host_unregister(addr)
+        assert (got == rows).all()
+    finally:
+        gpu_ctx.dev_free(d)
+        got = None
+        shm.close()
+        shm.unlink()
