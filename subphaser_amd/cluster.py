@@ -34,9 +34,28 @@ def load_matrix(datafile):
     return colnames, rownames, np.array(data, np.float64).reshape(len(rownames), len(colnames))
 
 
+def relabel_by_chromosome_order(chrs, raw_labels):
+    """Cluster ids renumbered 0, 1, 2 ... in the order in which they first occur when the chromosomes are
+    walked in sorted-name order (what the reference's sort_subgenomes produces, Cluster.py:119-127), as
+    array operations: the first position of every id in the name-sorted label vector ranks the ids."""
+    raw = np.asarray(raw_labels)
+    if raw.size != len(chrs):
+        raise ValueError("{} labels for {} chromosomes".format(raw.size, len(chrs)))
+    by_name = np.argsort(np.asarray(chrs, dtype=object), kind="stable")
+    ids, first, inverse = np.unique(raw[by_name], return_index=True, return_inverse=True)
+    rank_of_id = np.empty(ids.size, np.int64)
+    rank_of_id[np.argsort(first, kind="stable")] = np.arange(ids.size)
+    out = np.empty(raw.size, np.int64)
+    out[by_name] = rank_of_id[inverse]
+    return out
+
+
 class Cluster:
+    """Chromosome -> subgenome assignment (k-means on the Z-normalised matrix, or the `-sg_assigned` table),
+    bootstrap support and the subgenome-specific k-mer test."""
+
     def __init__(self, data, n_clusters, sg_prefix="SG", sg_assigned={}, re_assign=True, bootstrap=False,
-                 replicates=1000, jackknife=80, **kargs):
+                 replicates=1000, jackknife=80, seed=None, **kargs):
         """data: path of a `.kmer.mat` file or a FilteredMatrix (jellyfish.filter result)."""
         if isinstance(data, str):
             self.chrs, kmers, self.raw_data = load_matrix(data)
@@ -44,58 +63,67 @@ class Cluster:
             self.keys = kmerlib.encode_many(kmers)
         else:
             self.chrs, self.raw_data, self.keys, self.k = list(data.labels), data.freqs, data.keys, data.k
-        self.n_clusters, self.sg_prefix = n_clusters, sg_prefix
+        self.sg_prefix, self.seed = sg_prefix, seed
+        self.n_clusters = len(set(sg_assigned.values())) if sg_assigned else n_clusters
         if sg_assigned:
             logger.info("Skip k-means clustering")
-            labels = [sg_assigned[c] for c in self.chrs]
-            self.n_clusters = len(set(sg_assigned.values()))
-            self.d_sg = self.assign_subgenomes(labels=labels) if re_assign else sg_assigned
-            if not re_assign:
-                self.sg_names = sorted(set(sg_assigned.values()))
+            given = [sg_assigned[c] for c in self.chrs]
+            if re_assign:
+                self._name(relabel_by_chromosome_order(self.chrs, given))
+            else:
+                self.d_sg, self.sg_names = sg_assigned, sorted(set(sg_assigned.values()))
+                self.labels = relabel_by_chromosome_order(self.chrs, given)
         else:
-            self.kmean = self.fit(self.normalize_data(self.raw_data.transpose()), n_clusters)
-            self.d_sg = self.assign_subgenomes()
-        self.d_bs = {c: "NA" for c in self.chrs}
+            self._name(relabel_by_chromosome_order(self.chrs, self._kmeans(self.zscores()).labels_))
+        self.d_bs = self.bootstrap(replicates, jackknife) if bootstrap and replicates and replicates > 0 \
+            else {c: "NA" for c in self.chrs}
 
-    @staticmethod
-    def normalize_data(data, axis=0):
+    # chromosomes x k-mers, every k-mer column Z-normalised (Cluster.py:24-26, 78-82)
+    def zscores(self, freqs=None):
+        x = (self.raw_data if freqs is None else freqs).T
         with np.errstate(all="ignore"):
-            return (data - data.mean(axis=axis)) / data.std(axis=axis)
+            return (x - x.mean(axis=0)) / x.std(axis=0)
 
-    def fit(self, data, n_clusters, **kargs):
+    normalize_data = staticmethod(lambda data, axis=0: (data - data.mean(axis=axis)) / data.std(axis=axis))
+
+    def _kmeans(self, points):
         from sklearn.cluster import KMeans
-        kmean = KMeans(n_clusters=n_clusters)
-        kmean.fit(data)
-        return kmean
+        return KMeans(n_clusters=self.n_clusters, random_state=self.seed).fit(points)
 
-    def sort_subgenomes(self, labels):
-        assert len(self.chrs) == len(labels)
-        d_map = {}
-        for label, _ in sorted(zip(labels, self.chrs), key=lambda x: x[1]):
-            if label not in d_map:
-                d_map[label] = (max(d_map.values()) + 1) if d_map else 0
-        return [d_map[label] for label in labels]
+    def _name(self, labels):
+        width = len(str(self.n_clusters))
+        self.labels = np.asarray(labels, np.int64)
+        names = ["{}{:0>{}d}".format(self.sg_prefix, int(l) + 1, width) for l in self.labels]
+        self.d_sg = OrderedDict(zip(self.chrs, names))
+        self.sg_names = sorted(set(names))
 
-    def assign_subgenomes(self, base=1, labels=None):
-        if labels is None:
-            labels = self.kmean.labels_
-        fmt = "{{}}{{:0>{}d}}".format(len(str(self.n_clusters)))
-        self.labels = labels = self.sort_subgenomes(list(labels))
-        d_sg = OrderedDict((c, fmt.format(self.sg_prefix, lab + base)) for lab, c in zip(labels, self.chrs))
-        self.sg_names = sorted(set(d_sg.values()))
-        return d_sg
+    def bootstrap(self, replicates=1000, jackknife=80):
+        """Support of every chromosome's assignment: share of `replicates` k-means runs, each on `replicates`
+        k-mers drawn with replacement (the reference resamples n_samples=replicates and ignores the jackknife
+        size it computes, Cluster.py:85-90), that give the chromosome the same renumbered cluster id."""
+        logger.info("Performing bootstrap of {} replicates, with each replicate resampling {}% data "
+                    "with replacement".format(replicates, jackknife))
+        z = self.zscores()                                   # C x M
+        rng = np.random.RandomState(self.seed)
+        M = z.shape[1]
+        agree = np.zeros(len(self.chrs), np.int64)
+        for _ in range(int(replicates)):
+            cols = rng.randint(0, M, size=int(replicates))
+            rep = relabel_by_chromosome_order(self.chrs, self._kmeans(z[:, cols]).labels_)
+            agree += rep == self.labels
+        return {c: int(100 * a / replicates) for c, a in zip(self.chrs, agree.tolist())}
 
     def output_subgenomes(self, fout=sys.stdout):
-        print("\t".join(["#chrom", "subgenome", "bootstrap"]), file=fout)
-        for c, sg in sorted(self.d_sg.items(), key=lambda x: x[1]):
-            print("\t".join(map(str, [c, sg, self.d_bs[c]])), file=fout)
+        fout.write("#chrom\tsubgenome\tbootstrap\n")
+        for c in sorted(self.d_sg, key=lambda x: self.d_sg[x]):      # stable: by subgenome, input order inside
+            fout.write("{}\t{}\t{}\n".format(c, self.d_sg[c], self.d_bs[c]))
 
     def output_kmers(self, fout=sys.stdout, max_pval=0.05, ncpu=4, method="map", test_method="ttest_ind"):
         """Student t-test (pooled variance, two-sided) between the highest-mean and the
         second-highest-mean subgenome groups of every k-mer; keeps p <= max_pval.
         Returns KmerLabels (array form of the reference's d_ksg dict)."""
-        if test_method != "ttest_ind":
-            raise ValueError("only ttest_ind is implemented in this build")
+        if test_method not in TEST_METHODS:
+            raise ValueError("test_method must be one of {}".format(TEST_METHODS))
         from scipy import special
         sgs = sorted(set(self.d_sg.values()))
         groups = [[i for i, c in enumerate(self.chrs) if self.d_sg[c] == sg] for sg in sgs]
@@ -112,8 +140,10 @@ class Cluster:
                 if a == b:
                     continue
                 sel = np.flatnonzero((top == a) & (second == b))
-                if sel.size:
+                if sel.size and test_method == "ttest_ind":
                     pvals[sel] = _ttest_ind(X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])], special)
+                elif sel.size:      # the other scipy tests the reference accepts (Cluster.py:178-194), row by row
+                    pvals[sel] = _scipy_rows(test_method, X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])])
         print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
         with np.errstate(invalid="ignore"):
             keep = np.flatnonzero(~(pvals > max_pval))      # `if pvalue > max_pval: continue` keeps NaN
@@ -128,6 +158,25 @@ class Cluster:
         write_chunks(fout, len(kkeys), fmt)
         canon = kmerlib.canonical(self.keys[keep], self.k)
         return KmerLabels(canon, top[keep].astype(np.uint8), sgs, self.k)
+
+
+TEST_METHODS = ("ttest_ind", "kruskal", "wilcoxon", "mannwhitneyu")
+
+
+def _scipy_rows(name, a, b):
+    """p-value of scipy.stats.<name>(a[i], b[i]) for every row (the reference calls the test per k-mer)."""
+    from scipy import stats as st
+    test = getattr(st, name)
+    out = np.empty(a.shape[0])
+    for i in range(a.shape[0]):
+        try:
+            out[i] = test(a[i], b[i])[1]
+        except ValueError as e:
+            if "identical" in str(e) or "zero" in str(e):     # all values equal: no evidence of a difference
+                out[i] = 1.0
+            else:
+                raise
+    return out
 
 
 def _ttest_ind(a, b, special):

@@ -1,12 +1,13 @@
-"""`subphaser` command line + pipeline for modules 1-2 (count -> matrix/filter ->
-cluster -> bin map -> window enrichment -> custom features).
+"""`subphaser` command line for modules 1-2: ingest -> count -> matrix/filter -> cluster -> bin map ->
+window enrichment -> custom features, on the MI355X hot path.
 
-Mirrors the flag surface and step order of the reference's Pipeline.run()
-(subphaser/__main__.py:29-248 argparse, :250-544 run) for the hot path only.
-Flags of the LTR / Circos groups (modules 3-4) are accepted so existing command
-lines keep working, and are reported as skipped: those modules stay with the
-reference and consume the files written here unchanged (`.kmer.mat`,
-`.subgenome.bin.count`, `.bin.enrich`, `.bin.group`, checkpoints `*.ok`).
+What is kept from the reference is its CONTRACT: the flag surface (subphaser/__main__.py:29-248), the names
+and formats of the files under `-o` / `-tmpdir` and the checkpoint files, so that
+modules 3-4 of the reference (LTR, circos) and existing command lines keep working on these outputs.
+How the run is organised is this build's own: a `Layout` that owns every path, five stages with explicit
+inputs and outputs, and a second half that never leaves the device between the bin map, the window stack
+and the Fisher tests -- `.subgenome.bin.count` is written FROM the device arrays as an output, it is not
+parsed back (the reference re-reads it with Circos.stack_matrix before it can enrich).
 """
 import argparse
 import os
@@ -15,302 +16,332 @@ import shutil
 import sys
 from collections import Counter, OrderedDict
 
+import numpy as np
+
 from . import REFERENCE_VERSION, __version__
-from . import circos as Circos
-from . import seqs as Seqs
-from . import stats as Stats
-from .cluster import Cluster
+from . import circos, seqs, stats
+from .cluster import TEST_METHODS, Cluster
 from .config import SGConfig, check_duplicates, parse_idmap
 from .jellyfish import JellyfishDumps, plot_histogram, run_jellyfish_dumps
-from .runtime import logger
+from .runtime import get_context, logger
 
 NCPU = len(os.sched_getaffinity(0))
+BIN_SIZE, CHUNK_SIZE, FEATURE_BIN = 10000, 10_000_000, 10_000_000   # Seqs.map_kmer3 defaults / __main__.py:509
+
+# ---------------------------------------------------------------------------------------------------- CLI
+# (group title, group description, [(flags, argparse keywords)]) -- the reference's options for modules 1-2;
+# options of modules 3-4 are accepted (and ignored) so that one command line serves both programs.
+_STR = dict(type=str, metavar="STR", default=None)
+_FLAG = dict(action="store_true", default=False)
+CLI = [
+    ("Input", "Input genome and config files", [
+        (("-i", "-genomes"), dict(dest="genomes", nargs="+", metavar="GENOME", required=True)),
+        (("-c", "-sg_cfgs"), dict(dest="sg_cfgs", nargs="+", metavar="CFGFILE", required=True)),
+        (("-labels",), dict(nargs="+", type=str, metavar="LABEL")),
+        (("-no_label",), _FLAG),
+        (("-target",), dict(type=str, metavar="FILE", default=None)),
+        (("-sg_assigned",), dict(type=str, metavar="FILE", default=None)),
+        (("-sep",), dict(type=str, metavar="STR", default="|")),
+        (("-custom_features",), dict(nargs="+", metavar="FASTA", default=None)),
+    ]),
+    ("Output", None, [
+        (("-pre", "-prefix"), dict(dest="prefix", metavar="STR", default=None)),
+        (("-o", "-outdir"), dict(dest="outdir", metavar="DIR", default="phase-results")),
+        (("-tmpdir",), dict(type=str, metavar="DIR", default="tmp")),
+        (("-colors",), dict(dest="colors", metavar="HEX,HEX[,...]", default=None)),
+    ]),
+    ("Kmer", "Options to count and filter kmers", [
+        (("-k",), dict(type=int, metavar="INT", default=15)),
+        (("-f", "-min_fold"), dict(dest="min_fold", type=float, metavar="FLOAT", default=2)),
+        (("-q", "-min_freq"), dict(dest="min_freq", type=int, metavar="INT", default=200)),
+        (("-baseline",), dict(type=int, default=1)),
+        (("-ratio",), dict(type=float, default=1)),
+        (("-lower_count",), dict(type=int, metavar="INT", default=3)),
+        (("-min_prop",), dict(type=float, metavar="FLOAT", default=None)),
+        (("-max_freq",), dict(type=int, metavar="INT", default=1e9)),
+        (("-max_prop",), dict(type=float, metavar="FLOAT", default=None)),
+        (("-low_mem",), dict(action="store_true", default=None)),
+        (("-by_count",), dict(help="parsed, never used: as in the reference (__main__.py:98 vs :422-426)", **_FLAG)),
+        (("-re_filter",), _FLAG),
+    ]),
+    ("Cluster", "Options for clustering to phase", [
+        (("-nsg",), dict(type=int, metavar="INT", default=None)),
+        (("-replicates",), dict(type=int, metavar="INT", default=1000)),
+        (("-jackknife",), dict(type=float, metavar="FLOAT", default=50)),
+        (("-max_pval",), dict(type=float, metavar="FLOAT", default=0.05)),
+        (("-test_method",), dict(choices=list(TEST_METHODS), default="ttest_ind")),
+        (("-figfmt",), dict(type=str, choices=["pdf", "png"], default="pdf")),
+        (("-heatmap_colors",), dict(nargs="+", metavar="COLOR", default=("green", "black", "red"))),
+        (("-heatmap_options",), dict(metavar="STR", default="")),
+        (("-just_core",), _FLAG),
+    ]),
+    ("LTR / Circos", "accepted for command-line compatibility; modules 3-4 stay with the reference",
+     [((o,), _STR) for o in ("-ltr_finder_options", "-ltr_harvest_options", "-tesorter_options", "-trimal_options",
+                             "-tree_method", "-tree_options", "-ggtree_options", "-aligner", "-aligner_options",
+                             "-chr_ordered")]
+     + [((o,), dict(nargs="+", default=None)) for o in ("-ltr_detectors", "-ltr_domains", "-alt_cfgs")]
+     + [((o,), _FLAG) for o in ("-disable_ltr", "-all_ltr", "-intact_ltr", "-exclude_exchanges", "-non_specific",
+                                "-disable_ltrtree", "-disable_circos", "-disable_blocks")]
+     + [(("-mu",), dict(type=float, default=13e-9)), (("-subsample",), dict(type=int, default=1000)),
+        (("-window_size",), dict(type=int, metavar="INT", default=1000000)),
+        (("-min_block",), dict(type=int, default=100000))]),
+    ("Other options", None, [
+        (("-p", "-ncpu"), dict(dest="ncpu", type=int, metavar="INT", default=NCPU)),
+        (("-max_memory",), dict(type=str, metavar="MEM", default=None)),
+        (("-cleanup",), _FLAG),
+        (("-overwrite",), _FLAG),
+        (("-engine",), dict(type=int, default=0, help="k-mer counting engine (0 auto, 1 atomic table, 2 LDS radix)")),
+        (("-write_dumps",), dict(help="also write jellyfish-style text dumps {chrom}_{k}.fa", **_FLAG)),
+        (("-bootstrap_seed",), dict(type=int, default=None, help="seed of k-means and of the bootstrap resampling")),
+    ]),
+]
 
 
 def makeArgparse(argv=None):
-    p = argparse.ArgumentParser(
-        prog="subphaser",
-        formatter_class=argparse.RawDescriptionHelpFormatter,
+    parser = argparse.ArgumentParser(
+        prog="subphaser", formatter_class=argparse.RawDescriptionHelpFormatter,
         description="Phase subgenomes of an allopolyploid or hybrid based on repetitive kmers "
-                    "(MI355X-native k-mer counting / enrichment; modules 1-2 of SubPhaser).")
-    g = p.add_argument_group("Input", "Input genome and config files")
-    g.add_argument("-i", "-genomes", dest="genomes", nargs="+", metavar="GENOME", required=True)
-    g.add_argument("-c", "-sg_cfgs", dest="sg_cfgs", nargs="+", required=True, metavar="CFGFILE")
-    g.add_argument("-labels", nargs="+", type=str, metavar="LABEL")
-    g.add_argument("-no_label", action="store_true", default=False)
-    g.add_argument("-target", default=None, type=str, metavar="FILE")
-    g.add_argument("-sg_assigned", default=None, type=str, metavar="FILE")
-    g.add_argument("-sep", default="|", type=str, metavar="STR")
-    g.add_argument("-custom_features", nargs="+", metavar="FASTA", default=None)
-    g = p.add_argument_group("Output")
-    g.add_argument("-pre", "-prefix", default=None, dest="prefix", metavar="STR")
-    g.add_argument("-o", "-outdir", default="phase-results", dest="outdir", metavar="DIR")
-    g.add_argument("-tmpdir", default="tmp", type=str, metavar="DIR")
-    g.add_argument("-colors", default=None, dest="colors", metavar="HEX,HEX[,...]")
-    g = p.add_argument_group("Kmer", "Options to count and filter kmers")
-    g.add_argument("-k", type=int, default=15, metavar="INT")
-    g.add_argument("-f", "-min_fold", type=float, default=2, metavar="FLOAT", dest="min_fold")
-    g.add_argument("-q", "-min_freq", type=int, default=200, metavar="INT", dest="min_freq")
-    g.add_argument("-baseline", type=int, default=1)
-    g.add_argument("-ratio", type=float, default=1)
-    g.add_argument("-lower_count", type=int, default=3, metavar="INT")
-    g.add_argument("-min_prop", type=float, default=None, metavar="FLOAT")
-    g.add_argument("-max_freq", type=int, default=1e9, metavar="INT")
-    g.add_argument("-max_prop", type=float, default=None, metavar="FLOAT")
-    g.add_argument("-low_mem", action="store_true", default=None)
-    g.add_argument("-by_count", action="store_true", default=False,
-                   help="parsed but never forwarded to the filter, as in the reference (__main__.py:98 vs :422-426)")
-    g.add_argument("-re_filter", action="store_true", default=False)
-    g = p.add_argument_group("Cluster", "Options for clustering to phase")
-    g.add_argument("-nsg", type=int, default=None, metavar="INT")
-    g.add_argument("-replicates", type=int, default=1000, metavar="INT")
-    g.add_argument("-jackknife", type=float, default=50, metavar="FLOAT")
-    g.add_argument("-max_pval", type=float, default=0.05, metavar="FLOAT")
-    g.add_argument("-test_method", default="ttest_ind", choices=["ttest_ind", "kruskal", "wilcoxon", "mannwhitneyu"])
-    g.add_argument("-figfmt", default="pdf", type=str, choices=["pdf", "png"])
-    g.add_argument("-heatmap_colors", nargs="+", default=("green", "black", "red"), metavar="COLOR")
-    g.add_argument("-heatmap_options", metavar="STR", default="")
-    g.add_argument("-just_core", action="store_true", default=False)
-    g = p.add_argument_group("LTR / Circos", "accepted for command-line compatibility; modules 3-4 stay with the reference")
-    g.add_argument("-disable_ltr", action="store_true", default=False)
-    for opt in ("-ltr_finder_options", "-ltr_harvest_options", "-tesorter_options", "-trimal_options",
-                "-tree_method", "-tree_options", "-ggtree_options", "-aligner", "-aligner_options", "-chr_ordered"):
-        g.add_argument(opt, default=None, metavar="STR")
-    for opt in ("-ltr_detectors", "-ltr_domains", "-alt_cfgs"):
-        g.add_argument(opt, nargs="+", default=None)
-    for opt in ("-all_ltr", "-intact_ltr", "-exclude_exchanges", "-non_specific", "-disable_ltrtree",
-                "-disable_circos", "-disable_blocks"):
-        g.add_argument(opt, action="store_true", default=False)
-    g.add_argument("-mu", type=float, default=13e-9)
-    g.add_argument("-subsample", type=int, default=1000)
-    g.add_argument("-window_size", type=int, default=1000000, metavar="INT")
-    g.add_argument("-min_block", type=int, default=100000)
-    g = p.add_argument_group("Other options")
-    g.add_argument("-p", "-ncpu", type=int, default=NCPU, metavar="INT", dest="ncpu")
-    g.add_argument("-max_memory", type=str, default=None, metavar="MEM")
-    g.add_argument("-cleanup", action="store_true", default=False)
-    g.add_argument("-overwrite", action="store_true", default=False)
-    g.add_argument("-engine", type=int, default=0, help="k-mer counting engine (0 auto, 1 atomic table, 2 LDS radix)")
-    g.add_argument("-write_dumps", action="store_true", default=False,
-                   help="also write jellyfish-style text dumps {chrom}_{k}.fa")
-    g.add_argument("-v", "-version", action="version",
-                   version="subphaser_amd {} (interface of SubPhaser {})".format(__version__, REFERENCE_VERSION))
-    args = p.parse_args(argv)
-    if args.prefix is not None:          # __main__.py:242-245
+                    "(MI355X-native k-mer counting / enrichment; modules 1-2 of SubPhaser).\n"
+                    "Limits of the dense path (k <= 15): at most 560 chromosomes in the filter, 8 subgenome columns "
+                    "per config line unless -baseline is 1 or -1, 32 subgenomes in the enrichment.")
+    for title, desc, options in CLI:
+        group = parser.add_argument_group(title, desc)
+        for flags, kw in options:
+            group.add_argument(*flags, **kw)
+    parser.add_argument("-v", "-version", action="version",
+                        version="subphaser_amd {} (interface of SubPhaser {})".format(__version__, REFERENCE_VERSION))
+    args = parser.parse_args(argv)
+    if args.prefix is not None:          # the prefix goes in front of directory names AND file names (__main__.py:242-245)
         args.prefix = args.prefix.replace("/", "_")
-        args.outdir = args.prefix + args.outdir
-        args.tmpdir = args.prefix + args.tmpdir
+        args.outdir, args.tmpdir = args.prefix + args.outdir, args.prefix + args.tmpdir
     return args
 
 
+# ------------------------------------------------------------------------------------------- paths, checkpoints
+class Layout:
+    """Every path of a run.  `out("x")` = <outdir>/<prefix>k15_q200_f2.x, `ckp(name)` = <tmpdir>/<prefix>name.ok"""
+
+    def __init__(self, outdir, tmpdir, prefix, k, min_freq, min_fold):
+        self.outdir, self.tmpdir = os.path.realpath(outdir) + "/", os.path.realpath(tmpdir) + "/"
+        os.makedirs(self.outdir, exist_ok=True)
+        os.makedirs(self.tmpdir, exist_ok=True)
+        self.out_prefix = self.outdir + (prefix or "")
+        self.tmp_prefix = self.tmpdir + (prefix or "")
+        self.basename = "k{}_q{}_f{}".format(k, min_freq, min_fold)
+
+    def out(self, ext):
+        return "{}{}.{}".format(self.out_prefix, self.basename, ext)
+
+    def ckp(self, file_or_name):
+        return "{}{}.ok".format(self.tmp_prefix, os.path.basename(file_or_name))
+
+    @property
+    def chromdir(self):
+        return self.tmp_prefix + "chromosomes/"
+
+
 def mk_ckp(ckpfile, *data):
-    """Checkpoint = sequentially pickled objects (small_tools.py:40-46)."""
+    """A checkpoint is the objects pickled one after the other (the reference's small_tools.mk_ckp)."""
     with open(ckpfile, "wb") as f:
-        for d in data:
-            pickle.dump(d, f)
+        for obj in data:
+            pickle.dump(obj, f)
     logger.info("New check point file: `{}`".format(ckpfile))
 
 
 def check_ckp(ckpfile):
-    """False if missing, True if empty, else the list of pickled objects (small_tools.py:49-70)."""
+    """False: no checkpoint.  True: an empty one.  Otherwise the list of objects it holds."""
     if not os.path.exists(ckpfile):
         return False
     logger.info("Check point file: `{}` exists; skip this step".format(ckpfile))
-    if os.path.getsize(ckpfile) == 0:
-        return True
-    data = []
+    objs = []
     with open(ckpfile, "rb") as f:
         while True:
             try:
-                data.append(pickle.load(f))
+                objs.append(pickle.load(f))
             except EOFError:
                 break
-    return data
+    return objs or True
 
 
+# ------------------------------------------------------------------------------------------------- the run
 class Pipeline:
-    def __init__(self, genomes, sg_cfgs, labels=None, **kargs):
-        self.genomes, self.sg_cfgs = genomes, sg_cfgs
-        self.__dict__.update(**kargs)
+    def __init__(self, genomes, sg_cfgs, labels=None, **opts):
+        self.__dict__.update(opts)
         check_duplicates(genomes)
         check_duplicates(labels)
-        if labels is None:
-            if len(genomes) == 1 or self.no_label:
-                self.labels = [""] * len(genomes)
-            else:
-                self.labels = ["{}-".format(i + 1) for i in range(len(genomes))]
+        self.genomes, self.sg_cfgs = genomes, sg_cfgs
+        n = len(genomes)
+        if self.no_label or (labels is None and n == 1):
+            self.labels = [""] * n
+        elif labels is None:
+            self.labels = ["{}-".format(i) for i in range(1, n + 1)]
         else:
             self.labels = labels
-        cfg_labels = self.labels if len(self.labels) == len(self.sg_cfgs) else [None] * len(self.sg_cfgs)
-        self.sgs, self.chrs, _nsg = [], [], 0
-        for cfgfile, label in zip(self.sg_cfgs, cfg_labels):
-            cfg = SGConfig(cfgfile, prefix=label, sep=self.sep)
-            self.sgs += cfg.sgs
-            self.chrs += cfg.chrs
-            _nsg += cfg.nsg
+        # one prefix per config file when the counts match, else none (__main__.py:274-281)
+        cfg_prefix = self.labels if len(self.labels) == len(sg_cfgs) else [None] * len(sg_cfgs)
+        cfgs = [SGConfig(f, prefix=p, sep=self.sep) for f, p in zip(sg_cfgs, cfg_prefix)]
+        self.sgs = [line for cfg in cfgs for line in cfg.sgs]
+        self.chrs = [c for cfg in cfgs for c in cfg.chrs]
         if not self.nsg or self.nsg < 2:
-            self.nsg = _nsg
-        if self.no_label:
-            self.labels = [""] * len(genomes)
+            self.nsg = sum(cfg.nsg for cfg in cfgs)
 
-    # ------------------------------------------------------------------ helpers
-    def mk_ckpfile(self, file):
-        return "{}{}.ok".format(self.tmpdir, os.path.basename(file))
-
-    def update_sgs(self, sgs, d_targets):
-        return [[[d_targets.get(c, c) for c in chrs] for chrs in sg] for sg in sgs]
-
-    def parse_assigned(self, d_targets):
-        d = {}
-        if not self.sg_assigned:
-            return d
-        for line in open(self.sg_assigned):
-            if line.startswith("#") or not line.strip():
-                continue
-            c, sg = line.strip().split()[:2]
-            d[d_targets.get(c, c)] = sg
-        return d
-
-    @staticmethod
-    def sort_labels(order, labels, chromfiles):
-        d = dict(zip(labels, chromfiles))
-        out = [(lab, d[lab]) for lab in order if lab in d]
-        return [x[0] for x in out], [x[1] for x in out]
-
-    # ------------------------------------------------------------------ run
-    def run(self):
-        self.outdir = os.path.realpath(self.outdir)
-        self.tmpdir = os.path.realpath(self.tmpdir)
-        os.makedirs(self.outdir, exist_ok=True)
-        os.makedirs(self.tmpdir, exist_ok=True)
-        self.outdir += "/"
-        self.tmpdir += "/"
-        if self.prefix is not None:
-            self.outdir += self.prefix
-            self.tmpdir += self.prefix
-
-        logger.info("Target chromosomes: {}".format(self.chrs))
-        logger.info("Splitting genomes by chromosome into `{}`".format(self.tmpdir))
-        ckp_file = self.mk_ckpfile("split")
-        ckp = check_ckp(ckp_file)
-        split = True
-        if isinstance(ckp, list) and len(ckp) == 4 and not self.overwrite:
-            chromfiles, labels, d_targets, d_size = ckp
-            split = set(d_targets) != set(self.chrs) or not all(os.access(f, os.R_OK) for f in chromfiles)
-            if set(d_targets) != set(self.chrs):
-                self.re_filter = True
-        if split:
-            d_targets = parse_idmap(self.target)
-            outdir = "{}chromosomes/".format(self.tmpdir)
-            os.makedirs(outdir, exist_ok=True)
-            data = chromfiles, labels, d_targets, d_size = Seqs.split_genomes(
-                self.genomes, self.labels, self.chrs, outdir, d_targets=d_targets, sep=self.sep)
-            mk_ckp(ckp_file, *data)
-        labels, chromfiles = self.sort_labels(d_targets.values(), labels, chromfiles)
-        logger.info("Chromosomes: {}".format(labels))
-        logger.info("Chromosome Number: {}".format(len(labels)))
-        self.chromfiles, self.labels = chromfiles, labels
-        self.sgs = self.update_sgs(self.sgs, d_targets)
-        self.sg_assigned = self.parse_assigned(d_targets)
-        logger.info("CONFIG: {}".format(self.sgs))
-        self.d_size = d_size
-        if len(chromfiles) == 0:
+    # ---- stage 1: chromosomes ---------------------------------------------------------------------------
+    def stage_ingest(self, lay):
+        """Target chromosomes as per-chromosome FASTA (+ in-memory records); checkpoint `split.ok` holds
+        (chromfiles, labels, d_targets, d_size) like the reference's."""
+        logger.info("chromosomes named in the config: {}".format(self.chrs))
+        logger.info("per-chromosome FASTA under `{}`".format(lay.chromdir))
+        ckp = lay.ckp("split")
+        saved = None if self.overwrite else check_ckp(ckp)
+        reuse = isinstance(saved, list) and len(saved) == 4
+        if reuse:
+            chromfiles, labels, d_targets, d_size = saved
+            if set(d_targets) != set(self.chrs):        # another target set: split again, and filter again
+                reuse, self.re_filter = False, True
+            elif not all(os.access(f, os.R_OK) for f in chromfiles):
+                reuse = False
+        if not reuse:
+            os.makedirs(lay.chromdir, exist_ok=True)
+            chromfiles, labels, d_targets, d_size = seqs.split_genomes(
+                self.genomes, self.labels, self.chrs, lay.chromdir, d_targets=parse_idmap(self.target), sep=self.sep)
+            mk_ckp(ckp, chromfiles, labels, d_targets, d_size)
+        # config order, not file order
+        where = dict(zip(labels, chromfiles))
+        labels = [lab for lab in d_targets.values() if lab in where]
+        chromfiles = [where[lab] for lab in labels]
+        if not chromfiles:
             raise ValueError("0 chromosome remained after filtering. Please check the inputs.")
+        logger.info("{} chromosomes, in config order: {}".format(len(labels), labels))
         logger.info("Genome size: {:,} bp".format(sum(d_size.values())))
+        rename = d_targets.get
+        self.sgs = [[[rename(c, c) for c in unit] for unit in line] for line in self.sgs]
+        logger.info("homoeologous sets after renaming: {}".format(self.sgs))
+        assigned = {}
+        if self.sg_assigned:
+            for line in open(self.sg_assigned):
+                if line.strip() and not line.startswith("#"):
+                    c, sg = line.split()[:2]
+                    assigned[rename(c, c)] = sg
+        return chromfiles, labels, d_size, assigned
 
+    # ---- stage 2: count + matrix + differential filter --------------------------------------------------
+    def stage_count_filter(self, lay, chromfiles, labels):
         logger.info("###Step: Kmer Count")
         logger.info("Counting kmer on the GPU (replaces jellyfish)")
         dumpfiles = run_jellyfish_dumps(chromfiles, k=self.k, ncpu=self.ncpu, lower_count=self.lower_count,
-                                        overwrite=self.overwrite, engine=self.engine,
-                                        write_dumps=self.write_dumps)
-
-        logger.info("Loading kmer matrix")
+                                        overwrite=self.overwrite, engine=self.engine, write_dumps=self.write_dumps)
+        logger.info("chromosome x k-mer matrix: the count tables in HBM")
         dumps = JellyfishDumps(dumpfiles, labels, ncpu=self.ncpu)
-        self.basename = "k{}_q{}_f{}".format(self.k, self.min_freq, self.min_fold)
-        self.para_prefix = "{}{}".format(self.outdir, self.basename)
-        matfile = self.para_prefix + ".kmer.mat"
-        ckp_file = self.mk_ckpfile(matfile)
         d_mat = dumps.to_matrix()
-        logger.info("Filtering differential kmers")
-        histfig = self.para_prefix + ".kmer_freq." + self.figfmt
-        d_mat2 = dumps.filter(d_mat, dumps.lengths, self.sgs, outfig=histfig,
-                              min_fold=self.min_fold, baseline=self.baseline, min_freq=self.min_freq,
-                              max_freq=self.max_freq, min_prop=self.min_prop, max_prop=self.max_prop,
-                              ratio=self.ratio)
+        logger.info("differential k-mer filter (K3)")
+        histfig = lay.out("kmer_freq." + self.figfmt)
+        d_mat2 = dumps.filter(d_mat, dumps.lengths, self.sgs, outfig=histfig, min_fold=self.min_fold,
+                              baseline=self.baseline, min_freq=self.min_freq, max_freq=self.max_freq,
+                              min_prop=self.min_prop, max_prop=self.max_prop, ratio=self.ratio)
         logger.info("{} kmers in total".format(len(d_mat)))
         if len(d_mat2) == 0:
             raise ValueError("0 kmer remained after filtering. Please reset the filter options.")
-        if self.overwrite or self.re_filter or not check_ckp(ckp_file) or not os.path.getsize(matfile):
-            with open(matfile, "w") as fout:
-                dumps.write_matrix(d_mat2, fout)
-            try:
-                plot_histogram(dumps.hist_tot(), histfig)
-            except Exception as e:     # plotting is optional
-                logger.warning("histogram not plotted: {}".format(e))
-            mk_ckp(ckp_file)
+        # The matrix in memory is what every later stage uses, so the file always describes THIS run's filter:
+        # it is rewritten whenever it is recomputed (an old file next to new calls would be inconsistent).
+        matfile = lay.out("kmer.mat")
+        with open(matfile, "w") as fout:
+            dumps.write_matrix(d_mat2, fout)
+        try:
+            plot_histogram(dumps.hist_tot(), histfig)
+        except Exception as e:     # the figure is optional
+            logger.warning("histogram not plotted: {}".format(e))
+        mk_ckp(lay.ckp(matfile))
+        return d_mat2
 
+    # ---- stage 3: subgenome assignment + subgenome-specific k-mers --------------------------------------
+    def stage_cluster(self, lay, d_mat2, assigned):
         logger.info("###Step: Cluster")
-        cluster = Cluster(d_mat2, n_clusters=self.nsg, sg_prefix="SG", sg_assigned=self.sg_assigned)
-        self.d_sg = d_sg = cluster.d_sg
-        logger.info("Subgenome assignments: {}".format(dict(d_sg)))
-        self.sg_names = cluster.sg_names
-        sg_chrs = self.para_prefix + ".chrom-subgenome.tsv"
-        with open(sg_chrs, "w") as fout:
-            cluster.output_subgenomes(fout)
-        sg_kmers = self.para_prefix + ".sig.kmer-subgenome.tsv"
-        logger.info("Outputing significant differiential `kmer` - `subgenome` maps to `{}`".format(sg_kmers))
+        cl = Cluster(d_mat2, n_clusters=self.nsg, sg_prefix="SG", sg_assigned=assigned, bootstrap=True,
+                     replicates=self.replicates, jackknife=self.jackknife, seed=self.bootstrap_seed)
+        logger.info("Subgenome assignments: {}".format(dict(cl.d_sg)))
+        with open(lay.out("chrom-subgenome.tsv"), "w") as fout:
+            cl.output_subgenomes(fout)
+        sg_kmers = lay.out("sig.kmer-subgenome.tsv")
+        logger.info("subgenome-specific k-mers -> `{}`".format(sg_kmers))
         with open(sg_kmers, "w") as fout:
-            d_kmers = cluster.output_kmers(fout, max_pval=self.max_pval, test_method=self.test_method)
-        logger.info("{} significant subgenome-specific kmers".format(len(d_kmers) // 2))
-        for sg, count in sorted(Counter(d_kmers.values()).items()):
-            logger.info("\t{} {}-specific kmers".format(count // 2, sg))
-        if self.just_core:
-            self.step_final()
-            logger.info("Pipeline completed early")
-            return
+            kmer_labels = cl.output_kmers(fout, max_pval=self.max_pval, test_method=self.test_method)
+        per_sg = np.bincount(kmer_labels.sg_idx, minlength=len(kmer_labels.sg_names))
+        logger.info("{} significant subgenome-specific kmers".format(len(kmer_labels.keys)))
+        for sg, n in zip(kmer_labels.sg_names, per_sg.tolist()):
+            if n:
+                logger.info("\t{} {}-specific kmers".format(n, sg))
+        return cl, kmer_labels
 
-        sg_map = self.para_prefix + ".subgenome.bin.count"
-        ckp_file = self.mk_ckpfile(sg_map)
-        logger.info("Outputing `coordinate` - `subgenome` maps to `{}`".format(sg_map))
-        with open(sg_map, "w") as fout:
-            Seqs.map_kmer3(chromfiles, d_kmers, fout=fout, k=self.k, bin_size=10000, sg_names=self.sg_names)
-        mk_ckp(ckp_file)
-        logger.info("Enriching subgenome by chromosome window (size: {})".format(self.window_size))
-        bins, counts = Circos.stack_matrix(sg_map, window_size=self.window_size)
-        bin_enrich = self.para_prefix + ".bin.enrich"
-        bin_exchange = self.para_prefix + ".bin.group"
-        with open(bin_enrich, "w") as fout, open(bin_exchange, "w") as fout2:
-            self.sg_lines = Stats.enrich_bin(fout, fout2, self.d_sg, counts, colnames=self.sg_names,
-                                             rownames=bins, max_pval=self.max_pval)
-        logger.info("Output: {}".format(bin_enrich))
+    # ---- stage 4: bin map -> window stack -> enrichment, on the device -----------------------------------
+    def stage_windows(self, lay, chromfiles, labels, d_size, cl, kmer_labels):
+        ctx = get_context()
+        S, names = len(cl.sg_names), cl.sg_names
+        lengths = [d_size[lab] for lab in labels]
+        sg_map = lay.out("subgenome.bin.count")
+        logger.info("10-kb bin counts -> `{}`".format(sg_map))
+        ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, S)
+        slots, n_mapped = ctx.map_bins_all(BIN_SIZE, CHUNK_SIZE)
+        with open(sg_map, "w") as fout:     # an OUTPUT of the device arrays; nothing below reads it
+            fout.write("\t".join(["#chrom", "start", "end"] + names) + "\n")
+            for lab, n, sl in zip(labels, lengths, slots):
+                seqs._write_lines(fout, lab, *seqs.bin_lines(lab, n, sl, BIN_SIZE, CHUNK_SIZE, self.k))
+        mk_ckp(lay.ckp(sg_map))
+        n_chunks = [max(1, -(-n // CHUNK_SIZE)) for n in lengths]
+        hit = sum(c for c, m in zip(n_chunks, n_mapped.tolist()) if m)
+        logger.info("Processed {} sequences".format(sum(n_chunks)))
+        logger.info("{} ({:.2%}) sequences contain subgenome-specific kmers".format(hit, hit / max(1, sum(n_chunks))))
+        if len(kmer_labels.keys):
+            logger.info("{:.2%} of {} subgenome-specific kmers are mapped".format(
+                ctx.labels_hit() / len(kmer_labels.keys), len(kmer_labels.keys)))
+        logger.info("window enrichment, {}-bp windows (K6)".format(self.window_size))
+        ws = int(self.window_size)
+        win, woff, pvals, argmin, sig, ratios = ctx.stack_enrich(BIN_SIZE, CHUNK_SIZE, ws, lengths, self.max_pval, 0.5)
+        nz = np.flatnonzero(win.any(axis=1))       # only windows that received a bin line exist (Circos.py:734-742)
+        chrom = np.searchsorted(woff, nz, side="right") - 1
+        rows = [(labels[c], int(w) * ws, int(w) * ws + ws) for c, w in zip(chrom.tolist(), (nz - woff[chrom]).tolist())]
+        bin_enrich = lay.out("bin.enrich")
+        with open(bin_enrich, "w") as f1, open(lay.out("bin.group"), "w") as f2:
+            self.sg_lines = stats.enrich_bin(f1, f2, cl.d_sg, win[nz].astype(np.int64), colnames=names, rownames=rows,
+                                             max_pval=self.max_pval,
+                                             results=(pvals[nz], argmin[nz], sig[nz].astype(bool), ratios[nz]))
+        logger.info("wrote {}".format(bin_enrich))
 
-        if self.custom_features is not None:
-            feat_map = self.para_prefix + ".custom.bin.count"
-            logger.info("Mapping subgenome-specific kmers to custom features: {}".format(self.custom_features))
-            with open(feat_map, "w") as fout:
-                Seqs.map_kmer3(self.custom_features, d_kmers, fout=fout, k=self.k, bin_size=10000000,
-                               sg_names=self.sg_names, chunk=False, log=False)
-            logger.info("Enriching subgenome-specific features")
-            bins, counts = Circos.stack_matrix(feat_map, window_size=100000000)
-            feat_enrich = self.para_prefix + ".custom.enrich"
-            with open(feat_enrich, "w") as fout:
-                d_enriched, _ = Stats.enrich_ltr(fout, self.d_sg, counts, colnames=self.sg_names,
-                                                 rownames=bins, max_pval=self.max_pval)
-            logger.info("Output: {}".format(feat_enrich))
-            logger.info("{} significant subgenome-specific features".format(len(d_enriched)))
-            for sg, count in sorted(Counter(d_enriched.values()).items()):
-                logger.info("\t{} {}-specific features".format(count, sg))
+    # ---- stage 5: custom feature sets ----------------------------------------------------------------------
+    def stage_features(self, lay, cl, kmer_labels):
+        feat_map = lay.out("custom.bin.count")
+        logger.info("feature sets: {}".format(self.custom_features))
+        with open(feat_map, "w") as fout:
+            seqs.map_kmer3(self.custom_features, kmer_labels, fout=fout, k=self.k, bin_size=FEATURE_BIN,
+                           sg_names=cl.sg_names, chunk=False, log=False)
+        logger.info("feature enrichment")
+        ids, counts = circos.stack_matrix(feat_map, window_size=100000000)
+        feat_enrich = lay.out("custom.enrich")
+        with open(feat_enrich, "w") as fout:
+            enriched, _ = stats.enrich_ltr(fout, cl.d_sg, counts, colnames=cl.sg_names, rownames=ids,
+                                           max_pval=self.max_pval)
+        logger.info("wrote {}".format(feat_enrich))
+        logger.info("{} significant subgenome-specific features".format(len(enriched)))
+        for sg, n in sorted(Counter(enriched.values()).items()):
+            logger.info("\t{} {}-specific features".format(n, sg))
 
-        if not self.disable_ltr or not self.disable_circos:
-            logger.info("Modules 3-4 (LTR, circos) are not part of this build; run the reference on the "
-                        "outputs above, or pass -disable_ltr -disable_circos to silence this note")
-        self.step_final()
-        logger.info("Pipeline completed")
-
-    def step_final(self):
+    def run(self):
+        lay = Layout(self.outdir, self.tmpdir, self.prefix, self.k, self.min_freq, self.min_fold)
+        chromfiles, labels, d_size, assigned = self.stage_ingest(lay)
+        self.chromfiles, self.labels, self.d_size = chromfiles, labels, d_size
+        d_mat2 = self.stage_count_filter(lay, chromfiles, labels)
+        cl, kmer_labels = self.stage_cluster(lay, d_mat2, assigned)
+        self.d_sg, self.sg_names = cl.d_sg, cl.sg_names
+        if not self.just_core:
+            self.stage_windows(lay, chromfiles, labels, d_size, cl, kmer_labels)
+            if self.custom_features is not None:
+                self.stage_features(lay, cl, kmer_labels)
+            if not (self.disable_ltr and self.disable_circos):
+                logger.info("Modules 3-4 (LTR, circos) are not part of this build; run the reference on the "
+                            "outputs above, or pass -disable_ltr -disable_circos to silence this note")
         if self.cleanup:
-            logger.info("Cleaning {}".format(self.tmpdir))
-            shutil.rmtree(self.tmpdir, ignore_errors=True)
+            logger.info("Cleaning {}".format(lay.tmpdir))
+            shutil.rmtree(lay.tmpdir, ignore_errors=True)
+        logger.info("Pipeline completed" + (" early" if self.just_core else ""))
 
 
 def main(argv=None):

@@ -58,8 +58,10 @@ class Pvalue:
     __slots__ = ("pval", "key", "idx", "sig", "counts", "pvals", "ratios", "ratio", "enrich", "rowname")
 
 
-def enrich(matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval=0.05, ctx=None, **kargs):
-    """Yield one Pvalue record per row (Stats.py:140-168)."""
+def enrich(matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval=0.05, ctx=None, results=None,
+           **kargs):
+    """Yield one Pvalue record per row (Stats.py:140-168).  results = (pvals, argmin, sig, ratios) when the
+    device has already tested these rows (the fused stack -> enrich call of the pipeline)."""
     arr = np.asarray(matrix, np.int64)
     if arr.ndim != 2:
         arr = arr.reshape(len(matrix), -1)
@@ -67,8 +69,11 @@ def enrich(matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval
         assert arr.shape == (len(rownames), len(colnames)), "{} != {}".format(
             arr.shape, (len(rownames), len(colnames)))
     assert len(colnames) > 1     # Stats.py:172
-    ctx = ctx or get_context()
-    pvals, argmin, sig, ratios = ctx.enrich(arr, max_pval, min_ratio)
+    if results is not None:
+        pvals, argmin, sig, ratios = results
+    else:
+        ctx = ctx or get_context()
+        pvals, argmin, sig, ratios = ctx.enrich(arr, max_pval, min_ratio)
     S = arr.shape[1]
     for w in range(arr.shape[0]):
         r = Pvalue()
