@@ -6,15 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from subphaser_amd import _native
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 667_000_000
 engine = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 ctx = _native.Context(0)
 d = ctx.dev_alloc(n)
 ctx.synth_chrom(d, n, 3, 0, 0, 3, 0)
 ctx.genome_reset(1)
 ctx.genome_add_device(0, d, n)
-ctx.count(15, 3, engine)
+ctx.count(K, 3, engine)
 ctx.prof_enable(True)
 for _ in range(3):
-    ctx.count(15, 3, engine)
+    ctx.count(K, 3, engine)
 ctx.prof_enable(False)
 rep = ctx.prof_report()
 tot = sum(v["ms"] / v["calls"] for v in rep.values())
