@@ -43,8 +43,10 @@ def parse():
 def algorithmic_bytes(kernel, bases, nslots, C, S, extra):
     """SURVEY.md 8(d) per-unit figures x the units one launch processes."""
     k = extra.get("k", 15)
-    if k > 16 and (kernel.startswith("sps_") or "radix" in kernel or "rocprim" in kernel or "run_length" in kernel):
+    if k > 16 and kernel.startswith("s3_"):
         return 16.25 * bases                      # 0.25 B read + 8 B key read + 4 B counter read + 4 B write per base
+    if kernel.startswith("sps_"):                 # matrix + filter, 64-bit keys: (Kb + 4) B per dumped k-mer + the rows
+        return extra.get("sum_dump", 0) * 12.0 + extra.get("M", 0) * C * 8.0
     if kernel == "k5_map_sparse":
         return 9.25 * bases + extra.get("nbins", 0) * S * 4
     if kernel.startswith("k1_") or kernel.startswith("c2_"):
@@ -208,33 +210,37 @@ def main():
     extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
                  sum_dump=int(n_dumped), k=args.k)
     try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_wheat_pmc_traffic.json")))["kernels"]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_wheat_pmc.json")))["kernels"]
         if not (args.config == "wheat" and args.k == 15 and world == 1):
             tj = {}
     except (OSError, ValueError, KeyError):
         tj = {}
 
-    def price(names, label):
+    def price(names, label, per_chrom=True):
         """achieved algorithmic GB/s of one kernel, or of a chain of kernels launched once per chromosome"""
         sts = [prof[n] for n in names if n in prof]
         if not sts:
             return None
-        launches_per_step = max(st["calls"] for st in sts) / args.steps
-        per_launch = local_bases / launches_per_step if launches_per_step >= n_local else local_bases
+        units = n_local if per_chrom else 1     # a chain runs once per local chromosome, or once per step
+        per_launch = local_bases / units
         alg = algorithmic_bytes(names[0], per_launch, nslots, C, S, extra)
         if not alg:
             return None
-        avg_s = sum(st["ms"] / st["calls"] for st in sts) / 1e3
+        avg_s = sum(st["ms"] for st in sts) / args.steps / units / 1e3     # HIP-event time of one pass of the chain
         traffic = None
         if all(n in tj for n in names if n in prof):
-            traffic = int(sum(tj[n]["read_bytes_per_call"] + tj[n]["write_bytes_per_call"] for n in names if n in prof))
+            traffic = int(sum((tj[n].get("read_bytes", 0) + tj[n].get("write_bytes", 0)) * tj[n].get("calls", 1)
+                              for n in names if n in prof) / (n_local if units > 1 else 1))
         ach = alg / avg_s
         return {"bound": "hbm", "kernel": label, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
 
-    COUNT_CHAIN = [n for n in ("c2_hist", "c2_tilescan", "c2_offsets", "c2_part1", "c2_part2", "c2_count",
-                               "k1_count", "k2_lengths") if n in prof]
+    COUNT_CHAIN = [n for n in ("c2_hist", "c2_tilescan", "c2_offsets", "c2_part1", "c2_part2", "c2_count", "ovf_scan", "ovf_place",
+                               "k1_count_atomic", "k1_narrow") if n in prof]
+    if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
+        COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))
+    FILTER_CHAIN = ["k3_eval", "k3_slow"] if args.k <= 15 else sorted(n for n in prof if n.startswith("sps_") and "hash" not in n)
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
     if dom:
@@ -244,11 +250,11 @@ def main():
             # kernels launched once per chromosome, so the chain is priced together, never one link alone
             roofline = price(COUNT_CHAIN, "count engine: " + "+".join(COUNT_CHAIN))
         else:
-            roofline = price([name], name)
+            roofline = price([name], name, per_chrom=name not in FILTER_CHAIN)
     # the three stages of the path, each against its own SURVEY 8(d) bytes (context for the line above)
     stage_roofline = {}
-    for label, names in (("count", COUNT_CHAIN), ("filter", ["k3_eval"]), ("map", ["k5_map"] if args.k <= 15 else ["k5_map_sparse"])):
-        pr = price(names, "+".join(names)) if names else None
+    for label, names in (("count", COUNT_CHAIN), ("filter", FILTER_CHAIN), ("map", ["k5_map"] if args.k <= 15 else ["k5_map_sparse"])):
+        pr = price(names, "+".join(names), per_chrom=label != "filter") if names else None
         if pr:
             stage_roofline[label] = {"kernels": pr["kernel"], "achieved_GBps": pr["achieved"], "frac": pr["frac"],
                                      "chain_ms": pr["avg_launch_ms"], "traffic": pr["traffic"]}

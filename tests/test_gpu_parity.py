@@ -887,3 +887,42 @@ def test_shared_host_segment_copy(gpu_ctx):
         got = None
         shm.close()
         shm.unlink()
+
+
+@pytest.mark.parametrize("k", [15, 17])
+def test_feature_join_at_reduced_scale(gpu_ctx, k):
+    """BASELINE config 5's feature-window join at 1/100 of its size: 20,000 features of U[0.2, 10] kb cut from a
+    synthetic chromosome (N runs, soft-masked repeats, features that overlap each other), mapped back to back in one
+    upload (sp_map_features: k-mers across feature boundaries rejected in the kernel) -- per-feature totals and the
+    number of labelled k-mers seen against the oracle, which maps every feature on its own."""
+    from oracle_ctx import OracleContext
+    n, n_feat = 40_000_000, 20000
+    d = gpu_ctx.dev_alloc(n)
+    try:
+        gpu_ctx.synth_chrom(d, n, seed=5, set_id=0, sg_id=1, n_sg=2, chrom_id=3)
+        gpu_ctx.genome_reset(1)
+        gpu_ctx.genome_add_device(0, d, n)
+        host = gpu_ctx.dev_to_host(d, n)
+    finally:
+        gpu_ctx.sync()
+        gpu_ctx.dev_free(d)
+    gpu_ctx.count(k, 3, 0)
+    keys, cnts = gpu_ctx.dump(0)
+    sel = np.flatnonzero(cnts >= 40)[::3]                    # labelled: every third k-mer seen >= 40 times
+    lab_keys, lab_sg = keys[sel], (np.arange(sel.size) % 2).astype(np.uint8)
+    assert lab_keys.size > 1000
+    rng = np.random.RandomState(4)
+    ln = rng.randint(200, 10001, size=n_feat)
+    ln[:50] = rng.randint(1, k + 3, size=50)                # shorter than / around k
+    st = rng.randint(0, n - 10001, size=n_feat)
+    off = np.concatenate(([0], np.cumsum(ln))).astype(np.int64)
+    cat = np.concatenate([host[s:s + l] for s, l in zip(st.tolist(), ln.tolist())])
+    gpu_ctx.labels_set(lab_keys, lab_sg, 2)
+    got = gpu_ctx.map_features_cat(cat, off)
+    octx = OracleContext(nthreads=1)
+    octx.k = k
+    octx.labels_set(lab_keys, lab_sg, 2)
+    exp = octx.map_features_cat(cat, off)
+    assert got.shape == exp.shape and (got == exp).all()
+    assert int(got.sum()) > 10 * n_feat
+    assert gpu_ctx.labels_hit() == octx.labels_hit()
