@@ -125,8 +125,8 @@ def main():
     if runner is None:
         hp = HotPath(ctx, gen.labels, [c["length"] for c in gen.chroms], gen.sgs, k=args.k, engine=args.engine)
 
-        def first_half():
-            return hp.count_and_filter(d_ascii)
+        def first_half(overlap=False):
+            return hp.count_and_filter(d_ascii, overlap=overlap)
 
         def second_half(lab):
             return hp.map_and_enrich(lab, S)
@@ -152,8 +152,11 @@ def main():
     del mat
 
     def step():
-        a = first_half()
+        # the M x C matrix goes to the host on a copy stream while the map stage runs; it is complete (wait) before
+        # the step counts as done
+        a = first_half(overlap=True) if runner is None else first_half()
         b = second_half(kmer_labels)
+        a.wait()
         return a, b
 
     def barrier():

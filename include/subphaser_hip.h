@@ -133,6 +133,11 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
  * fp64 exactly as Jellyfish.py:647 (may be NULL); tot = row sums (may be NULL) */
 int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot,
                     int64_t cap_rows);
+/* the same rows, copied to PAGE-LOCKED host buffers (sp_host_alloc) by a copy stream while the calling stream is
+ * free for the next stage; the buffers are valid after sp_filter_fetch_wait (k > 15: copies synchronously).
+ * The emit buffers on the device are reused by the next sp_filter_fetch*: wait before calling it again.     */
+int sp_filter_fetch_async(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t *tot, int64_t cap_rows);
+int sp_filter_fetch_wait(sp_ctx *ctx);
 /* same rows written to caller-owned DEVICE buffers (any may be NULL): multi-GPU callers gather
  * them over xGMI without a host round trip.  d_keys/d_tot: uint64 x n_rows, d_counts: uint32 x n_rows x C. */
 int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_tot, int64_t cap_rows);

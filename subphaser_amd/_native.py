@@ -21,7 +21,7 @@ SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
     "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
-    "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_device", "sp_filter_hist",
+    "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_async", "sp_filter_fetch_wait", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_labels_hit",
     "sp_enrich", "sp_enrich_dev",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
@@ -76,6 +76,8 @@ def load():
     L.sp_filter.argtypes = [vp, ci, vp, vp, vp, dbl, ci, dbl, dbl, dbl, P(i64), P(i64), P(i64)]
     L.sp_filter_fetch.argtypes = [vp, vp, vp, vp, vp, i64]
     L.sp_filter_fetch_device.argtypes = [vp, vp, vp, vp, i64]
+    L.sp_filter_fetch_async.argtypes = [vp, vp, vp, vp, i64]
+    L.sp_filter_fetch_wait.argtypes = [vp]
     L.sp_filter_hist.argtypes = [vp, vp, i64]
     L.sp_labels_set.argtypes = [vp, vp, vp, i64, ci]
     L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
@@ -372,6 +374,19 @@ class Context:
             if freqs is not None:
                 freqs = freqs[o]
         return keys, counts, freqs, tot
+
+    def filter_fetch_async(self, n_rows):
+        """Rows into page-locked buffers through the copy stream; valid after filter_fetch_wait().
+        Returns (keys, counts, tot) views."""
+        Cn = getattr(self, "_view_C", None) or self.n_chrom
+        keys = self.pinned_empty("ff_keys", (n_rows,), np.uint64)
+        counts = self.pinned_empty("ff_counts", (n_rows, Cn), np.uint32)
+        tot = self.pinned_empty("ff_tot", (n_rows,), np.uint64)
+        self._ck(self.L.sp_filter_fetch_async(self.h, _p(keys), _p(counts), _p(tot), n_rows))
+        return keys, counts, tot
+
+    def filter_fetch_wait(self):
+        self._ck(self.L.sp_filter_fetch_wait(self.h))
 
     def filter_fetch_device(self, d_keys, d_counts, d_tot, n_rows):
         """Surviving rows into caller-owned device buffers (raw pointers or None), slot order."""

@@ -75,6 +75,8 @@ struct sp_prof_entry {
 struct sp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // device->host copies that overlap the next stage (sp_filter_fetch_async)
+    hipEvent_t copy_event = nullptr;
     bool own_stream = false;
     int n_cu = 256;
     std::string err;

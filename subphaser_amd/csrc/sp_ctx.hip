@@ -152,6 +152,11 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_wtab);
     sp_buf_free(ctx->b_enr);
     sp_buf_free(ctx->b_win);
+    if (ctx->copy_stream) {
+        hipStreamSynchronize(ctx->copy_stream);
+        hipStreamDestroy(ctx->copy_stream);
+        hipEventDestroy(ctx->copy_event);
+    }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SP_OK;

@@ -936,7 +936,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
 }
 
 static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs,
-                       uint64_t *tot, int64_t cap) {
+                       uint64_t *tot, int64_t cap, bool async = false) {
     if (!ctx->filtered) return sp_fail(ctx, SP_EINVAL, "call sp_filter first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
@@ -973,11 +973,23 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     SP_LAUNCH(ctx, hist ? "k3_emit_hist" : "k3_emit", k3_emit, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_tabs, C,
               (uint32_t)ctx->lower, M, filter_base(ctx), kp, (const uint32_t *)d_slots, (const double *)d_len, d_keys,
               d_counts, d_freqs, d_tot);
-    if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, d_keys, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, d_tot, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (counts) SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (freqs) SP_HIP(ctx, hipMemcpyAsync(freqs, d_freqs, (size_t)M * C * 8, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // async: the rows are gathered on the compute stream, then a copy stream takes them to the (page-locked) host
+    // buffers while the compute stream goes on with the map stage; sp_filter_fetch_wait joins the two
+    hipStream_t cs = ctx->stream;
+    if (async) {
+        if (!ctx->copy_stream) {
+            SP_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            SP_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
+        }
+        SP_HIP(ctx, hipEventRecord(ctx->copy_event, ctx->stream));
+        SP_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0));
+        cs = ctx->copy_stream;
+    }
+    if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, d_keys, (size_t)M * 8, hipMemcpyDeviceToHost, cs));
+    if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, d_tot, (size_t)M * 8, hipMemcpyDeviceToHost, cs));
+    if (counts) SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)M * C * 4, hipMemcpyDeviceToHost, cs));
+    if (freqs) SP_HIP(ctx, hipMemcpyAsync(freqs, d_freqs, (size_t)M * C * 8, hipMemcpyDeviceToHost, cs));
+    if (!async) SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }
 
@@ -985,6 +997,18 @@ int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs
                     int64_t cap_rows) {
     if (!ctx) return SP_EINVAL;
     return emit_common(ctx, false, keys, counts, freqs, tot, cap_rows);
+}
+
+int sp_filter_fetch_async(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t *tot, int64_t cap_rows) {
+    if (!ctx) return SP_EINVAL;
+    if (ctx->sparse_mode) return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows);   // synchronous
+    return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows, true);
+}
+
+int sp_filter_fetch_wait(sp_ctx *ctx) {
+    if (!ctx) return SP_EINVAL;
+    if (ctx->copy_stream) SP_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return SP_OK;
 }
 
 int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_tot, int64_t cap_rows) {

@@ -20,6 +20,7 @@ class HotPathResult:
     """Plain result record.  `coords` (window row names, Circos.stack_matrix style) are built on first use
     from the chromosome / window index arrays: 14 K tuples are 1.5 ms of Python per pass."""
     _coords = None
+    wait = staticmethod(lambda: None)     # overlapped device->host copies: valid after wait()
     coord_chrom = coord_win = None
     coord_labels = None
     coord_ws = 0
@@ -57,8 +58,10 @@ class HotPath:
         return t1
 
     # ---- first half: K0..K3 ------------------------------------------------
-    def count_and_filter(self, d_ascii, want_freqs=False, sort=False):
-        """d_ascii: device pointers of the ASCII chromosomes (already in HBM)."""
+    def count_and_filter(self, d_ascii, want_freqs=False, sort=False, overlap=False):
+        """d_ascii: device pointers of the ASCII chromosomes (already in HBM).
+        overlap=True: the matrix rows travel to page-locked host memory on a copy stream while the caller goes on
+        (e.g. with map_and_enrich); `result.wait()` makes keys / counts / tot valid."""
         ctx = self.ctx
         t = time.perf_counter()
         ctx.genome_reset(len(self.labels))
@@ -73,6 +76,12 @@ class HotPath:
         r.n_union, r.n_rows, r.n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                                    self.max_freq, self.ratio)
         t = self._t("filter", t)
+        if overlap and not want_freqs and not sort and hasattr(ctx, "filter_fetch_async"):
+            r.keys, r.counts, r.tot = ctx.filter_fetch_async(r.n_rows)
+            r.freqs = None
+            r.wait = ctx.filter_fetch_wait
+            self.wall["filter_fetch"] = self.wall.get("filter_fetch", 0.0) + (time.perf_counter() - t)   # issue only
+            return r
         r.keys, r.counts, r.freqs, r.tot = ctx.filter_fetch(r.n_rows, want_freqs=want_freqs, sort=sort,
                                                             pinned=not sort)
         t = self._t("filter_fetch", t)
