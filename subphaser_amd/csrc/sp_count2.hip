@@ -27,11 +27,13 @@
 #define C2_P1_UNIT 32
 #define C2_P1_KEYS (C2_P1_THREADS * C2_P1_UNIT)   // starts (<= keys) per part1 tile
 #ifndef C2_P2_THREADS
-#define C2_P2_THREADS 768             // part2: 768 threads x 12 keys (9 K-key tiles; with the software pipeline:
-                                      // 512 x 8 -> 1.37 ms per 667-Mb chromosome, 768 x 10 -> 1.28, 768 x 12 -> 1.22, 768 x 16 -> 1.24)
+#define C2_P2_THREADS 512             // part2 tile = threads x keys per thread.  Round 1 (software pipeline): 512 x 8 -> 1.37 ms per
+                                      // 667-Mb chromosome, 768 x 12 -> 1.22.  Round 2 (rank from the histogram atomic, one table read
+                                      // in the copy-out): 768 x 12 1.21, 768 x 16 1.31, 768 x 20 1.25, 1024 x 12 1.23, 1024 x 16 1.17,
+                                      // 512 x 24 1.16 (adopted: 12 K-key tiles, 288-byte runs, three blocks per CU)
 #endif
 #ifndef C2_P2_PER
-#define C2_P2_PER 12
+#define C2_P2_PER 24
 #endif
 #define C2_TILE_KEYS (C2_P2_THREADS * C2_P2_PER)  // keys per part2 tile
 #define C2_HIST_THREADS 512
