@@ -217,6 +217,16 @@ __device__ __forceinline__ uint32_t sp_win_msb(const sp_words32 &x) {
     return __builtin_amdgcn_alignbit(x.m[q], x.m[q + 1], 32 - 2 * r);
 }
 
+// the same for an index that is constant only after loop unrolling
+__device__ __forceinline__ uint32_t sp_win_lsb_at(const sp_words32 &x, int j) {
+    const int q = j >> 4, r = j & 15;
+    return r == 0 ? x.l[q] : __builtin_amdgcn_alignbit(x.l[q + 1], x.l[q], 2 * r);
+}
+__device__ __forceinline__ uint32_t sp_win_msb_at(const sp_words32 &x, int j) {
+    const int q = j >> 4, r = j & 15;
+    return r == 0 ? x.m[q] : __builtin_amdgcn_alignbit(x.m[q], x.m[q + 1], 32 - 2 * r);
+}
+
 template <int J, int STEP, typename F>
 struct sp_win_loop {
     static __device__ __forceinline__ void run(const sp_words32 &x, F &f) {

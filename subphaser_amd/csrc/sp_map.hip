@@ -120,6 +120,9 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
 // candidate start: labelled k-mers come in runs (repeat copies), so almost every candidate pair carries
 // two hits.  4^(k-1) entries (1 GiB at k = 15); S <= 7 (the label-table path below stays for S > 7).
 #define MAP_PAIR_MAX_SG 7
+#ifndef MAP_BATCH
+#define MAP_BATCH 4     // pairs whose probes / gathers are in flight together (16 pairs per 32-start unit)
+#endif
 
 struct map_pair_loc {
     uint32_t idx;   // canonical (k-1)-mer
@@ -196,25 +199,43 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
     const sp_words32 x = sp_load_words32(pk, pm, s0);
     const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
     const uint32_t m1mask = kp.kmask >> 2;
-    auto f = [&](int j, uint32_t V, uint32_t W) {
-        const uint32_t xf = (V >> sh) & m1mask;          // shared (k-1)-mer, forward, key order
-        const uint32_t xr = (~W >> 2) & m1mask;          // its reverse complement
-        const uint32_t canon = xf < xr ? xf : xr;
-        if (!((ok_x >> j) & 1u) || !map_bloom_test(bloom, nbits, (uint64_t)canon)) return;
-        const uint32_t e = ptab[canon];
-        if (!(e & 0x77777777u)) return;
-        const bool fwd = xf <= xr;
-        const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
-        const int f0 = fwd ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
-        const int f1 = fwd ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
-        const uint32_t v0 = ((ok_k >> j) & 1u) ? (e >> (4 * f0)) & 15u : 0u;
-        const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e >> (4 * f1)) & 15u : 0u;
-        uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
-        if ((v0 & 7u) && hit(s0 + j, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
-        if ((v1 & 7u) && hit(s0 + j + 1, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
-        if (mark) atomicOr(&ptab[canon], mark);           // "seen": first touch only
-    };
-    sp_win_loop<0, 2, decltype(f)>::run(x, f);
+    // MAP_BATCH pairs at a time: their filter probes are issued together, then the pair-table gathers of the
+    // candidates, then the hits are taken in position order.  One probe in flight per lane left the kernel bound by
+    // the latency of the scan -> probe -> gather chain (168 G L2 requests/s at 24 waves per CU against the ~270 G/s
+    // the chip serves).
+#pragma unroll
+    for (int g = 0; g < 16; g += MAP_BATCH) {
+        uint32_t V[MAP_BATCH], canon[MAP_BATCH], fw[MAP_BATCH], want[MAP_BATCH], wd[MAP_BATCH], e[MAP_BATCH];
+#pragma unroll
+        for (int q = 0; q < MAP_BATCH; q++) {
+            const int j = 2 * (g + q);
+            V[q] = sp_win_msb_at(x, j);
+            const uint32_t W = sp_win_lsb_at(x, j);
+            const uint32_t xf = (V[q] >> sh) & m1mask;       // shared (k-1)-mer, forward, key order
+            const uint32_t xr = (~W >> 2) & m1mask;          // its reverse complement
+            canon[q] = xf < xr ? xf : xr;
+            fw[q] = xf <= xr;
+            const map_bloom_probe p = map_bloom((uint64_t)canon[q], nbits);
+            want[q] = p.bits;
+            wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < MAP_BATCH; q++) e[q] = ((wd[q] & want[q]) == want[q]) ? ptab[canon[q]] : 0u;
+#pragma unroll
+        for (int q = 0; q < MAP_BATCH; q++) {
+            if (!(e[q] & 0x77777777u)) continue;
+            const int j = 2 * (g + q);
+            const uint32_t b0 = V[q] >> 30, b1 = (V[q] >> sh1) & 3u;
+            const int f0 = fw[q] ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
+            const int f1 = fw[q] ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
+            const uint32_t v0 = ((ok_k >> j) & 1u) ? (e[q] >> (4 * f0)) & 15u : 0u;
+            const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e[q] >> (4 * f1)) & 15u : 0u;
+            uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
+            if ((v0 & 7u) && hit(s0 + j, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
+            if ((v1 & 7u) && hit(s0 + j + 1, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
+            if (mark) atomicOr(&ptab[canon[q]], mark);         // "seen": first touch only
+        }
+    }
 }
 
 // ----------------------------------------------------------------- K5
@@ -275,21 +296,37 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const u
             __syncthreads();
         }
         if (u < P.n_units) {
+            // A lane's 64 starts lie in one or two output slots: hits are tallied in a register, one byte per
+            // subgenome (<= 64 hits per unit, <= 7 subgenomes), and reach the LDS histogram once per slot -- not
+            // one LDS atomic and a 64-bit slot computation per hit (the hit path runs for every pair of every wave:
+            // some lane always has one).
             int64_t cur_end = -1, cur_os = 0;   // starts are visited in ascending order: [.., cur_end) -> cur_os
+            unsigned long long acc = 0;
+            auto flush = [&]() {
+                if (!acc) return;
+                for (int sg = 0; sg < P.S; sg++) {
+                    const int v = (int)((acc >> (8 * sg)) & 255ULL);
+                    if (!v) continue;
+                    if (P.use_lds)
+                        atomicAdd(&hist[(int)(cur_os - slot_lo) * P.S + sg], v);
+                    else if (cur_os < P.nslots)
+                        atomicAdd(&slot_counts[cur_os * P.S + sg], v);
+                    mapped += v;
+                }
+                acc = 0;
+            };
             auto hit = [&](int64_t start, int sg) {
                 if (start >= cur_end) {
+                    flush();
                     cur_os = map_slot(start, P, kp.k);
                     cur_end = map_slot_end(start, P, kp.k);
                 }
-                if (P.use_lds)
-                    atomicAdd(&hist[(cur_os - slot_lo) * P.S + sg], 1);
-                else if (cur_os < P.nslots)
-                    atomicAdd(&slot_counts[cur_os * P.S + sg], 1);
-                mapped++;
+                acc += 1ULL << (8 * sg);
                 return true;
             };
             map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
             map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+            flush();
         }
         if (P.use_lds) {
             __syncthreads();
