@@ -145,6 +145,7 @@ def main():
     mat = _Mat()
     mat.labels, mat.keys, mat.k = gen.labels, r1.keys, args.k
     mat.freqs = r1.counts.astype(np.float64) / np.asarray(r1.kmer_lengths, np.float64)
+    mat.counts, mat.lengths, mat.ctx = r1.counts, np.asarray(r1.kmer_lengths, np.int64), ctx    # t-test on the device
     if r1.n_rows == 0:
         raise SystemExit("synthetic genome produced 0 differential k-mers")
     cl = cluster.Cluster(mat, n_clusters=S, sg_assigned=gen.sg_assigned)

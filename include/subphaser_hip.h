@@ -202,6 +202,17 @@ int sp_stack_enrich(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t w
                     const int64_t *win_off, double max_pval, double min_ratio, int64_t *win_counts, double *pvals,
                     int32_t *argmin, uint8_t *sig, double *ratios);
 
+/* ---- subgenome-specific k-mer test ------------------------------------------
+ * Replaces Cluster.output_kmers / _output_kmers for test_method = ttest_ind (Cluster.py:151-194): per
+ * differential k-mer (row of `counts`, M x C thresholded counts as sp_filter_fetch returns them) the
+ * frequencies count / lengths[c] are grouped by subgenome (group g owns the chromosome indices
+ * group_chrom[group_off[g] .. group_off[g+1]), groups in sorted subgenome-name order), the groups are ordered
+ * by mean (descending, ties in group order) and scipy.stats.ttest_ind(top, second) -- pooled variance,
+ * two-sided -- gives pvals[row].  means: M x n_groups.  The caller keeps rows with !(p > max_pval).      */
+int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int C, const int64_t *lengths, int n_groups,
+                  const int32_t *group_off, const int32_t *group_chrom, int32_t *top, int32_t *second,
+                  double *pvals, double *means);
+
 /* ---- multi-GPU, k > 15 ----------------------------------------------------------------------
  * Twin of sp_tables_bind / sp_filter_view for 64-bit keys ("for k > 16 the exchange
  * becomes key-partitioned").  After sp_count (k > 15) every local chromosome is a sorted list of

@@ -23,7 +23,7 @@ SYMBOLS = [
     "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_async", "sp_filter_fetch_wait", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_labels_hit",
-    "sp_enrich", "sp_enrich_dev",
+    "sp_enrich", "sp_enrich_dev", "sp_kmer_ttest",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_host_register", "sp_host_unregister", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
@@ -92,6 +92,7 @@ def load():
     L.sp_labels_hit.argtypes = [vp, P(i64)]
     L.sp_enrich.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
     L.sp_enrich_dev.argtypes = [vp, vp, i64, ci, dbl, dbl, vp, vp, vp, vp]
+    L.sp_kmer_ttest.argtypes = [vp, vp, i64, ci, vp, ci, vp, vp, vp, vp, vp, vp]
     L.sp_sparse_sizes.argtypes = [vp, vp]
     L.sp_sparse_sample.argtypes = [vp, ci, i64, vp, P(i64)]
     L.sp_sparse_split.argtypes = [vp, ci, vp, ci, vp]
@@ -521,6 +522,22 @@ class Context:
         self._ck(self.L.sp_enrich(self.h, _p(counts), W, S, float(max_pval), float(min_ratio), _p(pvals),
                                   _p(argmin), _p(sig), _p(ratios)))
         return pvals, argmin, sig.astype(bool), ratios
+
+    def kmer_ttest(self, counts, lengths, groups):
+        """Cluster.output_kmers' per-k-mer t-test on the device.  counts: uint32 [M, C] (thresholded, as
+        filter_fetch returns them), lengths: int64 [C], groups: list of chromosome-index lists in sorted
+        subgenome-name order.  Returns (top, second, pvals, means [M, n_groups])."""
+        counts = np.ascontiguousarray(counts, np.uint32)
+        M, Cn = counts.shape
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        goff = np.zeros(len(groups) + 1, np.int32)
+        goff[1:] = np.cumsum([len(g) for g in groups])
+        gch = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in groups]), np.int32)
+        top, second = np.empty(M, np.int32), np.empty(M, np.int32)
+        pvals, means = np.empty(M, np.float64), np.empty((M, len(groups)), np.float64)
+        self._ck(self.L.sp_kmer_ttest(self.h, _p(counts), M, Cn, _p(lengths), len(groups), _p(goff), _p(gch),
+                                      _p(top), _p(second), _p(pvals), _p(means)))
+        return top, second, pvals, means
 
     # -------------------------------------------------------------- profiling / bench support
     def prof_enable(self, on=True):

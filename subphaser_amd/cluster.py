@@ -63,6 +63,9 @@ class Cluster:
             self.keys = kmerlib.encode_many(kmers)
         else:
             self.chrs, self.raw_data, self.keys, self.k = list(data.labels), data.freqs, data.keys, data.k
+            # the integer matrix behind the frequencies: lets the k-mer test run on the device (sp_kmer_ttest)
+            self._counts, self._lengths = getattr(data, "counts", None), getattr(data, "lengths", None)
+            self._ctx = getattr(data, "ctx", None)
         self.sg_prefix, self.seed = sg_prefix, seed
         self.n_clusters = len(set(sg_assigned.values())) if sg_assigned else n_clusters
         if sg_assigned:
@@ -129,6 +132,13 @@ class Cluster:
         groups = [[i for i, c in enumerate(self.chrs) if self.d_sg[c] == sg] for sg in sgs]
         X = self.raw_data
         M = X.shape[0]
+        ctx = getattr(self, "_ctx", None)
+        if (test_method == "ttest_ind" and M and ctx is not None and hasattr(ctx, "kmer_ttest")
+                and getattr(self, "_counts", None) is not None and self._lengths is not None):
+            # device path: one thread per k-mer (csrc/sp_enrich.hip k7_ttest); the numpy code below is the same test
+            # for matrices that only exist as a `.kmer.mat` file or behind a context without the kernel
+            top, second, pvals, means = ctx.kmer_ttest(self._counts, self._lengths, groups)
+            return self._write_kmers(fout, sgs, top, pvals, means, max_pval)
         means = np.stack([X[:, g].mean(axis=1) for g in groups], axis=1) if M else np.zeros((0, len(sgs)))
         # the reference orders groups by -sum/len (Cluster.py:182); ties keep SG-name order (stable)
         keyv = np.stack([-(X[:, g].sum(axis=1) / len(g)) for g in groups], axis=1) if M else means
@@ -144,6 +154,9 @@ class Cluster:
                     pvals[sel] = _ttest_ind(X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])], special)
                 elif sel.size:      # the other scipy tests the reference accepts (Cluster.py:178-194), row by row
                     pvals[sel] = _scipy_rows(test_method, X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])])
+        return self._write_kmers(fout, sgs, top, pvals, means, max_pval)
+
+    def _write_kmers(self, fout, sgs, top, pvals, means, max_pval):
         print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
         with np.errstate(invalid="ignore"):
             keep = np.flatnonzero(~(pvals > max_pval))      # `if pvalue > max_pval: continue` keeps NaN

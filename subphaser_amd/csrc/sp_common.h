@@ -128,6 +128,7 @@ struct sp_ctx {
     int64_t sf_n = 0;
     uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers: 16-B entries {key, label}
     int64_t hcap = 0;
+    sp_buf b_tt;            // k-mer t-test workspace (sp_enrich.hip)
     sp_buf b_wtab, b_enr;   // window table (device) and the enrichment outputs
     sp_buf b_fq;      // global slow queue of the filter
     sp_buf b_fflat;   // flat set tables of the filter (sp_filter.hip)

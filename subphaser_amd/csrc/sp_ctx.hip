@@ -151,6 +151,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_fq);
     sp_buf_free(ctx->b_wtab);
     sp_buf_free(ctx->b_enr);
+    sp_buf_free(ctx->b_tt);
     sp_buf_free(ctx->b_win);
     if (ctx->copy_stream) {
         hipStreamSynchronize(ctx->copy_stream);

@@ -182,6 +182,144 @@ k6_enrich(const long long *__restrict__ counts, const long long *__restrict__ to
     sig[w] = sg ? 1 : 0;
 }
 
+// ----------------------------------------------------------------- f-1: subgenome-specific k-mer test
+// Cluster.output_kmers / _output_kmers (Cluster.py:151-194) for test_method = ttest_ind: per differential
+// k-mer, the chromosome frequencies count/length are grouped by subgenome, the groups are ordered by mean
+// (descending, ties in subgenome order) and scipy.stats.ttest_ind(top, second) -- pooled variance, two-sided --
+// gives the p-value: 2 * stdtr(df, -|t|) = I_x(df/2, 1/2) with x = df / (df + t^2) (regularised incomplete beta,
+// continued fraction in fp64).  One thread per k-mer.
+#define SP_TT_MAXG 64
+__device__ double d_betacf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 500; m++) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+__device__ double d_betainc(double a, double b, double x) {
+    if (!(x > 0.0)) return 0.0;
+    if (!(x < 1.0)) return 1.0;
+    const double bt = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x));
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * d_betacf(a, b, x) / a;
+    return 1.0 - bt * d_betacf(b, a, 1.0 - x) / b;
+}
+
+__global__ void __launch_bounds__(128)
+k7_ttest(const uint32_t *__restrict__ counts, long long M, int C, const double *__restrict__ chrom_len, int G,
+         const int *__restrict__ goff, const int *__restrict__ gchrom, int *__restrict__ top, int *__restrict__ second,
+         double *__restrict__ pvals, double *__restrict__ means) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const uint32_t *row = counts + r * C;
+    int t1 = -1, t2 = -1;
+    double m1 = 0, m2 = 0;
+    for (int g = 0; g < G; g++) {            // means in numpy's summation order; descending, ties in group order
+        double v[SP_TT_MAXG];
+        const int n = goff[g + 1] - goff[g];
+        for (int i = 0; i < n; i++) v[i] = (double)row[gchrom[goff[g] + i]] / chrom_len[gchrom[goff[g] + i]];
+        const double mean = d_np_sum(v, n) / (double)n;
+        means[r * G + g] = mean;
+        if (t1 < 0 || mean > m1) { t2 = t1; m2 = m1; t1 = g; m1 = mean; }
+        else if (t2 < 0 || mean > m2) { t2 = g; m2 = mean; }
+    }
+    if (t2 < 0) t2 = t1;
+    top[r] = t1;
+    second[r] = t2;
+    double var[2], mu[2];
+    int nn[2];
+    for (int s = 0; s < 2; s++) {
+        const int g = s ? t2 : t1;
+        double v[SP_TT_MAXG];
+        const int n = goff[g + 1] - goff[g];
+        for (int i = 0; i < n; i++) v[i] = (double)row[gchrom[goff[g] + i]] / chrom_len[gchrom[goff[g] + i]];
+        const double mean = d_np_sum(v, n) / (double)n;
+        for (int i = 0; i < n; i++) { const double d = v[i] - mean; v[i] = d * d; }
+        var[s] = n > 1 ? d_np_sum(v, n) / (double)(n - 1) : 0.0;
+        mu[s] = mean;
+        nn[s] = n;
+    }
+    const double df = (double)(nn[0] + nn[1]) - 2.0;
+    double p;
+    if (!(df > 0.0)) {
+        p = __longlong_as_double(0x7ff8000000000000LL);
+    } else {
+        const double svar = ((nn[0] - 1) * var[0] + (nn[1] - 1) * var[1]) / df;
+        const double denom = sqrt(svar * (1.0 / nn[0] + 1.0 / nn[1]));
+        const double t = (mu[0] - mu[1]) / denom;
+        if (t != t) p = t;                               // 0 / 0: NaN, kept by the caller like the reference does
+        else if (isinf(t)) p = 0.0;
+        else p = d_betainc(0.5 * df, 0.5, df / (df + t * t));
+    }
+    pvals[r] = p;
+}
+
+extern "C" int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int C, const int64_t *lengths, int n_groups,
+                             const int32_t *group_off, const int32_t *group_chrom, int32_t *top, int32_t *second,
+                             double *pvals, double *means) {
+    if (!ctx || M < 0 || C < 1 || n_groups < 1 || !lengths || !group_off || !group_chrom ||
+        (M > 0 && (!counts || !top || !second || !pvals || !means)))
+        return sp_fail(ctx, SP_EINVAL, "sp_kmer_ttest: bad arguments");
+    for (int g = 0; g < n_groups; g++) {
+        const int n = group_off[g + 1] - group_off[g];
+        if (n < 1 || n > SP_TT_MAXG) return sp_fail(ctx, SP_EUNSUP, "sp_kmer_ttest: a subgenome with %d chromosomes (1..%d supported)", n, SP_TT_MAXG);
+        for (int j = group_off[g]; j < group_off[g + 1]; j++)
+            if (group_chrom[j] < 0 || group_chrom[j] >= C) return sp_fail(ctx, SP_EINVAL, "sp_kmer_ttest: chromosome index out of range");
+    }
+    if (M == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nuc = (size_t)group_off[n_groups];
+    const size_t need = al((size_t)M * C * 4) + al((size_t)C * 8) + al((size_t)(n_groups + 1) * 4) + al(nuc * 4) +
+                        2 * al((size_t)M * 4) + al((size_t)M * 8) + al((size_t)M * n_groups * 8);
+    int rc = sp_buf_ensure(ctx, ctx->b_tt, (int64_t)need);
+    if (rc) return rc;
+    char *q = (char *)ctx->b_tt.p;
+    uint32_t *d_counts = (uint32_t *)q; q += al((size_t)M * C * 4);
+    double *d_len = (double *)q; q += al((size_t)C * 8);
+    int *d_goff = (int *)q; q += al((size_t)(n_groups + 1) * 4);
+    int *d_gch = (int *)q; q += al(nuc * 4);
+    int *d_top = (int *)q; q += al((size_t)M * 4);
+    int *d_sec = (int *)q; q += al((size_t)M * 4);
+    double *d_p = (double *)q; q += al((size_t)M * 8);
+    double *d_means = (double *)q;
+    std::vector<double> hl((size_t)C);
+    for (int c = 0; c < C; c++) hl[(size_t)c] = (double)lengths[c];
+    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, (size_t)M * C * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_len, hl.data(), (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_goff, group_off, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_gch, group_chrom, nuc * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_LAUNCH(ctx, "k7_ttest", k7_ttest, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, (const uint32_t *)d_counts,
+              (long long)M, C, (const double *)d_len, n_groups, (const int *)d_goff, (const int *)d_gch, d_top, d_sec, d_p,
+              d_means);
+    SP_HIP(ctx, hipMemcpyAsync(top, d_top, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(second, d_sec, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(pvals, d_p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(means, d_means, (size_t)M * n_groups * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
 // column sums of the window table (Stats.py:142) + their sum, on the device
 __global__ void __launch_bounds__(256)
 k6_totals(const long long *__restrict__ counts, long long W, int S, long long *__restrict__ total /* S + 1 */) {

@@ -88,9 +88,10 @@ class DeviceMatrix:
 class FilteredMatrix:
     """The reference's d_mat2 (k-mer -> [count/length per chromosome]) as arrays."""
 
-    def __init__(self, keys, counts, freqs, tot, k, labels):
+    def __init__(self, keys, counts, freqs, tot, k, labels, lengths=None, ctx=None):
         self.keys, self.counts, self.freqs, self.tot = keys, counts, freqs, tot
         self.k, self.labels = k, labels
+        self.lengths, self.ctx = lengths, ctx      # count / length is how freqs was formed (Jellyfish.py:648)
 
     def __len__(self):
         return len(self.keys)
@@ -161,7 +162,7 @@ class JellyfishDumps:
             if n_hist == 0:
                 raise ValueError("0 kmer with fold > {}. Please reset the filter options.".format(min_fold))
             self.tot_freqs = None   # fetched lazily by plot_histogram
-        return FilteredMatrix(keys, counts, freqs, tot, self.k, self.labels)
+        return FilteredMatrix(keys, counts, freqs, tot, self.k, self.labels, lengths=list(self.lengths), ctx=self.ctx)
 
     def hist_tot(self):
         """tot of every fold-passing k-mer (the reference's tot_freqs, Jellyfish.py:499-502)."""

@@ -926,3 +926,41 @@ def test_feature_join_at_reduced_scale(gpu_ctx, k):
     assert got.shape == exp.shape and (got == exp).all()
     assert int(got.sum()) > 10 * n_feat
     assert gpu_ctx.labels_hit() == octx.labels_hit()
+
+
+def test_kmer_ttest_device_vs_scipy(gpu_ctx):
+    """f-1: the per-k-mer Student test on the device against scipy.stats.ttest_ind row by row, incl. constant
+    groups (0 / 0 -> NaN, kept like the reference keeps it), a perfect separation (t = inf -> p = 0), ties between
+    group means (subgenome order decides) and unequal group sizes."""
+    from scipy import stats as st
+    rng = np.random.RandomState(12)
+    C, groups = 13, [[0, 3, 4, 9, 12], [1, 2, 5, 6, 7, 8, 10, 11]]        # the Arabidopsis suecica 5 + 8 split
+    lengths = rng.randint(10**6, 10**8, size=C).astype(np.int64)
+    counts = rng.poisson(30, size=(4000, C)).astype(np.uint32)
+    counts[:500, groups[0]] += rng.poisson(200, size=(500, 5)).astype(np.uint32)
+    counts[500:900, groups[1]] += rng.poisson(90, size=(400, 8)).astype(np.uint32)
+    counts[900:950] = 0                                   # all zero: 0 / 0
+    counts[950:960] = 7                                   # constant row
+    counts[960:970, :] = 0
+    counts[960:970, groups[0]] = 5                        # zero variance in both groups, different means: t = inf
+    lengths_eq = lengths.copy()
+    top, second, pvals, means = gpu_ctx.kmer_ttest(counts, lengths, groups)
+    X = counts.astype(np.float64) / lengths.astype(np.float64)
+    for r in list(range(0, 4000, 37)) + list(range(895, 975)):
+        m = [X[r, g].mean() for g in groups]
+        order = sorted(range(2), key=lambda g: (-(X[r, groups[g]].sum() / len(groups[g])), g))
+        assert top[r] == order[0] and second[r] == order[1], r
+        assert np.allclose(means[r], m, rtol=1e-14, atol=0)
+        with np.errstate(all="ignore"):
+            exp = st.ttest_ind(X[r, groups[order[0]]], X[r, groups[order[1]]]).pvalue
+        if np.isnan(exp):
+            assert np.isnan(pvals[r]), r
+        else:
+            assert np.isclose(pvals[r], exp, rtol=1e-9, atol=1e-300), (r, pvals[r], exp)
+    three = [[0, 1, 2], [3, 4, 5, 6], [7, 8, 9, 10, 11, 12]]
+    top3, sec3, p3, _ = gpu_ctx.kmer_ttest(counts[:300], lengths, three)
+    for r in range(0, 300, 11):
+        order = sorted(range(3), key=lambda g: (-(X[r, three[g]].sum() / len(three[g])), g))
+        assert (top3[r], sec3[r]) == (order[0], order[1])
+        exp = st.ttest_ind(X[r, three[order[0]]], X[r, three[order[1]]]).pvalue
+        assert np.isclose(p3[r], exp, rtol=1e-9, atol=1e-300)
