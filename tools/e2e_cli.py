@@ -40,9 +40,9 @@ t0 = time.perf_counter()
 r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
 dt = time.perf_counter() - t0
 open(os.path.join(work, "cli.stderr"), "w").write(r.stderr)
-keep = ("Splitting", "Chromosome Number", "Genome size", "###Step", "Counting", "Loading kmer matrix", "Filtering",
-        "After filtering", "kmers in total", "Outputing", "significant subgenome", "Processed", "Enriching", "Output:",
-        "Pipeline completed", "New check point")
+keep = ("per-chromosome FASTA", "chromosomes, in config order", "Genome size", "###Step", "Counting", "matrix", "filter (K3)",
+        "After filtering", "kmers in total", "bootstrap", "Bootstrap", "->", "significant subgenome", "Processed",
+        "enrichment", "wrote", "Pipeline completed", "New check point")
 for line in r.stderr.splitlines():
     if any(k in line for k in keep) and "Loading /" not in line:
         print(line[:160])
