@@ -12,6 +12,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <sys/mman.h>
 #endif
 
 static __thread char g_err[512];
@@ -24,6 +25,19 @@ int spo_version(void) { return 1; }
  * site is Jellyfish.py:697-699, `jellyfish count -m K --canonical`). */
 static int8_t g_code[256];
 static int g_code_init = 0;
+static double g_t0;
+static int timing_on(void) { static int v = -1; if (v < 0) v = getenv("SPO_TIMING") != NULL; return v; }
+#define TICK(name) do { if (timing_on()) { double t__ = omp_get_wtime(); fprintf(stderr, "[spo] %-28s %.3f s\n", name, t__ - g_t0); g_t0 = t__; } } while (0)
+/* large arrays: 2-MiB aligned + MADV_HUGEPAGE, so that 256 threads first-touching them do not serialise on
+ * 4-KiB page faults */
+static void *big_alloc(size_t bytes) {   /* transparent huge pages unless SPO_NO_THP is set */
+    size_t n = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (n == 0) n = (size_t)2 << 20;
+    void *p = NULL;
+    if (posix_memalign(&p, (size_t)2 << 20, n)) return NULL;
+    if (!getenv("SPO_NO_THP")) madvise(p, n, MADV_HUGEPAGE);
+    return p;
+}
 static void init_code(void) {
     if (g_code_init) return;
     memset(g_code, -1, sizeof g_code);
@@ -97,53 +111,98 @@ spo_counts *spo_count(const uint8_t *ascii, int64_t len, int k, int nthreads) {
         if (len >= slots / 16) dense = 1;
     }
     if (dense) {
-        /* direct-addressed table indexed by the canonical value */
-        int64_t slots = 1LL << (2 * k);
-        uint32_t *tab = (uint32_t *)calloc((size_t)slots, sizeof(uint32_t));
-        if (!tab) {
-            snprintf(g_err, sizeof g_err, "out of memory for dense table");
-            free(res);
-            return NULL;
-        }
-        int64_t nblk = nthreads * 8;
+        /* Same result as one direct-addressed table indexed by the canonical value, built the way a tuned
+         * CPU counter builds it: every thread scatters the keys of its share of the sequence into
+         * key-range buckets (two scans: count, place -- no atomics), then each bucket is counted in a
+         * table small enough to stay in the core's cache and its non-zero slots go out in ascending order. */
+        int pb = 2 * k - 8;
+        if (pb > 12) pb = 12;
+        if (pb < 0) pb = 0;
+        const int sh = 2 * k - pb;
+        const int64_t nbkt = 1LL << pb, bslots = 1LL << sh;
+        const int64_t nblk = nthreads;
         int64_t per = (len + nblk - 1) / nblk;
         if (per < 1) per = 1;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        g_t0 = omp_get_wtime();
+        int64_t *off = (int64_t *)calloc((size_t)(nblk * nbkt + 1), sizeof(int64_t));
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
         for (int64_t b = 0; b < nblk; b++) {
             int64_t lo = b * per, hi = lo + per;
             if (hi > len) hi = len;
             if (lo >= hi) continue;
-            SCAN_WINDOWS(ascii, len, k, lo, hi,
-                         { __atomic_fetch_add(&tab[key], 1u, __ATOMIC_RELAXED); });
+            int64_t *mine = (int64_t *)calloc((size_t)nbkt, sizeof(int64_t));
+            SCAN_WINDOWS(ascii, len, k, lo, hi, { mine[key >> sh]++; });
+            for (int64_t q = 0; q < nbkt; q++) off[q * nblk + b + 1] = mine[q];
+            free(mine);
         }
-        /* compact non-zero slots, ascending */
-        int64_t nb2 = nthreads * 4;
-        int64_t per2 = (slots + nb2 - 1) / nb2;
-        int64_t *cnt = (int64_t *)calloc((size_t)nb2 + 1, sizeof(int64_t));
-#pragma omp parallel for num_threads(nthreads)
-        for (int64_t b = 0; b < nb2; b++) {
-            int64_t lo = b * per2, hi = lo + per2, c = 0;
-            if (hi > slots) hi = slots;
-            for (int64_t i = lo; i < hi; i++) c += tab[i] != 0;
-            cnt[b + 1] = c;
-        }
-        for (int64_t b = 0; b < nb2; b++) cnt[b + 1] += cnt[b];
-        res->n = cnt[nb2];
-        res->keys = (uint64_t *)malloc((size_t)(res->n ? res->n : 1) * sizeof(uint64_t));
-        res->counts = (uint32_t *)malloc((size_t)(res->n ? res->n : 1) * sizeof(uint32_t));
-#pragma omp parallel for num_threads(nthreads)
-        for (int64_t b = 0; b < nb2; b++) {
-            int64_t lo = b * per2, hi = lo + per2, o = cnt[b];
-            if (hi > slots) hi = slots;
-            for (int64_t i = lo; i < hi; i++)
-                if (tab[i]) {
-                    res->keys[o] = (uint64_t)i;
-                    res->counts[o] = tab[i];
-                    o++;
+        TICK("count: scan 1 (bucket sizes)");
+        for (int64_t i = 0; i < nblk * nbkt; i++) off[i + 1] += off[i];
+        const int64_t total = off[nblk * nbkt];
+        uint32_t *part = (uint32_t *)big_alloc((size_t)(total ? total : 1) * sizeof(uint32_t));
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+        for (int64_t b = 0; b < nblk; b++) {
+            int64_t lo = b * per, hi = lo + per;
+            if (hi > len) hi = len;
+            if (lo >= hi) continue;
+            /* software write combining: 16 keys (one cache line) per bucket are staged before they go out */
+            int64_t *cur = (int64_t *)malloc((size_t)nbkt * sizeof(int64_t));
+            uint32_t *stage = (uint32_t *)malloc((size_t)nbkt * 16 * sizeof(uint32_t));
+            uint8_t *fill = (uint8_t *)calloc((size_t)nbkt, 1);
+            for (int64_t q = 0; q < nbkt; q++) cur[q] = off[q * nblk + b];
+            SCAN_WINDOWS(ascii, len, k, lo, hi, {
+                const int64_t q = (int64_t)(key >> sh);
+                stage[q * 16 + fill[q]] = (uint32_t)(key & (uint64_t)(bslots - 1));
+                if (++fill[q] == 16) {
+                    memcpy(part + cur[q], stage + q * 16, 64);
+                    cur[q] += 16;
+                    fill[q] = 0;
                 }
+            });
+            for (int64_t q = 0; q < nbkt; q++)
+                if (fill[q]) memcpy(part + cur[q], stage + q * 16, (size_t)fill[q] * 4);
+            free(cur);
+            free(stage);
+            free(fill);
         }
-        free(cnt);
-        free(tab);
+        TICK("count: scan 2 (scatter)");
+        int64_t *nd = (int64_t *)calloc((size_t)nbkt + 1, sizeof(int64_t));
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                for (int64_t q = 0; q < nbkt; q++) nd[q + 1] += nd[q];
+                res->n = nd[nbkt];
+                res->keys = (uint64_t *)big_alloc((size_t)(res->n ? res->n : 1) * sizeof(uint64_t));
+                res->counts = (uint32_t *)big_alloc((size_t)(res->n ? res->n : 1) * sizeof(uint32_t));
+            }
+#pragma omp parallel num_threads(nthreads)
+            {
+                uint32_t *tab = (uint32_t *)malloc((size_t)bslots * sizeof(uint32_t));
+#pragma omp for schedule(dynamic, 1)
+                for (int64_t q = 0; q < nbkt; q++) {
+                    const int64_t lo = off[q * nblk], hi = off[(q + 1) * nblk];
+                    if (lo == hi) continue;
+                    memset(tab, 0, (size_t)bslots * sizeof(uint32_t));
+                    for (int64_t i = lo; i < hi; i++) tab[part[i]]++;
+                    if (pass == 0) {
+                        int64_t c = 0;
+                        for (int64_t i = 0; i < bslots; i++) c += tab[i] != 0;
+                        nd[q + 1] = c;
+                    } else {
+                        int64_t o = nd[q];
+                        for (int64_t i = 0; i < bslots; i++)
+                            if (tab[i]) {
+                                res->keys[o] = ((uint64_t)q << sh) | (uint64_t)i;
+                                res->counts[o] = tab[i];
+                                o++;
+                            }
+                    }
+                }
+                free(tab);
+            }
+            TICK(pass ? "count: buckets, emit" : "count: buckets, distinct");
+        }
+        free(nd);
+        free(part);
+        free(off);
         return res;
     }
     /* sort path: all canonical keys, radix sort, run-length encode */
@@ -172,19 +231,36 @@ spo_counts *spo_count(const uint8_t *ascii, int64_t len, int k, int nthreads) {
 
 int64_t spo_counts_n(const spo_counts *c, uint32_t lower) {
     int64_t n = 0;
+#pragma omp parallel for reduction(+ : n) if (c->n > (1 << 20))
     for (int64_t i = 0; i < c->n; i++) n += c->counts[i] >= lower;
     return n;
 }
 /* `jellyfish dump -c -L lower_count` keeps counts >= lower_count (Jellyfish.py:699) */
 int64_t spo_counts_fetch(const spo_counts *c, uint32_t lower, uint64_t *keys, uint32_t *counts) {
-    int64_t n = 0;
-    for (int64_t i = 0; i < c->n; i++)
-        if (c->counts[i] >= lower) {
-            keys[n] = c->keys[i];
-            counts[n] = c->counts[i];
-            n++;
-        }
-    return n;
+    enum { NB = 512 };
+    int64_t start[NB + 1];
+    const int64_t per = (c->n + NB - 1) / NB;
+    start[0] = 0;
+#pragma omp parallel for if (c->n > (1 << 20))
+    for (int b = 0; b < NB; b++) {
+        int64_t lo = b * per, hi = lo + per, m = 0;
+        if (hi > c->n) hi = c->n;
+        for (int64_t i = lo; i < hi; i++) m += c->counts[i] >= lower;
+        start[b + 1] = m;
+    }
+    for (int b = 0; b < NB; b++) start[b + 1] += start[b];
+#pragma omp parallel for if (c->n > (1 << 20))
+    for (int b = 0; b < NB; b++) {
+        int64_t lo = b * per, hi = lo + per, n = start[b];
+        if (hi > c->n) hi = c->n;
+        for (int64_t i = lo; i < hi; i++)
+            if (c->counts[i] >= lower) {
+                keys[n] = c->keys[i];
+                counts[n] = c->counts[i];
+                n++;
+            }
+    }
+    return start[NB];
 }
 void spo_counts_free(spo_counts *c) {
     if (!c) return;
@@ -403,6 +479,13 @@ int64_t spo_map_bins(const uint8_t *ascii, int64_t len, int k, const uint64_t *l
         hk[h] = lab_keys[i];
         hv[h] = i;
     }
+    /* cache-sized prefilter: one bit per hashed key, so that most windows never touch the big table */
+    const uint64_t pf_mask = ((uint64_t)1 << 27) - 1;
+    uint64_t *pf = (uint64_t *)calloc((size_t)1 << 21, sizeof(uint64_t));
+    for (int64_t i = 0; i < n_lab; i++) {
+        uint64_t h = (mix64(lab_keys[i]) >> 20) & pf_mask;
+        pf[h >> 6] |= (uint64_t)1 << (h & 63);
+    }
     int64_t mapped = 0;
     int64_t nblk = nthreads * 8;
     int64_t per = (len + nblk - 1) / nblk;
@@ -412,8 +495,17 @@ int64_t spo_map_bins(const uint8_t *ascii, int64_t len, int k, const uint64_t *l
         int64_t lo = b * per, hi = lo + per;
         if (hi > len) hi = len;
         if (lo >= hi) continue;
+        /* bins this block can touch: starts lo-(k-1) .. hi-k; counted privately, merged once */
+        int64_t s0 = lo - (k - 1);
+        if (s0 < 0) s0 = 0;
+        const int64_t slot0 = s0 / bin_size + (chunk_size > 0 ? s0 / chunk_size : 0);
+        const int64_t slot1 = hi / bin_size + (chunk_size > 0 ? (hi + k) / chunk_size : 0) + 2;
+        int32_t *mine = (int32_t *)calloc((size_t)((slot1 - slot0 + 1) * S), sizeof(int32_t));
         SCAN_WINDOWS(ascii, len, k, lo, hi, {
-            uint64_t h = mix64(key) & (uint64_t)(cap - 1);
+            const uint64_t hm = mix64(key);
+            const uint64_t hb = (hm >> 20) & pf_mask;
+            if (!((pf[hb >> 6] >> (hb & 63)) & 1)) continue;
+            uint64_t h = hm & (uint64_t)(cap - 1);
             while (hk[h] != ~0ULL && hk[h] != key) h = (h + 1) & (uint64_t)(cap - 1);
             if (hk[h] == key) {
                 int64_t li = hv[h];
@@ -421,13 +513,18 @@ int64_t spo_map_bins(const uint8_t *ascii, int64_t len, int k, const uint64_t *l
                 if (chunk_size > 0 && start >= chunk_size - (k - 1))
                     chunk = (start + (k - 1)) / chunk_size;
                 int64_t slot = start / bin_size + chunk;
-                if (slot < nslots)
-                    __atomic_fetch_add(&slot_counts[slot * S + lab_sg[li]], 1, __ATOMIC_RELAXED);
-                if (hit) hit[li] = 1;
+                if (slot < nslots) mine[(slot - slot0) * S + lab_sg[li]]++;
+                if (hit && !hit[li]) hit[li] = 1;
                 mapped++;
             }
         });
+        for (int64_t q = slot0; q <= slot1 && q < nslots; q++)
+            for (int j = 0; j < S; j++)
+                if (mine[(q - slot0) * S + j])
+                    __atomic_fetch_add(&slot_counts[q * S + j], mine[(q - slot0) * S + j], __ATOMIC_RELAXED);
+        free(mine);
     }
+    free(pf);
     free(hk);
     free(hv);
     return mapped;

@@ -125,6 +125,13 @@ class DistHotPath:
         self.shared_rows = kw.get("shared_rows", self.device.type == "cuda")
         self.wall = {}
         self._pin = {}
+        self._fence()
+
+    def _fence(self):
+        """torch allocates and fills on ITS stream, the library launches on the context's own non-blocking
+        stream: wait for torch's pending work before a library call reads or writes a fresh torch tensor."""
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def _t(self, name, t0):
         t1 = time.perf_counter()
@@ -194,6 +201,7 @@ class DistHotPath:
         ctx, t, dist = self.ctx, self.torch, self.dist
         mine = self.local_pieces
         tt = time.perf_counter()
+        self._fence()
         ctx.genome_reset(len(mine))
         for li, pc in enumerate(mine):
             ctx.tables_bind(li, self._ptr(self.tabs[li]))
@@ -217,6 +225,7 @@ class DistHotPath:
         tt = self._t("count(+exchange issue)", tt)
         # overflow pairs of every piece to every rank (small: counts >= 255 are rare)
         mine_ovf = t.zeros((max(int(n_ovf.sum()), 1), 2), dtype=t.int32, device=self.device)
+        self._fence()
         off = 0
         for i in range(len(mine)):
             if n_ovf[i]:
@@ -253,6 +262,7 @@ class DistHotPath:
                 split[gi] = True
                 cap = int(ons[gi]) + n + self.lengths_bp[gi] // 255 + 16
                 merged = t.zeros((cap, 2), dtype=t.int32, device=self.device)
+                self._fence()
                 m = ctx.table_merge(ptrs[gi], optrs[gi], int(ons[gi]), src, src_ovf, n, base, self.nview,
                                     merged.data_ptr(), cap) if self.nview else 0
                 self._merged.append(merged)
@@ -281,6 +291,7 @@ class DistHotPath:
         # surviving rows stay on the device: gathered over xGMI, copied to the host once, where needed
         keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
         counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
+        self._fence()
         if self.nview:
             ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
             ctx.filter_view(None, 0, 0, None, 0, 0)
@@ -423,6 +434,7 @@ class DistHotPath:
         recv_counts = szall[:, :, self.rank].sum(axis=1)
         n_send, n_recv = int(send_counts.sum()), int(recv_counts.sum())
         keys_send, cnts_send = self._buf("ks", n_send, t.int64), self._buf("cs", n_send, t.int32)
+        self._fence()
         off = 0
         for d in range(W):
             for li in range(len(mine)):
@@ -458,6 +470,7 @@ class DistHotPath:
                                                  self.max_freq, self.ratio)
             keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
             counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
+            self._fence()
             ctx.filter_fetch_device(keys_t.data_ptr(), counts_t.data_ptr(), None, n_rows)
         finally:
             ctx.sparse_view(None, None, None, None, 0, 0)
@@ -477,6 +490,7 @@ class DistHotPath:
         for c, n in enumerate(self.lengths_bp):
             woff[c + 1] = woff[c] + (int(n) + ws - 1) // ws + 1
         win_t = t.zeros((int(woff[-1]), S), dtype=t.int64, device=self.device)
+        self._fence()
         r.bins, r.n_mapped = [], 0
         if mine:
             ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
