@@ -7,7 +7,8 @@
 //   c2_hist   scan the packed chromosome, histogram the top B1+B2 slot bits
 //             (LDS histogram per block, one global atomic per non-empty bin)
 //   c2_part1  scan again; LDS counting sort of a 16K-key tile on the top B1
-//             bits; each bucket run is written as one coalesced burst (u32 keys)
+//             bits; each bucket run is written as one coalesced burst (3 bytes per key:
+//             a u16 plane and a u8 plane)
 //   c2_part2  per level-1 bucket: LDS counting sort of 16K-key tiles on the next
 //             B2 bits; only the low 15 slot bits survive, written as u16
 //   c2_count  one workgroup per fine bucket (2^15 consecutive slots): 128 KiB of
@@ -16,7 +17,7 @@
 //
 // All table writes and all key reads/writes are coalesced; the only random
 // accesses left are LDS atomics.  Physical HBM bytes per base (k = 15):
-//   0.375 x3 (scans) + 4 w + 4 r + 2 w + 2 r + 4 x slots/base (table write).
+//   0.625 x2 (scans) + 3 w + 3 r + 2 w + 2 r + 1 x slots/base (table write).
 #include "sp_device.h"
 
 #define C2_B3 15                      // slot bits resolved inside LDS
@@ -133,7 +134,7 @@ c2_tilescan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, int64_
 // also level-1 bucket offsets off1[F1+1] = off_fine[b*F2] and tile starts for part2
 __global__ void __launch_bounds__(1024)
 c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2,
-           unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1,
+           unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1 /*2*(F1+1): starts, ends*/,
            unsigned long long *__restrict__ tile_start /*F1+1*/) {
     __shared__ unsigned long long part[1024];
     const int T = 1024;
@@ -162,21 +163,25 @@ c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int
     __threadfence_block();
     __syncthreads();
     // level-1 offsets and tile starts: one thread per bucket, then a short serial prefix over <= 256 counts in LDS
-    __shared__ unsigned long long tcount[C2_MAXF];
+    // (level-1 runs start at multiples of 4 keys so that part2 can read them with 8- and 4-byte loads)
+    __shared__ unsigned long long tcount[C2_MAXF], bsize[C2_MAXF];
     if (threadIdx.x < F1) {
         const int b = threadIdx.x;
         const unsigned long long o = off_fine[(size_t)b * F2], e = off_fine[(size_t)(b + 1) * F2];
-        off1[b] = o;
+        bsize[b] = e - o;
         tcount[b] = (e - o + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long tiles = 0;
+        unsigned long long tiles = 0, o = 0;
         for (int b = 0; b < F1; b++) {
             tile_start[b] = tiles;
             tiles += tcount[b];
+            off1[b] = o;
+            off1[F1 + 1 + b] = o + bsize[b];
+            o += (bsize[b] + 3ULL) & ~3ULL;
         }
-        off1[F1] = off_fine[n_fine];
+        off1[F1] = o;
         tile_start[F1] = tiles;
     }
 }
@@ -215,7 +220,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
          int64_t n_units /* of 32 starts */,
          sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
          const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, int64_t n_tiles,
-         uint32_t *__restrict__ buf1) {
+         uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
     __shared__ uint32_t hist[C2_MAXF], cur[C2_MAXF], wsum[4];
     __shared__ unsigned long long delta[C2_MAXF];
     __shared__ uint32_t keys[C2_P1_KEYS];
@@ -242,8 +247,12 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
+            // 3 bytes per key leave the chip (the level-1 bucket is implied by where the key lands; <= 23 slot bits
+            // are left): the low 16 bits and the byte above them go to two planes, both in coalesced runs
             const uint32_t s = keys[i];
-            buf1[delta[s >> shift1] + i] = s;
+            const unsigned long long o = delta[s >> shift1] + i;
+            lo1[o] = (uint16_t)s;
+            hi1[o] = (uint8_t)(s >> 16);
         }
         __syncthreads();
     }
@@ -265,7 +274,7 @@ __device__ __forceinline__ int c2_bucket_of(const unsigned long long *__restrict
 }
 
 __global__ void __launch_bounds__(C2_P2_THREADS)
-c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
          uint16_t *__restrict__ buf2) {
@@ -279,26 +288,37 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
     if (tile >= n_tiles) return;
     if (threadIdx.x == 0) s_bucket[0] = c2_bucket_of(tile_start, F1, tile);
     __syncthreads();
-    uint32_t nxt[C2_P2_PER];
+    static_assert(C2_P2_PER % 4 == 0, "part2 reads its keys four at a time");
+    constexpr int NG = C2_P2_PER / 4;
+    uint2 nlo[NG];      // four 16-bit low parts
+    uint32_t nhi[NG];   // four high bytes
     int nnext = 0;
-    {
-        const int nb = s_bucket[0];
-        const unsigned long long base = off1[nb] + (tile - tile_start[nb]) * C2_TILE_KEYS, end = off1[nb + 1];
+    auto fetch = [&](int nb, unsigned long long t_in_bucket) {
+        const unsigned long long base = off1[nb] + t_in_bucket * C2_TILE_KEYS, end = off1[F1 + 1 + nb];
+        nnext = 0;
 #pragma unroll
-        for (int j = 0; j < C2_P2_PER; j++) {
-            const unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
+        for (int g = 0; g < NG; g++) {
+            const unsigned long long idx = base + ((unsigned long long)g * C2_P2_THREADS + threadIdx.x) * 4ULL;
             if (idx < end) {
-                nxt[j] = buf1[idx];
-                nnext = j + 1;
+                nlo[g] = *reinterpret_cast<const uint2 *>(lo1 + idx);
+                nhi[g] = *reinterpret_cast<const uint32_t *>(hi1 + idx);
+                const unsigned long long left = end - idx;
+                nnext = 4 * g + (left < 4ULL ? (int)left : 4);
             }
         }
-    }
+    };
+    fetch(s_bucket[0], tile - tile_start[s_bucket[0]]);
     int p = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         const int b1 = s_bucket[p];
         uint32_t my[C2_P2_PER];
 #pragma unroll
-        for (int j = 0; j < C2_P2_PER; j++) my[j] = nxt[j];
+        for (int g = 0; g < NG; g++) {
+            my[4 * g + 0] = (nlo[g].x & 0xFFFFu) | ((nhi[g] & 0xFFu) << 16);
+            my[4 * g + 1] = (nlo[g].x >> 16) | ((nhi[g] & 0xFF00u) << 8);
+            my[4 * g + 2] = (nlo[g].y & 0xFFFFu) | (nhi[g] & 0xFF0000u);
+            my[4 * g + 3] = (nlo[g].y >> 16) | ((nhi[g] >> 24) << 16);
+        }
         const int nmine = nnext;
         const unsigned long long ntile = tile + gridDim.x;
         if (threadIdx.x < F2) hist[threadIdx.x] = 0;
@@ -318,15 +338,7 @@ c2_part2(const uint32_t *__restrict__ buf1, const unsigned long long *__restrict
         nnext = 0;
         if (ntile < n_tiles) {  // next tile's keys: in flight across the rest of this iteration
             const int nb = s_bucket[p ^ 1];
-            const unsigned long long base = off1[nb] + (ntile - tile_start[nb]) * C2_TILE_KEYS, end = off1[nb + 1];
-#pragma unroll
-            for (int j = 0; j < C2_P2_PER; j++) {
-                const unsigned long long idx = base + (unsigned long long)j * C2_P2_THREADS + threadIdx.x;
-                if (idx < end) {
-                    nxt[j] = buf1[idx];
-                    nnext = j + 1;
-                }
-            }
+            fetch(nb, ntile - tile_start[nb]);
         }
         const uint32_t total = c2_scan_F(hist, start, F2, wsum);
         if (threadIdx.x < F2) gbase[threadIdx.x] = g - start[threadIdx.x];   // out index = gbase[b] + LDS index
@@ -509,7 +521,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_ghist = 0;
     size_t o_offf = o_ghist + al(nf * 8);
     size_t o_off1 = o_offf + al((nf + 1) * 8);
-    size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 8);
+    size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 16);       // level-1 starts, then ends
     size_t o_cur1 = o_tile + al((size_t)(P.F1 + 1) * 8);
     size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
     const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
@@ -517,7 +529,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_tcnt = o_cur2 + al(nf * 8);
     size_t o_toff = o_tcnt + al((size_t)P.F1 * (size_t)n_tiles * 4);
     size_t o_buf1 = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
-    size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64);
+    size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64 + (size_t)P.F1 * 16);
     size_t o_segb = o_buf2 + al((size_t)c.len * 2 + 64);          // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
@@ -544,6 +556,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
     uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
+    uint16_t *lo1 = (uint16_t *)buf1;                                  // level-1 records: 3 bytes per key in two planes
+    uint8_t *hi1 = (uint8_t *)buf1 + al((size_t)c.len * 2 + 64 + (size_t)P.F1 * 8);
     uint2 *ovf_tmp = (uint2 *)buf1;
     const unsigned long long ovf_cap = (unsigned long long)c.len / 2 + 8;   // pairs that fit in buf1 (>= len/255 + 16)
     // zero ghist .. cursor2 in one memset (they are contiguous)
@@ -562,11 +576,12 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3(P.F1), dim3(256), 0, (const uint32_t *)tile_cnt, tile_off,
               n_tiles);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
-              kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, buf1);
+              kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, lo1, hi1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
     int64_t max_tiles2 = n_tiles + P.F1;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
-    SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, buf1, off1, tile_start, P.F1,
+    SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, (const uint16_t *)lo1, (const uint8_t *)hi1, off1,
+              tile_start, P.F1,
               P.F2, C2_B3, off_fine, cur2, buf2);
     hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4);
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
