@@ -436,18 +436,168 @@ s3_final_small(const KR2 *__restrict__ buf2, const unsigned long long *__restric
     if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
 }
 
+// ---------------------------------------------------------------- s3_final_bitmap (k = 16, 17)
+// With <= 16 residual bits a fine bucket is a sparse set over <= 65536 values (~1.3 K keys for a wheat-sized
+// chromosome at k = 17), and sorting is more than the job needs: (1) every key sets its bit in an LDS bitmap,
+// (2) a prefix popcount over the bitmap words turns "bit position" into "rank among the distinct residuals",
+// (3) every key adds one to cnt[rank], (4) each thread walks the set bits of ITS words in ascending order and
+// writes the (residual, count) pairs that pass `lower` at the offset an ordered block scan gives it.  Ascending
+// output without a sort: ~6 LDS operations per key and two block scans per bucket instead of four radix passes
+// (s3_final_small + s3_final were 200 of the 507 ms of a wheat-like pass at k = 17; this kernel + the rest of
+// s3_final: 86 ms.  PMC: VALU 43 % and LDS 45 % busy, half of the LDS cycles bank conflicts of the random bitmap /
+// counter accesses; a variant whose first-arriving copy writes the pair out instead of the bit walk was no faster).
+#define S3_BM_MAXBITS 16
+#ifndef S3_BM_CAP
+#define S3_BM_CAP 2048      // distinct residuals per bucket this kernel takes (cnt[] entries); beyond: s3_final
+#endif
+#define S3_BM_NMAX (1u << 22)   // keys per bucket it is willing to stream (hot buckets: few distinct, many copies)
+#define S3_BM_PER 8             // keys per thread prefetched into registers (buckets up to 2048 keys never re-read)
+#define S3_BM_PUNT (~0ULL)      // kept[bucket] value that hands the bucket to s3_final
+
+// exclusive prefix of v over the block (value in a register); *total = block sum.  Ends with a barrier.
+__device__ __forceinline__ uint32_t s3_scan_reg(uint32_t v, uint32_t *wsum /* >= THREADS/64 */, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < S3_SORT_THREADS / 64; w++) {
+        const uint32_t x = wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_final_bitmap(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+                uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
+                unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t bm_lds[];   // bm[nw] | cnt[S3_BM_CAP] | pre[nw] (u16)
+    __shared__ uint32_t ws1[S3_SORT_THREADS / 64], ws2[S3_SORT_THREADS / 64];
+    __shared__ unsigned long long red[16];
+    const int nw = R2 > 5 ? 1 << (R2 - 5) : 1;
+    uint32_t *bm = bm_lds, *cnt = bm_lds + nw;
+    uint16_t *pre = reinterpret_cast<uint16_t *>(cnt + S3_BM_CAP);
+    const int wpt = (nw + S3_SORT_THREADS - 1) / S3_SORT_THREADS;
+    const int w0 = (int)threadIdx.x * wpt, w1 = w0 + wpt < nw ? w0 + wpt : nw;
+    unsigned long long lsum = 0;
+    // software pipeline: offsets and the first S3_BM_PER x 256 keys of the NEXT bucket travel while this one is
+    // processed (a bucket is ~7 barrier-separated steps of a few hundred cycles; two exposed global round trips on
+    // top of them made the first version of this kernel 40 % slower)
+    unsigned long long p_o = 0, p_n = 0;
+    uint32_t p_key[S3_BM_PER];
+    auto fetch = [&](int64_t b) {
+        p_n = 0;
+        if (b >= n_fine) return;
+        p_o = off_fine[b];
+        p_n = off_fine[b + 1] - p_o;
+        if (p_n > S3_BM_NMAX) return;
+#pragma unroll
+        for (int j = 0; j < S3_BM_PER; j++) {
+            const uint32_t i = threadIdx.x + (uint32_t)j * S3_SORT_THREADS;
+            if (i < p_n) p_key[j] = (uint32_t)buf2[p_o + i];
+        }
+    };
+    fetch(blockIdx.x);
+    for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
+        const unsigned long long o = p_o, n64 = p_n;
+        uint32_t key[S3_BM_PER];
+#pragma unroll
+        for (int j = 0; j < S3_BM_PER; j++) key[j] = p_key[j];
+        fetch(bucket + gridDim.x);
+        if (n64 == 0 || n64 > S3_BM_NMAX) {
+            if (threadIdx.x == 0) kept[bucket] = n64 ? S3_BM_PUNT : 0ULL;
+            continue;
+        }
+        const uint32_t n = (uint32_t)n64;
+        const KR2 *seg = buf2 + o;
+        for (int i = threadIdx.x; i < nw; i += S3_SORT_THREADS) bm[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < S3_BM_PER; j++)
+            if (threadIdx.x + (uint32_t)j * S3_SORT_THREADS < n) atomicOr(&bm[key[j] >> 5], 1u << (key[j] & 31));
+        for (uint32_t i = threadIdx.x + S3_BM_PER * S3_SORT_THREADS; i < n; i += S3_SORT_THREADS) {
+            const uint32_t r = (uint32_t)seg[i];
+            atomicOr(&bm[r >> 5], 1u << (r & 31));
+        }
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int w = w0; w < w1; w++) mine += (uint32_t)__popc(bm[w]);
+        uint32_t distinct;
+        const uint32_t first = s3_scan_reg(mine, ws1, &distinct);   // rank of this thread's first distinct residual
+        if (distinct > S3_BM_CAP) {                                 // block-uniform
+            if (threadIdx.x == 0) kept[bucket] = S3_BM_PUNT;
+            __syncthreads();
+            continue;
+        }
+        {
+            uint32_t run = first;
+            for (int w = w0; w < w1; w++) {
+                pre[w] = (uint16_t)run;
+                run += (uint32_t)__popc(bm[w]);
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < distinct; i += S3_SORT_THREADS) cnt[i] = 0;
+        __syncthreads();
+        auto bump = [&](uint32_t r) {
+            atomicAdd(&cnt[(uint32_t)pre[r >> 5] + (uint32_t)__popc(bm[r >> 5] & ((1u << (r & 31)) - 1u))], 1u);
+        };
+#pragma unroll
+        for (int j = 0; j < S3_BM_PER; j++)
+            if (threadIdx.x + (uint32_t)j * S3_SORT_THREADS < n) bump(key[j]);
+        for (uint32_t i = threadIdx.x + S3_BM_PER * S3_SORT_THREADS; i < n; i += S3_SORT_THREADS) bump((uint32_t)seg[i]);
+        __syncthreads();
+        uint32_t nk = 0;
+        for (uint32_t q = first; q < first + mine; q++) nk += cnt[q] >= lower;
+        uint32_t n_kept;
+        uint32_t wpos = s3_scan_reg(nk, ws2, &n_kept);
+        if (nk) {
+            uint32_t q = first;
+            for (int w = w0; w < w1; w++) {
+                uint32_t bits = bm[w];
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    const uint32_t c = cnt[q++];
+                    if (c >= lower) {
+                        tmp_keys[o + wpos] = (KR2)(((uint32_t)w << 5) | (uint32_t)b);
+                        tmp_cnts[o + wpos] = c;
+                        lsum += c;
+                        wpos++;
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) kept[bucket] = n_kept;
+        __syncthreads();   // bm / cnt / pre are rewritten at the top of the next bucket
+    }
+    const unsigned long long tot = sp_block_sum_u64(lsum, red);
+    if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
+}
+
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
 s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned long long *__restrict__ off_fine,
          int64_t n_fine, int R2, uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
          unsigned long long *__restrict__ kept, unsigned long long *__restrict__ big_list,
-         unsigned long long *__restrict__ n_big, unsigned long long big_cap, unsigned long long *__restrict__ len_sum) {
+         unsigned long long *__restrict__ n_big, unsigned long long big_cap, unsigned long long *__restrict__ len_sum,
+         unsigned long long light_cap /* buckets up to this size were the light kernel's; S3_BM_PUNT: the ones
+                                         the bitmap kernel marked in kept[] */) {
     __shared__ s3_final_lds<KR2> L;
     unsigned long long lsum = 0;
     for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
         const unsigned long long o = off_fine[bucket];
         const unsigned long long n64 = off_fine[bucket + 1] - o;
-        if (n64 <= S3_SMALL_CAP) continue;           // the light kernel's
+        if (light_cap == S3_BM_PUNT ? kept[bucket] != S3_BM_PUNT : n64 <= light_cap) continue;   // the light kernel's
         if (n64 <= S3_SORT_CAP) {
             const uint32_t nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
             if (threadIdx.x == 0) kept[bucket] = nk;
@@ -799,11 +949,20 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
               (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
               (const unsigned long long *)d_of, d_c2, buf2);
     int64_t g4 = n_fine < (int64_t)ctx->n_cu * 64 ? n_fine : (int64_t)ctx->n_cu * 64;
-    SP_LAUNCH(ctx, "s3_final_small", s3_final_small<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
-              (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_small + 2);
+    const bool bitmap = P.R2 <= S3_BM_MAXBITS && sizeof(KR2) == 4;      // k = 16, 17
+    if (bitmap)
+        SP_LAUNCH(ctx, "s3_final_bitmap", s3_final_bitmap<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS),
+                  (size_t)(P.R2 > 5 ? 1 << (P.R2 - 5) : 1) * 6 + (size_t)S3_BM_CAP * 4,
+                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  d_kp, d_small + 2);
+    else
+        SP_LAUNCH(ctx, "s3_final_small", s3_final_small<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
+                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  d_kp, d_small + 2);
     SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
               (KR2 *)buf1, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
-              d_small + 1, (unsigned long long)big_cap, d_small + 2);
+              d_small + 1, (unsigned long long)big_cap, d_small + 2,
+              bitmap ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP);
     unsigned long long n_big = 0;
     SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));

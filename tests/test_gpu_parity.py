@@ -124,6 +124,15 @@ def test_count_sparse_engine_hot_buckets(gpu_ctx):
     seqs = [np.concatenate([_rand_seq(rng, 50000), hot, _rand_seq(rng, 1000), crowd])]
     _count_both(gpu_ctx, seqs, k, 1, 0)
     _count_both(gpu_ctx, seqs, k, 3, 0)
+    # k = 16 / 17 finish their buckets with the bitmap kernel (<= 16 residual bits): few distinct residuals with
+    # many copies stream through it (keys beyond the registers), > 2048 distinct residuals or > 2^22 keys in one
+    # bucket are handed to the sort kernel / the device-wide fallback through kept[] = punt
+    for k in (16, 17):
+        polya = np.frombuffer(b"A" * 4_300_000, np.uint8)
+        seqs = [np.concatenate([_rand_seq(rng, 30000), hot[:23 * 6000], _rand_seq(rng, 500), crowd[:18 * 9000], polya,
+                                _rand_seq(rng, 200)])]
+        _count_both(gpu_ctx, seqs, k, 1, 0)
+        _count_both(gpu_ctx, seqs, k, 3, 0)
     # k = 32: 5000 distinct k-mers (each twice) behind one 14-base prefix share all partition and split
     # bits, so the piece exceeds the LDS hash table as well -> device-wide fallback for that bucket
     k = 32
