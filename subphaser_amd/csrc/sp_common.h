@@ -109,6 +109,8 @@ struct sp_ctx {
     // labels
     uint8_t *d_label = nullptr;  // [nslots] 0 = none, 1+sg; bit 7 = seen
     sp_buf b_ptab, b_labkeys;    // pair table (sp_map.hip: 4^(k-1) x u32) and the labelled keys it was built from
+    int ptab_k = 0;              // k the pair table currently holds a label set for (0: not built / unknown state)
+    int64_t ptab_n = 0;          // number of keys of that set (still in b_labkeys): sp_labels_set un-builds them
     int map_engine = 0;          // 0 = pair table (S <= 7), 1 = label table
     bool labels_ready = false;
     uint32_t *d_bloom = nullptr; // L2-resident pair filter over hashed (k-1)-mers (sp_map.hip), 2^bloom_bits bits

@@ -13,6 +13,7 @@ import argparse
 import os
 import pickle
 import shutil
+import time
 import sys
 from collections import Counter, OrderedDict
 
@@ -201,10 +202,15 @@ class Pipeline:
             elif not all(os.access(f, os.R_OK) for f in chromfiles):
                 reuse = False
         if not reuse:
+            # The per-chromosome copies are an OUTPUT for the reference's later modules; counting uses the records
+            # in memory.  Their writer threads keep going while the GPU counts; `split.ok` is recorded once they
+            # are done (_finish_background).
             os.makedirs(lay.chromdir, exist_ok=True)
-            chromfiles, labels, d_targets, d_size = seqs.split_genomes(
-                self.genomes, self.labels, self.chrs, lay.chromdir, d_targets=parse_idmap(self.target), sep=self.sep)
-            mk_ckp(ckp, chromfiles, labels, d_targets, d_size)
+            chromfiles, labels, d_targets, d_size, waiting = seqs.split_genomes(
+                self.genomes, self.labels, self.chrs, lay.chromdir, d_targets=parse_idmap(self.target), sep=self.sep,
+                defer=True)
+            self._background.append(("chromosome files", waiting.wait,
+                                     lambda: mk_ckp(ckp, chromfiles, labels, d_targets, d_size)))
         # config order, not file order
         where = dict(zip(labels, chromfiles))
         labels = [lab for lab in d_targets.values() if lab in where]
@@ -243,15 +249,53 @@ class Pipeline:
             raise ValueError("0 kmer remained after filtering. Please reset the filter options.")
         # The matrix in memory is what every later stage uses, so the file always describes THIS run's filter:
         # it is rewritten whenever it is recomputed (an old file next to new calls would be inconsistent).
+        # It is 0.5 GB of text at wheat scale (4 s): a forked writer formats it from copy-on-write views of the
+        # arrays while the clustering and mapping stages run; the checkpoint follows the writer's exit.
         matfile = lay.out("kmer.mat")
-        with open(matfile, "w") as fout:
-            dumps.write_matrix(d_mat2, fout)
-        try:
-            plot_histogram(dumps.hist_tot(), histfig)
-        except Exception as e:     # the figure is optional
-            logger.warning("histogram not plotted: {}".format(e))
-        mk_ckp(lay.ckp(matfile))
+        t0 = time.perf_counter()
+        self._write_matrix_in_background(dumps, d_mat2, matfile, histfig, lay)
+        logger.info("`{}` + histogram figure: writer started in {:.2f} s".format(os.path.basename(matfile),
+                                                                             time.perf_counter() - t0))
         return d_mat2
+
+    def _write_matrix_in_background(self, dumps, d_mat2, matfile, histfig, lay):
+        import multiprocessing as mp
+        tot = dumps.hist_tot()          # device -> host here: the child must not touch the GPU
+
+        def work():
+            with open(matfile, "w") as fout:
+                dumps.write_matrix(d_mat2, fout)
+            try:
+                plot_histogram(tot, histfig)
+            except Exception as e:     # the figure is optional
+                logger.warning("histogram not plotted: {}".format(e))
+
+        if len(d_mat2) < 200000:      # small: not worth a process
+            work()
+            mk_ckp(lay.ckp(matfile))
+            return
+        proc = mp.get_context("fork").Process(target=work, daemon=False)
+        proc.start()
+
+        def wait():
+            proc.join()
+            if proc.exitcode != 0:
+                raise RuntimeError("writing {} failed (exit code {})".format(matfile, proc.exitcode))
+        self._background.append((matfile, wait, lambda: mk_ckp(lay.ckp(matfile))))
+
+    def _finish_background(self):
+        """Wait for the writers started along the way, then record their checkpoints."""
+        pending, self._background = self._background, []
+        err = None
+        for name, wait, done in pending:
+            try:
+                wait()
+                done()
+            except Exception as e:      # keep waiting for the others; report the first failure
+                logger.error("background writer of {} failed: {}".format(name, e))
+                err = err or e
+        if err is not None:
+            raise err
 
     # ---- stage 3: subgenome assignment + subgenome-specific k-mers --------------------------------------
     def stage_cluster(self, lay, d_mat2, assigned):
@@ -325,7 +369,23 @@ class Pipeline:
             logger.info("\t{} {}-specific features".format(n, sg))
 
     def run(self):
-        lay = Layout(self.outdir, self.tmpdir, self.prefix, self.k, self.min_freq, self.min_fold)
+        self._background = []
+        try:
+            self._run()
+        except BaseException:
+            try:
+                self._finish_background()      # do not leave writers behind; the stage's error is the one to report
+            except Exception:
+                pass
+            raise
+        self._finish_background()
+        if self.cleanup:
+            logger.info("Cleaning {}".format(self._lay.tmpdir))
+            shutil.rmtree(self._lay.tmpdir, ignore_errors=True)
+        logger.info("Pipeline completed" + (" early" if self.just_core else ""))
+
+    def _run(self):
+        lay = self._lay = Layout(self.outdir, self.tmpdir, self.prefix, self.k, self.min_freq, self.min_fold)
         chromfiles, labels, d_size, assigned = self.stage_ingest(lay)
         self.chromfiles, self.labels, self.d_size = chromfiles, labels, d_size
         d_mat2 = self.stage_count_filter(lay, chromfiles, labels)
@@ -338,10 +398,6 @@ class Pipeline:
             if not (self.disable_ltr and self.disable_circos):
                 logger.info("Modules 3-4 (LTR, circos) are not part of this build; run the reference on the "
                             "outputs above, or pass -disable_ltr -disable_circos to silence this note")
-        if self.cleanup:
-            logger.info("Cleaning {}".format(lay.tmpdir))
-            shutil.rmtree(lay.tmpdir, ignore_errors=True)
-        logger.info("Pipeline completed" + (" early" if self.just_core else ""))
 
 
 def main(argv=None):

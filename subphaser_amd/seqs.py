@@ -210,10 +210,29 @@ class ChromRecord:
 _REG = {}   # chromfile path -> ChromRecord
 
 
-def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", write_files=True):
+class PendingWrites:
+    """Per-chromosome FASTA copies still being written by the writer threads of split_genomes(defer=True)."""
+
+    def __init__(self, pool, futures):
+        self.pool, self.futures = pool, futures
+
+    def wait(self):
+        try:
+            for fut in self.futures:
+                fut.result()        # re-raises a writer's exception
+        finally:
+            self.futures = []
+            if self.pool is not None:
+                self.pool.shutdown()
+                self.pool = None
+
+
+def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", write_files=True, defer=False):
     """Select target chromosomes, apply `new|old` renaming and label prefixes.
     Returns (chromfiles, labels, d_targets2, d_size) like the reference.  The
-    sequences are also kept in memory so the counting step need not re-read them."""
+    sequences are also kept in memory so the counting step need not re-read them.
+    defer=True: a fifth value, a PendingWrites -- the per-chromosome files (which nothing in modules 1-2 reads
+    back) are still being written when the call returns; the caller waits before it records the checkpoint."""
     d_targets2 = OrderedDict()
     if not d_targets:
         d_targets = OrderedDict()
@@ -250,13 +269,14 @@ def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", w
             outfas.append(outfa)
             labels.append(rid)
             d_size[rid] = len(seq)
-    for fut in pending:
-        fut.result()
-    if writer is not None:
-        writer.shutdown()
+    waiting = PendingWrites(writer, pending)
+    if not defer:
+        waiting.wait()
     missing = set(d_targets) - got
     if missing:
         logger.error("Chromosomes {} are not found in sequences files".format(missing))
+    if defer:
+        return outfas, labels, d_targets2, d_size, waiting
     return outfas, labels, d_targets2, d_size
 
 
