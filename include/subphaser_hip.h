@@ -261,6 +261,18 @@ int sp_dev_free(sp_ctx *ctx, void *d_ptr);
 int sp_dev_copy_to_host(sp_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
 int sp_dev_copy_from_host(sp_ctx *ctx, void *d_dst, const void *src, int64_t bytes);
 
+
+/* ---- host-side FASTA scanner (no GPU work; replaces the Bio.SeqIO record loops of Seqs.py:27-71, 121-153) ----
+ * `data`/`n`: the file image (mmap or decompressed bytes), which must stay valid until sp_fasta_close.  A record
+ * starts at a '>' that is the first byte of a line; bytes <= 0x20 are dropped from the sequence lines.
+ * sp_fasta_fetch: hdr_start[r] .. hdr_end[r] = header text of record r (without '>' and the line break),
+ * seq_off[r] .. seq_off[r + 1] = its bases inside `cat` (n_bases bytes, caller-owned, may be page-locked). */
+typedef struct sp_fasta sp_fasta;
+int sp_fasta_open(const void *data, int64_t n, int threads, sp_fasta **out);
+int sp_fasta_counts(const sp_fasta *h, int64_t *n_records, int64_t *n_bases);
+int sp_fasta_fetch(const sp_fasta *h, int64_t *hdr_start, int64_t *hdr_end, int64_t *seq_off, void *cat);
+void sp_fasta_close(sp_fasta *h);
+
 #ifdef __cplusplus
 }
 #endif

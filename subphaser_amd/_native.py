@@ -27,6 +27,7 @@ SYMBOLS = [
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_host_register", "sp_host_unregister", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
+    "sp_fasta_open", "sp_fasta_counts", "sp_fasta_fetch", "sp_fasta_close",
 ]
 
 
@@ -109,8 +110,13 @@ def load():
     L.sp_host_register.argtypes = [vp, vp, i64]
     L.sp_host_unregister.argtypes = [vp, vp]
     L.sp_dev_copy_from_host.argtypes = [vp, vp, vp, i64]
+    L.sp_fasta_open.argtypes = [vp, i64, ci, P(vp)]
+    L.sp_fasta_counts.argtypes = [vp, P(i64), P(i64)]
+    L.sp_fasta_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.sp_fasta_close.argtypes = [vp]
+    L.sp_fasta_close.restype = None
     for name in SYMBOLS:
-        if name not in ("sp_last_error", "sp_stream"):
+        if name not in ("sp_last_error", "sp_stream", "sp_fasta_close"):
             getattr(L, name).restype = ci
     _lib = L
     return L
@@ -118,6 +124,41 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def fasta_scan(data, threads=None, out=None):
+    """Records of a FASTA file image (uint8 array / memmap / bytes) through the library's host-side scanner:
+    returns (ids, cat, off) -- ids list of str (first token of each header), cat uint8 array of all sequences back
+    to back without line breaks or blanks, off int64 [n + 1].  `out(n_bases)` may supply the buffer for cat (e.g.
+    page-locked memory).  No GPU is involved."""
+    L = load()
+    data = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data
+    if data.dtype != np.uint8 or not data.flags.c_contiguous:
+        data = np.ascontiguousarray(data, np.uint8)
+    n = int(data.size)
+    if threads is None:
+        threads = min(32, len(os.sched_getaffinity(0)))
+    h = C.c_void_p()
+    rc = L.sp_fasta_open(C.c_void_p(data.ctypes.data) if n else None, n, int(threads), C.byref(h))
+    if rc == SP_ENOMEM:
+        raise MemoryError("sp_fasta_open")
+    if rc:
+        raise ValueError("sp_fasta_open: bad arguments")
+    try:
+        nr, nb = C.c_int64(), C.c_int64()
+        L.sp_fasta_counts(h, C.byref(nr), C.byref(nb))
+        nr, nb = nr.value, nb.value
+        hs, he, off = np.empty(nr, np.int64), np.empty(nr, np.int64), np.empty(nr + 1, np.int64)
+        cat = out(nb) if out is not None else np.empty(nb, np.uint8)
+        if L.sp_fasta_fetch(h, _p(hs), _p(he), _p(off), _p(cat) if nb else None):
+            raise ValueError("sp_fasta_fetch: bad arguments")
+    finally:
+        L.sp_fasta_close(h)
+    ids = []
+    for a, b in zip(hs.tolist(), he.tolist()):
+        t = bytes(data[a:b]).split()
+        ids.append(t[0].decode() if t else "")
+    return ids, cat, off
 
 
 def as_ascii(seq):

@@ -83,7 +83,25 @@ def stack_bins(starts, counts, window_size):
 def stack_matrix(inBedCount, window_size=100000):
     """stack short bins: returns (coords, counts) like the reference (Circos.py:831-842).
     Rows: chromosomes in first-appearance order, windows of a chromosome in first-appearance order."""
-    names, code, starts, vals = read_bin_counts_arrays(inBedCount)
+    return stack_arrays(*read_bin_counts_arrays(inBedCount), window_size=window_size)
+
+
+def factorize_first(ids):
+    """(names in first-appearance order, code[i] into names) of a list of str."""
+    try:
+        import pandas as pd
+        codes, names = pd.factorize(np.asarray(ids, dtype=object), sort=False)
+        return list(names), codes.astype(np.int64)
+    except ImportError:
+        seen = {}
+        code = np.fromiter((seen.setdefault(x, len(seen)) for x in ids), np.int64, len(ids))
+        return list(seen), code
+
+
+def stack_arrays(names, code, starts, vals, window_size=100000):
+    """stack_matrix on the parsed form of a `.bin.count` file (names, code[n], starts[n], counts[n, S]): what the
+    CLI hands over when it already holds the lines as arrays (no text round trip)."""
+    starts, vals = np.asarray(starts, np.int64), np.asarray(vals, np.int64)
     if len(starts) == 0:
         return [], []
     ws = int(window_size) if float(window_size).is_integer() else window_size

@@ -10,3 +10,4 @@
 #include "sp_sparse2.hip"
 #include "sp_enrich.hip"
 #include "sp_synth.hip"
+#include "sp_fasta.hip"

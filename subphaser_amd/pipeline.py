@@ -354,11 +354,16 @@ class Pipeline:
     def stage_features(self, lay, cl, kmer_labels):
         feat_map = lay.out("custom.bin.count")
         logger.info("feature sets: {}".format(self.custom_features))
+        lines = []       # the written lines as arrays: `custom.bin.count` is an output, nothing below parses it back
         with open(feat_map, "w") as fout:
             seqs.map_kmer3(self.custom_features, kmer_labels, fout=fout, k=self.k, bin_size=FEATURE_BIN,
-                           sg_names=cl.sg_names, chunk=False, log=False)
+                           sg_names=cl.sg_names, chunk=False, log=False, collect=lines)
         logger.info("feature enrichment")
-        ids, counts = circos.stack_matrix(feat_map, window_size=100000000)
+        names, code = circos.factorize_first([x for part in lines for x in part[0]])
+        ids, counts = circos.stack_arrays(
+            names, code, np.concatenate([part[1] for part in lines]) if lines else np.zeros(0, np.int64),
+            np.concatenate([part[2] for part in lines], axis=0) if lines else np.zeros((0, len(cl.sg_names)), np.int64),
+            window_size=100000000)
         feat_enrich = lay.out("custom.enrich")
         with open(feat_enrich, "w") as fout:
             enriched, _ = stats.enrich_ltr(fout, cl.d_sg, counts, colnames=cl.sg_names, rownames=ids,

@@ -14,6 +14,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import _native
 from . import kmer as kmerlib
 from .runtime import get_context, logger
 
@@ -52,6 +53,11 @@ def _strip_newlines(body):
     return body[keep]
 
 
+def _native_scanner():
+    """The library's host-side scanner (sp_fasta.hip) unless SP_FASTA_NUMPY is set (the numpy twin below)."""
+    return not os.environ.get("SP_FASTA_NUMPY")
+
+
 def read_fasta(path, as_array=False):
     """Yield (id, sequence without line breaks) for every record of a (gz) FASTA file.
     as_array=True yields uint8 numpy arrays (no extra copy for multi-GB genomes), else bytes."""
@@ -66,6 +72,13 @@ def read_fasta(path, as_array=False):
         data = np.memmap(path, dtype=np.uint8, mode="r")
     if data.size == 0:
         return
+    if _native_scanner():
+        ids, cat, off = _native.fasta_scan(data)
+        for i, rid in enumerate(ids):
+            seq = cat[off[i]:off[i + 1]]
+            yield rid, (seq if as_array else seq.tobytes())
+        return
+    # numpy twin of the scanner (kept as its cross-check, tests/test_abi_and_host.py)
     # record starts: '>' at the beginning of a line (numpy passes run in threads: they release the GIL)
     from concurrent.futures import ThreadPoolExecutor
     n = int(data.size)
@@ -117,6 +130,8 @@ def read_fasta_bulk(path):
     empty = ([], np.empty(0, np.uint8), np.zeros(1, np.int64))
     if n == 0:
         return empty
+    if _native_scanner():
+        return _native.fasta_scan(data)
     from concurrent.futures import ThreadPoolExecutor
     step = _BULK_STEP
     spans = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
@@ -355,9 +370,11 @@ def bin_lines(rid, length, slot_counts, bin_size, chunk_size, k):
 
 
 def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bin_size=10000, sg_names=[],
-              ncpu="autodetect", method="map", log=True, chunk=True, chunksize=None, ctx=None):
+              ncpu="autodetect", method="map", log=True, chunk=True, chunksize=None, ctx=None, collect=None):
     """Same arguments as the reference (ncpu/method/chunksize are accepted and ignored:
-    the GPU replaces the process pool).  Writes `#chrom start end SG...` lines to fout."""
+    the GPU replaces the process pool).  Writes `#chrom start end SG...` lines to fout.
+    collect (chunk=False only): a list that receives, per feature file, the written lines as arrays
+    (ids list, starts int64[n], counts int64[n, S]) so that a caller need not parse the text back."""
     ctx = ctx or get_context()
     labels = _as_labels(d_kmers, sg_names, k)
     if k is None:
@@ -416,6 +433,24 @@ def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bi
                     else:
                         out.append("%s\t0\t%d\t%s\n" % (ids[i], ends[i], "\t".join(map(str, counts[i].tolist()))))
                 return "".join(out)
+            if collect is not None:
+                if not big:
+                    collect.append(([ids[i] for i in sel.tolist()], np.zeros(sel.size, np.int64),
+                                    counts[sel].astype(np.int64)))
+                else:
+                    r_ids, r_st, r_cc = [], [], []
+                    for i in sel.tolist():
+                        if i in big:
+                            st, _, cc = big[i]
+                            r_ids += [ids[i]] * len(st)
+                            r_st += st.tolist()
+                            r_cc += cc.tolist()
+                        else:
+                            r_ids.append(ids[i])
+                            r_st.append(0)
+                            r_cc.append(counts[i].tolist())
+                    collect.append((r_ids, np.asarray(r_st, np.int64),
+                                    np.asarray(r_cc, np.int64).reshape(len(r_ids), counts.shape[1])))
             fout.flush() if hasattr(fout, "flush") else None
             write_chunks(fout, len(sel), fmt)
     logger.info("Processed {} sequences".format(n_seq))

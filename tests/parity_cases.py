@@ -132,10 +132,24 @@ def check_map_features(ctx, golden, toy, tmp_path):
     with open(ff, "w") as f:
         for fid, s in case["features"]:
             f.write(">%s\n%s\n" % (fid, s))
-    buf = io.StringIO()
+    buf, rows = io.StringIO(), []
     seqs.map_kmer3([str(ff)], labels, fout=buf, k=K, bin_size=10000000, sg_names=cl.sg_names, chunk=False,
-                   log=False, ctx=ctx)
+                   log=False, ctx=ctx, collect=rows)
     assert buf.getvalue() == case["text"]
+    _check_collected(rows, buf.getvalue(), tmp_path, 100000000)
+
+
+def _check_collected(rows, text, tmp_path, window_size):
+    """the arrays map_kmer3 hands the CLI stack to the same windows as the text it wrote, parsed back"""
+    import numpy as np
+    from subphaser_amd import circos
+    f = tmp_path / "collected.bin.count"
+    f.write_text(text)
+    names, code = circos.factorize_first([x for part in rows for x in part[0]])
+    got = circos.stack_arrays(names, code, np.concatenate([p_[1] for p_ in rows]),
+                              np.concatenate([p_[2] for p_ in rows], axis=0), window_size=window_size)
+    assert got == circos.stack_matrix(str(f), window_size=window_size)
+    assert len(got[0]) > 0
 
 
 def check_dict_labels(ctx, golden, toy):
@@ -316,9 +330,10 @@ def check_long_feature(ctx, golden, toy, tmp_path):
     seq = toy["seqs"]["B1"][:12345]
     ff = tmp_path / "long.fa"
     ff.write_text(">B1:0-12345\n%s\n>short:1-40\n%s\n" % (seq, seq[5000:5040]))
-    buf = io.StringIO()
+    buf, rows = io.StringIO(), []
     seqs.map_kmer3([str(ff)], labels, fout=buf, k=K, bin_size=1000, sg_names=cl.sg_names, chunk=False, log=False,
-                   ctx=ctx)
+                   ctx=ctx, collect=rows)
+    _check_collected(rows, buf.getvalue(), tmp_path, 5000)
     exp, _, _ = po.map_bins(seq, K, labels.keys, labels.sg_idx, len(cl.sg_names), 1000, 0)
     lines = [l.split("\t") for l in buf.getvalue().strip().split("\n")[1:] if l.startswith("B1:")]
     got = {int(l[1]) // 1000: [int(x) for x in l[3:]] for l in lines}

@@ -162,3 +162,50 @@ def test_fasta_bulk_reader_matches_record_reader(tmp_path):
     empty = tmp_path / "e.fa"
     empty.write_text("")
     assert seqs.read_fasta_bulk(str(empty))[0] == []
+
+
+def test_fasta_scanner_matches_numpy_twin(tmp_path, monkeypatch):
+    """sp_fasta_* (host code of the library) against the numpy readers it replaces: CRLF, blank lines, blanks inside
+    lines, empty records, text before the first record, no final line break, records larger than a work piece."""
+    import numpy as np
+    from subphaser_amd import _native, seqs
+    rng = np.random.RandomState(5)
+    alpha = np.frombuffer(b"ACGTNacgtn", np.uint8)
+    parts = [b"; a comment line before any record\n"]
+    want = []
+    for r in range(300):
+        n = int(rng.choice([0, 1, 59, 60, 61, 500, 20000]))
+        if r == 7:
+            n = 9_500_000       # spans two 8-MiB work pieces
+        seq = alpha[rng.randint(0, len(alpha), size=n)].tobytes()
+        rid = "rec%d" % r
+        want.append((rid, seq))
+        eol = b"\r\n" if r % 3 == 0 else b"\n"
+        parts.append(b">" + rid.encode() + (b" some description" if r % 2 else b"") + eol)
+        w = int(rng.choice([60, 70, 80, 100000]))
+        for i in range(0, n, w):
+            line = seq[i:i + w]
+            if r % 5 == 0 and len(line) > 4:
+                line = line[:2] + b" " + line[2:4] + b"\t" + line[4:]
+            parts.append(line + eol)
+        if r % 11 == 0:
+            parts.append(eol)
+    blob = b"".join(parts)
+    blob = blob[:-1] if blob.endswith(b"\n") else blob        # no final line break
+    path = tmp_path / "messy.fa"
+    path.write_bytes(blob)
+    for threads in (1, 3, 16):
+        ids, cat, off = _native.fasta_scan(np.frombuffer(blob, np.uint8), threads=threads)
+        assert ids == [w_[0] for w_ in want]
+        assert off.tolist() == np.concatenate(([0], np.cumsum([len(w_[1]) for w_ in want]))).tolist()
+        assert bytes(cat) == b"".join(w_[1] for w_ in want)
+    got_native = list(seqs.read_fasta(str(path)))
+    bulk_native = seqs.read_fasta_bulk(str(path))
+    monkeypatch.setenv("SP_FASTA_NUMPY", "1")
+    got_numpy = list(seqs.read_fasta(str(path)))
+    bulk_numpy = seqs.read_fasta_bulk(str(path))
+    assert got_native == got_numpy == want
+    assert bulk_native[0] == bulk_numpy[0] and bytes(bulk_native[1]) == bytes(bulk_numpy[1])
+    assert bulk_native[2].tolist() == bulk_numpy[2].tolist()
+    ids, cat, off = _native.fasta_scan(np.empty(0, np.uint8))
+    assert ids == [] and cat.size == 0 and off.tolist() == [0]

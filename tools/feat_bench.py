@@ -65,11 +65,14 @@ d_sg = {c["label"]: gen.sg_assigned[c["label"]] for c in gen.chroms} if isinstan
 sg_names = sorted(set(d_sg.values())) or ["SG%d" % (i + 1) for i in range(S)]
 t0 = time.perf_counter()
 feat_map = os.path.join(work, "custom.bin.count")
+rows = []
 with open(feat_map, "w") as fout:
-    Seqs.map_kmer3([fa], labels, fout=fout, k=k, bin_size=10000000, sg_names=sg_names, chunk=False, ctx=ctx)
+    Seqs.map_kmer3([fa], labels, fout=fout, k=k, bin_size=10000000, sg_names=sg_names, chunk=False, ctx=ctx, collect=rows)
 t1 = time.perf_counter()
 from subphaser_amd import circos as Circos
-bins, counts = Circos.stack_matrix(feat_map, window_size=100000000)
+names, code = Circos.factorize_first([x for part in rows for x in part[0]])      # as Pipeline.stage_features does
+bins, counts = Circos.stack_arrays(names, code, np.concatenate([p[1] for p in rows]),
+                                   np.concatenate([p[2] for p in rows], axis=0), window_size=100000000)
 t15 = time.perf_counter()
 with open(os.path.join(work, "custom.enrich"), "w") as fout:
     d_enriched, _ = Stats.enrich_ltr(fout, d_sg, counts, colnames=sg_names, rownames=bins, max_pval=0.05)
