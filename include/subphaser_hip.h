@@ -208,7 +208,8 @@ int sp_stack_enrich(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int64_t w
  * frequencies count / lengths[c] are grouped by subgenome (group g owns the chromosome indices
  * group_chrom[group_off[g] .. group_off[g+1]), groups in sorted subgenome-name order), the groups are ordered
  * by mean (descending, ties in group order) and scipy.stats.ttest_ind(top, second) -- pooled variance,
- * two-sided -- gives pvals[row].  means: M x n_groups.  The caller keeps rows with !(p > max_pval).      */
+ * two-sided -- gives pvals[row].  means: M x n_groups.  The caller keeps rows with !(p > max_pval).
+ * `counts` may also be a device pointer (rows staged with sp_dev_copy_from_host earlier).                   */
 int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int C, const int64_t *lengths, int n_groups,
                   const int32_t *group_off, const int32_t *group_chrom, int32_t *top, int32_t *second,
                   double *pvals, double *means);
@@ -272,6 +273,18 @@ int sp_fasta_open(const void *data, int64_t n, int threads, sp_fasta **out);
 int sp_fasta_counts(const sp_fasta *h, int64_t *n_records, int64_t *n_bases);
 int sp_fasta_fetch(const sp_fasta *h, int64_t *hdr_start, int64_t *hdr_end, int64_t *seq_off, void *cat);
 void sp_fasta_close(sp_fasta *h);
+
+
+/* ---- host-side text writers (no GPU work) --------------------------------------------------------------------
+ * Rows of `.kmer.mat` (Jellyfish.py:515-520) and `.sig.kmer-subgenome.tsv` (Cluster.py:165-176) formatted by
+ * threads of the calling process and written to the open file descriptor `fd` in row order; floats are printed as
+ * Python's repr() prints them.  The caller writes the header line (and flushes) first.  names: n_names
+ * '\0'-separated strings.  sp_text_repr: repr of x[i] back to back in out (>= 40 bytes per value), off[n + 1]. */
+int sp_text_kmer_matrix(const uint64_t *keys, int k, const double *freqs, int64_t M, int C, int threads, int fd,
+                        int64_t *bytes);
+int sp_text_sig_kmers(const uint64_t *keys, int k, const int32_t *top, const char *names, int n_names,
+                      const double *pvals, const double *means, int G, int64_t M, int threads, int fd, int64_t *bytes);
+int sp_text_repr(const double *x, int64_t n, char *out, int64_t *off);
 
 #ifdef __cplusplus
 }

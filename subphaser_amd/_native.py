@@ -28,6 +28,7 @@ SYMBOLS = [
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_host_register", "sp_host_unregister", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
     "sp_fasta_open", "sp_fasta_counts", "sp_fasta_fetch", "sp_fasta_close",
+    "sp_text_kmer_matrix", "sp_text_sig_kmers", "sp_text_repr",
 ]
 
 
@@ -115,6 +116,9 @@ def load():
     L.sp_fasta_fetch.argtypes = [vp, vp, vp, vp, vp]
     L.sp_fasta_close.argtypes = [vp]
     L.sp_fasta_close.restype = None
+    L.sp_text_kmer_matrix.argtypes = [vp, ci, vp, i64, ci, ci, ci, P(i64)]
+    L.sp_text_sig_kmers.argtypes = [vp, ci, vp, C.c_char_p, ci, vp, vp, ci, i64, ci, ci, P(i64)]
+    L.sp_text_repr.argtypes = [vp, i64, vp, vp]
     for name in SYMBOLS:
         if name not in ("sp_last_error", "sp_stream", "sp_fasta_close"):
             getattr(L, name).restype = ci
@@ -159,6 +163,60 @@ def fasta_scan(data, threads=None, out=None):
         t = bytes(data[a:b]).split()
         ids.append(t[0].decode() if t else "")
     return ids, cat, off
+
+
+def _fd_of(fout):
+    """file descriptor of a real file object (flushed), or None (StringIO, sys.stdout wrappers without one...)"""
+    try:
+        fd = fout.fileno()
+        fout.flush()
+        return fd
+    except Exception:
+        return None
+
+
+def _text_threads():
+    return min(64, len(os.sched_getaffinity(0)))
+
+
+def text_kmer_matrix(fout, keys, k, freqs):
+    """rows of `.kmer.mat` through the library's threaded writer; False when fout has no file descriptor"""
+    fd = _fd_of(fout)
+    if fd is None:
+        return False
+    keys = np.ascontiguousarray(keys, np.uint64)
+    freqs = np.ascontiguousarray(freqs, np.float64)
+    M, Cn = freqs.shape
+    rc = load().sp_text_kmer_matrix(_p(keys), int(k), _p(freqs), M, Cn, _text_threads(), fd, None)
+    if rc:
+        raise OSError("sp_text_kmer_matrix failed (%d)" % rc)
+    return True
+
+
+def text_sig_kmers(fout, keys, k, top, names, pvals, means):
+    fd = _fd_of(fout)
+    if fd is None:
+        return False
+    keys = np.ascontiguousarray(keys, np.uint64)
+    top = np.ascontiguousarray(top, np.int32)
+    pvals = np.ascontiguousarray(pvals, np.float64)
+    means = np.ascontiguousarray(means, np.float64)
+    blob = b"".join(n.encode() + b"\0" for n in names)
+    rc = load().sp_text_sig_kmers(_p(keys), int(k), _p(top), blob, len(names), _p(pvals), _p(means), means.shape[1],
+                                  len(keys), _text_threads(), fd, None)
+    if rc:
+        raise OSError("sp_text_sig_kmers failed (%d)" % rc)
+    return True
+
+
+def text_repr(x):
+    """[repr(v) for v in x] through the library (test hook)"""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(max(1, x.size * 40), np.uint8)
+    off = np.empty(x.size + 1, np.int64)
+    load().sp_text_repr(_p(x), x.size, _p(out), _p(off))
+    b = out.tobytes()
+    return [b[off[i]:off[i + 1]].decode() for i in range(x.size)]
 
 
 def as_ascii(seq):
@@ -567,18 +625,38 @@ class Context:
     def kmer_ttest(self, counts, lengths, groups):
         """Cluster.output_kmers' per-k-mer t-test on the device.  counts: uint32 [M, C] (thresholded, as
         filter_fetch returns them), lengths: int64 [C], groups: list of chromosome-index lists in sorted
-        subgenome-name order.  Returns (top, second, pvals, means [M, n_groups])."""
-        counts = np.ascontiguousarray(counts, np.uint32)
-        M, Cn = counts.shape
+        subgenome-name order.  Returns (top, second, pvals, means [M, n_groups]).
+        counts may also be (device pointer, M, C): rows staged on the device earlier (stage_rows)."""
+        if isinstance(counts, tuple):
+            d_ptr, M, Cn = counts
+            cptr = C.c_void_p(int(d_ptr))
+        else:
+            counts = np.ascontiguousarray(counts, np.uint32)
+            M, Cn = counts.shape
+            cptr = _p(counts)
         lengths = np.ascontiguousarray(lengths, np.int64)
         goff = np.zeros(len(groups) + 1, np.int32)
         goff[1:] = np.cumsum([len(g) for g in groups])
         gch = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in groups]), np.int32)
         top, second = np.empty(M, np.int32), np.empty(M, np.int32)
         pvals, means = np.empty(M, np.float64), np.empty((M, len(groups)), np.float64)
-        self._ck(self.L.sp_kmer_ttest(self.h, _p(counts), M, Cn, _p(lengths), len(groups), _p(goff), _p(gch),
+        self._ck(self.L.sp_kmer_ttest(self.h, cptr, M, Cn, _p(lengths), len(groups), _p(goff), _p(gch),
                                       _p(top), _p(second), _p(pvals), _p(means)))
         return top, second, pvals, means
+
+    def stage_rows(self, counts):
+        """Copy a uint32 [M, C] matrix to a device buffer owned by the context (one at a time; the previous one is
+        released) and return (device pointer, M, C) for kmer_ttest."""
+        counts = np.ascontiguousarray(counts, np.uint32)
+        old = getattr(self, "_staged_rows", None)
+        if old:
+            self.dev_free(old)
+            self._staged_rows = None
+        if counts.size == 0:
+            return None
+        self._staged_rows = self.dev_alloc(counts.nbytes)
+        self.host_to_dev(self._staged_rows, counts)
+        return (self._staged_rows, counts.shape[0], counts.shape[1])
 
     # -------------------------------------------------------------- profiling / bench support
     def prof_enable(self, on=True):

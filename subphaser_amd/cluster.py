@@ -15,9 +15,11 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import _native
 from . import kmer as kmerlib
 from .runtime import logger
 from .seqs import KmerLabels
+from .textio import write_chunks
 
 
 def load_matrix(datafile):
@@ -66,6 +68,7 @@ class Cluster:
             # the integer matrix behind the frequencies: lets the k-mer test run on the device (sp_kmer_ttest)
             self._counts, self._lengths = getattr(data, "counts", None), getattr(data, "lengths", None)
             self._ctx = getattr(data, "ctx", None)
+            self._counts_dev = getattr(data, "counts_dev", None)
         self.sg_prefix, self.seed = sg_prefix, seed
         self.n_clusters = len(set(sg_assigned.values())) if sg_assigned else n_clusters
         if sg_assigned:
@@ -121,10 +124,12 @@ class Cluster:
         for c in sorted(self.d_sg, key=lambda x: self.d_sg[x]):      # stable: by subgenome, input order inside
             fout.write("{}\t{}\t{}\n".format(c, self.d_sg[c], self.d_bs[c]))
 
-    def output_kmers(self, fout=sys.stdout, max_pval=0.05, ncpu=4, method="map", test_method="ttest_ind"):
+    def output_kmers(self, fout=sys.stdout, max_pval=0.05, ncpu=4, method="map", test_method="ttest_ind", defer=False):
         """Student t-test (pooled variance, two-sided) between the highest-mean and the
         second-highest-mean subgenome groups of every k-mer; keeps p <= max_pval.
-        Returns KmerLabels (array form of the reference's d_ksg dict)."""
+        Returns KmerLabels (array form of the reference's d_ksg dict).
+        defer=True: nothing is written; returns (KmerLabels, write) where write(fout) produces the same text later
+        (the CLI runs it in a forked writer while the mapping stage uses the labels)."""
         if test_method not in TEST_METHODS:
             raise ValueError("test_method must be one of {}".format(TEST_METHODS))
         from scipy import special
@@ -137,8 +142,9 @@ class Cluster:
                 and getattr(self, "_counts", None) is not None and self._lengths is not None):
             # device path: one thread per k-mer (csrc/sp_enrich.hip k7_ttest); the numpy code below is the same test
             # for matrices that only exist as a `.kmer.mat` file or behind a context without the kernel
-            top, second, pvals, means = ctx.kmer_ttest(self._counts, self._lengths, groups)
-            return self._write_kmers(fout, sgs, top, pvals, means, max_pval)
+            staged = getattr(self, "_counts_dev", None)      # rows already on the device (the CLI stages them early)
+            top, second, pvals, means = ctx.kmer_ttest(staged if staged else self._counts, self._lengths, groups)
+            return self._write_kmers(fout, sgs, top, pvals, means, max_pval, defer)
         means = np.stack([X[:, g].mean(axis=1) for g in groups], axis=1) if M else np.zeros((0, len(sgs)))
         # the reference orders groups by -sum/len (Cluster.py:182); ties keep SG-name order (stable)
         keyv = np.stack([-(X[:, g].sum(axis=1) / len(g)) for g in groups], axis=1) if M else means
@@ -154,23 +160,30 @@ class Cluster:
                     pvals[sel] = _ttest_ind(X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])], special)
                 elif sel.size:      # the other scipy tests the reference accepts (Cluster.py:178-194), row by row
                     pvals[sel] = _scipy_rows(test_method, X[np.ix_(sel, groups[a])], X[np.ix_(sel, groups[b])])
-        return self._write_kmers(fout, sgs, top, pvals, means, max_pval)
+        return self._write_kmers(fout, sgs, top, pvals, means, max_pval, defer)
 
-    def _write_kmers(self, fout, sgs, top, pvals, means, max_pval):
-        print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
+    def _write_kmers(self, fout, sgs, top, pvals, means, max_pval, defer=False):
         with np.errstate(invalid="ignore"):
             keep = np.flatnonzero(~(pvals > max_pval))      # `if pvalue > max_pval: continue` keeps NaN
-        from .textio import write_chunks
         kkeys, ktop, kp, kmeans, k = self.keys[keep], top[keep], pvals[keep], means[keep], self.k
 
         def fmt(lo, hi):
             kmers = kmerlib.decode_many(kkeys[lo:hi], k)
             return "".join("\t".join([km, sgs[t], repr(p), ",".join(map(repr, mv))]) + "\n"
                            for km, t, p, mv in zip(kmers, ktop[lo:hi].tolist(), kp[lo:hi].tolist(), kmeans[lo:hi].tolist()))
-        fout.flush() if hasattr(fout, "flush") else None
-        write_chunks(fout, len(kkeys), fmt)
+        def write(fout):
+            print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
+            fout.flush() if hasattr(fout, "flush") else None
+            if len(kkeys) and _native.text_sig_kmers(fout, kkeys, k, ktop, sgs, kp, kmeans):
+                return      # formatted by threads of this process (the fork()ed pool below serves non-file objects)
+            write_chunks(fout, len(kkeys), fmt)
+
         canon = kmerlib.canonical(self.keys[keep], self.k)
-        return KmerLabels(canon, top[keep].astype(np.uint8), sgs, self.k)
+        labels = KmerLabels(canon, top[keep].astype(np.uint8), sgs, self.k)
+        if defer:
+            return labels, write
+        write(fout)
+        return labels
 
 
 TEST_METHODS = ("ttest_ind", "kruskal", "wilcoxon", "mannwhitneyu")

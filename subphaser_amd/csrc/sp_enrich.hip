@@ -305,7 +305,8 @@ extern "C" int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int
     double *d_means = (double *)q;
     std::vector<double> hl((size_t)C);
     for (int c = 0; c < C; c++) hl[(size_t)c] = (double)lengths[c];
-    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, (size_t)M * C * 4, hipMemcpyHostToDevice, ctx->stream));
+    // `counts` may be a host or a DEVICE pointer (a caller that staged the rows earlier): unified addressing decides
+    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, (size_t)M * C * 4, hipMemcpyDefault, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_len, hl.data(), (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_goff, group_off, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_gch, group_chrom, nuc * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -11,3 +11,4 @@
 #include "sp_enrich.hip"
 #include "sp_synth.hip"
 #include "sp_fasta.hip"
+#include "sp_text.hip"

@@ -249,39 +249,68 @@ class Pipeline:
             raise ValueError("0 kmer remained after filtering. Please reset the filter options.")
         # The matrix in memory is what every later stage uses, so the file always describes THIS run's filter:
         # it is rewritten whenever it is recomputed (an old file next to new calls would be inconsistent).
-        # It is 0.5 GB of text at wheat scale (4 s): a forked writer formats it from copy-on-write views of the
-        # arrays while the clustering and mapping stages run; the checkpoint follows the writer's exit.
+        # It is 0.5 GB of text at wheat scale: a writer thread (the library formats the rows on its own threads) works
+        # while the clustering and mapping stages run; the checkpoint follows the writer's end.
         matfile = lay.out("kmer.mat")
         t0 = time.perf_counter()
+        # the k-mer tests of the next stage read the rows on the device: copy them there now, while nothing else
+        # competes for the host memory bus
+        if getattr(d_mat2, "counts", None) is not None and getattr(d_mat2, "ctx", None) is not None \
+                and hasattr(d_mat2.ctx, "stage_rows"):
+            d_mat2.counts_dev = d_mat2.ctx.stage_rows(d_mat2.counts)
         self._write_matrix_in_background(dumps, d_mat2, matfile, histfig, lay)
         logger.info("`{}` + histogram figure: writer started in {:.2f} s".format(os.path.basename(matfile),
                                                                              time.perf_counter() - t0))
         return d_mat2
 
     def _write_matrix_in_background(self, dumps, d_mat2, matfile, histfig, lay):
-        import multiprocessing as mp
-        tot = dumps.hist_tot()          # device -> host here: the child must not touch the GPU
+        tot = dumps.hist_tot()          # device -> host here: the writer thread makes no GPU calls
 
-        def work():
-            with open(matfile, "w") as fout:
-                dumps.write_matrix(d_mat2, fout)
+        def work(fout):
+            dumps.write_matrix(d_mat2, fout)
+
+        def done():
+            # The figure is drawn on the MAIN thread, after the writers: importing matplotlib's extension modules
+            # (dlopen under the GIL) on a writer thread while scikit-learn's threadpoolctl walks the loaded
+            # libraries (dl_iterate_phdr calling back into Python) on a bootstrap thread is a lock-order deadlock
+            # -- one wheat-scale run in four hung there.
+            mk_ckp(lay.ckp(matfile))
             try:
                 plot_histogram(tot, histfig)
             except Exception as e:     # the figure is optional
                 logger.warning("histogram not plotted: {}".format(e))
+        self._write_in_background(matfile, work, len(d_mat2) >= 200000, done=done)
 
-        if len(d_mat2) < 200000:      # small: not worth a process
+    def _write_in_background(self, path, write, big, done=None):
+        """write(fout) into `path`: on a thread of this process when the output is large (the library's text writers
+        release the GIL and use their own threads; nothing is forked out of the GPU process), inline otherwise;
+        `done` (e.g. the checkpoint) runs on the main thread once the file is complete.  `write` must not import
+        anything (see _write_matrix_in_background)."""
+        import threading
+        done = done or (lambda: None)
+        failure = []
+
+        def work():
+            try:
+                with open(path, "w") as fout:
+                    write(fout)
+            except BaseException as e:      # re-raised by wait()
+                failure.append(e)
+
+        if not big:
             work()
-            mk_ckp(lay.ckp(matfile))
+            if failure:
+                raise failure[0]
+            done()
             return
-        proc = mp.get_context("fork").Process(target=work, daemon=False)
-        proc.start()
+        th = threading.Thread(target=work, name="writer:" + os.path.basename(path), daemon=False)
+        th.start()
 
         def wait():
-            proc.join()
-            if proc.exitcode != 0:
-                raise RuntimeError("writing {} failed (exit code {})".format(matfile, proc.exitcode))
-        self._background.append((matfile, wait, lambda: mk_ckp(lay.ckp(matfile))))
+            th.join()
+            if failure:
+                raise failure[0]
+        self._background.append((path, wait, done))
 
     def _finish_background(self):
         """Wait for the writers started along the way, then record their checkpoints."""
@@ -307,8 +336,11 @@ class Pipeline:
             cl.output_subgenomes(fout)
         sg_kmers = lay.out("sig.kmer-subgenome.tsv")
         logger.info("subgenome-specific k-mers -> `{}`".format(sg_kmers))
-        with open(sg_kmers, "w") as fout:
-            kmer_labels = cl.output_kmers(fout, max_pval=self.max_pval, test_method=self.test_method)
+        t0 = time.perf_counter()
+        kmer_labels, write = cl.output_kmers(None, max_pval=self.max_pval, test_method=self.test_method, defer=True)
+        t1 = time.perf_counter()
+        self._write_in_background(sg_kmers, write, len(kmer_labels.keys) >= 200000)
+        logger.info("k-mer tests {:.2f} s, text writer started in {:.2f} s".format(t1 - t0, time.perf_counter() - t1))
         per_sg = np.bincount(kmer_labels.sg_idx, minlength=len(kmer_labels.sg_names))
         logger.info("{} significant subgenome-specific kmers".format(len(kmer_labels.keys)))
         for sg, n in zip(kmer_labels.sg_names, per_sg.tolist()):
@@ -407,6 +439,9 @@ class Pipeline:
 
 def main(argv=None):
     args = makeArgparse(argv)
+    if os.environ.get("SP_STACKS_AFTER"):      # debugging aid: dump every thread's Python stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SP_STACKS_AFTER"]), exit=True)
     logger.info("Command: {}".format(" ".join(sys.argv)))
     logger.info("Version: subphaser_amd {}".format(__version__))
     logger.info("Arguments: {}".format(args.__dict__))

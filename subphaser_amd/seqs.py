@@ -265,7 +265,7 @@ def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", w
     outfas, labels, d_size, got = [], [], {}, set()
     from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=4) if write_files else None   # file writes overlap the parsing
-    pending = []
+    pending, last_write = [], {}
     for genome, prefix in zip(genomes, prefixes):
         for old_id, seq in read_fasta(genome, as_array=True):
             new_id = "{}{}".format(prefix, old_id)
@@ -279,7 +279,13 @@ def split_genomes(genomes, prefixes, targets, outdir, d_targets=None, sep="|", w
             rid = d_targets[rid]
             outfa = "{}{}.fasta".format(outdir, rid)
             if write_files:
-                pending.append(writer.submit(write_fasta, outfa, rid, seq))
+                # two records that end up under one id (same name in two genomes, no label prefix): the later one
+                # wins, like the reference's sequential loop -- never two writers on one path at a time
+                prev = last_write.get(outfa)
+                if prev is not None:
+                    prev.result()
+                last_write[outfa] = writer.submit(write_fasta, outfa, rid, seq)
+                pending.append(last_write[outfa])
             _REG[outfa] = ChromRecord(rid, seq)
             outfas.append(outfa)
             labels.append(rid)

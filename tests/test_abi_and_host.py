@@ -209,3 +209,48 @@ def test_fasta_scanner_matches_numpy_twin(tmp_path, monkeypatch):
     assert bulk_native[2].tolist() == bulk_numpy[2].tolist()
     ids, cat, off = _native.fasta_scan(np.empty(0, np.uint8))
     assert ids == [] and cat.size == 0 and off.tolist() == [0]
+
+
+def test_text_writers_match_python_formatting(tmp_path):
+    """sp_text_* (host code of the library): repr(float) digit for digit, and the `.kmer.mat` / sig-k-mer rows
+    byte for byte against the Python formatting the mirror uses for non-file objects."""
+    import io
+    import numpy as np
+    from subphaser_amd import _native, cluster, jellyfish
+    rng = np.random.default_rng(11)
+    xs = [0.0, -0.0, 1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9007199254740992.0, 1e22, 5e-324,
+          1.7976931348623157e308, float("nan"), float("inf"), -float("inf"), 2.2250738585072014e-308, 1 / 3, 100.0]
+    xs += list(rng.random(20000)) + list(np.exp(rng.uniform(-700, 700, 20000)))
+    xs += [c / l for c, l in zip(rng.integers(0, 5000, 20000), rng.integers(1, 10 ** 9, 20000))]
+    for e in range(-1070, 1023, 13):
+        xs += [2.0 ** e, np.nextafter(2.0 ** e, 0), np.nextafter(2.0 ** e, np.inf)]
+    xs = np.array(xs, np.float64)
+    assert _native.text_repr(xs) == [repr(float(v)) for v in xs]
+    # .kmer.mat rows
+    M, Cn, k = 30011, 7, 15
+
+    class _Mat:
+        pass
+    mat = _Mat()
+    mat.keys = rng.integers(0, 4 ** k, M, dtype=np.int64).astype(np.uint64)
+    mat.freqs = rng.integers(0, 3000, (M, Cn)) / rng.integers(10 ** 6, 10 ** 9, Cn)
+    mat.k = k
+    dumps = jellyfish.JellyfishDumps.__new__(jellyfish.JellyfishDumps)
+    dumps.labels = ["c%d" % i for i in range(Cn)]
+    buf = io.StringIO()
+    dumps.write_matrix(mat, buf)                     # Python formatting (no file descriptor)
+    with open(tmp_path / "m.mat", "w") as f:
+        dumps.write_matrix(mat, f)                   # library writer
+    assert open(tmp_path / "m.mat").read() == buf.getvalue()
+    # sig k-mer rows
+    top = rng.integers(0, 3, M).astype(np.int32)
+    pv = rng.random(M)
+    pv[::97] = np.nan
+    means = rng.random((M, 3)) * 1e-5
+    buf = io.StringIO()
+    with open(tmp_path / "s.tsv", "w") as f:
+        assert _native.text_sig_kmers(f, mat.keys, k, top, ["SG1", "SG2", "SG10"], pv, means)
+    from subphaser_amd import kmer as kmerlib
+    exp = "".join("\t".join([km, ["SG1", "SG2", "SG10"][t], repr(p), ",".join(map(repr, mv))]) + "\n"
+                  for km, t, p, mv in zip(kmerlib.decode_many(mat.keys, k), top.tolist(), pv.tolist(), means.tolist()))
+    assert open(tmp_path / "s.tsv").read() == exp

@@ -16,8 +16,9 @@ gen = SynthGenome(cfg)
 ctx = _native.Context(0)
 fa = os.path.join(work, "genome.fa")
 t0 = time.perf_counter()
-with open(fa, "wb") as out:
-    for c in gen.chroms:
+reuse = os.path.exists(fa) and os.path.getsize(fa) > gen.total_bases      # a previous call left it there
+with open(os.devnull if reuse else fa, "wb") as out:
+    for c in ([] if reuse else gen.chroms):
         p = ctx.dev_alloc(c["length"])
         ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], gen.S, c["chrom_id"], c["exchange"])
         seq = ctx.dev_to_host(p, c["length"]).tobytes()
@@ -33,22 +34,26 @@ with open(os.path.join(work, "assigned.tsv"), "w") as f:
     for k, v in gen.sg_assigned.items():
         f.write("%s\t%s\n" % (k, v))
 print("synthetic FASTA: %.1f MB written in %.1f s" % (os.path.getsize(fa) / 1e6, time.perf_counter() - t0))
-cmd = [sys.executable, "-m", "subphaser_amd", "-i", fa, "-c", os.path.join(work, "sg.config"), "-sg_assigned",
+prof = ["-m", "cProfile", "-o", os.path.join(work, "cli.prof")] if os.environ.get("SP_E2E_PROFILE") else []
+cmd = [sys.executable] + prof + ["-m", "subphaser_amd", "-i", fa, "-c", os.path.join(work, "sg.config"), "-sg_assigned",
        os.path.join(work, "assigned.tsv"), "-o", os.path.join(work, "out"), "-tmpdir", os.path.join(work, "tmp"),
        "-disable_ltr", "-disable_circos", "-overwrite", "-figfmt", "png"]
 t0 = time.perf_counter()
-r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, SP_STACKS_AFTER=os.environ.get("SP_STACKS_AFTER", "240")))
 dt = time.perf_counter() - t0
 open(os.path.join(work, "cli.stderr"), "w").write(r.stderr)
 keep = ("per-chromosome FASTA", "chromosomes, in config order", "Genome size", "###Step", "Counting", "matrix", "filter (K3)",
         "After filtering", "kmers in total", "bootstrap", "Bootstrap", "->", "significant subgenome", "Processed",
-        "enrichment", "wrote", "Pipeline completed", "New check point")
+        "enrichment", "wrote", "writer", "Pipeline completed", "New check point")
 for line in r.stderr.splitlines():
     if any(k in line for k in keep) and "Loading /" not in line:
         print(line[:160])
 if r.returncode:
     print(r.stderr[-3000:])
 print("exit", r.returncode)
+if prof:
+    import pstats
+    pstats.Stats(os.path.join(work, "cli.prof")).sort_stats("cumtime").print_stats(45)
 print("END-TO-END %s: %.2f s wall for %.3f Gbases -> %.3f Gbases/s (FASTA parse + upload + all kernels + all output files)"
       % (cfg, dt, gen.total_bases / 1e9, gen.total_bases / dt / 1e9))
 for f in sorted(os.listdir(os.path.join(work, "out"))):
