@@ -431,6 +431,7 @@ class Pipeline:
         if not self.just_core:
             self.stage_windows(lay, chromfiles, labels, d_size, cl, kmer_labels)
             if self.custom_features is not None:
+                self._finish_background()      # the feature writers fork() a formatting pool: no live threads then
                 self.stage_features(lay, cl, kmer_labels)
             if not (self.disable_ltr and self.disable_circos):
                 logger.info("Modules 3-4 (LTR, circos) are not part of this build; run the reference on the "
