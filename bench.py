@@ -233,8 +233,9 @@ def main():
         avg_s = sum(st["ms"] for st in sts) / args.steps / units / 1e3     # HIP-event time of one pass of the chain
         traffic = None
         if all(n in tj for n in names if n in prof):
-            traffic = int(sum((tj[n].get("read_bytes", 0) + tj[n].get("write_bytes", 0)) * tj[n].get("calls", 1)
-                              for n in names if n in prof) / (n_local if units > 1 else 1))
+            # PMC bytes are per launch; launches per pass of the chain come from THIS run's launch counts
+            traffic = int(sum((tj[n].get("read_bytes", 0) + tj[n].get("write_bytes", 0))
+                              * (prof[n]["calls"] / args.steps / units) for n in names if n in prof))
         ach = alg / avg_s
         return {"bound": "hbm", "kernel": label, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
