@@ -53,6 +53,57 @@ def _strip_newlines(body):
     return body[keep]
 
 
+def read_gz(path):
+    """Decompressed image of a gzip file as a uint8 array.  BGZF files (bgzip: a series of <= 64-KiB gzip members
+    whose compressed size sits in a 'BC' extra field) are inflated block by block on a thread pool -- zlib releases
+    the GIL -- straight into the output array; plain gzip is one deflate stream and stays one thread."""
+    import zlib
+    raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.empty(0, np.uint8)
+    n = int(raw.size)
+
+    def bgzf_size(o):      # total size of the BGZF block at offset o, or 0
+        if o + 18 > n or raw[o] != 31 or raw[o + 1] != 139 or raw[o + 2] != 8 or not (raw[o + 3] & 4):
+            return 0
+        xlen = int(raw[o + 10]) | (int(raw[o + 11]) << 8)
+        p, e = o + 12, o + 12 + xlen
+        while p + 4 <= e and e <= n:
+            slen = int(raw[p + 2]) | (int(raw[p + 3]) << 8)
+            if raw[p] == 66 and raw[p + 1] == 67 and slen == 2:
+                return (int(raw[p + 4]) | (int(raw[p + 5]) << 8)) + 1
+            p += 4 + slen
+        return 0
+
+    blocks, o = [], 0
+    while o < n:
+        b = bgzf_size(o)
+        if b < 26 or o + b > n:
+            blocks = None
+            break
+        blocks.append((o, b))
+        o += b
+    if not blocks:
+        with gzip.open(path, "rb") as fh:
+            return np.frombuffer(fh.read(), np.uint8)
+    view = memoryview(raw)
+    isize = np.array([int.from_bytes(view[a + b - 4:a + b], "little") for a, b in blocks], np.int64)
+    off = np.concatenate(([0], np.cumsum(isize)))
+    out = np.empty(int(off[-1]), np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def inflate(span):
+        for j in range(*span):
+            a, b = blocks[j]
+            xlen = int(raw[a + 10]) | (int(raw[a + 11]) << 8)
+            chunk = zlib.decompress(view[a + 12 + xlen:a + b - 8], wbits=-15)
+            if len(chunk) != isize[j]:
+                raise ValueError("corrupt BGZF block at offset {} of {}".format(a, path))
+            out[off[j]:off[j + 1]] = np.frombuffer(chunk, np.uint8)
+    step = 256
+    with ThreadPoolExecutor(max_workers=min(32, len(os.sched_getaffinity(0)))) as pool:
+        list(pool.map(inflate, [(j, min(j + step, len(blocks))) for j in range(0, len(blocks), step)]))
+    return out
+
+
 def _native_scanner():
     """The library's host-side scanner (sp_fasta.hip) unless SP_FASTA_NUMPY is set (the numpy twin below)."""
     return not os.environ.get("SP_FASTA_NUMPY")
@@ -64,8 +115,7 @@ def read_fasta(path, as_array=False):
     with open(path, "rb") as fh:
         magic = fh.read(2)
     if magic == b"\x1f\x8b":
-        with gzip.open(path, "rb") as fh:
-            data = np.frombuffer(fh.read(), np.uint8)
+        data = read_gz(path)
     else:
         if os.path.getsize(path) == 0:
             return
@@ -120,8 +170,7 @@ def read_fasta_bulk(path):
     with open(path, "rb") as fh:
         magic = fh.read(2)
     if magic == b"\x1f\x8b":
-        with gzip.open(path, "rb") as fh:
-            data = np.frombuffer(fh.read(), np.uint8)
+        data = read_gz(path)
     elif os.path.getsize(path) == 0:
         data = np.empty(0, np.uint8)
     else:

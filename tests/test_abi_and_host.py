@@ -254,3 +254,34 @@ def test_text_writers_match_python_formatting(tmp_path):
     exp = "".join("\t".join([km, ["SG1", "SG2", "SG10"][t], repr(p), ",".join(map(repr, mv))]) + "\n"
                   for km, t, p, mv in zip(kmerlib.decode_many(mat.keys, k), top.tolist(), pv.tolist(), means.tolist()))
     assert open(tmp_path / "s.tsv").read() == exp
+
+
+def test_gz_and_bgzf_input(tmp_path):
+    """gz FASTA: plain gzip (one stream) and BGZF (bgzip blocks, inflated in parallel) give the same records"""
+    import gzip
+    import struct
+    import zlib
+    import numpy as np
+    from subphaser_amd import seqs
+    rng = np.random.default_rng(9)
+    recs = [("c%d" % i, np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, int(n))].tobytes().decode())
+            for i, n in enumerate([0, 17, 200000, 70001])]
+    raw = "".join(">%s\n%s\n" % (i, "\n".join(s[j:j + 60] for j in range(0, len(s), 60))) for i, s in recs).encode()
+    blocks = []
+    for i in range(0, len(raw), 65280):
+        blk = raw[i:i + 65280]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(blk) + c.flush()
+        blocks.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                      struct.pack("<II", zlib.crc32(blk), len(blk)))
+    blocks.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))     # BGZF EOF block
+    (tmp_path / "b.fa.gz").write_bytes(b"".join(blocks))
+    with gzip.open(tmp_path / "p.fa.gz", "wb") as f:
+        f.write(raw)
+    assert gzip.open(tmp_path / "b.fa.gz").read() == raw          # a valid multi-member gzip file
+    want = [(i, s.encode()) for i, s in recs]
+    for name in ("b.fa.gz", "p.fa.gz"):
+        assert bytes(seqs.read_gz(str(tmp_path / name))) == raw
+        assert list(seqs.read_fasta(str(tmp_path / name))) == want
+        ids, cat, off = seqs.read_fasta_bulk(str(tmp_path / name))
+        assert ids == [i for i, _ in recs] and bytes(cat) == b"".join(s for _, s in want)
