@@ -86,6 +86,28 @@ def test_count_engine2_edges(gpu_ctx):
     _count_both(gpu_ctx, seqs, 13, 2, engine=2)
 
 
+@pytest.mark.parametrize("k", [13, 15])
+def test_count_engine2_hot_slots(gpu_ctx, k):
+    """Hot k-mers with 70 K - 400 K copies (beyond 16 bits): homopolymers of both strands' representatives, every
+    rotation of a 13-mer unit (neighbouring slots both hot), a dinucleotide repeat, next to ordinary sequence; then
+    one slot with 18 M copies.  (Written for a 16-bit packed-counter variant of c2_count that was not kept; the
+    byte table + overflow list must carry these counts exactly whatever the LDS counter width.)"""
+    rng = np.random.RandomState(77 + k)
+    unit = _rand_seq(rng, 13, 0, 0)
+    hot = [np.frombuffer(b"A" * 300000, np.uint8), np.frombuffer(b"C" * 140000, np.uint8), np.tile(unit, 70000),
+           np.frombuffer(b"AC" * 200000, np.uint8), np.frombuffer(b"AAAAAAAAAAAAAAC" * 66000, np.uint8)]
+    sep = np.frombuffer(b"N", np.uint8)
+    parts = [_rand_seq(rng, 200000)]
+    for h in hot:
+        parts += [sep, h, sep, _rand_seq(rng, 1000)]
+    seqs = [np.concatenate(parts), _rand_seq(rng, 5000)]
+    _count_both(gpu_ctx, seqs, k, 1, engine=2)
+    _count_both(gpu_ctx, seqs, k, 3, engine=2)
+    seqs = [np.concatenate([_rand_seq(rng, 50000), sep, np.frombuffer(b"T" * 18_000_000, np.uint8), sep,
+                            np.tile(unit, 70000)]), _rand_seq(rng, 5000)]
+    _count_both(gpu_ctx, seqs, k, 2, engine=2)
+
+
 def test_count_engine2_unsupported_small_k(gpu_ctx):
     gpu_ctx.genome_reset(1)
     gpu_ctx.genome_add(0, b"ACGT" * 100)
