@@ -258,6 +258,76 @@ __device__ __forceinline__ void sp_scan32_slots(const uint32_t *__restrict__ pk,
     }
 }
 
+// ------------------------------------------------------------------ direct-window scan, 64-bit keys (k <= 32)
+// The same two-stream trick for the sparse engines: a 32-base window starting at ANY base of a 32-start unit is two
+// v_alignbit_b32 per stream (bases s0+j .. s0+j+31 live in words 0..3 of the unit's streams); the forward k-mer in
+// key order is the MSB-first window >> (64 - 2k), its reverse complement ~(LSB-first window) & kmask.  The rolling
+// scan these kernels used costs ~55 VALU instructions per k-mer in 64-bit arithmetic, this ~20.
+struct sp_words64 {
+    uint32_t l[4], m[4];
+};
+__device__ __forceinline__ sp_words64 sp_load_words64(const uint32_t *__restrict__ pk,
+                                                      const uint32_t *__restrict__ pm, int64_t s0) {
+    const int64_t w0 = s0 >> 4;   // even: 8-byte aligned
+    sp_words64 r;
+    const uint2 a = *reinterpret_cast<const uint2 *>(pk + w0), a2 = *reinterpret_cast<const uint2 *>(pk + w0 + 2);
+    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0), b2 = *reinterpret_cast<const uint2 *>(pm + w0 + 2);
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a2.x; r.l[3] = a2.y;
+    r.m[0] = b.x; r.m[1] = b.y; r.m[2] = b2.x; r.m[3] = b2.y;
+    return r;
+}
+template <int J>
+__device__ __forceinline__ uint32_t sp_w64_lsb16(const sp_words64 &x) {   // 16 bases from s0 + J, LSB-first
+    constexpr int q = J >> 4, r = J & 15;
+    if (r == 0) return x.l[q];
+    return __builtin_amdgcn_alignbit(x.l[q + 1], x.l[q], 2 * r);
+}
+template <int J>
+__device__ __forceinline__ uint32_t sp_w64_msb16(const sp_words64 &x) {   // 16 bases from s0 + J, MSB-first
+    constexpr int q = J >> 4, r = J & 15;
+    if (r == 0) return x.m[q];
+    return __builtin_amdgcn_alignbit(x.m[q], x.m[q + 1], 32 - 2 * r);
+}
+template <int J, typename F>
+struct sp_win64_loop {
+    static __device__ __forceinline__ void run(const sp_words64 &x, F &f) {
+        // J = 31, r = 15: the second half-window starts at base 47 and ends at base 62 -> words 2 and 3
+        const uint64_t V = ((uint64_t)sp_w64_msb16<J>(x) << 32) | sp_w64_msb16<J + 16>(x);
+        const uint64_t W = (uint64_t)sp_w64_lsb16<J>(x) | ((uint64_t)sp_w64_lsb16<J + 16>(x) << 32);
+        f(J, V, W);
+        sp_win64_loop<J + 1, F>::run(x, f);
+    }
+};
+template <typename F>
+struct sp_win64_loop<32, F> {
+    static __device__ __forceinline__ void run(const sp_words64 &, F &) {}
+};
+// J + 16 = 32 .. 47 with r == 0 only at J = 16 (q = 2): every index stays within words 0..3
+
+// step(j, fwd, rc) for EVERY start s0 + j of the 32-start unit (validity is the caller's: sp_bad_starts64)
+template <typename F>
+__device__ __forceinline__ void sp_scan32_keys64(const sp_words64 &x, const sp_kparams &kp, F &&step) {
+    const int sh = 64 - 2 * kp.k;
+    auto f = [&](int j, uint64_t V, uint64_t W) { step(j, V >> sh, ~W & kp.kmask); };
+    sp_win64_loop<0, decltype(f)>::run(x, f);
+}
+// emit(start, fwd, rc) for every VALID k-mer start of the unit [s0, s0 + 32), s0 a multiple of 32; 16 <= k <= 32
+template <typename F>
+__device__ __forceinline__ void sp_scan32_valid64(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                  const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
+                                                  F &&emit) {
+    const uint32_t ok = ~(uint32_t)sp_bad_starts64(nm, s0, kp.k);
+    if (__all(ok == 0u)) return;
+    const sp_words64 x = sp_load_words64(pk, pm, s0);
+    if (__all(ok == 0xffffffffu)) {
+        sp_scan32_keys64(x, kp, [&](int j, uint64_t fwd, uint64_t rc) { emit(s0 + j, fwd, rc); });
+    } else {
+        sp_scan32_keys64(x, kp, [&](int j, uint64_t fwd, uint64_t rc) {
+            if ((ok >> j) & 1u) emit(s0 + j, fwd, rc);
+        });
+    }
+}
+
 // ------------------------------------------------------------------ byte tables
 // raw count of `slot` (absolute) given its table byte: bytes below 255 are exact, 255 defers to the
 // chromosome's overflow list (ascending slots; binary search -- counts >= 255 are rare)

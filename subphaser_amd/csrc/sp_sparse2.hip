@@ -90,15 +90,40 @@ __device__ __forceinline__ uint32_t s3_block_scan(const uint32_t *hist, uint32_t
     return total;
 }
 
+// exclusive prefix of v over a THREADS-wide block (value in a register); *total = block sum.  Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ uint32_t s3_scan_reg_t(uint32_t v, uint32_t *wsum /* >= THREADS/64 */, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    __syncthreads();            // wsum may still be read by a previous scan's consumers
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) {
+        const uint32_t x = wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
 // ---------------------------------------------------------------- s3_hist1
 __global__ void __launch_bounds__(256)
-s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 64 starts */,
-         sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ ghist) {
+s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+         int64_t n_units /* of 32 starts */, sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ ghist) {
     __shared__ uint32_t lh[S3_MAXF];
     for (int i = threadIdx.x; i < F1; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x)
-        sp_scan_unit64<SP_UNIT>(pk, nm, u * SP_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+        sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
             const uint64_t key = fwd < rc ? fwd : rc;
             atomicAdd(&lh[key >> R1], 1u);
         });
@@ -110,24 +135,26 @@ s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
 }
 
 // ---------------------------------------------------------------- s3_part1
-// Two scans of the tile (count, then place): the 64-bit window arithmetic is cheap next to the LDS
-// atomics, and staging raw keys would double the LDS footprint.  Output runs are reserved with one
+// Two scans of the tile (count, then place; direct-window scan, sp_device.h): staging raw keys would double the
+// LDS footprint.  Output runs are reserved with one
 // global atomic per (tile, non-empty bucket); the order inside a bucket does not matter downstream.
 template <typename KR1, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64_t n_units /* of 32 starts */,
-         sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ cursor1, KR1 *__restrict__ buf1,
+s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+         int64_t n_units /* of 32 starts */, sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ cursor1, KR1 *__restrict__ buf1,
          int64_t n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     KR1 *keys = reinterpret_cast<KR1 *>(s3_lds);                        // [THREADS * 32]
-    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], wsum[THREADS / 64];
+    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], delta[S3_MAXF], wsum[THREADS / 64];
+    __shared__ uint32_t head[THREADS];      // tile positions / 32 = THREADS words
+    __shared__ uint16_t hpre[THREADS];
     const uint64_t rmask = (R1 >= 64) ? ~0ULL : ((1ULL << R1) - 1ULL);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
         __syncthreads();
         const int64_t u = tile * THREADS + threadIdx.x;
         if (u < n_units)
-            sp_scan_unit64<S3_P1_UNIT>(pk, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+            sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
                 const uint64_t key = fwd < rc ? fwd : rc;
                 atomicAdd(&hist[key >> R1], 1u);
             });
@@ -138,23 +165,36 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, int64
         }
         const uint32_t total = s3_block_scan<THREADS>(hist, start, F1, wsum);
         if (threadIdx.x == 0) start[F1] = total;
+        head[threadIdx.x] = 0;                                          // one bit per tile position: a run starts here
+        __syncthreads();
+        for (int b = threadIdx.x; b < F1; b += THREADS)
+            if (hist[b]) atomicOr(&head[start[b] >> 5], 1u << (start[b] & 31));
+        __syncthreads();
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;    // now the placement cursors
         __syncthreads();
         if (u < n_units)
-            sp_scan_unit64<S3_P1_UNIT>(pk, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
+            sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
                 const uint64_t key = fwd < rc ? fwd : rc;
                 const uint32_t b = (uint32_t)(key >> R1);
                 keys[start[b] + atomicAdd(&hist[b], 1u)] = (KR1)(key & rmask);
             });
+        // Which run does sorted position i belong to?  A binary search over start[] (10 dependent LDS reads and ~60
+        // VALU instructions per key) was most of this kernel; instead: rank of the last run head at or before i,
+        // from a prefix popcount over the head bitmap, indexes the runs' (global base - tile start) table.
+        uint32_t tot_runs;
+        const uint32_t wpre = s3_scan_reg_t<THREADS>((uint32_t)__popc(head[threadIdx.x]), wsum, &tot_runs);
+        hpre[threadIdx.x] = (uint16_t)wpre;      // ends with a barrier: placement is complete as well
+        __syncthreads();
+        for (int b = threadIdx.x; b < F1; b += THREADS)
+            if (hist[b]) {       // (the placement cursor = the run's length)
+                const uint32_t p0 = start[b];
+                const uint32_t r = (uint32_t)hpre[p0 >> 5] + (uint32_t)__popc(head[p0 >> 5] & ((1u << (p0 & 31)) - 1u));
+                delta[r] = gbase[b] - p0;
+            }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += THREADS) {
-            int lo = 0, hi = F1;   // bucket of sorted position i: last b with start[b] <= i
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (start[mid] <= i) lo = mid;
-                else hi = mid;
-            }
-            buf1[(size_t)gbase[lo] + (i - start[lo])] = keys[i];
+            const uint32_t r = (uint32_t)hpre[i >> 5] + (uint32_t)__popc(head[i >> 5] & (0xFFFFFFFFu >> (31 - (i & 31)))) - 1u;
+            buf1[(size_t)(delta[r] + i)] = keys[i];
         }
         __syncthreads();
     }
@@ -238,51 +278,78 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2,
          KR2 *__restrict__ buf2) {
-    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF], cur[S3_MAXF], wsum[S3_P2_THREADS / 64];
-    __shared__ unsigned long long gbase[S3_MAXF];
+    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF], wsum[S3_P2_THREADS / 64];
+    __shared__ unsigned long long gdelta[S3_MAXF];     // global base of a run - its start inside the tile
     __shared__ KR1 keys[S3_P2_KEYS];
-    __shared__ int s_b;
+    __shared__ int s_b[2];
     const unsigned long long n_tiles = tile_start[F1];
     const uint32_t mask2 = (uint32_t)F2 - 1u;
     const uint64_t rmask = (R2 >= 64) ? ~0ULL : ((1ULL << R2) - 1ULL);
-    for (unsigned long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x == 0) s_b = s3_bucket_of(tile_start, F1, tile);
-        for (int i = threadIdx.x; i < F2; i += S3_P2_THREADS) hist[i] = 0;
-        __syncthreads();
-        const int b1 = s_b;
-        const unsigned long long base = off1[b1] + (tile - tile_start[b1]) * S3_P2_KEYS, end = off1[b1 + 1];
-        KR1 my[S3_P2_PER];
-        int nmine = 0;
+    unsigned long long tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if (threadIdx.x == 0) s_b[0] = s3_bucket_of(tile_start, F1, tile);
+    __syncthreads();
+    // software pipeline as in c2_part2: the keys of the block's NEXT tile travel while this one is ranked (the rank
+    // of a key inside its run is what the histogram atomic returns), scattered and written out
+    KR1 nxt[S3_P2_PER];
+    int nnext = 0;
+    auto fetch = [&](int nb, unsigned long long t) {
+        const unsigned long long base = off1[nb] + (t - tile_start[nb]) * S3_P2_KEYS, end = off1[nb + 1];
+        nnext = 0;
 #pragma unroll
         for (int j = 0; j < S3_P2_PER; j++) {
             const unsigned long long idx = base + (unsigned long long)j * S3_P2_THREADS + threadIdx.x;
             if (idx < end) {
-                my[j] = buf1[idx];
-                nmine = j + 1;
-                atomicAdd(&hist[(uint32_t)(my[j] >> R2) & mask2], 1u);
+                nxt[j] = buf1[idx];
+                nnext = j + 1;
             }
         }
-        __syncthreads();
-        for (int d = threadIdx.x; d < F2; d += S3_P2_THREADS) {
-            const uint32_t c = hist[d];
-            const size_t fine = (size_t)b1 * F2 + d;
-            gbase[d] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
-            cur[d] = 0;
-        }
-        const uint32_t total = s3_block_scan<S3_P2_THREADS>(hist, start, F2, wsum);
+    };
+    fetch(s_b[0], tile);
+    int p = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int b1 = s_b[p];
+        KR1 my[S3_P2_PER];
+#pragma unroll
+        for (int j = 0; j < S3_P2_PER; j++) my[j] = nxt[j];
+        const int nmine = nnext;
+        const unsigned long long ntile = tile + gridDim.x;
+        for (int i = threadIdx.x; i < F2; i += S3_P2_THREADS) hist[i] = 0;
+        if (threadIdx.x == 0 && ntile < n_tiles) s_b[p ^ 1] = s3_bucket_of(tile_start, F1, ntile);
+        __syncthreads();   // (A) also: the previous tile's copy-out has finished reading keys / start / gdelta
+        uint32_t rank[S3_P2_PER];
 #pragma unroll
         for (int j = 0; j < S3_P2_PER; j++)
-            if (j < nmine) {
-                const uint32_t d = (uint32_t)(my[j] >> R2) & mask2;
-                keys[start[d] + atomicAdd(&cur[d], 1u)] = my[j];
+            if (j < nmine) rank[j] = atomicAdd(&hist[(uint32_t)(my[j] >> R2) & mask2], 1u);
+        __syncthreads();   // (B)
+        unsigned long long g[(S3_MAXF + S3_P2_THREADS - 1) / S3_P2_THREADS];
+#pragma unroll
+        for (int q = 0; q < (S3_MAXF + S3_P2_THREADS - 1) / S3_P2_THREADS; q++) {
+            const int d = threadIdx.x + q * S3_P2_THREADS;
+            g[q] = 0;
+            if (d < F2) {
+                const uint32_t c = hist[d];
+                const size_t fine = (size_t)b1 * F2 + d;
+                g[q] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
             }
-        __syncthreads();
+        }
+        nnext = 0;
+        if (ntile < n_tiles) fetch(s_b[p ^ 1], ntile);
+        const uint32_t total = s3_block_scan<S3_P2_THREADS>(hist, start, F2, wsum);
+#pragma unroll
+        for (int q = 0; q < (S3_MAXF + S3_P2_THREADS - 1) / S3_P2_THREADS; q++) {
+            const int d = threadIdx.x + q * S3_P2_THREADS;
+            if (d < F2) gdelta[d] = g[q] - start[d];
+        }
+#pragma unroll
+        for (int j = 0; j < S3_P2_PER; j++)
+            if (j < nmine) keys[start[(uint32_t)(my[j] >> R2) & mask2] + rank[j]] = my[j];
+        __syncthreads();   // (D)
         for (uint32_t i = threadIdx.x; i < total; i += S3_P2_THREADS) {
             const KR1 kk = keys[i];
-            const uint32_t d = (uint32_t)(kk >> R2) & mask2;
-            buf2[gbase[d] + (i - start[d])] = (KR2)((uint64_t)kk & rmask);
+            buf2[gdelta[(uint32_t)(kk >> R2) & mask2] + i] = (KR2)((uint64_t)kk & rmask);
         }
-        __syncthreads();
+        p ^= 1;
     }
 }
 
@@ -900,10 +967,10 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
                        *d_bsum = (unsigned long long *)(S + o_bsum);
     // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total
     SP_HIP(ctx, hipMemsetAsync(S, 0, small_bytes, ctx->stream));
-    const int64_t n_units64 = (len + SP_UNIT - 1) / SP_UNIT;
+    const int64_t n_units64 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;      // (units of 32 starts since the direct-window scan)
     int64_t grid = (n_units64 + 255) / 256;
     if (grid > (int64_t)ctx->n_cu * 8) grid = (int64_t)ctx->n_cu * 8;
-    SP_LAUNCH(ctx, "s3_hist1", s3_hist1, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_nm, n_units64, kp, P.R1, P.F1,
+    SP_LAUNCH(ctx, "s3_hist1", s3_hist1, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_pm, c.d_nm, n_units64, kp, P.R1, P.F1,
               d_h1);
     SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_h1, (int64_t)P.F1 + 1, d_small);
     unsigned long long nv = 0;
@@ -935,7 +1002,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     int64_t g1 = n_tiles1 < (int64_t)ctx->n_cu * 8 ? n_tiles1 : (int64_t)ctx->n_cu * 8;
     const size_t lds1 = (size_t)P1T * S3_P1_UNIT * sizeof(KR1);
     hipFuncSetAttribute((const void *)s3_part1<KR1, P1T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    SP_LAUNCH(ctx, "s3_part1", (s3_part1<KR1, P1T>), dim3((unsigned)g1), dim3(P1T), lds1, c.d_pk, c.d_nm, n_units32, kp,
+    SP_LAUNCH(ctx, "s3_part1", (s3_part1<KR1, P1T>), dim3((unsigned)g1), dim3(P1T), lds1, c.d_pk, c.d_pm, c.d_nm, n_units32, kp,
               P.R1, P.F1, d_c1, buf1, n_tiles1);
     SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, P.F1, d_ts);
     const int64_t est_tiles = (int64_t)(nv / S3_P2_KEYS) + P.F1 + 1;
