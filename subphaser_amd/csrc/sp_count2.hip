@@ -567,7 +567,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
     size_t sh_hist = nf * 4;
     if (sh_hist > 48 * 1024)
-        hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist);
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
     int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
     SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_pm, c.d_nm, n_units32,
               kp32, C2_B3, (int)nf, P.T - P.B1, P.F1, n_tiles, ghist, tile_cnt);
@@ -583,7 +583,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, (const uint16_t *)lo1, (const uint8_t *)hi1, off1,
               tile_start, P.F1,
               P.F2, C2_B3, off_fine, cur2, buf2);
-    hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4);
+    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
     SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, off_fine,
               (int64_t)nf, (uint32_t)lower, c.d_tab, d_len2, ovf_tmp, ovf_cap, seg_base, seg_cnt);

@@ -1001,7 +1001,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     const int64_t n_tiles1 = (n_units32 + P1T - 1) / P1T;
     int64_t g1 = n_tiles1 < (int64_t)ctx->n_cu * 8 ? n_tiles1 : (int64_t)ctx->n_cu * 8;
     const size_t lds1 = (size_t)P1T * S3_P1_UNIT * sizeof(KR1);
-    hipFuncSetAttribute((const void *)s3_part1<KR1, P1T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    SP_HIP(ctx, hipFuncSetAttribute((const void *)s3_part1<KR1, P1T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     SP_LAUNCH(ctx, "s3_part1", (s3_part1<KR1, P1T>), dim3((unsigned)g1), dim3(P1T), lds1, c.d_pk, c.d_pm, c.d_nm, n_units32, kp,
               P.R1, P.F1, d_c1, buf1, n_tiles1);
     SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, P.F1, d_ts);
