@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
         int64_t n_units /* of 32 starts */,
         sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine, int shift1, int F1, int64_t n_tiles,
-        unsigned long long *__restrict__ ghist, uint32_t *__restrict__ tile_cnt /* [F1][n_tiles] */) {
+        unsigned long long *__restrict__ ghist, uint32_t *__restrict__ tile_cnt /* [n_tiles][F1] */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
     __shared__ uint32_t th[C2_MAXF];
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
@@ -91,7 +91,7 @@ c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const 
             else scan(sp_even_tag{});
         }
         __syncthreads();
-        if (threadIdx.x < F1) tile_cnt[(int64_t)threadIdx.x * n_tiles + tile] = th[threadIdx.x];
+        if (threadIdx.x < F1) tile_cnt[tile * F1 + threadIdx.x] = th[threadIdx.x];   // [tile][bucket]: one coalesced row
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) {
@@ -100,33 +100,46 @@ c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const 
     }
 }
 
-// per level-1 bucket: exclusive scan of the tile counts over tiles (one block per bucket)
+// Exclusive scan, per level-1 bucket, of the tile counts over tiles.  Layout [tile][bucket] (rows written and read
+// coalesced by c2_hist / c2_part1; the transposed layout cost them one 4-byte request per element): chunks of
+// C2_TS_CHUNK tiles are summed (c2_tilesum), then every chunk adds the sums of the chunks before it and walks its
+// tiles (c2_tilescan).
+#define C2_TS_CHUNK 64
 __global__ void __launch_bounds__(256)
-c2_tilescan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, int64_t n_tiles) {
+c2_tilesum(const uint32_t *__restrict__ cnt, int F1, int64_t n_tiles, uint32_t *__restrict__ chunk_sum /* [chunks][F1] */) {
     __shared__ uint32_t part[256];
-    const uint32_t *c = cnt + (int64_t)blockIdx.x * n_tiles;
-    uint32_t *o = off + (int64_t)blockIdx.x * n_tiles;
-    const int64_t per = (n_tiles + 255) / 256;
-    int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
-    if (hi > n_tiles) hi = n_tiles;
+    const int b = threadIdx.x % F1, sub = threadIdx.x / F1, nsub = 256 / F1;
+    const int64_t t0 = (int64_t)blockIdx.x * C2_TS_CHUNK, t1 = t0 + C2_TS_CHUNK < n_tiles ? t0 + C2_TS_CHUNK : n_tiles;
     uint32_t s = 0;
-    for (int64_t i = lo; i < hi; i++) s += c[i];
+    if (sub < nsub)
+        for (int64_t t = t0 + sub; t < t1; t += nsub) s += cnt[t * F1 + b];
     part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < F1) {
+        uint32_t tot = 0;
+        for (int q = 0; q < nsub; q++) tot += part[q * F1 + threadIdx.x];
+        chunk_sum[(int64_t)blockIdx.x * F1 + threadIdx.x] = tot;
+    }
+}
+__global__ void __launch_bounds__(256)
+c2_tilescan(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ chunk_sum, int F1, int64_t n_tiles,
+            uint32_t *__restrict__ off) {
+    __shared__ uint32_t part[256];
+    const int b = threadIdx.x % F1, sub = threadIdx.x / F1, nsub = 256 / F1;
+    uint32_t s = 0;
+    if (sub < nsub)
+        for (int64_t c = sub; c < (int64_t)blockIdx.x; c += nsub) s += chunk_sum[c * F1 + b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < F1) {
         uint32_t run = 0;
-        for (int i = 0; i < 256; i++) {
-            uint32_t v = part[i];
-            part[i] = run;
+        for (int q = 0; q < nsub; q++) run += part[q * F1 + threadIdx.x];
+        const int64_t t0 = (int64_t)blockIdx.x * C2_TS_CHUNK, t1 = t0 + C2_TS_CHUNK < n_tiles ? t0 + C2_TS_CHUNK : n_tiles;
+        for (int64_t t = t0; t < t1; t++) {
+            const uint32_t v = cnt[t * F1 + threadIdx.x];
+            off[t * F1 + threadIdx.x] = run;
             run += v;
         }
-    }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (int64_t i = lo; i < hi; i++) {
-        uint32_t v = c[i];
-        o[i] = run;
-        run += v;
     }
 }
 
@@ -228,7 +241,7 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
         unsigned long long gb = 0;
         if (threadIdx.x < F1) {
-            const int64_t e = (int64_t)threadIdx.x * n_tiles + tile;
+            const int64_t e = tile * F1 + threadIdx.x;
             hist[threadIdx.x] = tile_cnt[e];
             gb = off1[threadIdx.x] + tile_off[e];
         }
@@ -528,7 +541,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
     size_t o_tcnt = o_cur2 + al(nf * 8);
     size_t o_toff = o_tcnt + al((size_t)P.F1 * (size_t)n_tiles * 4);
-    size_t o_buf1 = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
+    size_t o_csum = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
+    size_t o_buf1 = o_csum + al((size_t)P.F1 * (size_t)((n_tiles + C2_TS_CHUNK - 1) / C2_TS_CHUNK) * 4);
     size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64 + (size_t)P.F1 * 16);
     size_t o_segb = o_buf2 + al((size_t)c.len * 2 + 64);          // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
@@ -553,6 +567,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
     uint32_t *tile_cnt = (uint32_t *)(ws + o_tcnt);
     uint32_t *tile_off = (uint32_t *)(ws + o_toff);
+    uint32_t *chunk_sum = (uint32_t *)(ws + o_csum);
     uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
     uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
@@ -573,8 +588,11 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
               kp32, C2_B3, (int)nf, P.T - P.B1, P.F1, n_tiles, ghist, tile_cnt);
     SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
               off1, tile_start);
-    SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3(P.F1), dim3(256), 0, (const uint32_t *)tile_cnt, tile_off,
-              n_tiles);
+    const int64_t n_chunks = (n_tiles + C2_TS_CHUNK - 1) / C2_TS_CHUNK;
+    SP_LAUNCH(ctx, "c2_tilesum", c2_tilesum, dim3((unsigned)n_chunks), dim3(256), 0, (const uint32_t *)tile_cnt, P.F1, n_tiles,
+              chunk_sum);
+    SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3((unsigned)n_chunks), dim3(256), 0, (const uint32_t *)tile_cnt,
+              (const uint32_t *)chunk_sum, P.F1, n_tiles, tile_off);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
               kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, lo1, hi1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
