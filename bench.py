@@ -241,7 +241,7 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
 
-    COUNT_CHAIN = [n for n in ("c2_hist", "c2_tilescan", "c2_offsets", "c2_part1", "c2_part2", "c2_count", "ovf_scan", "ovf_place",
+    COUNT_CHAIN = [n for n in ("c2_hist_fine", "c2_offsets", "c2_part1", "c2_part2", "c2_count", "ovf_scan", "ovf_place",
                                "k1_count_atomic", "k1_narrow") if n in prof]
     if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
         COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))

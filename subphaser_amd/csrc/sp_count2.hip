@@ -4,7 +4,7 @@
 // MI355X (profiles/r01_ubench_mi355x.txt), LDS atomics at ~600 G/s.  This engine
 // turns the random updates into streaming traffic:
 //
-//   c2_hist   scan the packed chromosome, histogram the top B1+B2 slot bits
+//   c2_hist_fine  scan the packed chromosome, histogram the top B1+B2 slot bits
 //             (LDS histogram per block, one global atomic per non-empty bin)
 //   c2_part1  scan again; LDS counting sort of a 16K-key tile on the top B1
 //             bits; each bucket run is written as one coalesced burst (3 bytes per key:
@@ -63,83 +63,29 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
     return true;
 }
 
-// ---------------------------------------------------------------- c2_hist
-// One scan of the chromosome produces (a) the fine histogram (top B1+B2 slot bits; sizes every
-// bucket exactly) and (b) the level-1 bucket counts of every part1 tile, so that part1 needs
-// neither its own histogram pass nor global cursors: each tile's output offsets come from a
-// column scan over tiles (c2_tilescan) -- deterministic layout, no contended atomics.
+// ---------------------------------------------------------------- c2_hist_fine
+// One scan of the chromosome for the fine histogram (top B1+B2 slot bits): it sizes every level-1 and fine bucket
+// exactly.  (Until late in round 2 this kernel also counted every part1 tile's level-1 buckets -- a second, heavily
+// contended LDS atomic per key -- so that part1 needed no cursors; part1 now counts its own tile.)
 __global__ void __launch_bounds__(C2_P1_THREADS)
-c2_hist(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-        int64_t n_units /* of 32 starts */,
-        sp_kparams32 kp, int shift_fine /* = B3 */, int n_fine, int shift1, int F1, int64_t n_tiles,
-        unsigned long long *__restrict__ ghist, uint32_t *__restrict__ tile_cnt /* [n_tiles][F1] */) {
+c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+             int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift_fine, int n_fine,
+             unsigned long long *__restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
-    __shared__ uint32_t th[C2_MAXF];
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x < F1) th[threadIdx.x] = 0;
-        __syncthreads();
-        const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
-        if (u < n_units) {
-            auto scan = [&](auto parity) {
-                sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp, [&](uint32_t slot) {
-                    atomicAdd(&lh[slot >> shift_fine], 1u);
-                    atomicAdd(&th[slot >> shift1], 1u);
-                });
-            };
-            if (kp.odd) scan(sp_odd_tag{});
-            else scan(sp_even_tag{});
-        }
-        __syncthreads();
-        if (threadIdx.x < F1) tile_cnt[tile * F1 + threadIdx.x] = th[threadIdx.x];   // [tile][bucket]: one coalesced row
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x) {
+        auto scan = [&](auto parity) {
+            sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp,
+                                                     [&](uint32_t slot) { atomicAdd(&lh[slot >> shift_fine], 1u); });
+        };
+        if (kp.odd) scan(sp_odd_tag{});
+        else scan(sp_even_tag{});
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) {
         uint32_t v = lh[i];
         if (v) atomicAdd(&ghist[i], (unsigned long long)v);
-    }
-}
-
-// Exclusive scan, per level-1 bucket, of the tile counts over tiles.  Layout [tile][bucket] (rows written and read
-// coalesced by c2_hist / c2_part1; the transposed layout cost them one 4-byte request per element): chunks of
-// C2_TS_CHUNK tiles are summed (c2_tilesum), then every chunk adds the sums of the chunks before it and walks its
-// tiles (c2_tilescan).
-#define C2_TS_CHUNK 64
-__global__ void __launch_bounds__(256)
-c2_tilesum(const uint32_t *__restrict__ cnt, int F1, int64_t n_tiles, uint32_t *__restrict__ chunk_sum /* [chunks][F1] */) {
-    __shared__ uint32_t part[256];
-    const int b = threadIdx.x % F1, sub = threadIdx.x / F1, nsub = 256 / F1;
-    const int64_t t0 = (int64_t)blockIdx.x * C2_TS_CHUNK, t1 = t0 + C2_TS_CHUNK < n_tiles ? t0 + C2_TS_CHUNK : n_tiles;
-    uint32_t s = 0;
-    if (sub < nsub)
-        for (int64_t t = t0 + sub; t < t1; t += nsub) s += cnt[t * F1 + b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < F1) {
-        uint32_t tot = 0;
-        for (int q = 0; q < nsub; q++) tot += part[q * F1 + threadIdx.x];
-        chunk_sum[(int64_t)blockIdx.x * F1 + threadIdx.x] = tot;
-    }
-}
-__global__ void __launch_bounds__(256)
-c2_tilescan(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ chunk_sum, int F1, int64_t n_tiles,
-            uint32_t *__restrict__ off) {
-    __shared__ uint32_t part[256];
-    const int b = threadIdx.x % F1, sub = threadIdx.x / F1, nsub = 256 / F1;
-    uint32_t s = 0;
-    if (sub < nsub)
-        for (int64_t c = sub; c < (int64_t)blockIdx.x; c += nsub) s += chunk_sum[c * F1 + b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < F1) {
-        uint32_t run = 0;
-        for (int q = 0; q < nsub; q++) run += part[q * F1 + threadIdx.x];
-        const int64_t t0 = (int64_t)blockIdx.x * C2_TS_CHUNK, t1 = t0 + C2_TS_CHUNK < n_tiles ? t0 + C2_TS_CHUNK : n_tiles;
-        for (int64_t t = t0; t < t1; t++) {
-            const uint32_t v = cnt[t * F1 + threadIdx.x];
-            off[t * F1 + threadIdx.x] = run;
-            run += v;
-        }
     }
 }
 
@@ -225,43 +171,48 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 }
 
 // ---------------------------------------------------------------- c2_part1
-// LDS traffic per key: one returning atomic (rank inside its bucket run; the run starts come from the
-// tile counts c2_hist left behind), one LDS write, and in the copy-out one key read + ONE table read
+// LDS counting sort of a 16 K-key tile on the top B1 slot bits.  The tile's 32 slots per thread stay in registers
+// (two blocks per CU leave 128 VGPRs per thread); the rank inside the bucket run is what the tile-histogram atomic
+// returns; the run's global position is reserved with one global atomic per (tile, bucket) -- the order of the keys
+// inside a level-1 bucket is irrelevant downstream; the copy-out reads one key and ONE table entry
 // (delta[b] = global base of the run - its LDS start, so that out index = delta[b] + i).
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-         int64_t n_units /* of 32 starts */,
-         sp_kparams32 kp, int shift1 /* T-B1 */, int F1, const unsigned long long *__restrict__ off1,
-         const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, int64_t n_tiles,
-         uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
-    __shared__ uint32_t hist[C2_MAXF], cur[C2_MAXF], wsum[4];
+          int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift1 /* T-B1 */, int F1,
+          const unsigned long long *__restrict__ off1, unsigned long long *__restrict__ cursor1, int64_t n_tiles,
+          uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
+    __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], wsum[4];
     __shared__ unsigned long long delta[C2_MAXF];
     __shared__ uint32_t keys[C2_P1_KEYS];
+    const int sh = 32 - 2 * kp.k;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < F1) hist[threadIdx.x] = 0;
+        __syncthreads();
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
-        unsigned long long gb = 0;
-        if (threadIdx.x < F1) {
-            const int64_t e = tile * F1 + threadIdx.x;
-            hist[threadIdx.x] = tile_cnt[e];
-            gb = off1[threadIdx.x] + tile_off[e];
-        }
-        __syncthreads();
-        const uint32_t total = c2_scan_F(hist, cur, F1, wsum);   // cur[b] = LDS start of run b (then the cursor)
-        if (threadIdx.x < F1) delta[threadIdx.x] = gb - cur[threadIdx.x];
-        __syncthreads();
+        uint32_t slot[32], rank[32], ok = 0;
         if (u < n_units) {
-            auto scan = [&](auto parity) {
-                sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp, [&](uint32_t slot) {
-                    keys[atomicAdd(&cur[slot >> shift1], 1u)] = slot;
-                });
+            ok = ~(uint32_t)sp_bad_starts64(nm, u * C2_P1_UNIT, kp.k);
+            const sp_words32 x = sp_load_words32(pk, pm, u * C2_P1_UNIT);
+            auto f = [&](int j, uint32_t V, uint32_t W) {
+                slot[j] = kp.odd ? sp_slot_of32_t<true>(V >> sh, ~W & kp.kmask, kp)
+                                 : sp_slot_of32_t<false>(V >> sh, ~W & kp.kmask, kp);
+                if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[slot[j] >> shift1], 1u);
             };
-            if (kp.odd) scan(sp_odd_tag{});
-            else scan(sp_even_tag{});
+            sp_win_loop<0, 1, decltype(f)>::run(x, f);
         }
+        __syncthreads();
+        unsigned long long g = 0;
+        if (threadIdx.x < F1) {
+            const uint32_t c = hist[threadIdx.x];
+            g = off1[threadIdx.x] + (c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL);
+        }
+        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
+        if (threadIdx.x < F1) delta[threadIdx.x] = g - start[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+            if ((ok >> j) & 1u) keys[start[slot[j] >> shift1] + rank[j]] = slot[j];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
-            // 3 bytes per key leave the chip (the level-1 bucket is implied by where the key lands; <= 23 slot bits
-            // are left): the low 16 bits and the byte above them go to two planes, both in coalesced runs
             const uint32_t s = keys[i];
             const unsigned long long o = delta[s >> shift1] + i;
             lo1[o] = (uint16_t)s;
@@ -539,10 +490,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
     const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
     const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
-    size_t o_tcnt = o_cur2 + al(nf * 8);
-    size_t o_toff = o_tcnt + al((size_t)P.F1 * (size_t)n_tiles * 4);
-    size_t o_csum = o_toff + al((size_t)P.F1 * (size_t)n_tiles * 4);
-    size_t o_buf1 = o_csum + al((size_t)P.F1 * (size_t)((n_tiles + C2_TS_CHUNK - 1) / C2_TS_CHUNK) * 4);
+    size_t o_tcnt = o_cur2 + al(nf * 8);        // end of the zeroed head of the workspace
+    size_t o_buf1 = o_tcnt;
     size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64 + (size_t)P.F1 * 16);
     size_t o_segb = o_buf2 + al((size_t)c.len * 2 + 64);          // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
@@ -565,9 +514,6 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     unsigned long long *off1 = (unsigned long long *)(ws + o_off1);
     unsigned long long *tile_start = (unsigned long long *)(ws + o_tile);
     unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
-    uint32_t *tile_cnt = (uint32_t *)(ws + o_tcnt);
-    uint32_t *tile_off = (uint32_t *)(ws + o_toff);
-    uint32_t *chunk_sum = (uint32_t *)(ws + o_csum);
     uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
     uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
@@ -581,20 +527,15 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
     int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
     size_t sh_hist = nf * 4;
-    if (sh_hist > 48 * 1024)
-        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
     int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
-    SP_LAUNCH(ctx, "c2_hist", c2_hist, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_pm, c.d_nm, n_units32,
-              kp32, C2_B3, (int)nf, P.T - P.B1, P.F1, n_tiles, ghist, tile_cnt);
+    if (sh_hist > 48 * 1024)
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
+    SP_LAUNCH(ctx, "c2_hist_fine", c2_hist_fine, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_pm, c.d_nm,
+              n_units32, kp32, C2_B3, (int)nf, ghist);
     SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
               off1, tile_start);
-    const int64_t n_chunks = (n_tiles + C2_TS_CHUNK - 1) / C2_TS_CHUNK;
-    SP_LAUNCH(ctx, "c2_tilesum", c2_tilesum, dim3((unsigned)n_chunks), dim3(256), 0, (const uint32_t *)tile_cnt, P.F1, n_tiles,
-              chunk_sum);
-    SP_LAUNCH(ctx, "c2_tilescan", c2_tilescan, dim3((unsigned)n_chunks), dim3(256), 0, (const uint32_t *)tile_cnt,
-              (const uint32_t *)chunk_sum, P.F1, n_tiles, tile_off);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
-              kp32, P.T - P.B1, P.F1, off1, (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, n_tiles, lo1, hi1);
+              kp32, P.T - P.B1, P.F1, off1, (unsigned long long *)(ws + o_cur1), n_tiles, lo1, hi1);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
     int64_t max_tiles2 = n_tiles + P.F1;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
