@@ -5,13 +5,18 @@
 // engine is the 64-bit twin of engine 2: an MSD partition that moves every key twice, in shrinking
 // form, and finishes inside LDS.
 //
-//   s3_hist1   scan the packed chromosome, histogram the top B1 key bits (LDS, F1 <= 1024 bins)
-//   s3_part1   scan again; LDS counting sort of a tile on those bits; every bucket run goes out as
-//              one burst; only the low R1 = 2k - B1 bits survive (u32 for k <= 21, else u64)
+//   s3_hist1   scan the packed chromosome (64-bit direct-window scan, sp_device.h), histogram the top
+//              B1 key bits (LDS, F1 <= 1024 bins)
+//   s3_part1   scan again, the 32 keys of a thread stay in registers; LDS counting sort of a tile on
+//              those bits (rank = what the histogram atomic returns); every bucket run goes out as one
+//              burst (its run found by prefix popcount over a bitmap of run heads); only the low
+//              R1 = 2k - B1 bits survive (u32 for k <= 21, else u64)
 //   s3_hist2   per level-1 bucket: histogram of the next B2 = 9 bits  -> exact fine-bucket offsets
-//   s3_part2   per level-1 bucket: LDS counting sort of 4 K-key tiles on those bits; R2 = R1 - 9
-//              bits survive (u32 for k <= 25)
-//   s3_final   one workgroup per fine bucket (2^18..2^19 of them, ~1-3 K keys): block radix sort of
+//   s3_part2   per level-1 bucket: LDS counting sort of 8 K-key tiles on those bits, software-pipelined;
+//              R2 = R1 - 9 bits survive (u32 for k <= 25)
+//   s3_final_bitmap (k = 16, 17: R2 <= 16) one workgroup per fine bucket (2^18..2^19 of them, ~1-3 K
+//              keys): bitmap + prefix popcount ranking, no sort
+//   s3_final_small / s3_final (k >= 18, and what the bitmap kernel hands over): block radix sort of
 //              the residuals in registers/LDS, run-length encode, keep count >= lower_count
 //   s3_gather  ordered compaction of the kept (key, count) pairs -> the chromosome's sorted list
 //
@@ -135,8 +140,7 @@ s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
 }
 
 // ---------------------------------------------------------------- s3_part1
-// Two scans of the tile (count, then place; direct-window scan, sp_device.h): staging raw keys would double the
-// LDS footprint.  Output runs are reserved with one
+// Output runs are reserved with one
 // global atomic per (tile, non-empty bucket); the order inside a bucket does not matter downstream.
 template <typename KR1, int THREADS>
 __global__ void __launch_bounds__(THREADS)
@@ -152,12 +156,21 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
         __syncthreads();
+        // ONE scan: the unit's 32 canonical keys stay in registers (the 64-KiB tile leaves one block per CU, so
+        // registers are plentiful); the rank inside the bucket run is what the histogram atomic returns
         const int64_t u = tile * THREADS + threadIdx.x;
-        if (u < n_units)
-            sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-                const uint64_t key = fwd < rc ? fwd : rc;
-                atomicAdd(&hist[key >> R1], 1u);
-            });
+        uint64_t key[32];
+        uint32_t rank[32], ok = 0;
+        if (u < n_units) {
+            ok = ~(uint32_t)sp_bad_starts64(nm, u * S3_P1_UNIT, kp.k);
+            if (ok) {
+                const sp_words64 x = sp_load_words64(pk, pm, u * S3_P1_UNIT);
+                sp_scan32_keys64(x, kp, [&](int j, uint64_t fwd, uint64_t rc) {
+                    key[j] = fwd < rc ? fwd : rc;
+                    if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[key[j] >> R1], 1u);
+                });
+            }
+        }
         __syncthreads();
         for (int b = threadIdx.x; b < F1; b += THREADS) {
             const uint32_t c = hist[b];
@@ -169,15 +182,9 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         __syncthreads();
         for (int b = threadIdx.x; b < F1; b += THREADS)
             if (hist[b]) atomicOr(&head[start[b] >> 5], 1u << (start[b] & 31));
-        __syncthreads();
-        for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;    // now the placement cursors
-        __syncthreads();
-        if (u < n_units)
-            sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
-                const uint64_t key = fwd < rc ? fwd : rc;
-                const uint32_t b = (uint32_t)(key >> R1);
-                keys[start[b] + atomicAdd(&hist[b], 1u)] = (KR1)(key & rmask);
-            });
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+            if ((ok >> j) & 1u) keys[start[(uint32_t)(key[j] >> R1)] + rank[j]] = (KR1)(key[j] & rmask);
         // Which run does sorted position i belong to?  A binary search over start[] (10 dependent LDS reads and ~60
         // VALU instructions per key) was most of this kernel; instead: rank of the last run head at or before i,
         // from a prefix popcount over the head bitmap, indexes the runs' (global base - tile start) table.
