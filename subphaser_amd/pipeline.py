@@ -165,6 +165,11 @@ def check_ckp(ckpfile):
 
 
 # ------------------------------------------------------------------------------------------------- the run
+def _bg_min_rows():
+    """outputs with at least this many rows are written on a background thread (SP_BG_MIN_ROWS: tests force it)"""
+    return int(os.environ.get("SP_BG_MIN_ROWS", "200000"))
+
+
 class Pipeline:
     def __init__(self, genomes, sg_cfgs, labels=None, **opts):
         self.__dict__.update(opts)
@@ -279,7 +284,7 @@ class Pipeline:
                 plot_histogram(tot, histfig)
             except Exception as e:     # the figure is optional
                 logger.warning("histogram not plotted: {}".format(e))
-        self._write_in_background(matfile, work, len(d_mat2) >= 200000, done=done)
+        self._write_in_background(matfile, work, len(d_mat2) >= _bg_min_rows(), done=done)
 
     def _write_in_background(self, path, write, big, done=None):
         """write(fout) into `path`: on a thread of this process when the output is large (the library's text writers
@@ -339,7 +344,7 @@ class Pipeline:
         t0 = time.perf_counter()
         kmer_labels, write = cl.output_kmers(None, max_pval=self.max_pval, test_method=self.test_method, defer=True)
         t1 = time.perf_counter()
-        self._write_in_background(sg_kmers, write, len(kmer_labels.keys) >= 200000)
+        self._write_in_background(sg_kmers, write, len(kmer_labels.keys) >= _bg_min_rows())
         logger.info("k-mer tests {:.2f} s, text writer started in {:.2f} s".format(t1 - t0, time.perf_counter() - t1))
         per_sg = np.bincount(kmer_labels.sg_idx, minlength=len(kmer_labels.sg_names))
         logger.info("{} significant subgenome-specific kmers".format(len(kmer_labels.keys)))

@@ -585,6 +585,13 @@ def test_pipeline_cli(gpu_ctx, golden, toy, tmp_path):
     pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
 
 
+def test_pipeline_cli_background_writers(gpu_ctx, golden, toy, tmp_path, monkeypatch):
+    """the same CLI run with every text output forced onto the background writer threads (at toy size they are
+    written inline): identical files, checkpoints recorded after the writers"""
+    monkeypatch.setenv("SP_BG_MIN_ROWS", "1")
+    pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
+
+
 def test_map_vs_oracle_random(gpu_ctx):
     rng = np.random.RandomState(33)
     k = 13
