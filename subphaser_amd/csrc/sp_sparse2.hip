@@ -20,8 +20,8 @@
 //              the residuals in registers/LDS, run-length encode, keep count >= lower_count
 //   s3_gather  ordered compaction of the kept (key, count) pairs -> the chromosome's sorted list
 //
-// Fine buckets that do not fit one workgroup (> 4096 keys: hot keys such as telomere repeats) are
-// sorted one by one with the device-wide primitive; they are rare.
+// Fine buckets that neither fit one workgroup nor split (hot keys such as telomere repeats: ~70 per wheat-sized
+// chromosome at k = 21) are sorted together by one segmented device sort and run-length encoded by s3_big_rle.
 // Bytes per key (k = 21): 0.375 x 3 scans + 4 w + 4 r + 4 r + 4 w + 4 r  ~ 21 B against ~100 B.
 #include "sp_device.h"
 
@@ -836,34 +836,50 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned
     if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
 }
 
-// a bucket too large for one workgroup, after the device-wide sort + run-length encode of its residuals:
-// keep runs >= lower (single block, ordered)
+// All buckets too large for one workgroup at once: their residuals were sorted segment by segment by ONE
+// segmented device sort (they used to be sorted one by one from a host loop: 70 buckets per wheat-sized chromosome
+// at k = 21, 80 ms of launch latency per pass).  One block per bucket walks its sorted segment: a run head finds the
+// end of its run by binary search, runs >= lower are kept in order.
 template <typename KR2>
 __global__ void __launch_bounds__(256)
-s3_big_select(const KR2 *__restrict__ uniq, const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ n_runs_p,
-              uint32_t lower, unsigned long long o, int64_t bucket, KR2 *__restrict__ tmp_keys,
-              uint32_t *__restrict__ tmp_cnts, unsigned long long *__restrict__ kept,
-              unsigned long long *__restrict__ len_sum) {
+s3_big_rle(const KR2 *__restrict__ sorted, const unsigned long long *__restrict__ big, const unsigned long long *__restrict__ off_fine,
+           uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts, unsigned long long *__restrict__ kept,
+           unsigned long long *__restrict__ len_sum) {
     __shared__ uint32_t lds[16];
     __shared__ unsigned long long red[16];
-    const unsigned long long n_runs = *n_runs_p;
+    const unsigned long long b = big[blockIdx.x];
+    const unsigned long long o = off_fine[b], n = off_fine[b + 1] - o;
+    const KR2 *s = sorted + o;
     unsigned long long w = 0, lsum = 0;
-    for (unsigned long long base = 0; base < n_runs; base += 256) {
+    for (unsigned long long base = 0; base < n; base += 256) {
         const unsigned long long i = base + threadIdx.x;
-        const uint32_t c = (i < n_runs) ? counts[i] : 0u;
-        const bool p = (i < n_runs) && c >= lower;
+        KR2 key = 0;
+        unsigned long long c = 0;
+        if (i < n) {
+            key = s[i];
+            if (i == 0 || s[i - 1] != key) {     // run head: upper bound of the key in (i, n)
+                unsigned long long lo = i + 1, hi = n;
+                while (lo < hi) {
+                    const unsigned long long mid = (lo + hi) >> 1;
+                    if (s[mid] == key) lo = mid + 1;
+                    else hi = mid;
+                }
+                c = lo - i;
+            }
+        }
+        const bool p = c >= lower && c > 0;
         uint32_t tot;
         const uint32_t my = sp_block_excl_count(p, lds, tot);
         if (p) {
-            tmp_keys[o + w + my] = uniq[i];
-            tmp_cnts[o + w + my] = c;
+            tmp_keys[o + w + my] = key;
+            tmp_cnts[o + w + my] = (uint32_t)c;
             lsum += c;
         }
         w += tot;
     }
     const unsigned long long t = sp_block_sum_u64(lsum, red);
     if (threadIdx.x == 0) {
-        kept[bucket] = w;
+        kept[b] = w;
         if (t) atomicAdd(len_sum, t);
     }
 }
@@ -1041,34 +1057,32 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_big > big_cap) return sp_fail(ctx, SP_EUNSUP, "k > 15: %llu oversized k-mer buckets", n_big);
-    if (n_big) {   // hot keys: buckets beyond one workgroup, sorted one by one with the device-wide primitive
-        std::vector<unsigned long long> big((size_t)n_big), offs((size_t)n_fine + 1);
+    if (n_big) {   // hot keys: buckets beyond one workgroup -- ONE segmented device sort, then one block per bucket
+        std::vector<unsigned long long> big((size_t)n_big), offs((size_t)n_fine + 1), seg(2 * (size_t)n_big);
         SP_HIP(ctx, hipMemcpy(big.data(), d_big, (size_t)n_big * 8, hipMemcpyDeviceToHost));
         SP_HIP(ctx, hipMemcpy(offs.data(), d_of, (size_t)(n_fine + 1) * 8, hipMemcpyDeviceToHost));
-        for (unsigned long long bi = 0; bi < n_big; bi++) {
-            const int64_t b = (int64_t)big[(size_t)bi];
-            const unsigned long long o = offs[(size_t)b], n = offs[(size_t)b + 1] - o;
-            // sorted residuals -> buf1 area (free now), unique -> tmp of its own bucket range is too small for
-            // the unsorted copy, so use buf1 as scratch: [sorted n][unique n][counts n]
-            rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)(n * (2 * sizeof(KR2) + 4) + 256));
-            if (rc) return rc;
-            KR2 *srt = (KR2 *)ctx->b_sp_a.p, *unq = srt + n;
-            uint32_t *cn = (uint32_t *)(unq + n);
-            size_t tb = 0;
-            SP_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, buf2 + o, srt, (size_t)n, 0u, (unsigned)(P.R2 > 0 ? P.R2 : 1),
-                                                 ctx->stream));
-            size_t tb2 = 0;
-            SP_HIP(ctx, rocprim::run_length_encode(nullptr, tb2, srt, (unsigned int)n, unq, cn, d_small + 4, ctx->stream));
-            rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)(tb > tb2 ? tb : tb2) + 256);
-            if (rc) return rc;
-            SP_HIP(ctx, rocprim::radix_sort_keys(ctx->b_sp_tmp.p, tb, buf2 + o, srt, (size_t)n, 0u,
-                                                 (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
-            SP_HIP(ctx, rocprim::run_length_encode(ctx->b_sp_tmp.p, tb2, srt, (unsigned int)n, unq, cn, d_small + 4,
-                                                   ctx->stream));
-            SP_LAUNCH(ctx, "s3_big_select", s3_big_select<KR2>, dim3(1), dim3(256), 0, (const KR2 *)unq, (const uint32_t *)cn,
-                      (const unsigned long long *)(d_small + 4), (uint32_t)lower, o, b, tmp_keys, tmp_cnts, d_kp,
-                      d_small + 2);
+        for (size_t bi = 0; bi < (size_t)n_big; bi++) {
+            seg[bi] = offs[(size_t)big[bi]];
+            seg[(size_t)n_big + bi] = offs[(size_t)big[bi] + 1];
         }
+        KR2 *srt = (KR2 *)buf1;      // the level-1 buffer is free by now and holds nv keys of at least this width
+        size_t tb = 0;
+        const unsigned long long *nul = nullptr;
+        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, (const KR2 *)buf2, srt, (unsigned int)nv, (unsigned int)n_big,
+                                                       nul, nul, 0u, (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
+        const size_t seg_bytes = 2 * (size_t)n_big * 8;
+        rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)(tb + seg_bytes + 512));
+        if (rc) return rc;
+        unsigned long long *d_seg = (unsigned long long *)((char *)ctx->b_sp_tmp.p + ((tb + 255) & ~(size_t)255));
+        SP_HIP(ctx, hipMemcpyAsync(d_seg, seg.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(ctx->b_sp_tmp.p, tb, (const KR2 *)buf2, srt, (unsigned int)nv,
+                                                       (unsigned int)n_big, (const unsigned long long *)d_seg,
+                                                       (const unsigned long long *)(d_seg + n_big), 0u,
+                                                       (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
+        SP_LAUNCH(ctx, "s3_big_rle", s3_big_rle<KR2>, dim3((unsigned)n_big), dim3(256), 0, (const KR2 *)srt,
+                  (const unsigned long long *)d_big, (const unsigned long long *)d_of, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  d_kp, d_small + 2);
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `seg` (pageable) must outlive the copy
     }
     rc = s3_scan(ctx, d_kp, n_fine, d_small + 3, d_bsum);
     if (rc) return rc;
