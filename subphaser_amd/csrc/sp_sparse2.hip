@@ -35,7 +35,9 @@
 #endif
 #define S3_P2_KEYS (S3_P2_THREADS * S3_P2_PER)   // keys per part2 / hist2 tile
 #define S3_SORT_THREADS 256
-#define S3_SORT_PER 8
+#ifndef S3_SORT_PER
+#define S3_SORT_PER 16     // 8: s3_final 140 ms per wheat-like pass at k = 21, 16: 131 (fewer buckets need the split pass)
+#endif
 #define S3_SORT_CAP (S3_SORT_THREADS * S3_SORT_PER)   // keys one workgroup sorts
 
 struct s3_plan {
