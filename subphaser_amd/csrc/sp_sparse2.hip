@@ -36,7 +36,7 @@
 #define S3_P2_KEYS (S3_P2_THREADS * S3_P2_PER)   // keys per part2 / hist2 tile
 #define S3_SORT_THREADS 256
 #ifndef S3_SORT_PER
-#define S3_SORT_PER 16     // 8: s3_final 140 ms per wheat-like pass at k = 21, 16: 131 (fewer buckets need the split pass)
+#define S3_SORT_PER 8      // (16: s3_final 140 -> 131 ms per wheat-like pass at k = 21, but 11 -> 16 ms at k = 17 and more big-list buckets)
 #endif
 #define S3_SORT_CAP (S3_SORT_THREADS * S3_SORT_PER)   // keys one workgroup sorts
 
