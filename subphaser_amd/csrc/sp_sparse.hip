@@ -214,11 +214,136 @@ __device__ __forceinline__ int sps_lookup(uint64_t key, unsigned long long *__re
     }
 }
 
+// ------------------------------------------------------------------ pair-keyed label table (k > 15, <= 7 subgenomes)
+// The k <= 15 pair table, hashed: an entry is keyed by the canonical (k-1)-mer x that two neighbouring starts share
+// and its payload holds the same eight 4-bit fields (label of b + x and of x + b for the four bases b, seen flag in
+// bit 3), so ONE 16-byte look-up answers BOTH starts of a candidate pair -- the per-k-mer table above costs one L2
+// miss per candidate start, and those misses are what k5_map_sparse waits for.
+struct sps_pair_loc {
+    uint64_t idx;   // canonical (k-1)-mer
+    int field;
+};
+__host__ __device__ __forceinline__ sps_pair_loc sps_loc_prefix(uint64_t o, int k) {     // o = x + b
+    sps_pair_loc r;
+    const uint32_t b = (uint32_t)(o & 3ULL);
+    const uint64_t p = o >> 2, pc = sp_revcomp(p, k - 1);
+    if (p <= pc) { r.idx = p; r.field = 4 + (int)b; }
+    else { r.idx = pc; r.field = 3 - (int)b; }              // rc: comp(b) + rc(x)
+    return r;
+}
+__host__ __device__ __forceinline__ sps_pair_loc sps_loc_suffix(uint64_t o, int k) {     // o = b + x
+    sps_pair_loc r;
+    const uint32_t b = (uint32_t)(o >> (2 * (k - 1))) & 3u;
+    const uint64_t m1mask = (1ULL << (2 * (k - 1))) - 1ULL;
+    const uint64_t x = o & m1mask, xc = sp_revcomp(x, k - 1);
+    if (x <= xc) { r.idx = x; r.field = (int)b; }
+    else { r.idx = xc; r.field = 7 - (int)b; }              // rc: rc(x) + comp(b)
+    return r;
+}
+__global__ void __launch_bounds__(256)
+sps_pair_init(unsigned long long *__restrict__ htab, int64_t cap) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+        htab[2 * i] = SPS_SENTINEL;
+        htab[2 * i + 1] = 0ULL;
+    }
+}
+__device__ __forceinline__ void sps_pair_put(unsigned long long *__restrict__ htab, uint64_t mask, sps_pair_loc a, uint32_t l) {
+    uint64_t h = sps_mix(a.idx) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&htab[2 * h], SPS_SENTINEL, (unsigned long long)a.idx);
+        if (prev == SPS_SENTINEL || prev == a.idx) break;
+        h = (h + 1) & mask;
+    }
+    atomicOr(&htab[2 * h + 1], (unsigned long long)l << (4 * a.field));
+}
+__global__ void __launch_bounds__(256)
+sps_pair_insert(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n, int k,
+                unsigned long long *__restrict__ htab, uint64_t mask) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i], r = sp_revcomp(key, k);
+    const uint32_t l = 1u + sg[i];
+    sps_pair_put(htab, mask, sps_loc_prefix(key, k), l);
+    sps_pair_put(htab, mask, sps_loc_suffix(key, k), l);
+    sps_pair_put(htab, mask, sps_loc_prefix(r, k), l);      // (the same two entries and fields; kept for symmetry
+    sps_pair_put(htab, mask, sps_loc_suffix(r, k), l);      //  with k4_pair_table: the OR is idempotent)
+}
+// entry of the canonical (k-1)-mer `x`: payload (0 when absent) and its slot
+__device__ __forceinline__ uint32_t sps_pair_get(uint64_t x, const unsigned long long *__restrict__ htab, uint64_t mask,
+                                                 uint64_t &slot) {
+    uint64_t h = sps_mix(x) & mask;
+    for (;;) {
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(htab + 2 * h);
+        if (e.x == x) {
+            slot = h;
+            return (uint32_t)e.y;
+        }
+        if (e.x == SPS_SENTINEL) return 0u;
+        h = (h + 1) & mask;
+    }
+}
+__global__ void __launch_bounds__(256)
+sps_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, const unsigned long long *__restrict__ htab,
+              uint64_t mask, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i], r = sp_revcomp(key, k);
+        const sps_pair_loc L[4] = {sps_loc_prefix(key, k), sps_loc_suffix(key, k), sps_loc_prefix(r, k), sps_loc_suffix(r, k)};
+        uint32_t seen = 0;
+        for (int q = 0; q < 4; q++) {
+            uint64_t slot;
+            seen |= (sps_pair_get(L[q].idx, htab, mask, slot) >> (4 * L[q].field)) & 8u;
+        }
+        c += seen ? 1 : 0;
+    }
+    unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
+// Walk one unit of 64 starts: ONE filter probe and, for candidates, ONE table look-up per PAIR of starts;
+// hit(start, sg) says whether the position counts; a counted k-mer is marked seen (first touch only).
+template <typename F>
+__device__ __forceinline__ void map_pair_scan_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
+                                                int64_t s0, const sp_kparams &kp, const uint32_t *__restrict__ bloom,
+                                                int nbits, unsigned long long *__restrict__ htab, uint64_t mask, F &&hit) {
+    const uint64_t m1mask = kp.kmask >> 2;
+    const int top = 2 * (kp.k - 1);
+    uint32_t e = 0, mark = 0;
+    uint64_t slot = 0;
+    bool fw = true;
+    sp_scan_unit_all<SP_UNIT, uint64_t>(pk, nm, s0, kp, [&](int64_t start, uint64_t fwd, uint64_t rc, bool valid_k, bool valid_k1) {
+        if (!(start & 1)) {   // first of the pair: b0 + x
+            e = 0;
+            mark = 0;
+            if (valid_k1) {
+                const uint64_t xf = fwd & m1mask, xr = rc >> 2;
+                const uint64_t canon = xf < xr ? xf : xr;
+                fw = xf <= xr;
+                if (map_bloom_test(bloom, nbits, canon)) e = sps_pair_get(canon, htab, mask, slot);
+            }
+            if (e & 0x77777777u) {
+                const uint32_t b0 = (uint32_t)(fwd >> top) & 3u;
+                const int f0 = fw ? (int)b0 : 7 - (int)b0;
+                const uint32_t v0 = valid_k ? (e >> (4 * f0)) & 15u : 0u;
+                if ((v0 & 7u) && hit(start, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
+            }
+        } else if (e & 0x77777777u) {   // second of the pair: x + b1
+            const uint32_t b1 = (uint32_t)fwd & 3u;
+            const int f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
+            const uint32_t v1 = valid_k ? (e >> (4 * f1)) & 15u : 0u;
+            if ((v1 & 7u) && hit(start, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
+            if (mark) atomicOr(&htab[2 * slot + 1], (unsigned long long)mark);
+            mark = 0;
+        }
+    });
+}
+
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, sp_map_params P,
               unsigned long long *__restrict__ htab, uint64_t mask,
               const uint32_t *__restrict__ bloom, int bloom_bits, int *__restrict__ slot_counts,
-              unsigned long long *__restrict__ n_mapped) {
+              unsigned long long *__restrict__ n_mapped, int pairs /* htab is the pair-keyed table */) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
     unsigned long long mapped = 0;
@@ -231,16 +356,22 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
             __syncthreads();
         }
         if (u < P.n_units) {
-            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
-                if (sg < 0) return;
+            auto count = [&](int64_t start, int sg) {
                 const int64_t os = map_slot(start, P, kp.k);
                 if (P.use_lds)
                     atomicAdd(&hist[(os - slot_lo) * P.S + sg], 1);
                 else if (os < P.nslots)
                     atomicAdd(&slot_counts[os * P.S + sg], 1);
                 mapped++;
-            });
+                return true;
+            };
+            if (pairs)
+                map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, count);
+            else
+                map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                    const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+                    if (sg >= 0) count(start, sg);
+                });
         }
         if (P.use_lds) {
             __syncthreads();
@@ -262,19 +393,26 @@ __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
                    const int64_t *__restrict__ foff, int64_t n_feat, int S,
                    unsigned long long *__restrict__ htab, uint64_t mask,
-                   const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
+                   const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts, int pairs) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         map_feat_cursor cur;
         cur.f = -1;
         cur.next = 0;
-        map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-            if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return;   // runs into the next feature
-            const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
-            if (sg < 0) return;
-            atomicAdd(&counts[cur.f * S + sg], 1ULL);
-        });
+        if (pairs)
+            map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
+                if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return false;   // runs into the next feature
+                atomicAdd(&counts[cur.f * S + sg], 1ULL);
+                return true;
+            });
+        else
+            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return;   // runs into the next feature
+                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+                if (sg < 0) return;
+                atomicAdd(&counts[cur.f * S + sg], 1ULL);
+            });
     }
 }
 
@@ -567,28 +705,46 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
 int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n);   // sp_map.hip
 
 int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n) {
+    // <= 7 subgenomes: the pair-keyed table (one look-up per candidate PAIR of starts); else one entry per k-mer
+    const char *eng = getenv("SP_MAP_ENGINE");
+    ctx->map_engine = (ctx->n_sg > 7 || (eng && eng[0] == '1')) ? 1 : 0;
+    const bool pairs = ctx->map_engine == 0;
     int64_t cap = 1024;
-    while (cap < 2 * n + 16) cap <<= 1;
+    while (cap < (pairs ? 4 : 2) * n + 16) cap <<= 1;
     if (cap != ctx->hcap) {
         if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
         ctx->d_hkeys = nullptr;
         SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 16));
         ctx->hcap = cap;
     }
-    // {key = sentinel (all ones), label = 0}: 0xff everywhere, then the label words are written on insert
-    // and read only after a key match, so they need no clearing
-    SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 16, ctx->stream));
+    if (pairs) {
+        SP_LAUNCH(ctx, "sps_pair_init", sps_pair_init, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
+                  (unsigned long long *)ctx->d_hkeys, cap);
+    } else {
+        // {key = sentinel (all ones), label = 0}: 0xff everywhere, then the label words are written on insert
+        // and read only after a key match, so they need no clearing
+        SP_HIP(ctx, hipMemsetAsync(ctx->d_hkeys, 0xff, (size_t)cap * 16, ctx->stream));
+    }
     if (n == 0) return sp_map_filter_build(ctx, nullptr, 0);
-    sp_tmp<unsigned long long> d_keys;
-    sp_tmp<uint8_t> d_sg;
-    SP_HIP(ctx, d_keys.alloc((size_t)n));
-    SP_HIP(ctx, d_sg.alloc((size_t)n));
-    SP_HIP(ctx, hipMemcpyAsync(d_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_sg.p, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-              (const unsigned long long *)d_keys.p, (const uint8_t *)d_sg.p, n, (unsigned long long *)ctx->d_hkeys,
-              (uint64_t)(cap - 1));
-    const int rcf = sp_map_filter_build(ctx, d_keys.p, n);
+    // the labelled keys stay on the device (sp_labels_hit walks them in pair mode); the dense engine's pair table, if
+    // any, was built from the keys this overwrites: it must be cleared in full next time
+    ctx->ptab_k = 0;
+    ctx->ptab_n = 0;
+    int rcb = sp_buf_ensure(ctx, ctx->b_labkeys, n * 9 + 64);
+    if (rcb) return rcb;
+    unsigned long long *d_keys = (unsigned long long *)ctx->b_labkeys.p;
+    uint8_t *d_sg = (uint8_t *)(d_keys + n);
+    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (pairs)
+        SP_LAUNCH(ctx, "sps_pair_insert", sps_pair_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                  (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, (unsigned long long *)ctx->d_hkeys,
+                  (uint64_t)(cap - 1));
+    else
+        SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                  (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, (unsigned long long *)ctx->d_hkeys,
+                  (uint64_t)(cap - 1));
+    const int rcf = sp_map_filter_build(ctx, d_keys, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rcf;
 }
@@ -601,7 +757,7 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
               (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts,
-              d_n);
+              d_n, ctx->map_engine == 0 ? 1 : 0);
     return SP_OK;
 }
 
@@ -612,11 +768,18 @@ int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_n
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
               n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys,
-              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts);
+              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, ctx->map_engine == 0 ? 1 : 0);
     return SP_OK;
 }
 
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
+    if (ctx->map_engine == 0) {
+        if (ctx->n_labels > 0)
+            SP_LAUNCH(ctx, "sps_pair_seen", sps_pair_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
+                      (const unsigned long long *)ctx->b_labkeys.p, ctx->n_labels, ctx->k,
+                      (const unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), d_n);
+        return SP_OK;
+    }
     SP_LAUNCH(ctx, "sps_count_seen", sps_count_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
               (const unsigned long long *)ctx->d_hkeys, ctx->hcap, d_n);
     return SP_OK;

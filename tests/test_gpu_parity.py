@@ -168,9 +168,13 @@ def test_count_sparse_engine_hot_buckets(gpu_ctx):
     _count_both(gpu_ctx, seqs, k, 3, 0)
 
 
-@pytest.mark.parametrize("k", [17, 21])
-def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k):
-    """k = 17 / 21 (BASELINE config 5): matrix rows and bin counts bit-exact vs the oracle."""
+@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer"])
+@pytest.mark.parametrize("k", [17, 21, 32])
+def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkeypatch):
+    """k = 17 / 21 (BASELINE config 5) and 32: matrix rows and bin counts bit-exact vs the oracle, with the
+    pair-keyed label table (one look-up per pair of starts, <= 7 subgenomes) and with the per-k-mer table."""
+    if map_engine == "per-kmer":
+        monkeypatch.setenv("SP_MAP_ENGINE", "1")
     rng = np.random.RandomState(400 + k)
     reps = [_rand_seq(rng, 350, 0, 0) for _ in range(6)]
     seqs = []
