@@ -245,7 +245,7 @@ def main():
                                "k1_count_atomic", "k1_narrow") if n in prof]
     if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
         COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))
-    FILTER_CHAIN = ["k3_eval", "k3_slow"] if args.k <= 15 else sorted(n for n in prof if n.startswith("sps_") and "hash" not in n)
+    FILTER_CHAIN = ["k3_eval", "k3_slow"] if args.k <= 15 else sorted(n for n in prof if n.startswith("sps_") and "hash" not in n and "pair" not in n)
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
     if dom:
