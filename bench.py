@@ -214,8 +214,9 @@ def main():
     extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
                  sum_dump=int(n_dumped), k=args.k)
     try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_wheat_pmc.json")))["kernels"]
-        if not (args.config == "wheat" and args.k == 15 and world == 1):
+        pmc = "r02_wheat_pmc.json" if args.k == 15 else "r02_wheat_k%d_pmc.json" % args.k      # one table per measured k
+        tj = json.load(open(os.path.join(ROOT, "profiles", pmc)))["kernels"]
+        if not (args.config == "wheat" and world == 1):
             tj = {}
     except (OSError, ValueError, KeyError):
         tj = {}
