@@ -4,6 +4,7 @@
 // (reference: subphaser/Seqs.py:74-153, 209-244): every k-mer START position
 // whose canonical k-mer is subgenome-specific adds 1 to (bin of start, SG).
 #include "sp_device.h"
+#include "sp_map.h"
 
 // ----------------------------------------------------------------- K4
 // Two-level label lookup.  A random 1-byte gather from the 512-MiB label table
@@ -23,33 +24,6 @@
 // MAP_FILL_MAX, at most 2^25 bits (a 2-MiB filter leaves half of the L2 to the
 // genome stream and the table lines; 2^26 bits does not fit and is slower than
 // no growth).
-#ifndef MAP_BLOOM_MAX_BITS
-#define MAP_BLOOM_MAX_BITS 25
-#endif
-#ifndef MAP_BLOOM_MIN_BITS
-#define MAP_BLOOM_MIN_BITS 12
-#endif
-#ifndef MAP_FILL_MAX
-#define MAP_FILL_MAX 0.40
-#endif
-// Blocked Bloom filter: one 32-bit word per key (ONE memory access per probe), three bits in it.
-struct map_bloom_probe {
-    uint32_t word, bits;
-};
-__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t x64, int nbits) {
-    const uint32_t x = (uint32_t)x64 ^ (uint32_t)(x64 >> 32);
-    const uint32_t h = x * 0x9E3779B1u;
-    const uint32_t h2 = x * 0x85EBCA6Bu;
-    map_bloom_probe p;
-    p.word = h >> (32 - (nbits - 5));
-    p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)) | (1u << (h2 >> 27));
-    return p;
-}
-__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, int nbits, uint64_t x) {
-    const map_bloom_probe p = map_bloom(x, nbits);
-    return (bloom[p.word] & p.bits) == p.bits;
-}
-
 // pair filter: prefix and suffix (k-1)-mers of every labelled canonical k-mer
 __global__ void __launch_bounds__(256)
 k4_pair_filter(const unsigned long long *__restrict__ keys, int64_t n, int k, uint32_t *__restrict__ bloom, int nbits) {
@@ -81,25 +55,6 @@ k4_filter_fill(const uint32_t *__restrict__ bloom, int64_t n_words, unsigned lon
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
-// Walk one unit and call hit(start, fwd, rc) for every VALID start whose pair passes the filter.
-template <typename KeyT, typename KP, typename F>
-__device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
-                                              int64_t s0, const KP &kp, const uint32_t *__restrict__ bloom,
-                                              int nbits, F &&hit) {
-    bool pairhit = false;
-    const KeyT m1mask = (KeyT)(kp.kmask >> 2);
-    sp_scan_unit_all<SP_UNIT, KeyT>(pk, nm, s0, kp, [&](int64_t start, KeyT fwd, KeyT rc, bool valid_k, bool valid_k1) {
-        if (!(start & 1)) {   // first of the pair: screen both members through their shared (k-1)-mer
-            pairhit = false;
-            if (valid_k1) {
-                const KeyT mf = fwd & m1mask, mr = rc >> 2;
-                pairhit = map_bloom_test(bloom, nbits, (uint64_t)(mf < mr ? mf : mr));
-            }
-        }
-        if (pairhit && valid_k) hit(start, fwd, rc);
-    });
-}
-
 __global__ void __launch_bounds__(256)
 k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n,
           sp_kparams kp, uint8_t *__restrict__ label) {
@@ -119,36 +74,6 @@ k4_labels(const unsigned long long *__restrict__ keys, const uint8_t *__restrict
 // subgenome-specific k-mer) and a "seen" flag in bit 3.  One gather per candidate PAIR instead of one per
 // candidate start: labelled k-mers come in runs (repeat copies), so almost every candidate pair carries
 // two hits.  4^(k-1) entries (1 GiB at k = 15); S <= 7 (the label-table path below stays for S > 7).
-#define MAP_PAIR_MAX_SG 7
-#ifndef MAP_BATCH
-#define MAP_BATCH 4     // pairs whose probes / gathers are in flight together (16 pairs per 32-start unit)
-#endif
-
-struct map_pair_loc {
-    uint32_t idx;   // canonical (k-1)-mer
-    int field;
-};
-// where the k-mer `o` (any orientation; k >= 1) lives when it is looked up through its prefix / suffix (k-1)-mer
-__host__ __device__ __forceinline__ map_pair_loc map_pair_loc_prefix(uint64_t o, int k) {
-    map_pair_loc r;
-    const uint32_t b = (uint32_t)(o & 3ULL);
-    if (k == 1) { r.idx = 0; r.field = 4 + (int)b; return r; }
-    const uint64_t p = o >> 2, pc = sp_revcomp(p, k - 1);
-    if (p <= pc) { r.idx = (uint32_t)p; r.field = 4 + (int)b; }       // x + b
-    else { r.idx = (uint32_t)pc; r.field = 3 - (int)b; }              // rc: comp(b) + rc(x)
-    return r;
-}
-__host__ __device__ __forceinline__ map_pair_loc map_pair_loc_suffix(uint64_t o, int k) {
-    map_pair_loc r;
-    const uint32_t b = (uint32_t)(o >> (2 * (k - 1))) & 3u;
-    if (k == 1) { r.idx = 0; r.field = (int)b; return r; }
-    const uint64_t m1mask = (1ULL << (2 * (k - 1))) - 1ULL;
-    const uint64_t x = o & m1mask, xc = sp_revcomp(x, k - 1);
-    if (x <= xc) { r.idx = (uint32_t)x; r.field = (int)b; }           // b + x
-    else { r.idx = (uint32_t)xc; r.field = 7 - (int)b; }              // rc: rc(x) + comp(b)
-    return r;
-}
-
 __global__ void __launch_bounds__(256)
 k4_pair_table(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n, int k,
               uint32_t *__restrict__ ptab) {
@@ -250,47 +175,6 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             if (mark) atomicOr(&ptab[canon[q]], mark);         // "seen": first touch only
         }
     }
-}
-
-// ----------------------------------------------------------------- K5
-// One block-iteration covers MAP_UNITS_PER_BLOCK units of 64 starts.  Hits are
-// accumulated in an LDS histogram over the (few) output slots the range
-// touches and flushed with one global atomic per non-zero entry.
-#ifndef MAP_GRID_MULT
-#define MAP_GRID_MULT 16
-#endif
-#ifndef MAP_BLOCK
-#define MAP_BLOCK 768   // measured: 256 -> 70.5 ms, 512 -> 68.3, 768 -> 66.2, 1024 -> 73.8 (640 / 896: 76-79)
-#endif
-#define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // starts per block iteration
-#ifndef MAP_LDS_ENTRIES
-#define MAP_LDS_ENTRIES 4096
-#endif
-
-struct sp_map_params {
-    int64_t n_units;
-    int64_t bin_size;
-    int64_t chunk_size;
-    int64_t nslots;
-    int S;
-    int use_lds;
-};
-
-__device__ __forceinline__ int64_t map_slot(int64_t s, const sp_map_params &P, int k) {
-    int64_t chunk = 0;
-    if (P.chunk_size > 0 && s >= P.chunk_size - (k - 1)) chunk = (s + (k - 1)) / P.chunk_size;
-    return s / P.bin_size + chunk;
-}
-
-// first start after `s` whose output slot differs from map_slot(s) (next bin or next chunk boundary)
-__device__ __forceinline__ int64_t map_slot_end(int64_t s, const sp_map_params &P, int k) {
-    int64_t e = (s / P.bin_size + 1) * P.bin_size;
-    if (P.chunk_size > 0) {
-        const int64_t chunk = (s >= P.chunk_size - (k - 1)) ? (s + (k - 1)) / P.chunk_size : 0;
-        const int64_t c = (chunk + 1) * P.chunk_size - (k - 1);
-        e = c < e ? c : e;
-    }
-    return e;
 }
 
 // K5, pair-table engine (S <= 7): one block-iteration covers MAP_BLOCK units of 64 starts
@@ -436,31 +320,6 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
     }
     const int64_t win = ((seg_start ? seg_start[lo] : 0) + (slot - chunk) * bin_size) / window_size;
     atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
-}
-
-// feature mode: per-feature totals.  The features lie back to back in one packed sequence (no
-// separators): a k-mer belongs to feature f iff it lies entirely inside [foff[f], foff[f+1]).  The
-// feature of a unit's first hit is found by binary search, later hits of the unit walk forward.
-struct map_feat_cursor {
-    int64_t f, next;   // current feature and foff[f + 1]; f < 0: not located yet
-};
-__device__ __forceinline__ bool map_feat_locate(map_feat_cursor &c, int64_t start, int k,
-                                                const int64_t *__restrict__ foff, int64_t n_feat) {
-    if (c.f < 0) {
-        int64_t lo = 0, hi = n_feat;   // last f with foff[f] <= start
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (foff[mid] <= start) lo = mid;
-            else hi = mid;
-        }
-        c.f = lo;
-        c.next = foff[lo + 1];
-    }
-    while (start >= c.next && c.f + 1 < n_feat) {
-        c.f++;
-        c.next = foff[c.f + 1];
-    }
-    return start + k <= c.next;        // false: the k-mer runs into the next feature
 }
 
 __global__ void __launch_bounds__(MAP_BLOCK)

@@ -15,6 +15,8 @@
 #include <rocprim/rocprim.hpp>
 
 #include "sp_device.h"
+#include "sp_filter.h"
+#include "sp_map.h"
 
 #define SPS_SENTINEL (~0ULL)
 #define SPS_MAXC 64
