@@ -35,6 +35,8 @@ extern "C" {
 #define SP_ENODEV (-5)    /* no usable gfx950 device                       */
 #define SP_ESTATE (-6)    /* reference-level precondition (message mirrors
                              the reference's ValueError text)              */
+#define SP_EIO (-7)       /* write() to the caller's descriptor failed
+                             (errno in sp_last_error(NULL))                */
 
 typedef struct sp_ctx sp_ctx;
 
@@ -285,6 +287,26 @@ int sp_text_kmer_matrix(const uint64_t *keys, int k, const double *freqs, int64_
 int sp_text_sig_kmers(const uint64_t *keys, int k, const int32_t *top, const char *names, int n_names,
                       const double *pvals, const double *means, int G, int64_t M, int threads, int fd, int64_t *bytes);
 int sp_text_repr(const double *x, int64_t n, char *out, int64_t *off);
+
+/* Generic tab-separated rows for the feature-scale outputs: `.custom.enrich` / `.ltr.enrich` (Stats.py:59-70) and
+ * the feature-mode `.bin.count` lines (Seqs.py:228-244).  Row i = the columns joined by '\t' + '\n'.
+ *   SP_COL_STR   data = char blob, off[M + 1]: the string of row i is data[off[i] .. off[i + 1])
+ *   SP_COL_I64   data = int64 [M x width], printed in decimal, joined by `join`
+ *   SP_COL_F64   data = double [M x width], printed as Python's repr(), joined by `join`
+ *   SP_COL_NAME  data = int32 [M] indices into `names` (`width` strings; string j = names[off[j] .. off[j + 1])) */
+#define SP_COL_STR 0
+#define SP_COL_I64 1
+#define SP_COL_F64 2
+#define SP_COL_NAME 3
+typedef struct sp_text_col {
+    int kind;
+    int width;
+    char join;
+    const void *data;
+    const int64_t *off;
+    const char *names;
+} sp_text_col;
+int sp_text_table(const sp_text_col *cols, int n_cols, int64_t M, int threads, int fd, int64_t *bytes);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SUBPHASER_HIP_LIB") or os.path.join(_HERE, "lib", "libsubphaser_hip.so")
 
-SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE = 0, -1, -2, -3, -4, -5, -6
+SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE, SP_EIO = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/subphaser_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -28,7 +28,7 @@ SYMBOLS = [
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
     "sp_synth_chrom", "sp_synth_chrom_range", "sp_host_alloc", "sp_host_free", "sp_host_register", "sp_host_unregister", "sp_dev_alloc", "sp_dev_free", "sp_dev_copy_to_host", "sp_dev_copy_from_host",
     "sp_fasta_open", "sp_fasta_counts", "sp_fasta_fetch", "sp_fasta_close",
-    "sp_text_kmer_matrix", "sp_text_sig_kmers", "sp_text_repr",
+    "sp_text_kmer_matrix", "sp_text_sig_kmers", "sp_text_repr", "sp_text_table",
 ]
 
 
@@ -119,6 +119,7 @@ def load():
     L.sp_text_kmer_matrix.argtypes = [vp, ci, vp, i64, ci, ci, ci, P(i64)]
     L.sp_text_sig_kmers.argtypes = [vp, ci, vp, C.c_char_p, ci, vp, vp, ci, i64, ci, ci, P(i64)]
     L.sp_text_repr.argtypes = [vp, i64, vp, vp]
+    L.sp_text_table.argtypes = [vp, ci, i64, ci, ci, P(i64)]
     for name in SYMBOLS:
         if name not in ("sp_last_error", "sp_stream", "sp_fasta_close"):
             getattr(L, name).restype = ci
@@ -179,6 +180,13 @@ def _text_threads():
     return min(64, len(os.sched_getaffinity(0)))
 
 
+def _text_fail(name, rc):
+    msg = load().sp_last_error(None).decode(errors="replace")
+    if rc == SP_ENOMEM:
+        raise MemoryError("%s: %s" % (name, msg or "out of memory"))
+    raise OSError("%s failed (%d): %s" % (name, rc, msg))
+
+
 def text_kmer_matrix(fout, keys, k, freqs):
     """rows of `.kmer.mat` through the library's threaded writer; False when fout has no file descriptor"""
     fd = _fd_of(fout)
@@ -189,7 +197,7 @@ def text_kmer_matrix(fout, keys, k, freqs):
     M, Cn = freqs.shape
     rc = load().sp_text_kmer_matrix(_p(keys), int(k), _p(freqs), M, Cn, _text_threads(), fd, None)
     if rc:
-        raise OSError("sp_text_kmer_matrix failed (%d)" % rc)
+        _text_fail("sp_text_kmer_matrix", rc)
     return True
 
 
@@ -205,7 +213,55 @@ def text_sig_kmers(fout, keys, k, top, names, pvals, means):
     rc = load().sp_text_sig_kmers(_p(keys), int(k), _p(top), blob, len(names), _p(pvals), _p(means), means.shape[1],
                                   len(keys), _text_threads(), fd, None)
     if rc:
-        raise OSError("sp_text_sig_kmers failed (%d)" % rc)
+        _text_fail("sp_text_sig_kmers", rc)
+    return True
+
+
+class _TextCol(C.Structure):
+    _fields_ = [("kind", C.c_int), ("width", C.c_int), ("join", C.c_char), ("data", C.c_void_p),
+                ("off", C.c_void_p), ("names", C.c_void_p)]
+
+
+def str_blob(strings):
+    """list of str -> (uint8 blob, int64 offsets [n + 1]) for a SP_COL_STR / SP_COL_NAME column"""
+    enc = [s.encode() for s in strings]
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum(np.fromiter((len(e) for e in enc), np.int64, len(enc)), out=off[1:])
+    return np.frombuffer(b"".join(enc) or b"\0", np.uint8), off
+
+
+def text_table(fout, n_rows, cols):
+    """Tab-separated rows through the library's threaded writer (sp_text_table).  cols: list of
+    ("str", blob, off) | ("i64", array [n x w], join) | ("f64", array [n x w], join) | ("name", idx int32 [n], names).
+    Returns False when fout has no file descriptor (the caller formats in Python then)."""
+    fd = _fd_of(fout)
+    if fd is None:
+        return False
+    arr = (_TextCol * len(cols))()
+    keep = []
+    for c, col in zip(arr, cols):
+        kind = col[0]
+        if kind == "str":
+            blob, off = np.ascontiguousarray(col[1], np.uint8), np.ascontiguousarray(col[2], np.int64)
+            assert off.size == n_rows + 1
+            c.kind, c.width, c.join, c.data, c.off = 0, 1, b"\t", blob.ctypes.data, off.ctypes.data
+            keep += [blob, off]
+        elif kind in ("i64", "f64"):
+            a = np.ascontiguousarray(col[1], np.int64 if kind == "i64" else np.float64).reshape(n_rows, -1)
+            c.kind, c.width, c.join, c.data = (1 if kind == "i64" else 2), max(1, a.shape[1]), col[2].encode(), a.ctypes.data
+            keep.append(a)
+        elif kind == "name":
+            idx = np.ascontiguousarray(col[1], np.int32)
+            blob, off = str_blob(col[2])
+            assert idx.size == n_rows
+            c.kind, c.width, c.join, c.data, c.off, c.names = 3, len(col[2]), b"\t", idx.ctypes.data, off.ctypes.data, blob.ctypes.data
+            keep += [idx, blob, off]
+        else:
+            raise ValueError(kind)
+    rc = load().sp_text_table(arr, len(cols), int(n_rows), _text_threads(), fd, None)
+    if rc:
+        _text_fail("sp_text_table", rc)
     return True
 
 
@@ -657,6 +713,13 @@ class Context:
         self._staged_rows = self.dev_alloc(counts.nbytes)
         self.host_to_dev(self._staged_rows, counts)
         return (self._staged_rows, counts.shape[0], counts.shape[1])
+
+    def release_rows(self):
+        """free the matrix stage_rows left on the device (the k-mer test was its only reader)"""
+        old = getattr(self, "_staged_rows", None)
+        if old:
+            self.dev_free(old)
+            self._staged_rows = None
 
     # -------------------------------------------------------------- profiling / bench support
     def prof_enable(self, on=True):

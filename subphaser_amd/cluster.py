@@ -129,7 +129,7 @@ class Cluster:
         second-highest-mean subgenome groups of every k-mer; keeps p <= max_pval.
         Returns KmerLabels (array form of the reference's d_ksg dict).
         defer=True: nothing is written; returns (KmerLabels, write) where write(fout) produces the same text later
-        (the CLI runs it in a forked writer while the mapping stage uses the labels)."""
+        (the CLI runs it on a writer thread while the mapping stage uses the labels)."""
         if test_method not in TEST_METHODS:
             raise ValueError("test_method must be one of {}".format(TEST_METHODS))
         from scipy import special
@@ -138,12 +138,20 @@ class Cluster:
         X = self.raw_data
         M = X.shape[0]
         ctx = getattr(self, "_ctx", None)
+        # the kernel keeps a group's values in registers: at most TTEST_MAX_GROUP chromosomes per subgenome
+        # (sp_kmer_ttest returns SP_EUNSUP beyond); scaffold-level runs with larger groups take the numpy code below
         if (test_method == "ttest_ind" and M and ctx is not None and hasattr(ctx, "kmer_ttest")
-                and getattr(self, "_counts", None) is not None and self._lengths is not None):
+                and getattr(self, "_counts", None) is not None and self._lengths is not None
+                and max(len(g) for g in groups) <= TTEST_MAX_GROUP):
             # device path: one thread per k-mer (csrc/sp_enrich.hip k7_ttest); the numpy code below is the same test
             # for matrices that only exist as a `.kmer.mat` file or behind a context without the kernel
             staged = getattr(self, "_counts_dev", None)      # rows already on the device (the CLI stages them early)
-            top, second, pvals, means = ctx.kmer_ttest(staged if staged else self._counts, self._lengths, groups)
+            try:
+                top, second, pvals, means = ctx.kmer_ttest(staged if staged else self._counts, self._lengths, groups)
+            finally:
+                if staged and hasattr(ctx, "release_rows"):     # M x C x 4 bytes of HBM nobody reads again
+                    ctx.release_rows()
+                    self._counts_dev = None
             return self._write_kmers(fout, sgs, top, pvals, means, max_pval, defer)
         means = np.stack([X[:, g].mean(axis=1) for g in groups], axis=1) if M else np.zeros((0, len(sgs)))
         # the reference orders groups by -sum/len (Cluster.py:182); ties keep SG-name order (stable)
@@ -175,7 +183,7 @@ class Cluster:
             print("\t".join(["#kmer", "subgenome", "p_value", "ratios"]), file=fout)
             fout.flush() if hasattr(fout, "flush") else None
             if len(kkeys) and _native.text_sig_kmers(fout, kkeys, k, ktop, sgs, kp, kmeans):
-                return      # formatted by threads of this process (the fork()ed pool below serves non-file objects)
+                return      # formatted by threads of this process (write_chunks below serves non-file objects, in this process)
             write_chunks(fout, len(kkeys), fmt)
 
         canon = kmerlib.canonical(self.keys[keep], self.k)
@@ -187,6 +195,7 @@ class Cluster:
 
 
 TEST_METHODS = ("ttest_ind", "kruskal", "wilcoxon", "mannwhitneyu")
+TTEST_MAX_GROUP = 64     # SP_TT_MAXG in csrc/sp_enrich.hip
 
 
 def _scipy_rows(name, a, b):

@@ -213,7 +213,10 @@ __device__ double d_betacf(double a, double b, double x) {
         d = 1.0 / d;
         const double del = d * c;
         h *= del;
-        if (fabs(del - 1.0) < 1e-16) break;
+        // a few eps: 1e-16 lies below the spacing of doubles around 1 (1.1e-16 / 2.2e-16) and only ever fired on
+        // del == 1.0 exactly -- otherwise every thread ran all 500 iterations.  p-values agree with scipy's
+        // stdtr to a relative 1e-9 (tests/test_gpu_parity.py::test_kmer_ttest_device_vs_scipy), not bit for bit.
+        if (fabs(del - 1.0) < 3e-16) break;
     }
     return h;
 }
@@ -290,12 +293,23 @@ extern "C" int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int
     SP_HIP(ctx, hipSetDevice(ctx->device));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nuc = (size_t)group_off[n_groups];
-    const size_t need = al((size_t)M * C * 4) + al((size_t)C * 8) + al((size_t)(n_groups + 1) * 4) + al(nuc * 4) +
+    // `counts` may be a host or a DEVICE pointer (a caller that staged the rows earlier, Context.stage_rows): rows
+    // that already live on this device are read in place -- no second M x C copy inside the workspace
+    bool on_device = false;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, counts) == hipSuccess)
+            on_device = at.type == hipMemoryTypeDevice && at.device == ctx->device;
+        else
+            (void)hipGetLastError();   // a plain malloc'ed pointer is "invalid value" for this query on some runtimes
+    }
+    const size_t rows_bytes = on_device ? 0 : al((size_t)M * C * 4);
+    const size_t need = rows_bytes + al((size_t)C * 8) + al((size_t)(n_groups + 1) * 4) + al(nuc * 4) +
                         2 * al((size_t)M * 4) + al((size_t)M * 8) + al((size_t)M * n_groups * 8);
     int rc = sp_buf_ensure(ctx, ctx->b_tt, (int64_t)need);
     if (rc) return rc;
     char *q = (char *)ctx->b_tt.p;
-    uint32_t *d_counts = (uint32_t *)q; q += al((size_t)M * C * 4);
+    const uint32_t *d_counts = on_device ? counts : (const uint32_t *)q; q += rows_bytes;
     double *d_len = (double *)q; q += al((size_t)C * 8);
     int *d_goff = (int *)q; q += al((size_t)(n_groups + 1) * 4);
     int *d_gch = (int *)q; q += al(nuc * 4);
@@ -305,12 +319,12 @@ extern "C" int sp_kmer_ttest(sp_ctx *ctx, const uint32_t *counts, int64_t M, int
     double *d_means = (double *)q;
     std::vector<double> hl((size_t)C);
     for (int c = 0; c < C; c++) hl[(size_t)c] = (double)lengths[c];
-    // `counts` may be a host or a DEVICE pointer (a caller that staged the rows earlier): unified addressing decides
-    SP_HIP(ctx, hipMemcpyAsync(d_counts, counts, (size_t)M * C * 4, hipMemcpyDefault, ctx->stream));
+    if (!on_device)
+        SP_HIP(ctx, hipMemcpyAsync((void *)d_counts, counts, (size_t)M * C * 4, hipMemcpyDefault, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_len, hl.data(), (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_goff, group_off, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_gch, group_chrom, nuc * 4, hipMemcpyHostToDevice, ctx->stream));
-    SP_LAUNCH(ctx, "k7_ttest", k7_ttest, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, (const uint32_t *)d_counts,
+    SP_LAUNCH(ctx, "k7_ttest", k7_ttest, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, d_counts,
               (long long)M, C, (const double *)d_len, n_groups, (const int *)d_goff, (const int *)d_gch, d_top, d_sec, d_p,
               d_means);
     SP_HIP(ctx, hipMemcpyAsync(top, d_top, (size_t)M * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -29,6 +29,10 @@ struct sp_fasta {
     int64_t n_bases = 0;
 };
 
+// body(i) for every item on a pool of threads.  A body that throws (std::bad_alloc from a vector that grows) must
+// not escape its std::thread -- that is std::terminate for the whole GPU process -- and the calling thread must not
+// unwind past joinable threads: failures raise a flag, everything is joined, then ONE std::bad_alloc is rethrown
+// on the caller's thread, where sp_fasta_open turns it into SP_ENOMEM.
 template <typename F>
 static void fasta_parallel(int threads, int64_t n_items, F &&body) {
     if (n_items <= 0) return;
@@ -37,18 +41,28 @@ static void fasta_parallel(int threads, int64_t n_items, F &&body) {
         return;
     }
     std::atomic<int64_t> next(0);
-    auto run = [&]() {
-        for (;;) {
-            const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_items) return;
-            body(i);
+    std::atomic<int> failed(0);
+    auto run = [&]() noexcept {
+        try {
+            for (;;) {
+                const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n_items || failed.load(std::memory_order_relaxed)) return;
+                body(i);
+            }
+        } catch (...) {
+            failed.store(1);
         }
     };
     std::vector<std::thread> pool;
     const int nt = (int)(n_items < threads ? n_items : threads);
-    for (int t = 1; t < nt; t++) pool.emplace_back(run);
+    try {
+        pool.reserve((size_t)nt);
+        for (int t = 1; t < nt; t++) pool.emplace_back(run);
+    } catch (...) {   // thread creation failed: the ones that started (and this thread) do the work
+    }
     run();
     for (auto &th : pool) th.join();
+    if (failed.load()) throw std::bad_alloc();
 }
 
 static inline int64_t fasta_count_kept(const uint8_t *p, int64_t n) {
@@ -168,6 +182,7 @@ extern "C" int sp_fasta_fetch(const sp_fasta *h, int64_t *hdr_start, int64_t *hd
     seq_off[R] = run;
     uint8_t *out = (uint8_t *)cat;
     const uint8_t *d = h->data;
+    try {
     fasta_parallel(h->threads, (int64_t)h->item.size() - 1, [&](int64_t b) {
         const int64_t p1 = h->item[(size_t)b + 1];
         for (int64_t i = h->item[(size_t)b]; i < p1; i++) {
@@ -191,6 +206,9 @@ extern "C" int sp_fasta_fetch(const sp_fasta *h, int64_t *hdr_start, int64_t *hd
             }
         }
     });
+    } catch (...) {
+        return SP_ENOMEM;
+    }
     return SP_OK;
 }
 

@@ -13,6 +13,7 @@
 #include "sp_common.h"
 
 #include <atomic>
+#include <cerrno>
 #include <charconv>
 #include <cmath>
 #include <cstring>
@@ -112,38 +113,69 @@ static inline void sp_text_kmer(uint64_t key, int k, char *o) {
     for (int j = 0; j < k; j++) o[j] = "ACGT"[(key >> (2 * (k - 1 - j))) & 3ULL];
 }
 
-// rows [lo, hi) -> buf; chunks are formatted by a pool of threads, waves of chunks are written to fd in order
+// rows [lo, hi) -> buf; chunks are formatted by a pool of threads, waves of chunks are written to fd in order.
+// A worker that fails (std::bad_alloc in a buffer, anything else thrown by the formatter) raises a shared flag and
+// stops; every thread is joined before the wave's verdict is read, so nothing escapes a std::thread (that would be
+// std::terminate for the whole GPU process) and no joinable thread is ever destroyed.  write() is retried on EINTR;
+// any other failure is SP_EIO with errno in sp_last_error (ENOSPC on a 0.5-GB `.kmer.mat` must be readable).
 template <typename F>
 static int sp_text_rows(int64_t M, int threads, int fd, int64_t *bytes, F &&format_rows) {
     const int64_t CH = 8192;
     const int64_t n_ch = (M + CH - 1) / CH;
     const int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
     const int64_t wave = (int64_t)T * 4;
-    std::vector<std::string> bufs((size_t)wave);
+    std::vector<std::string> bufs;
+    try {
+        bufs.resize((size_t)wave);
+    } catch (const std::bad_alloc &) {
+        return SP_ENOMEM;
+    }
     int64_t total = 0;
     for (int64_t c0 = 0; c0 < n_ch; c0 += wave) {
         const int64_t c1 = c0 + wave < n_ch ? c0 + wave : n_ch;
         std::atomic<int64_t> next(c0);
-        auto run = [&]() {
-            for (;;) {
-                const int64_t c = next.fetch_add(1, std::memory_order_relaxed);
-                if (c >= c1) return;
-                std::string &b = bufs[(size_t)(c - c0)];
-                b.clear();
-                format_rows(c * CH, (c + 1) * CH < M ? (c + 1) * CH : M, b);
+        std::atomic<int> failed(0);      // 0 ok, 1 out of memory, 2 other
+        auto run = [&]() noexcept {
+            try {
+                for (;;) {
+                    const int64_t c = next.fetch_add(1, std::memory_order_relaxed);
+                    if (c >= c1 || failed.load(std::memory_order_relaxed)) return;
+                    std::string &b = bufs[(size_t)(c - c0)];
+                    b.clear();
+                    format_rows(c * CH, (c + 1) * CH < M ? (c + 1) * CH : M, b);
+                }
+            } catch (const std::bad_alloc &) {
+                failed.store(1);
+            } catch (...) {
+                failed.store(2);
             }
         };
         std::vector<std::thread> pool;
         const int nt = (int)((c1 - c0) < T ? (c1 - c0) : T);
-        for (int t = 1; t < nt; t++) pool.emplace_back(run);
+        try {
+            pool.reserve((size_t)nt);
+            for (int t = 1; t < nt; t++) pool.emplace_back(run);   // may throw std::system_error: the threads started so far still run
+        } catch (...) {
+        }
         run();
         for (auto &th : pool) th.join();
+        if (failed.load()) {
+            g_sp_err = failed.load() == 1 ? "text writer: out of memory while formatting rows" : "text writer: formatter failed";
+            return failed.load() == 1 ? SP_ENOMEM : SP_EINVAL;
+        }
         for (int64_t c = c0; c < c1; c++) {
             const std::string &b = bufs[(size_t)(c - c0)];
             size_t done = 0;
             while (done < b.size()) {
                 const ssize_t w = write(fd, b.data() + done, b.size() - done);
-                if (w < 0) return SP_EINVAL;
+                if (w < 0) {
+                    if (errno == EINTR) continue;
+                    char msg[160];
+                    snprintf(msg, sizeof msg, "text writer: write(fd %d) failed after %lld bytes: %s (errno %d)", fd,
+                             (long long)(total + (int64_t)done), strerror(errno), errno);
+                    g_sp_err = msg;
+                    return SP_EIO;
+                }
                 done += (size_t)w;
             }
             total += (int64_t)b.size();
@@ -153,11 +185,67 @@ static int sp_text_rows(int64_t M, int threads, int fd, int64_t *bytes, F &&form
     return SP_OK;
 }
 
+// Generic TSV rows for the feature-scale outputs (`.custom.enrich` / `.ltr.enrich`, Stats.py:33-73; the feature-mode
+// `.bin.count`, Seqs.py:228-244): columns are joined by '\t', rows end in '\n'.
+extern "C" int sp_text_table(const sp_text_col *cols, int n_cols, int64_t M, int threads, int fd, int64_t *bytes) {
+    if (M < 0 || n_cols < 1 || !cols) return SP_EINVAL;
+    for (int c = 0; c < n_cols; c++) {
+        const sp_text_col &q = cols[c];
+        if (q.kind < SP_COL_STR || q.kind > SP_COL_NAME || (M > 0 && !q.data)) return SP_EINVAL;
+        if ((q.kind == SP_COL_STR || q.kind == SP_COL_NAME) && !q.off) return SP_EINVAL;
+        if ((q.kind == SP_COL_I64 || q.kind == SP_COL_F64) && q.width < 1) return SP_EINVAL;
+        if (q.kind == SP_COL_NAME) {
+            if (!q.names || q.width < 1) return SP_EINVAL;
+            const int32_t *ix = (const int32_t *)q.data;
+            for (int64_t i = 0; i < M; i++)
+                if (ix[i] < 0 || ix[i] >= q.width) return SP_EINVAL;
+        }
+    }
+    return sp_text_rows(M, threads, fd, bytes, [&](int64_t lo, int64_t hi, std::string &b) {
+        char tmp[48];
+        for (int64_t i = lo; i < hi; i++) {
+            for (int c = 0; c < n_cols; c++) {
+                const sp_text_col &q = cols[c];
+                if (c) b.push_back('\t');
+                switch (q.kind) {
+                case SP_COL_STR: {
+                    const char *s = (const char *)q.data;
+                    b.append(s + q.off[i], (size_t)(q.off[i + 1] - q.off[i]));
+                    break;
+                }
+                case SP_COL_NAME: {
+                    const int32_t j = ((const int32_t *)q.data)[i];
+                    b.append(q.names + q.off[j], (size_t)(q.off[j + 1] - q.off[j]));
+                    break;
+                }
+                case SP_COL_I64: {
+                    const int64_t *row = (const int64_t *)q.data + i * q.width;
+                    for (int j = 0; j < q.width; j++) {
+                        if (j) b.push_back(q.join);
+                        auto r = std::to_chars(tmp, tmp + sizeof tmp, (long long)row[j]);
+                        b.append(tmp, (size_t)(r.ptr - tmp));
+                    }
+                    break;
+                }
+                default: {
+                    const double *row = (const double *)q.data + i * q.width;
+                    for (int j = 0; j < q.width; j++) {
+                        if (j) b.push_back(q.join);
+                        b.append(tmp, (size_t)sp_py_repr(row[j], tmp));
+                    }
+                }
+                }
+            }
+            b.push_back('\n');
+        }
+    });
+}
+
 // rows of `.kmer.mat` (without the header line): kmer \t repr(f[0]) \t ... \t repr(f[C-1]) \n
 extern "C" int sp_text_kmer_matrix(const uint64_t *keys, int k, const double *freqs, int64_t M, int C, int threads,
                                    int fd, int64_t *bytes) {
     if (M < 0 || C < 1 || k < 1 || k > 32 || (M > 0 && (!keys || !freqs))) return SP_EINVAL;
-    try {
+    {
         return sp_text_rows(M, threads, fd, bytes, [&](int64_t lo, int64_t hi, std::string &b) {
             char tmp[48];
             b.reserve((size_t)(hi - lo) * (size_t)(k + 1 + C * 24));
@@ -172,8 +260,6 @@ extern "C" int sp_text_kmer_matrix(const uint64_t *keys, int k, const double *fr
                 b.push_back('\n');
             }
         });
-    } catch (const std::bad_alloc &) {
-        return SP_ENOMEM;
     }
 }
 
@@ -194,7 +280,7 @@ extern "C" int sp_text_sig_kmers(const uint64_t *keys, int k, const int32_t *top
     }
     for (int64_t i = 0; i < M; i++)
         if (top[i] < 0 || top[i] >= n_names) return SP_EINVAL;
-    try {
+    {
         return sp_text_rows(M, threads, fd, bytes, [&](int64_t lo, int64_t hi, std::string &b) {
             char tmp[48];
             b.reserve((size_t)(hi - lo) * (size_t)(k + 40 + G * 24));
@@ -214,7 +300,5 @@ extern "C" int sp_text_sig_kmers(const uint64_t *keys, int k, const int32_t *top
                 b.push_back('\n');
             }
         });
-    } catch (const std::bad_alloc &) {
-        return SP_ENOMEM;
     }
 }

@@ -376,10 +376,17 @@ class DistHotPath:
         except Exception:
             pass
         shm, self._shm, self._shm_addr, self._shm_cap = self._shm, None, 0, 0
+        # unlink first and on its own: close() raises BufferError while a HotPathResult still holds np.frombuffer
+        # views of the segment, and a skipped unlink leaks hundreds of MB of page-locked /dev/shm until exit
+        if self.rank == 0:
+            try:
+                shm.unlink()
+            except Exception:
+                pass
         try:
             shm.close()
-            if self.rank == 0:
-                shm.unlink()
+        except BufferError:
+            pass      # views alive: the mapping goes away with them; the name is already gone
         except Exception:
             pass
 

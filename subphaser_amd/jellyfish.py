@@ -175,7 +175,7 @@ class JellyfishDumps:
         (Jellyfish.py:515-520; read back by Data.py:6-21)."""
         fout.write("\t".join(["kmer"] + list(self.labels)) + "\n")
         keys, freqs, k = d_mat.keys, d_mat.freqs, d_mat.k
-        if len(keys) and _native.text_kmer_matrix(fout, keys, k, freqs):     # threads of this process, no fork
+        if len(keys) and _native.text_kmer_matrix(fout, keys, k, freqs):     # rows formatted by the library's threads
             return
 
         def fmt(lo, hi):

@@ -288,7 +288,7 @@ class Pipeline:
 
     def _write_in_background(self, path, write, big, done=None):
         """write(fout) into `path`: on a thread of this process when the output is large (the library's text writers
-        release the GIL and use their own threads; nothing is forked out of the GPU process), inline otherwise;
+        release the GIL and use their own threads; no child processes: the GPU process stays single), inline otherwise;
         `done` (e.g. the checkpoint) runs on the main thread once the file is complete.  `write` must not import
         anything (see _write_matrix_in_background)."""
         import threading
@@ -318,7 +318,9 @@ class Pipeline:
         self._background.append((path, wait, done))
 
     def _finish_background(self):
-        """Wait for the writers started along the way, then record their checkpoints."""
+        """Wait for the writers started along the way, then record their checkpoints.  A checkpoint describes ITS
+        file only: run() also calls this after a later stage raised, and a `.kmer.mat` that was written completely
+        keeps its checkpoint then (the file is valid; a rerun recomputes whatever depends on the failed stage)."""
         pending, self._background = self._background, []
         err = None
         for name, wait, done in pending:
@@ -436,7 +438,7 @@ class Pipeline:
         if not self.just_core:
             self.stage_windows(lay, chromfiles, labels, d_size, cl, kmer_labels)
             if self.custom_features is not None:
-                self._finish_background()      # the feature writers fork() a formatting pool: no live threads then
+                self._finish_background()      # `.kmer.mat` / sig-k-mer writers done: their threads would compete with the feature writers' 
                 self.stage_features(lay, cl, kmer_labels)
             if not (self.disable_ltr and self.disable_circos):
                 logger.info("Modules 3-4 (LTR, circos) are not part of this build; run the reference on the "

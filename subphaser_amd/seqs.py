@@ -506,8 +506,14 @@ def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bi
                             r_cc.append(counts[i].tolist())
                     collect.append((r_ids, np.asarray(r_st, np.int64),
                                     np.asarray(r_cc, np.int64).reshape(len(r_ids), counts.shape[1])))
-            fout.flush() if hasattr(fout, "flush") else None
-            write_chunks(fout, len(sel), fmt)
+            done = False
+            if not big and sel.size:     # the common case: one line per feature, rows formatted by the library's threads
+                sid = [ids[i] for i in sel.tolist()]
+                blob, boff = _native.str_blob(sid)
+                done = _native.text_table(fout, sel.size, [("str", blob, boff), ("i64", np.zeros(sel.size, np.int64), "\t"),
+                                                           ("i64", ends[sel], "\t"), ("i64", counts[sel], "\t")])
+            if not done:
+                write_chunks(fout, len(sel), fmt)
     logger.info("Processed {} sequences".format(n_seq))
     total = len(labels.keys)
     if n_seq and total:

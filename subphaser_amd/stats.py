@@ -144,54 +144,82 @@ def group_exchanges(lines, d_sg):
 
 
 _FEAT_ID = re.compile(r"(\S+?):\d+\-\d+")
+# one pass of the regex engine over all ids joined by line breaks: group 1 of every line, '' where the id is not
+# chrom:start-end (a per-row .match() is a microsecond of interpreter per feature, seconds at 2 x 10^6 features)
+_FEAT_LINES = re.compile(r"^(?:(\S+?):\d+\-\d+)?.*$", re.M)
+_EXCH = ("none", "no", "yes")
+
+
+def feature_chroms(ids):
+    """chromosome part of every feature id (`ltr.split(':')`-like, Stats.py:42-43), '' where it has none"""
+    if not ids:
+        return []
+    if any("\n" in i for i in ids[:1]):       # ids are FASTA tokens: no blanks; guard the join below anyway
+        return [(_FEAT_ID.match(i).groups()[0] if _FEAT_ID.match(i) else "") for i in ids]
+    got = _FEAT_LINES.findall("\n".join(ids))
+    if len(got) != len(ids):                   # an id containing a line break
+        return [(_FEAT_ID.match(i).groups()[0] if _FEAT_ID.match(i) else "") for i in ids]
+    return got
 
 
 def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval=0.05, ctx=None,
-               **kargs):
+               row_chroms=None, **kargs):
     """Output LTR / custom-feature enrichments (`.ltr.enrich`, `.custom.enrich`; Stats.py:33-73).
-    Array code throughout: feature sets have millions of rows (BASELINE config 5)."""
+    Array code throughout: feature sets have millions of rows (BASELINE config 5); the rows are formatted by the
+    library's threaded writer when fout is a real file.  row_chroms: the chromosome of every row when the caller
+    already has it (BED intervals), else it is parsed from the id (`chrom:start-end`)."""
+    from . import _native
     from .textio import write_chunks
-    arr = np.asarray(matrix, np.int64)
+    arr = np.ascontiguousarray(matrix, np.int64)
     if arr.ndim != 2:
         arr = arr.reshape(len(matrix), -1)
     if colnames is not None and rownames is not None:
         assert arr.shape == (len(rownames), len(colnames)), "{} != {}".format(arr.shape, (len(rownames), len(colnames)))
     assert len(colnames) > 1     # Stats.py:172
+    colnames = list(colnames)
     ctx = ctx or get_context()
     n = arr.shape[0]
     if n:
         pvals, argmin, sig, _ = ctx.enrich(arr, max_pval, min_ratio)
+        argmin = np.asarray(argmin, np.int64)
         pmin = pvals[np.arange(n), argmin]
     else:
         pvals, argmin, sig, pmin = np.zeros((0, arr.shape[1])), np.zeros(0, np.int64), np.zeros(0, bool), np.zeros(0)
     sig = np.asarray(sig, bool)
-    ids = [r[0] for r in rownames]            # `ltr, *_ = res.rowname`
+    ids = [r[0] for r in rownames] if n and not isinstance(rownames[0], str) else list(rownames)   # `ltr, *_ = res.rowname`
     # the reference crashes (AttributeError) on ids that are not chrom:start-end
     # (Stats.py:42-43); the evident intent is "unknown chromosome"
-    cache = {}
-    exch = []
-    for i, ltr in enumerate(ids):
-        m = _FEAT_ID.match(ltr)
-        chrom = m.groups()[0] if m else None
-        obs = cache.get(chrom)
-        if obs is None and chrom not in cache:
-            obs = cache[chrom] = d_sg.get(chrom)
-        exch.append(is_exchange(obs, colnames[argmin[i]] if sig[i] else None))
-    exch_a = np.array(exch, dtype=object)
-    total, exchange, consistent = n, int((exch_a == "yes").sum()), int((exch_a == "no").sum())
+    chroms = list(row_chroms) if row_chroms is not None else feature_chroms(ids)
+    col_of = {name: j for j, name in enumerate(colnames)}
+    obs_of = {}
+    for c in set(chroms):
+        sg = d_sg.get(c) if c else None
+        obs_of[c] = (col_of.get(sg, len(colnames)) if sg else -1)    # -1: unknown chromosome; len: a name outside colnames
+    obs = np.fromiter((obs_of[c] for c in chroms), np.int64, n)
+    exp = np.where(sig, argmin, -1)
+    # is_exchange(obs, exp): "none" when either side is missing, else "no" / "yes"
+    exch_code = np.where((obs < 0) | (exp < 0), 0, np.where(obs == exp, 1, 2)).astype(np.int32)
+    total, exchange, consistent = n, int((exch_code == 2).sum()), int((exch_code == 1).sum())
     if exchange > 0 and consistent > 0:
         logger.info("Consistent with subgenome assignment: {} ({:.2%}); potential exchange: {} ({:.2%})".format(
             consistent, consistent / total, exchange, exchange / total))
     qvals = correct_pvals(pmin)
     fout.write("\t".join(["#id", "subgenome", "p_value", "counts", "potential_exchange", "p_corrected"]) + "\n")
-    sgcol = [colnames[m] if s_ else None for m, s_ in zip(argmin.tolist(), sig.tolist())]
-
-    def fmt(lo, hi):
-        return "".join("%s\t%s\t%s\t%s\t%s\t%s\n" % (ids[i], sgcol[i], repr(float(pmin[i])),
-                                                   ",".join(map(str, arr[i].tolist())), exch[i], repr(float(qvals[i])))
-                       for i in range(lo, hi))
-    fout.flush() if hasattr(fout, "flush") else None
-    write_chunks(fout, n, fmt)
-    d_enriched = {ltr: sg for ltr, sg in zip(ids, sgcol) if sg}
-    d_exchange = dict(zip(ids, exch))
+    sg_idx = np.where(sig, argmin, len(colnames)).astype(np.int32)     # last name: str(None)
+    sg_names = colnames + ["None"]
+    done = False
+    if n:
+        blob, off = _native.str_blob(ids)
+        done = _native.text_table(fout, n, [("str", blob, off), ("name", sg_idx, sg_names), ("f64", pmin, ","),
+                                            ("i64", arr, ","), ("name", exch_code, list(_EXCH)), ("f64", qvals, ",")])
+    if not done:
+        def fmt(lo, hi):
+            return "".join("%s\t%s\t%s\t%s\t%s\t%s\n" % (ids[i], sg_names[sg_idx[i]], repr(float(pmin[i])),
+                                                       ",".join(map(str, arr[i].tolist())), _EXCH[exch_code[i]],
+                                                       repr(float(qvals[i])))
+                           for i in range(lo, hi))
+        write_chunks(fout, n, fmt)
+    hit = np.flatnonzero(sig)
+    d_enriched = {ids[i]: colnames[j] for i, j in zip(hit.tolist(), argmin[hit].tolist())}
+    d_exchange = dict(zip(ids, map(_EXCH.__getitem__, exch_code.tolist())))
     return d_enriched, d_exchange

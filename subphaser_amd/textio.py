@@ -1,35 +1,13 @@
-"""Parallel text formatting for the big output files (`.kmer.mat`, `.sig.kmer-subgenome.tsv`).
+"""Ordered text output for writers whose target is not a real file (StringIO, wrapped stdout).
 
-The reference writes these line by line with str(float) (shortest round-trip repr); at wheat scale
-that is 47 M reprs (15 s single-threaded).  The rows are formatted by a fork()ed worker pool
-(copy-on-write views of the arrays, nothing pickled in), chunk order preserved, bytes identical."""
-import multiprocessing as mp
-import os
-
-_STATE = {}
+Real files go through the library's threaded writers (`_native.text_kmer_matrix`, `text_sig_kmers`, `text_table`:
+rows formatted by threads of this process, `csrc/sp_text.hip`).  What is left is formatted here, chunk by chunk, in
+this process: a process that owns a HIP context must not spawn copy-on-write children (every later pageable host<->device copy of the
+parent paid about a second while such children were alive, and one CLI run in four hung), so there is no
+worker pool -- the rows that reach this function are the small or the non-file cases."""
 
 
-def _work(span):
-    lo, hi = span
-    return _STATE["fn"](lo, hi)
-
-
-def write_chunks(fout, n_rows, format_rows, chunk=50000, workers=None):
+def write_chunks(fout, n_rows, format_rows, chunk=50000):
     """format_rows(lo, hi) -> str for rows [lo, hi); results are written to fout in order."""
-    if n_rows <= 0:
-        return
-    if workers is None:
-        workers = min(32, len(os.sched_getaffinity(0)))
-    spans = [(i, min(i + chunk, n_rows)) for i in range(0, n_rows, chunk)]
-    if workers <= 1 or len(spans) < 4:
-        for lo, hi in spans:
-            fout.write(format_rows(lo, hi))
-        return
-    _STATE["fn"] = format_rows
-    try:
-        ctx = mp.get_context("fork")
-        with ctx.Pool(min(workers, len(spans))) as pool:
-            for text in pool.imap(_work, spans):
-                fout.write(text)
-    finally:
-        _STATE.pop("fn", None)
+    for lo in range(0, max(0, n_rows), chunk):
+        fout.write(format_rows(lo, min(lo + chunk, n_rows)))

@@ -285,3 +285,128 @@ def test_gz_and_bgzf_input(tmp_path):
         assert list(seqs.read_fasta(str(tmp_path / name))) == want
         ids, cat, off = seqs.read_fasta_bulk(str(tmp_path / name))
         assert ids == [i for i, _ in recs] and bytes(cat) == b"".join(s for _, s in want)
+
+
+def test_text_table_and_enrich_ltr_file_vs_stream(tmp_path):
+    """sp_text_table (generic TSV rows, host code of the library) against Python formatting, and stats.enrich_ltr
+    written to a real file (library threads) against the same call on a StringIO (Python formatting): byte-identical.
+    The enrichment itself is stubbed -- this is the writer's test and runs without a GPU."""
+    import io
+    import numpy as np
+    from subphaser_amd import _native, stats
+    rng = np.random.default_rng(5)
+    n = 50021
+    ids = ["chr%d:%d-%d" % (i % 7, i * 10, i * 10 + 9) for i in range(n)]
+    ids[17] = "weird_id_without_coords"
+    ids[18] = "a:b:3-4"
+    ints = rng.integers(-5, 10 ** 12, (n, 3))
+    fl = np.exp(rng.uniform(-300, 300, n))
+    fl[::101] = np.nan
+    idx = rng.integers(0, 3, n).astype(np.int32)
+    blob, off = _native.str_blob(ids)
+    with open(tmp_path / "t.tsv", "w") as f:
+        f.write("#head\n")
+        assert _native.text_table(f, n, [("str", blob, off), ("name", idx, ["x", "", "long name"]), ("f64", fl, ","),
+                                         ("i64", ints, ","), ("i64", ints[:, :1], "\t")])
+    exp = "#head\n" + "".join("%s\t%s\t%s\t%s\t%d\n" % (ids[i], ["x", "", "long name"][idx[i]], repr(float(fl[i])),
+                                                      ",".join(map(str, ints[i].tolist())), ints[i, 0]) for i in range(n))
+    assert open(tmp_path / "t.tsv").read() == exp
+    assert _native.text_table(io.StringIO(), 0, []) is False      # no descriptor: the caller formats
+
+    class _Ctx:
+        def enrich(self, arr, max_pval, min_ratio):
+            r = np.random.default_rng(9)
+            p = r.random(arr.shape) ** 8
+            return p, p.argmin(axis=1), p.min(axis=1) <= max_pval, None
+    counts = rng.integers(0, 500, (n, 3))
+    d_sg = {"chr%d" % i: "SG%d" % (1 + i % 3) for i in range(6)}          # chr6 unknown
+    d_sg["a:b"] = "SGx"                                                  # a subgenome outside colnames
+    rows = [(i,) for i in ids]
+    buf = io.StringIO()
+    e1, x1 = stats.enrich_ltr(buf, d_sg, counts, colnames=["SG1", "SG2", "SG3"], rownames=rows, ctx=_Ctx())
+    with open(tmp_path / "e.tsv", "w") as f:
+        e2, x2 = stats.enrich_ltr(f, d_sg, counts, colnames=["SG1", "SG2", "SG3"], rownames=rows, ctx=_Ctx())
+    text = open(tmp_path / "e.tsv").read()
+    assert text == buf.getvalue() and e1 == e2 and x1 == x2
+    lines = text.splitlines()
+    assert lines[0].split("\t") == ["#id", "subgenome", "p_value", "counts", "potential_exchange", "p_corrected"]
+    assert x1["weird_id_without_coords"] == "none" and len(lines) == n + 1
+    # the row-by-row rule of the reference (Stats.py:42-57, 133-138) on a sample
+    import re
+    p, am, sig, _ = _Ctx().enrich(counts, 0.05, 0.5)
+    for i in list(range(0, 40)) + list(range(n - 40, n)):
+        m = re.compile(r"(\S+?):\d+\-\d+").match(ids[i])
+        obs = d_sg.get(m.groups()[0]) if m else None
+        expc = ["SG1", "SG2", "SG3"][am[i]] if sig[i] else None
+        want = "none" if (not expc or not obs) else ("no" if obs == expc else "yes")
+        col = lines[1 + i].split("\t")
+        assert col[0] == ids[i] and col[1] == str(expc) and col[4] == want, (i, col)
+        assert col[3] == ",".join(map(str, counts[i].tolist())) and col[2] == repr(float(p[i, am[i]]))
+    # an unwritable descriptor surfaces errno, not "failed (-1)"
+    import os
+    import pytest
+    with open(tmp_path / "ro.tsv", "w") as f:
+        pass
+    fd = os.open(tmp_path / "ro.tsv", os.O_RDONLY)
+    try:
+        with pytest.raises(OSError, match="errno"):
+            _native.text_table(os.fdopen(fd, "r", closefd=False), 10, [("i64", np.arange(10), ",")])
+    finally:
+        os.close(fd)
+
+
+def test_output_kmers_group_larger_than_kernel_limit():
+    """A subgenome of more than 64 chromosomes (scaffold-level assemblies): sp_kmer_ttest refuses it (SP_EUNSUP),
+    so Cluster.output_kmers must take the numpy test instead of aborting -- and must still use the device at 64."""
+    import io
+    import numpy as np
+    from scipy import stats as st
+    from subphaser_amd import cluster
+
+    class _Ctx:
+        calls = 0
+
+        def kmer_ttest(self, counts, lengths, groups):
+            _Ctx.calls += 1
+            if max(len(g) for g in groups) > cluster.TTEST_MAX_GROUP:
+                raise RuntimeError("sp_kmer_ttest: a subgenome with 65 chromosomes (1..64 supported)")
+            raise AssertionError("stub: not reached in this test")
+
+    rng = np.random.default_rng(3)
+    for na, expect_device in ((65, False), (64, True)):
+        C, M = na + 5, 200
+
+        class _Mat:
+            pass
+        mat = _Mat()
+        mat.labels = ["c%03d" % i for i in range(C)]
+        mat.k = 15
+        mat.keys = rng.integers(0, 4 ** 15, M, dtype=np.int64).astype(np.uint64)
+        mat.counts = rng.integers(0, 50, (M, C)).astype(np.uint32)
+        mat.counts[:, :na] += rng.integers(0, 30, (M, 1)).astype(np.uint32)
+        mat.lengths = rng.integers(10 ** 6, 10 ** 7, C)
+        mat.freqs = mat.counts / mat.lengths.astype(np.float64)
+        mat.ctx = _Ctx()
+        sg = {c: ("SG1" if i < na else "SG2") for i, c in enumerate(mat.labels)}
+        cl = cluster.Cluster(mat, n_clusters=2, sg_assigned=sg)
+        before = _Ctx.calls
+        buf = io.StringIO()
+        if expect_device:
+            try:
+                cl.output_kmers(buf, max_pval=1.0)
+            except AssertionError:
+                pass
+            assert _Ctx.calls == before + 1
+            continue
+        labels = cl.output_kmers(buf, max_pval=1.0)
+        assert _Ctx.calls == before and len(labels.keys) == M
+        rows = buf.getvalue().strip().split("\n")[1:]
+        assert len(rows) == M
+        for line in rows[:25]:
+            km, sgname, p, ratios = line.split("\t")
+            from subphaser_amd import kmer as kmerlib
+            r = int(np.flatnonzero(mat.keys == kmerlib.encode_many([km])[0])[0])
+            a, b = mat.freqs[r, :na], mat.freqs[r, na:]
+            if b.mean() > a.mean():
+                a, b = b, a
+            assert np.isclose(float(p), st.ttest_ind(a, b)[1], rtol=1e-9, atol=1e-300)
