@@ -66,11 +66,18 @@ int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
 /* ---- k-mer counting (K1 + K2) -------------------------------------------
  * Replaces run_jellyfish_dumps (Jellyfish.py:671-704): for every chromosome,
  * canonical k-mer counts, kept when count >= lower_count (`jellyfish dump -L`).
- * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter. */
+ * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter (byte tables), 3 = the same partition
+ * chain ending in per-chromosome (slot, count) LISTS -- no byte tables; what auto picks for small genomes, where a
+ * chromosome fills less than 1/8 of its dense table (k <= 15 with 2^17..2^31 slots, <= 64 chromosomes, whole-genome
+ * sp_count calls only; sp_table_overflow / sp_filter_view / the table exchange are byte-table interfaces). */
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
 /* same for chromosomes [first, last) only (k <= 15): lets a multi-GPU caller ship the finished
  * table of chromosome i over xGMI while chromosome i+1 is being counted.          */
 int sp_count_range(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last);
+/* Engine 2 sizes its partition buckets from a 1-in-16 sample of the chromosome and counts a chromosome again, with
+ * exact sizes, when a bucket outgrows its region: *recounts = chromosomes counted twice since the context was
+ * created (0 on ordinary genomes; results are identical either way -- this is a performance diagnostic). */
+int sp_count_recounts(sp_ctx *ctx, int64_t *recounts);
 /* number of slots of the dense count table for this k (2^(2k-1) for odd k, 4^k for even k) */
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots);
 /* Count tables (k <= 15) are BYTE tables: one byte per dense slot holding the RAW count, saturated --

@@ -20,7 +20,7 @@ SP_OK, SP_EINVAL, SP_EUNSUP, SP_ENOMEM, SP_EHIP, SP_ENODEV, SP_ESTATE, SP_EIO = 
 SYMBOLS = [
     "sp_version", "sp_last_error", "sp_ctx_create", "sp_ctx_destroy", "sp_sync", "sp_stream",
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
-    "sp_count", "sp_count_range", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
+    "sp_count", "sp_count_range", "sp_count_recounts", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_async", "sp_filter_fetch_wait", "sp_filter_fetch_device", "sp_filter_hist",
     "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_labels_hit",
     "sp_enrich", "sp_enrich_dev", "sp_kmer_ttest",
@@ -67,6 +67,7 @@ def load():
     L.sp_count.argtypes = [vp, ci, ci, ci]
     L.sp_count_range.argtypes = [vp, ci, ci, ci, ci, ci]
     L.sp_nslots.argtypes = [vp, ci, P(i64)]
+    L.sp_count_recounts.argtypes = [vp, P(i64)]
     L.sp_tables_bind.argtypes = [vp, ci, vp]
     L.sp_table_overflow.argtypes = [vp, ci, vp, i64, P(i64)]
     L.sp_table_merge.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i64, vp, i64, P(i64)]
@@ -384,6 +385,12 @@ class Context:
     def count_range(self, k, lower_count, engine, first, last):
         self._ck(self.L.sp_count_range(self.h, int(k), int(lower_count), int(engine), int(first), int(last)))
         self.k = int(k)
+
+    def count_recounts(self):
+        """chromosomes engine 2 counted twice so far (a partition bucket outgrew its sampled region)"""
+        n = C.c_int64()
+        self._ck(self.L.sp_count_recounts(self.h, C.byref(n)))
+        return n.value
 
     def nslots(self, k):
         n = C.c_int64()

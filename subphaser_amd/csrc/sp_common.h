@@ -87,6 +87,7 @@ struct sp_ctx {
     int lower = 0;
     int64_t nslots = 0;   // dense table size
     bool counted = false;
+    int64_t c2_recounts = 0;   // chromosomes engine 2 had to count twice (a bucket outgrew its sampled region)
     // filter view: which tables / slot range sp_filter works on (default: the local chromosomes,
     // all slots).  Multi-GPU runs point it at slot-range slices gathered from every rank.
     bool fv_on = false;
@@ -125,6 +126,8 @@ struct sp_ctx {
     sp_buf b_tab32, b_ovfw;      // engine 1: u32 scratch table; overflow staging (unordered pairs + per-bucket index)
     // sparse engine (k = 16..32)
     bool sparse_mode = false;
+    bool list_mode = false;     // k <= 15, engine 3: per-chromosome sorted (SLOT, count) lists in `sparse`, no byte tables;
+                                // the map stage stays the dense pair-table one
     std::vector<sp_sparse_chrom> sparse;
     sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist, b_s3_small, b_slots;
     int64_t sf_n = 0;
@@ -134,7 +137,7 @@ struct sp_ctx {
     sp_buf b_wtab, b_enr;   // window table (device) and the enrichment outputs
     sp_buf b_fq;      // global slow queue of the filter
     sp_buf b_fflat;   // flat set tables of the filter (sp_filter.hip)
-    sp_buf b_map, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
+    sp_buf b_map, b_mapdesc, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
     bool map_all_valid = false;
     // profiling
     bool prof = false;

@@ -90,46 +90,83 @@ k1_narrow(const uint32_t *__restrict__ tab32, int64_t nslots, uint32_t lower, ui
 // exclusive scan of the per-bucket overflow counts (n <= 2^16 buckets; single block)
 __global__ void __launch_bounds__(1024)
 ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t wsum[16];
     const int64_t per = (n + 1023) / 1024;
     int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
     if (lo > n) lo = n;
     if (hi > n) hi = n;
     uint32_t s = 0;
     for (int64_t i = lo; i < hi; i++) s += seg_cnt[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < 1024; i++) {
-            const uint32_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        seg_off[n] = run;
-    }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
+    uint32_t total;
+    uint32_t run = sp_block_excl_scan(s, wsum, total);
+    if (threadIdx.x == 0) seg_off[n] = total;
     for (int64_t i = lo; i < hi; i++) {
         seg_off[i] = run;
         run += seg_cnt[i];
     }
 }
-// one wave per bucket: its (few) pairs are ranked by slot and written to their final place
+// one wave per bucket: its pairs are ranked by slot and written to their final place.  A few pairs (the usual
+// overflow case: ~9 per bucket) are ranked by brute force; a bucket with many (engine 3 stages EVERY kept slot) marks
+// its slots in a 2^15-bit LDS bitmap and ranks by prefix popcount -- O(m + 1024) instead of O(m^2).
+// SPLIT: the pairs go to separate (u64 slot, u32 count) arrays, the form the list engines work on.
+#define OVF_BRUTE 96
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 ovf_place(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
-          const uint32_t *__restrict__ seg_off, int64_t n_buckets, uint2 *__restrict__ out) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+          const uint32_t *__restrict__ seg_off, int64_t n_buckets, uint2 *__restrict__ out,
+          unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_cnts) {
+    __shared__ uint32_t bits[4][1 << (SP_OVF_SHIFT - 5)], pre[4][1 << (SP_OVF_SHIFT - 5)];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + w;
     if (b >= n_buckets) return;
     const uint32_t m = seg_cnt[b];
     if (!m) return;
     const uint2 *src = tmp + seg_base[b];
-    uint2 *dst = out + seg_off[b];
-    for (uint32_t j = threadIdx.x & 63; j < m; j += 64) {
+    const size_t dst0 = seg_off[b];
+    auto put = [&](uint32_t rank, uint2 e) {
+        if (SPLIT) {
+            out_keys[dst0 + rank] = e.x;
+            out_cnts[dst0 + rank] = e.y;
+        } else {
+            out[dst0 + rank] = e;
+        }
+    };
+    if (m <= OVF_BRUTE) {
+        for (uint32_t j = lane; j < m; j += 64) {
+            const uint2 e = src[j];
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < m; i++) rank += src[i].x < e.x;
+            put(rank, e);
+        }
+        return;
+    }
+    constexpr int NW = 1 << (SP_OVF_SHIFT - 5);     // 1024 words
+    for (int i = lane; i < NW; i += 64) bits[w][i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < m; j += 64) {
+        const uint32_t r = src[j].x & ((1u << SP_OVF_SHIFT) - 1u);
+        atomicOr(&bits[w][r >> 5], 1u << (r & 31u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // exclusive prefix popcount over the words: lane l owns words [16 l, 16 l + 16)
+    uint32_t mine = 0;
+    for (int i = 0; i < NW / 64; i++) mine += __popc(bits[w][lane * (NW / 64) + i]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t nb = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nb;
+    }
+    uint32_t run = incl - mine;
+    for (int i = 0; i < NW / 64; i++) {
+        pre[w][lane * (NW / 64) + i] = run;
+        run += __popc(bits[w][lane * (NW / 64) + i]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < m; j += 64) {
         const uint2 e = src[j];
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < m; i++) rank += src[i].x < e.x;
-        dst[rank] = e;
+        const uint32_t r = e.x & ((1u << SP_OVF_SHIFT) - 1u);
+        put(pre[w][r >> 5] + __popc(bits[w][r >> 5] & ((1u << (r & 31u)) - 1u)), e);
     }
 }
 
@@ -211,7 +248,8 @@ static int grid_for(sp_ctx *ctx, int64_t work_items, int per_block, int max_per_
 }
 
 int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower,
-                     unsigned long long *d_len2);  // sp_count2.hip
+                     unsigned long long *d_len4, bool exact, sp_sparse_chrom *list);  // sp_count2.hip
+void sp_sparse_release(sp_ctx *ctx);                                                  // sp_sparse.hip
 bool sp_engine2_supported(int64_t nslots);
 int sp_sparse_count(sp_ctx *ctx, int k, int lower);                                   // sp_sparse.hip
 int sp_sparse_count3(sp_ctx *ctx, int k, int lower);                                  // sp_sparse2.hip
@@ -290,13 +328,20 @@ kx_lengths(sp_tabref T, int64_t slot_base, int64_t n, uint32_t lower, unsigned l
 static int ovf_finalize_to(sp_ctx *ctx, uint2 *out, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
                            uint32_t *seg_off, int64_t n_buckets) {
     SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
-    SP_LAUNCH(ctx, "ovf_place", ovf_place, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base, seg_cnt,
-              (const uint32_t *)seg_off, n_buckets, out);
+    SP_LAUNCH(ctx, "ovf_place", ovf_place<false>, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base, seg_cnt,
+              (const uint32_t *)seg_off, n_buckets, out, (unsigned long long *)nullptr, (uint32_t *)nullptr);
     return SP_OK;
 }
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
                     uint32_t *seg_off, int64_t n_buckets) {
     return ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets);
+}
+int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
+                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets) {
+    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
+    SP_LAUNCH(ctx, "ovf_place_list", ovf_place<true>, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base,
+              seg_cnt, (const uint32_t *)seg_off, n_buckets, (uint2 *)nullptr, keys, cnts);
+    return SP_OK;
 }
 
 extern "C" {
@@ -325,6 +370,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         ctx->lower = lower_count;
         ctx->nslots = 0;
         ctx->sparse_mode = true;
+        ctx->list_mode = false;
         int rcs = (engine == 1) ? sp_sparse_count(ctx, k, lower_count) : sp_sparse_count3(ctx, k, lower_count);
         if (rcs) return rcs;
         ctx->counted = true;
@@ -333,6 +379,30 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     ctx->sparse_mode = false;
     const sp_kparams kp = sp_make_kparams(k);
     const int64_t nslots = sp_dense_slots(k);
+    // Engine choice by table occupancy.  A chromosome fills at most len / nslots of its dense table; below 1/8 (the
+    // Arabidopsis-like 20-Mb chromosomes at k = 15: 4 %) writing 512 MiB per chromosome and streaming all of them
+    // through the filter is most of the pass, so the counts are kept as LISTS of (slot, count >= lower) pairs in
+    // ascending slot order instead (engine 3: the same partition chain, c2_count<LIST>), joined by the list filter.
+    // Whole-genome calls on library-owned tables only (the multi-GPU table exchange needs the byte tables).
+    bool list_mode = false;
+    {
+        const char *env3 = getenv("SP_LIST_ENGINE");      // "0": never, "1": whenever possible (tests)
+        bool whole = first == 0 && last == (int)ctx->chroms.size();
+        bool possible = whole && sp_engine2_supported(nslots) && ctx->chroms.size() <= 64;
+        int64_t longest = 0;
+        for (auto &c : ctx->chroms) {
+            possible = possible && !c.tab_external;
+            longest = c.len > longest ? c.len : longest;
+        }
+        if (engine == 3) {
+            if (!possible)
+                return sp_fail(ctx, SP_EUNSUP, "count engine 3 (lists) needs k with 2^17..2^31 dense slots, a whole-genome call, "
+                                               "library-owned tables and at most 64 chromosomes");
+            list_mode = true;
+        } else if (engine == 0 && possible) {
+            list_mode = (env3 && env3[0] == '1') || (!(env3 && env3[0] == '0') && longest > 0 && longest * 8 < nslots);
+        }
+    }
     // a new k invalidates old tables
     if (ctx->k != k || ctx->nslots != nslots) {
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -352,15 +422,47 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     ctx->nslots = nslots;
     ctx->counted = false;
     ctx->filtered = false;
+    ctx->list_mode = list_mode;
     const size_t C = ctx->chroms.size();
+    if (list_mode && ctx->sparse.size() != C) {
+        sp_sparse_release(ctx);
+        ctx->sparse.assign(C, sp_sparse_chrom());
+    }
     void *scr = nullptr;
-    int rc = sp_scratch(ctx, (int64_t)(3 * C * sizeof(unsigned long long)), &scr);
+    int rc = sp_scratch(ctx, (int64_t)(4 * C * sizeof(unsigned long long)), &scr);
     if (rc) return rc;
-    unsigned long long *d_len = (unsigned long long *)scr;   // per chromosome: sum, n (counts >= lower), overflow pairs
-    SP_HIP(ctx, hipMemsetAsync(d_len, 0, 3 * C * sizeof(unsigned long long), ctx->stream));
+    // per chromosome: sum, n (counts >= lower), overflow pairs, engine 2's region-overrun flag
+    unsigned long long *d_len = (unsigned long long *)scr;
+    SP_HIP(ctx, hipMemsetAsync(d_len, 0, 4 * C * sizeof(unsigned long long), ctx->stream));
+    const char *env_exact = getenv("SP_C2_EXACT");      // "1": size the buckets from the full histogram (round-2 path)
+    const bool sized_by_sample = !(env_exact && env_exact[0] == '1');
+    std::vector<char> by_engine2(C, 0);
     for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
         sp_chrom &c = ctx->chroms[ci];
         if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
+        if (list_mode) {
+            sp_sparse_chrom &o = ctx->sparse[ci];
+            o.n = 0;
+            o.length_sum = 0;
+            // every kept slot accounts for >= lower k-mer occurrences (and there are at most nslots of them)
+            int64_t need = c.len / lower_count + 16;
+            if (need > nslots) need = nslots;
+            if (need > o.cap) {
+                SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (o.d_keys) hipFree(o.d_keys);
+                if (o.d_cnts) hipFree(o.d_cnts);
+                o.d_keys = nullptr;
+                o.d_cnts = nullptr;
+                o.cap = 0;
+                SP_HIP(ctx, hipMalloc(&o.d_keys, (size_t)(need + 1) * 8));
+                SP_HIP(ctx, hipMalloc(&o.d_cnts, (size_t)(need + 1) * 4));
+                o.cap = need;
+            }
+            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, &o);
+            if (rc) return rc;
+            by_engine2[ci] = 1;
+            continue;
+        }
         if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots));
         // every overflow pair accounts for >= 255 k-mer occurrences
         const int64_t need_ovf = c.len / 255 + 16;
@@ -376,8 +478,9 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         int eng = engine;
         if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
         if (eng == 2) {
-            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 3 * ci);
+            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, nullptr);
             if (rc) return rc;
+            by_engine2[ci] = 1;
             continue;
         }
         // engine 1: global atomics into a u32 scratch table, then one pass to the byte table
@@ -398,19 +501,48 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         }
         int grid2 = (int)(n_buckets < (int64_t)ctx->n_cu * 8 ? n_buckets : (int64_t)ctx->n_cu * 8);
         SP_LAUNCH(ctx, "k1_narrow", k1_narrow, dim3(grid2), dim3(256), 0, (const uint32_t *)tab32, nslots,
-                  (uint32_t)lower_count, c.d_tab, d_len + 3 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
+                  (uint32_t)lower_count, c.d_tab, d_len + 4 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
                   n_buckets);
         rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets);
         if (rc) return rc;
     }
-    std::vector<unsigned long long> h(3 * C);
-    SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 3 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    std::vector<unsigned long long> h(4 * C);
+    SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 4 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // engine 2 laid its bucket regions out from a sample: a chromosome whose flag is up had a bucket outgrow its
+    // region (keys were dropped) and is counted again with regions from the exact histogram
+    int redone = 0;
     for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
-        ctx->chroms[ci].length_sum = (int64_t)h[3 * ci];
-        ctx->chroms[ci].n_dump = (int64_t)h[3 * ci + 1];
-        ctx->chroms[ci].n_ovf = (int64_t)h[3 * ci + 2];
+        if (!by_engine2[ci] || !sized_by_sample || h[4 * ci + 3] == 0) continue;
+        SP_HIP(ctx, hipMemsetAsync(d_len + 4 * ci, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        rc = sp_count_engine2(ctx, ctx->chroms[ci], kp, lower_count, d_len + 4 * ci, true,
+                              list_mode ? &ctx->sparse[ci] : nullptr);
+        if (rc) return rc;
+        redone++;
+    }
+    if (redone) {
+        if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] engine 2: %d chromosome(s) recounted with exact bucket sizes\n", redone);
+        SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 4 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->c2_recounts += redone;
+    for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
+        if (by_engine2[ci] && h[4 * ci + 3] != 0)
+            return sp_fail(ctx, SP_ESTATE, "count engine 2: chromosome %zu overran its bucket regions with exact sizes", ci);
+        ctx->chroms[ci].length_sum = (int64_t)h[4 * ci];
+        ctx->chroms[ci].n_dump = (int64_t)h[4 * ci + 1];
+        ctx->chroms[ci].n_ovf = (int64_t)h[4 * ci + 2];
+        if (list_mode) {     // the pairs ARE the dump: n_ovf of them, in ctx->sparse[ci]
+            sp_sparse_chrom &o = ctx->sparse[ci];
+            if (ctx->chroms[ci].n_ovf > o.cap || ctx->chroms[ci].n_ovf != ctx->chroms[ci].n_dump)
+                return sp_fail(ctx, SP_ESTATE, "count engine 3: chromosome %zu kept %lld pairs for %lld dump k-mers (capacity %lld)",
+                               ci, (long long)ctx->chroms[ci].n_ovf, (long long)ctx->chroms[ci].n_dump, (long long)o.cap);
+            o.n = ctx->chroms[ci].n_ovf;
+            o.length_sum = ctx->chroms[ci].length_sum;
+            ctx->chroms[ci].n_ovf = 0;
+            continue;
+        }
         if (ctx->chroms[ci].n_ovf > ctx->chroms[ci].cap_ovf)
             return sp_fail(ctx, SP_ESTATE, "overflow list of chromosome %zu: %lld pairs exceed the capacity %lld", ci,
                            (long long)ctx->chroms[ci].n_ovf, (long long)ctx->chroms[ci].cap_ovf);
@@ -425,6 +557,12 @@ int sp_count(sp_ctx *ctx, int k, int lower_count, int engine) {
 
 int sp_count_range(sp_ctx *ctx, int k, int lower_count, int engine, int first, int last) {
     return count_impl(ctx, k, lower_count, engine, first, last);
+}
+
+int sp_count_recounts(sp_ctx *ctx, int64_t *recounts) {
+    if (!ctx || !recounts) return sp_fail(ctx, SP_EINVAL, "sp_count_recounts: bad arguments");
+    *recounts = ctx->c2_recounts;
+    return SP_OK;
 }
 
 int sp_nslots(sp_ctx *ctx, int k, int64_t *nslots) {
@@ -452,7 +590,8 @@ int sp_tables_bind(sp_ctx *ctx, int chrom, void *d_table) {
 int sp_table_overflow(sp_ctx *ctx, int chrom, void *d_pairs, int64_t cap, int64_t *n_pairs) {
     if (!ctx || !n_pairs || cap < 0 || chrom < 0 || chrom >= (int)ctx->chroms.size())
         return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: bad arguments");
-    if (ctx->sparse_mode || !ctx->counted) return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: call sp_count (k <= 15) first");
+    if (ctx->sparse_mode || ctx->list_mode || !ctx->counted)
+        return sp_fail(ctx, SP_EINVAL, "sp_table_overflow: call sp_count (k <= 15, byte-table engines 1 / 2) first");
     sp_chrom &c = ctx->chroms[(size_t)chrom];
     *n_pairs = c.n_ovf;
     if (!d_pairs) return SP_OK;   // size query
@@ -545,7 +684,7 @@ int sp_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts, int64_t ca
     if (cap < c.n_dump) return sp_fail(ctx, SP_EINVAL, "sp_dump: capacity %lld < %lld", (long long)cap,
                                        (long long)c.n_dump);
     if (c.n_dump == 0) return SP_OK;
-    if (ctx->sparse_mode) return sp_sparse_dump(ctx, chrom, keys, counts);
+    if (ctx->sparse_mode || ctx->list_mode) return sp_sparse_dump(ctx, chrom, keys, counts);
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t nblk = (ctx->nslots + DUMP_SLOTS - 1) / DUMP_SLOTS;
     sp_tmp<unsigned long long> d_blk, d_keys;

@@ -4,8 +4,12 @@
 // MI355X (profiles/r01_ubench_mi355x.txt), LDS atomics at ~600 G/s.  This engine
 // turns the random updates into streaming traffic:
 //
-//   c2_hist_fine  scan the packed chromosome, histogram the top B1+B2 slot bits
-//             (LDS histogram per block, one global atomic per non-empty bin)
+//   c2_hist_fine  histogram of the top B1+B2 slot bits (LDS histogram per block, one global atomic per
+//             non-empty bin).  Round 3: it scans ONE STRIPE IN 16 of the chromosome and the bucket regions are
+//             laid out from the estimate with slack (memory is plentiful: 288 GB); the exact sizes are what the
+//             cursors of part1 / part2 hold afterwards.  A bucket that outgrows its region raises a flag and the
+//             chromosome is counted again with the exact histogram (the round-2 path), so results never depend on
+//             the estimate.  (The whole-genome scan this replaces was 6.3 of 136 ms per wheat-like pass.)
 //   c2_part1  scan again; LDS counting sort of a 16K-key tile on the top B1
 //             bits; each bucket run is written as one coalesced burst (3 bytes per key:
 //             a u16 plane and a u8 plane)
@@ -39,6 +43,7 @@
 #define C2_TILE_KEYS (C2_P2_THREADS * C2_P2_PER)  // keys per part2 tile
 #define C2_HIST_THREADS 512
 #define C2_MAXF 256                   // max fan-out per level
+#define C2_DROP (~0ULL)               // delta / gbase of a run that does not fit its region (estimate mode)
 
 struct c2_plan {
     int T;        // log2(nslots)
@@ -64,17 +69,27 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
 }
 
 // ---------------------------------------------------------------- c2_hist_fine
-// One scan of the chromosome for the fine histogram (top B1+B2 slot bits): it sizes every level-1 and fine bucket
-// exactly.  (Until late in round 2 this kernel also counted every part1 tile's level-1 buckets -- a second, heavily
-// contended LDS atomic per key -- so that part1 needed no cursors; part1 now counts its own tile.)
+// Fine histogram (top B1+B2 slot bits) over the units of 32 starts, all of them (sample_shift = 0: exact bucket
+// sizes) or one stripe of C2_STRIPE units in every 2^sample_shift stripes (an estimate).  The sampled stripe of a
+// group rotates with the group index so that no period of the sequence can hide from the sample.
+#define C2_STRIPE 64                  // units per stripe: 2048 starts = 512 B of each packed stream, one wave
+#define C2_SAMPLE_SHIFT 4             // one stripe in 16
+__device__ __forceinline__ int64_t c2_sample_unit(int64_t j, int sample_shift) {
+    if (sample_shift == 0) return j;
+    const int64_t g = j / C2_STRIPE;                      // sampled stripe number = stripe group
+    const int64_t phase = (g * 7 + (g >> 4)) & ((1 << sample_shift) - 1);
+    return ((g << sample_shift) + phase) * C2_STRIPE + (j % C2_STRIPE);
+}
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-             int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift_fine, int n_fine,
-             unsigned long long *__restrict__ ghist) {
+             int64_t n_units /* of 32 starts */, int64_t n_visit, int sample_shift, sp_kparams32 kp, int shift_fine,
+             int n_fine, unsigned long long *__restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
     for (int i = threadIdx.x; i < n_fine; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_visit; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = c2_sample_unit(j, sample_shift);
+        if (u >= n_units) continue;
         auto scan = [&](auto parity) {
             sp_scan32_slots<decltype(parity)::value>(pk, pm, nm, u * C2_P1_UNIT, kp,
                                                      [&](uint32_t slot) { atomicAdd(&lh[slot >> shift_fine], 1u); });
@@ -89,60 +104,93 @@ c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
     }
 }
 
-// exclusive scan of the fine histogram (n_fine <= 65536) -> off_fine[n_fine+1];
-// also level-1 bucket offsets off1[F1+1] = off_fine[b*F2] and tile starts for part2
+// Region layout from the fine histogram (n_fine <= 65536): cap(f) = ghist[f] (exact mode: mult = 1, slack = 0) or
+// ghist[f] * mult / 8 + slack rounded up to a multiple of 4 (estimate mode).  off_fine[n_fine + 1] = exclusive
+// scan of the capacities = where every fine bucket's residuals start in buf2; off1[b] = where level-1 bucket b
+// starts in the level-1 planes (sum of its fine capacities, rounded up to a multiple of 4 keys so that part2 can
+// read runs with 8- and 4-byte loads).  Sizes and tile starts come later, from part1's cursors (c2_tiles).
 __global__ void __launch_bounds__(1024)
-c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2,
-           unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1 /*2*(F1+1): starts, ends*/,
-           unsigned long long *__restrict__ tile_start /*F1+1*/) {
-    __shared__ unsigned long long part[1024];
+c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2, unsigned long long mult8,
+           unsigned long long mult8_1, unsigned long long slack, unsigned long long slack1, unsigned long long *__restrict__ off_fine,
+           unsigned long long *__restrict__ off1 /* F1 + 1 starts */) {
+    __shared__ unsigned long long wsum[16];
     const int T = 1024;
     int per = (n_fine + T - 1) / T;
     int lo = threadIdx.x * per, hi = lo + per;
+    if (lo > n_fine) lo = n_fine;
     if (hi > n_fine) hi = n_fine;
-    unsigned long long s = 0;
-    for (int i = lo; i < hi; i++) s += ghist[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < T; i++) {
-            unsigned long long v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        off_fine[n_fine] = run;
+    auto cap = [&](int i) -> unsigned long long {
+        const unsigned long long h = ghist[i];
+        if (!slack && mult8 == 8ULL) return h;
+        return ((h * mult8 + 7ULL) / 8ULL + slack + 3ULL) & ~3ULL;
+    };
+    unsigned long long s = 0, raw = 0;
+    for (int i = lo; i < hi; i++) {
+        s += cap(i);
+        raw += ghist[i];
     }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
+    unsigned long long total, total_raw;
+    unsigned long long run = sp_block_excl_scan(s, wsum, total);
+    const unsigned long long raw0 = sp_block_excl_scan(raw, wsum, total_raw);
+    // level-1 bucket boundaries are thread boundaries (F2 and the per-thread count are powers of two, F2 the larger)
+    __shared__ unsigned long long cap_at[C2_MAXF + 1], raw_at[C2_MAXF + 1];
+    if (lo < n_fine && lo % F2 == 0) {
+        cap_at[lo / F2] = run;
+        raw_at[lo / F2] = raw0;
+    }
+    if (threadIdx.x == 0) {
+        off_fine[n_fine] = total;
+        cap_at[F1] = total;
+        raw_at[F1] = total_raw;
+    }
     for (int i = lo; i < hi; i++) {
         off_fine[i] = run;
-        run += ghist[i];
+        run += cap(i);
     }
-    __threadfence_block();
     __syncthreads();
-    // level-1 offsets and tile starts: one thread per bucket, then a short serial prefix over <= 256 counts in LDS
-    // (level-1 runs start at multiples of 4 keys so that part2 can read them with 8- and 4-byte loads)
-    __shared__ unsigned long long tcount[C2_MAXF], bsize[C2_MAXF];
+    // level-1 regions: a level-1 bucket is the union of F2 fine buckets and its relative sampling error is that much
+    // smaller, so it gets its own, tighter, bound (estimate x 33/32 + slack1) instead of the sum of the fine regions
+    // (the span of the level-1 planes is what part1's scattered bursts pay for: 22.7 -> 23.6 ms at 2.4x)
+    __shared__ unsigned long long bcap[C2_MAXF];
     if (threadIdx.x < F1) {
         const int b = threadIdx.x;
-        const unsigned long long o = off_fine[(size_t)b * F2], e = off_fine[(size_t)(b + 1) * F2];
-        bsize[b] = e - o;
-        tcount[b] = (e - o + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+        const unsigned long long h = raw_at[b + 1] - raw_at[b], sum_fine = cap_at[b + 1] - cap_at[b];
+        bcap[b] = (!slack && mult8 == 8ULL) ? h : (h * mult8_1 + 7ULL) / 8ULL + slack1;
+        if (bcap[b] > sum_fine) bcap[b] = sum_fine;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tiles = 0, o = 0;
-        for (int b = 0; b < F1; b++) {
-            tile_start[b] = tiles;
-            tiles += tcount[b];
-            off1[b] = o;
-            off1[F1 + 1 + b] = o + bsize[b];
-            o += (bsize[b] + 3ULL) & ~3ULL;
-        }
-        off1[F1] = o;
-        tile_start[F1] = tiles;
+    {
+        const unsigned long long mine = threadIdx.x < F1 ? (bcap[threadIdx.x] + 3ULL) & ~3ULL : 0ULL;
+        unsigned long long tot1;
+        const unsigned long long o = sp_block_excl_scan(mine, wsum, tot1);
+        if (threadIdx.x < F1) off1[threadIdx.x] = o;
+        if (threadIdx.x == 0) off1[F1] = tot1;
     }
+}
+
+// After part1: the exact level-1 bucket sizes are its cursors.  off1[F1 + 1 + b] = end of the keys of bucket b,
+// tile_start[] = first part2 tile of every bucket.  A bucket that outgrew its region (estimate mode only) had its
+// surplus runs dropped by part1: the flag makes the host count the chromosome again with exact sizes.
+__global__ void __launch_bounds__(C2_MAXF)
+c2_tiles(const unsigned long long *__restrict__ cursor1, int F1, unsigned long long *__restrict__ off1,
+         unsigned long long *__restrict__ tile_start /* F1 + 1 */, unsigned long long *__restrict__ flag) {
+    __shared__ unsigned long long tcount[C2_MAXF];
+    const int b = threadIdx.x;
+    if (b < F1) {
+        unsigned long long n = cursor1[b];
+        const unsigned long long cap = off1[b + 1] - off1[b];
+        if (n > cap) {
+            n = cap;
+            atomicAdd(flag, 1ULL);
+        }
+        off1[F1 + 1 + b] = off1[b] + n;
+        tcount[b] = (n + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+    }
+    __shared__ unsigned long long wsum[16];
+    unsigned long long tot;
+    const unsigned long long t0 = sp_block_excl_scan(b < F1 ? tcount[b] : 0ULL, wsum, tot);
+    if (b < F1) tile_start[b] = t0;
+    if (b == 0) tile_start[F1] = tot;
 }
 
 // block-wide exclusive scan of hist[0..F) (F <= 256 <= blockDim) -> start[]; returns total
@@ -202,19 +250,26 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         }
         __syncthreads();
         unsigned long long g = 0;
+        bool fits = true;
         if (threadIdx.x < F1) {
             const uint32_t c = hist[threadIdx.x];
-            g = off1[threadIdx.x] + (c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL);
+            const unsigned long long at = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL;
+            g = off1[threadIdx.x] + at;
+            // estimate mode: a run that does not fit its bucket's region is dropped (c2_tiles sees the cursor and
+            // raises the flag; the chromosome is then counted again from the exact histogram)
+            fits = at + c <= off1[threadIdx.x + 1] - off1[threadIdx.x];
         }
         const uint32_t total = c2_scan_F(hist, start, F1, wsum);
-        if (threadIdx.x < F1) delta[threadIdx.x] = g - start[threadIdx.x];
+        if (threadIdx.x < F1) delta[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;
 #pragma unroll
         for (int j = 0; j < 32; j++)
             if ((ok >> j) & 1u) keys[start[slot[j] >> shift1] + rank[j]] = slot[j];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
             const uint32_t s = keys[i];
-            const unsigned long long o = delta[s >> shift1] + i;
+            const unsigned long long d = delta[s >> shift1];
+            if (d == C2_DROP) continue;
+            const unsigned long long o = d + i;
             lo1[o] = (uint16_t)s;
             hi1[o] = (uint8_t)(s >> 16);
         }
@@ -294,10 +349,14 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
             if (j < nmine) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
         __syncthreads();  // (B)
         unsigned long long g = 0;
+        bool fits = true;
         if (threadIdx.x < F2) {  // reserve the output ranges now; the result is needed only after the scan
             const uint32_t c = hist[threadIdx.x];
             const size_t fine = (size_t)b1 * F2 + threadIdx.x;
-            g = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+            const unsigned long long o0 = off_fine[fine];
+            const unsigned long long at = c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL;
+            g = o0 + at;
+            fits = at + c <= off_fine[fine + 1] - o0;    // estimate mode: see part1; c2_count raises the flag
         }
         nnext = 0;
         if (ntile < n_tiles) {  // next tile's keys: in flight across the rest of this iteration
@@ -305,7 +364,7 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
             fetch(nb, ntile - tile_start[nb]);
         }
         const uint32_t total = c2_scan_F(hist, start, F2, wsum);
-        if (threadIdx.x < F2) gbase[threadIdx.x] = g - start[threadIdx.x];   // out index = gbase[b] + LDS index
+        if (threadIdx.x < F2) gbase[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;   // out index = gbase[b] + LDS index
         __syncthreads();  // (C)
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++)
@@ -313,10 +372,29 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
         __syncthreads();  // (D)
         for (uint32_t i = threadIdx.x; i < total; i += C2_P2_THREADS) {
             const uint32_t s = keys[i];
-            buf2[gbase[(s >> shift2) & mask2] + i] = (uint16_t)(s & (C2_FINE - 1));
+            const unsigned long long gb = gbase[(s >> shift2) & mask2];
+            if (gb != C2_DROP) buf2[gb + i] = (uint16_t)(s & (C2_FINE - 1));
         }
         p ^= 1;
     }
+}
+
+// After part2: the exact fine-bucket sizes are its cursors.  span[f] = [first, last) key of fine bucket f in buf2,
+// written with plain stores so that c2_count's per-bucket look-up is one L2-resident 16-byte load (the cursors
+// themselves were updated by atomics and live beyond L2: reading them inside c2_count's per-bucket prefetch
+// cost 3.8 ms per wheat-like pass).  A bucket that outgrew its region (estimate mode) raises the flag.
+__global__ void __launch_bounds__(256)
+c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
+         ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fine) return;
+    const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
+    unsigned long long n = cursor2[f];
+    if (n > cap) {
+        n = cap;
+        atomicAdd(flag, 1ULL);
+    }
+    span[f] = make_ulonglong2(lo, lo + n);
 }
 
 // ---------------------------------------------------------------- c2_count
@@ -332,10 +410,15 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
 #define C2_PF 8         // prefetched 8-byte loads per thread (32 K keys per block: most of an average bucket)
 #endif
 #define C2_STAGE 1024   // overflow pairs staged in LDS per bucket (8 KiB next to the 128 KiB of counters)
+// LIST = true (engine 3, small genomes): no table at all -- EVERY slot with count >= lower becomes a (slot, count)
+// pair of the same segment protocol, i.e. the chromosome's dump as a list in ascending slot order.  A 20-Mb
+// chromosome fills 4 % of the 2^29 slots at k = 15: writing and re-reading 512 MiB of zeros per chromosome was 8 of
+// the 13 ms of an Arabidopsis-like pass.
+template <bool LIST>
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
-c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict__ off_fine,
+c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span /* [first, last) key of every fine bucket */,
          int64_t n_fine, uint32_t lower, uint8_t *__restrict__ tab,
-         unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[2]=overflow cursor*/,
+         unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[2]=overflow cursor,[3]=region-overrun flag*/,
          uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap, uint32_t *__restrict__ seg_base,
          uint32_t *__restrict__ seg_cnt) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE
@@ -344,6 +427,7 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
     __shared__ unsigned long long s_base;
     __shared__ uint2 stage[C2_STAGE];
     unsigned long long s = 0, n = 0;
+    const uint32_t thr = LIST ? lower : 255u;     // counts from here on become pairs
     // Software pipeline over the buckets a block processes: the first C2_PF x 4 keys per thread of the NEXT
     // bucket are loaded while this bucket's counters are written out and cleared (one block per CU: nothing else
     // would hide those round trips; the kernel ran at 2.5 TB/s of its 4.6).
@@ -351,8 +435,9 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
     unsigned long long pf_lo = 0, pf_hi = 0;
     auto prefetch = [&](int64_t fbn) {
         if (fbn >= n_fine) return;
-        pf_lo = off_fine[fbn];
-        pf_hi = off_fine[fbn + 1];
+        const ulonglong2 d = span[fbn];      // one 16-byte load: where the bucket's keys lie (c2_spans)
+        pf_lo = d.x;
+        pf_hi = d.y;
         unsigned long long a = (pf_lo + 3ULL) & ~3ULL;
         if (a > pf_hi) a = pf_hi;
         const unsigned long long n4 = (pf_hi - a) >> 2;
@@ -410,7 +495,7 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
             atomicAdd(&cnt[buf2[t]], 1u);
         prefetch(fb + gridDim.x);   // in flight across the write-out below and the next clear
         __syncthreads();
-        uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
+        uint32_t *t32 = LIST ? nullptr : reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
             const uint4 v = c4[i];
             const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
@@ -419,13 +504,13 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
             for (int j = 0; j < 4; j++) {
                 const uint32_t c = a4[j];
                 if (c >= lower) { s += c; n++; }
-                if (c >= 255u) {   // rare: staged in LDS; a bucket with more than C2_STAGE of them re-scans its counters
+                if (c >= thr) {   // rare: staged in LDS; a bucket with more than C2_STAGE of them re-scans its counters
                     const uint32_t pos = atomicAdd(&s_nov, 1u);
                     if (pos < C2_STAGE) stage[pos] = make_uint2((uint32_t)(fb * C2_FINE + 4 * i + j), c);
                 }
                 packed |= (c < 255u ? c : 255u) << (8 * j);
             }
-            t32[i] = packed;
+            if (!LIST) t32[i] = packed;
         }
         __syncthreads();
         const uint32_t nov = s_nov;   // block-uniform
@@ -442,7 +527,7 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
                     const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (a4[j] >= 255u) {
+                        if (a4[j] >= thr) {
                             const unsigned long long pos = base + atomicAdd(&s_rank, 1u);
                             if (pos < ovf_cap) ovf_tmp[pos] = make_uint2((uint32_t)(fb * C2_FINE + 4 * i + j), a4[j]);
                         }
@@ -463,24 +548,51 @@ c2_count(const uint16_t *__restrict__ buf2, const unsigned long long *__restrict
 
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
                     uint32_t *seg_off, int64_t n_buckets);   // sp_count.hip
+int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
+                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets);
 
 bool sp_engine2_supported(int64_t nslots) {
     c2_plan p;
     return c2_make_plan(nslots, p);
 }
 
-int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, unsigned long long *d_len2) {
+// exact = false: bucket regions from the 1-in-16 sample (the caller re-runs the chromosome with exact = true when
+// d_len4[3] comes back non-zero); exact = true: regions = the exact histogram (a full scan), nothing can overrun.
+// list != nullptr (engine 3): no byte table; the chromosome's (slot, count >= lower) pairs go to list->d_keys /
+// d_cnts (capacity list->cap pairs, ascending slot order); their number comes back in d_len4[2].
+int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, unsigned long long *d_len4, bool exact,
+                     sp_sparse_chrom *list) {
     c2_plan P;
     if (!c2_make_plan(ctx->nslots, P))
         return sp_fail(ctx, SP_EUNSUP, "count engine 2 needs a dense table of 2^17..2^31 slots (k=%d)", kp.k);
     const int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
     if (n_units == 0) {
-        SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots, ctx->stream));
+        if (!list) SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots, ctx->stream));
         c.n_ovf = 0;
         return SP_OK;
     }
-    // workspace: ghist | off_fine | off1 | tile_start | cursor1 | cursor2 | buf1 (u32 x len) | buf2 (u16 x len)
     const size_t nf = (size_t)P.n_fine;
+    const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
+    const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
+    // estimate mode: cap(f) = sample(f) * 16 * 9/8 + slack.  The slack absorbs what a 1-in-16 stripe sample cannot
+    // see: a local array of one repeat shorter than 16 stripes (32 K starts) that falls between sampled stripes.
+    const char *env_mult = getenv("SP_C2_MULT8"), *env_slack = getenv("SP_C2_SLACK");   // test hooks (force overruns)
+    const int sample_shift = exact ? 0 : C2_SAMPLE_SHIFT;
+    unsigned long long mult8 = exact ? 8ULL : (unsigned long long)(env_mult ? atoll(env_mult) : (9 << C2_SAMPLE_SHIFT));
+    unsigned long long slack = 0;
+    if (!exact) {
+        int64_t sl = c.len / 64;
+        sl = sl < 4096 ? 4096 : (sl > 32768 ? 32768 : sl);
+        slack = (unsigned long long)(env_slack ? atoll(env_slack) : sl);
+    }
+    const unsigned long long slack1 = env_slack ? slack : 4ULL * slack + 65536ULL;
+    const unsigned long long mult8_1 = (exact || env_mult) ? mult8 : (unsigned long long)(33 << (C2_SAMPLE_SHIFT - 2));   // x 1 1/32
+    const int64_t n_stripes = (n_units32 + C2_STRIPE - 1) / C2_STRIPE;
+    const int64_t n_visit = exact ? n_units32 : ((n_stripes + (1 << C2_SAMPLE_SHIFT) - 1) >> C2_SAMPLE_SHIFT) * C2_STRIPE;
+    // keys the regions can hold at most (a rigorous bound: the sample sees at most n_visit * 32 k-mers)
+    const size_t cap_keys = exact ? (size_t)c.len + 4 * nf
+                                  : (size_t)(((unsigned long long)n_visit * C2_P1_UNIT * mult8 + 7) / 8) + nf * (size_t)(slack + 4);
+    // workspace: ghist | off_fine | off1 | tile_start | cursor1 | cursor2 | level-1 planes (3 B / key) | buf2 (u16 / key)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_ghist = 0;
     size_t o_offf = o_ghist + al(nf * 8);
@@ -488,16 +600,17 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 16);       // level-1 starts, then ends
     size_t o_cur1 = o_tile + al((size_t)(P.F1 + 1) * 8);
     size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
-    const int64_t n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
-    const int64_t n_tiles = (n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;   // 16384 starts each
     size_t o_tcnt = o_cur2 + al(nf * 8);        // end of the zeroed head of the workspace
+    size_t o_span = o_tcnt;
+    o_tcnt = o_span + al(nf * 16);              // (the spans are written before they are read: not zeroed)
+    const size_t zero_bytes = o_span;
+    const size_t lo1_bytes = al(cap_keys * 2 + 64 + (size_t)P.F1 * 8);
     size_t o_buf1 = o_tcnt;
-    size_t o_buf2 = o_buf1 + al((size_t)c.len * 4 + 64 + (size_t)P.F1 * 16);
-    size_t o_segb = o_buf2 + al((size_t)c.len * 2 + 64);          // overflow segments: base, count, offsets per fine bucket
+    size_t o_buf2 = o_buf1 + lo1_bytes + al(cap_keys + 64 + (size_t)P.F1 * 4);
+    size_t o_segb = o_buf2 + al(cap_keys * 2 + 64);               // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
     size_t total = o_sego + al((nf + 1) * 4);
-    // the unordered overflow pairs live in buf1 (u32 keys of level 1: dead once part2 has run)
     if ((int64_t)total > ctx->ws2_bytes) {
         if (ctx->d_ws2) {
             SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -513,38 +626,61 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     unsigned long long *off_fine = (unsigned long long *)(ws + o_offf);
     unsigned long long *off1 = (unsigned long long *)(ws + o_off1);
     unsigned long long *tile_start = (unsigned long long *)(ws + o_tile);
-    unsigned long long *cur2 = (unsigned long long *)(ws + o_cur2);
-    uint32_t *buf1 = (uint32_t *)(ws + o_buf1);
+    unsigned long long *cur1 = (unsigned long long *)(ws + o_cur1), *cur2 = (unsigned long long *)(ws + o_cur2);
     uint16_t *buf2 = (uint16_t *)(ws + o_buf2);
     uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
-    uint16_t *lo1 = (uint16_t *)buf1;                                  // level-1 records: 3 bytes per key in two planes
-    uint8_t *hi1 = (uint8_t *)buf1 + al((size_t)c.len * 2 + 64 + (size_t)P.F1 * 8);
-    uint2 *ovf_tmp = (uint2 *)buf1;
-    const unsigned long long ovf_cap = (unsigned long long)c.len / 2 + 8;   // pairs that fit in buf1 (>= len/255 + 16)
+    uint16_t *lo1 = (uint16_t *)(ws + o_buf1);                         // level-1 records: 3 bytes per key in two planes
+    uint8_t *hi1 = (uint8_t *)(ws + o_buf1) + lo1_bytes;
+    // the unordered overflow pairs live in the level-1 planes (dead once part2 has run); a LIST run stages every
+    // kept slot and gets a buffer of its own
+    uint2 *ovf_tmp = (uint2 *)(ws + o_buf1);
+    unsigned long long ovf_cap = (unsigned long long)c.len / 4 + 8;   // pairs that fit in the u16 plane (>= len/255 + 16)
+    if (list) {
+        int rcl = sp_buf_ensure(ctx, ctx->b_ovfw, (list->cap + 16) * 8);
+        if (rcl) return rcl;
+        ovf_tmp = (uint2 *)ctx->b_ovfw.p;
+        ovf_cap = (unsigned long long)list->cap;
+    }
     // zero ghist .. cursor2 in one memset (they are contiguous)
-    SP_HIP(ctx, hipMemsetAsync(ws, 0, o_tcnt, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(ws, 0, zero_bytes, ctx->stream));
 
     const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
     int grid_scan = (int)(n_tiles < (int64_t)ctx->n_cu * 8 ? n_tiles : (int64_t)ctx->n_cu * 8);
     size_t sh_hist = nf * 4;
-    int grid_hist = (int)(n_tiles < (int64_t)ctx->n_cu * 2 ? n_tiles : (int64_t)ctx->n_cu * 2);
+    const int64_t hist_tiles = (n_visit + C2_P1_THREADS - 1) / C2_P1_THREADS;
+    // (every block flushes its LDS histogram with one global atomic per non-empty bin: the sample runs on fewer blocks)
+    const int64_t hist_blocks = exact ? (int64_t)ctx->n_cu * 2 : (int64_t)ctx->n_cu / 2;
+    int grid_hist = (int)(hist_tiles < hist_blocks ? hist_tiles : hist_blocks);
     if (sh_hist > 48 * 1024)
         SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
-    SP_LAUNCH(ctx, "c2_hist_fine", c2_hist_fine, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist, c.d_pk, c.d_pm, c.d_nm,
-              n_units32, kp32, C2_B3, (int)nf, ghist);
-    SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, off_fine,
-              off1, tile_start);
+    SP_LAUNCH(ctx, exact ? "c2_hist_fine" : "c2_hist_sample", c2_hist_fine, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist,
+              c.d_pk, c.d_pm, c.d_nm, n_units32, n_visit, sample_shift, kp32, C2_B3, (int)nf, ghist);
+    SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, mult8, mult8_1, slack, slack1, off_fine,
+              off1);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
-              kp32, P.T - P.B1, P.F1, off1, (unsigned long long *)(ws + o_cur1), n_tiles, lo1, hi1);
+              kp32, P.T - P.B1, P.F1, off1, cur1, n_tiles, lo1, hi1);
+    SP_LAUNCH(ctx, "c2_tiles", c2_tiles, dim3(1), dim3(C2_MAXF), 0, (const unsigned long long *)cur1, P.F1, off1, tile_start,
+              d_len4 + 3);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
-    int64_t max_tiles2 = n_tiles + P.F1;
+    int64_t max_tiles2 = (c.len + C2_TILE_KEYS - 1) / C2_TILE_KEYS + P.F1;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
     SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, (const uint16_t *)lo1, (const uint8_t *)hi1, off1,
               tile_start, P.F1,
               P.F2, C2_B3, off_fine, cur2, buf2);
-    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
-    SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, off_fine,
-              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len2, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+    ulonglong2 *span = (ulonglong2 *)(ws + o_span);
+    SP_LAUNCH(ctx, "c2_spans", c2_spans, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, (const unsigned long long *)off_fine,
+              (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3);
+    if (list) {
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+        SP_LAUNCH(ctx, "c2_count_list", c2_count<true>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
+                  (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, (uint8_t *)nullptr, d_len4, ovf_tmp, ovf_cap, seg_base,
+                  seg_cnt);
+        return sp_ovf_finalize_split(ctx, (unsigned long long *)list->d_keys, list->d_cnts, ovf_tmp, seg_base, seg_cnt, seg_off,
+                                     (int64_t)nf);
+    }
+    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+    SP_LAUNCH(ctx, "c2_count", c2_count<false>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
+              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
     return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf);
 }

@@ -371,6 +371,31 @@ __device__ __forceinline__ uint32_t sp_block_excl_count(bool pred, uint32_t *lds
     return base + in_wave;
 }
 
+// Exclusive prefix sum of one value per thread over the block (<= 1024 threads); lds: >= 16 elements.  Wave scans by
+// shuffles, the (<= 16) wave totals through LDS -- a single thread walking 1024 partial sums in LDS took 20-25 us in
+// the one-block offset kernels that run once per chromosome.
+template <typename T>
+__device__ __forceinline__ T sp_block_excl_scan(T v, T *lds, T &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    T incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) {
+        const T x = lds[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
 __device__ __forceinline__ unsigned long long sp_block_sum_u64(unsigned long long v,
                                                                unsigned long long *lds) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -555,7 +555,7 @@ extern "C" {
 int sp_filter_view(sp_ctx *ctx, int C, const void *const *d_tabs, int64_t slot_base, int64_t nslots_view,
                    const int64_t *lengths, int k, int lower_count, const void *const *d_ovf, const int64_t *n_ovf) {
     if (!ctx) return SP_EINVAL;
-    if (d_tabs && ctx->sparse_mode) return sp_fail(ctx, SP_EUNSUP, "sp_filter_view: k <= 15 only");
+    if (d_tabs && (ctx->sparse_mode || ctx->list_mode)) return sp_fail(ctx, SP_EUNSUP, "sp_filter_view: byte-table engines (k <= 15) only");
     if (!d_tabs) {   // back to the local chromosomes
         ctx->fv_on = false;
         ctx->fv_tabs.clear();
@@ -624,7 +624,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
         if (unit_chrom[j] < 0 || unit_chrom[j] >= C)
             return sp_fail(ctx, SP_EINVAL, "sp_filter: chromosome index %d out of range", unit_chrom[j]);
 
-    if (ctx->sparse_mode) {
+    if (ctx->sparse_mode || ctx->list_mode) {
         std::vector<double> den_s((size_t)n_units * 2);   // denominators, then their reciprocals
         for (int u = 0; u < n_units; u++) {
             int64_t d = 0;
@@ -836,7 +836,7 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (cap < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap, (long long)M);
     if (M == 0) return SP_OK;
-    if (ctx->sparse_mode) return sp_sparse_fetch(ctx, hist, keys, counts, freqs, tot);
+    if (ctx->sparse_mode || ctx->list_mode) return sp_sparse_fetch(ctx, hist, keys, counts, freqs, tot);
     const int C = filter_C(ctx);
     const sp_tabref *d_tabs = nullptr;
     double *d_len = nullptr;
@@ -895,7 +895,7 @@ int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs
 
 int sp_filter_fetch_async(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t *tot, int64_t cap_rows) {
     if (!ctx) return SP_EINVAL;
-    if (ctx->sparse_mode) return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows);   // synchronous
+    if (ctx->sparse_mode || ctx->list_mode) return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows);   // synchronous
     return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows, true);
 }
 
@@ -913,7 +913,7 @@ int sp_filter_fetch_device(sp_ctx *ctx, void *d_keys, void *d_counts, void *d_to
     if (cap_rows < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap_rows, (long long)M);
     if (M == 0) return SP_OK;
     const int C = filter_C(ctx);
-    if (ctx->sparse_mode) {   // the sparse filter leaves its rows in device buffers already
+    if (ctx->sparse_mode || ctx->list_mode) {   // the list filter leaves its rows in device buffers already
         if (d_keys) SP_HIP(ctx, hipMemcpyAsync(d_keys, ctx->b_sf_keys.p, (size_t)M * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_counts) SP_HIP(ctx, hipMemcpyAsync(d_counts, ctx->b_sf_counts.p, (size_t)M * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_tot) SP_HIP(ctx, hipMemcpyAsync(d_tot, ctx->b_sf_tot.p, (size_t)M * 8, hipMemcpyDeviceToDevice, ctx->stream));

@@ -177,23 +177,52 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
     }
 }
 
-// K5, pair-table engine (S <= 7): one block-iteration covers MAP_BLOCK units of 64 starts
+// K5, pair-table engine (S <= 7): one block-iteration covers MAP_BLOCK units of 64 starts.  ONE launch maps every
+// chromosome of the call: ranges are numbered through the whole genome (desc[c].range0 = first range of chromosome
+// c) and dealt to the blocks round-robin, so the tail of the launch is one range per block instead of one partly
+// filled round of blocks per chromosome (21 launches of 3.3 rounds each on the wheat-like genome).
+struct map_chrom_desc {
+    const uint32_t *pk, *pm, *nm;
+    int64_t n_units;       // units of 64 starts
+    int64_t nslots;        // output slots (bins + chunk duplicates) of this chromosome
+    int64_t range0;        // number of ranges of the chromosomes before it
+    int *counts;           // [nslots x S]
+    unsigned long long *n_mapped;
+};
+
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-       sp_kparams32 kp, sp_map_params P, uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom,
-       int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
+k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, sp_kparams32 kp, sp_map_params P,
+       uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
     unsigned long long mapped = 0;
-    const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
-    for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+    int cur = -1;          // chromosome the block is accumulating `mapped` for
+    auto flush_mapped = [&]() {     // block-uniform control flow
+        if (cur < 0) return;
+        const unsigned long long t = sp_block_sum_u64(mapped, red);
+        if (threadIdx.x == 0 && t) atomicAdd(desc[cur].n_mapped, t);
+        mapped = 0;
+    };
+    for (int64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        int lo = 0, hi = n_chrom;              // last chromosome with range0 <= rg (uniform: scalar loads)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (desc[mid].range0 <= rg) lo = mid;
+            else hi = mid;
+        }
+        if (lo != cur) {
+            flush_mapped();
+            cur = lo;
+        }
+        const map_chrom_desc D = desc[lo];
+        const int64_t r = rg - D.range0;
         const int64_t u = r * MAP_BLOCK + threadIdx.x;
         const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k);
         if (P.use_lds) {
             for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
             __syncthreads();
         }
-        if (u < P.n_units) {
+        if (u < D.n_units) {
             // A lane's 64 starts lie in one or two output slots: hits are tallied in a register, one byte per
             // subgenome (<= 64 hits per unit, <= 7 subgenomes), and reach the LDS histogram once per slot -- not
             // one LDS atomic and a 64-bit slot computation per hit (the hit path runs for every pair of every wave:
@@ -207,8 +236,8 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const u
                     if (!v) continue;
                     if (P.use_lds)
                         atomicAdd(&hist[(int)(cur_os - slot_lo) * P.S + sg], v);
-                    else if (cur_os < P.nslots)
-                        atomicAdd(&slot_counts[cur_os * P.S + sg], v);
+                    else if (cur_os < D.nslots)
+                        atomicAdd(&D.counts[cur_os * P.S + sg], v);
                     mapped += v;
                 }
                 acc = 0;
@@ -222,8 +251,8 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const u
                 acc += 1ULL << (8 * sg);
                 return true;
             };
-            map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-            map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32(D.pk, D.pm, D.nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
             flush();
         }
         if (P.use_lds) {
@@ -232,14 +261,29 @@ k5_map(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const u
                 int v = hist[i];
                 if (v) {
                     int64_t os = slot_lo + i / P.S;
-                    if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + (i % P.S)], v);
+                    if (os < D.nslots) atomicAdd(&D.counts[os * P.S + (i % P.S)], v);
                 }
             }
             __syncthreads();
         }
     }
-    unsigned long long t = sp_block_sum_u64(mapped, red);
-    if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
+    flush_mapped();
+}
+
+// descriptors of the chromosomes [first, first + n) -> device, then the one launch
+static int map_launch_dense(sp_ctx *ctx, const std::vector<map_chrom_desc> &hd, int64_t n_ranges, const sp_map_params &P) {
+    if (n_ranges <= 0) return SP_OK;
+    int rcb = sp_buf_ensure(ctx, ctx->b_mapdesc, (int64_t)(hd.size() * sizeof(map_chrom_desc)));
+    if (rcb) return rcb;
+    // (pageable source: hipMemcpyAsync returns once the runtime has staged it, `hd` may die afterwards)
+    SP_HIP(ctx, hipMemcpyAsync(ctx->b_mapdesc.p, hd.data(), hd.size() * sizeof(map_chrom_desc), hipMemcpyHostToDevice,
+                              ctx->stream));
+    const sp_kparams32 kp = sp_make_kparams32(ctx->k);
+    int64_t grid = n_ranges;
+    if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
+    SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+              (int)hd.size(), n_ranges, kp, P, (uint32_t *)ctx->b_ptab.p, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+    return SP_OK;
 }
 
 // K5, label-table engine (any S <= 126; the rolling scan + one byte gather per candidate start)
@@ -538,10 +582,12 @@ int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, in
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        if (ctx->map_engine == 0)
-            SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
-                      (uint32_t *)ctx->b_ptab.p, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
-        else
+        if (ctx->map_engine == 0) {
+            std::vector<map_chrom_desc> hd(1);
+            hd[0] = map_chrom_desc{c.d_pk, c.d_pm, c.d_nm, P.n_units, nslots, 0, d_counts, d_n};
+            int rcl = map_launch_dense(ctx, hd, n_ranges, P);
+            if (rcl) return rcl;
+        } else
             SP_LAUNCH(ctx, "k5_map_lab", k5_map_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
                       ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
     }
@@ -577,6 +623,15 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
     SP_HIP(ctx, hipMemsetAsync(d_counts, 0, bytes8 + 8 * (size_t)C, ctx->stream));
     const sp_kparams32 kp = sp_make_kparams32(ctx->k);
     int64_t local = MAP_RANGE / bin_size + 3 + (chunk_size > 0 ? MAP_RANGE / chunk_size + 2 : 0);
+    std::vector<map_chrom_desc> hd;     // pair-table engine: every chromosome in ONE launch
+    int64_t all_ranges = 0;
+    sp_map_params Pall;
+    Pall.n_units = 0;
+    Pall.bin_size = bin_size;
+    Pall.chunk_size = chunk_size;
+    Pall.nslots = 0;
+    Pall.S = S;
+    Pall.use_lds = (local * S <= MAP_LDS_ENTRIES) ? 1 : 0;
     for (int i = 0; i < C; i++) {
         sp_chrom &c = ctx->chroms[(size_t)i];
         sp_map_params P;
@@ -593,14 +648,20 @@ int sp_map_bins_all(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, const int
             continue;
         }
         int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+        if (ctx->map_engine == 0) {
+            hd.push_back(map_chrom_desc{c.d_pk, c.d_pm, c.d_nm, P.n_units, P.nslots, all_ranges, d_counts + slot_off[i] * S,
+                                        d_n + i});
+            all_ranges += n_ranges;
+            continue;
+        }
         int64_t grid = n_ranges;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        if (ctx->map_engine == 0)
-            SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
-                      (uint32_t *)ctx->b_ptab.p, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
-        else
-            SP_LAUNCH(ctx, "k5_map_lab", k5_map_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-                      ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
+        SP_LAUNCH(ctx, "k5_map_lab", k5_map_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+                  ctx->d_label, ctx->d_bloom, ctx->bloom_bits, d_counts + slot_off[i] * S, d_n + i);
+    }
+    if (!hd.empty()) {
+        int rcl = map_launch_dense(ctx, hd, all_ranges, Pall);
+        if (rcl) return rcl;
     }
     SP_HIP(ctx, hipMemcpyAsync(slot_counts, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<unsigned long long> hn((size_t)C, 0);

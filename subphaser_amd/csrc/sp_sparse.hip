@@ -11,7 +11,9 @@
 //
 // The sort and the run-length encode are rocPRIM device primitives (plain library ops on this
 // secondary path); everything specific to the problem is hand-written.  k <= 15 never comes here.
+#include <algorithm>
 #include <cstring>
+#include <utility>
 #include <rocprim/rocprim.hpp>
 
 #include "sp_device.h"
@@ -561,7 +563,30 @@ int sp_sparse_dump(sp_ctx *ctx, int chrom, uint64_t *keys, uint32_t *counts) {
     SP_HIP(ctx, hipMemcpyAsync(keys, o.d_keys, (size_t)o.n * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(counts, o.d_cnts, (size_t)o.n * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->list_mode) {
+        // engine 3 keeps dense SLOTS (ascending); a dump is canonical k-mers in ascending order: convert and sort
+        // here, on the host -- the dump is the compatibility export (jellyfish-format files, tests), not the hot path
+        const sp_kparams kp = sp_make_kparams(ctx->k);
+        try {
+            std::vector<std::pair<uint64_t, uint32_t>> v((size_t)o.n);
+            for (int64_t i = 0; i < o.n; i++) v[(size_t)i] = {sp_key_of_slot(keys[i], kp), counts[i]};
+            std::sort(v.begin(), v.end());
+            for (int64_t i = 0; i < o.n; i++) {
+                keys[i] = v[(size_t)i].first;
+                counts[i] = v[(size_t)i].second;
+            }
+        } catch (const std::bad_alloc &) {
+            return sp_fail(ctx, SP_ENOMEM, "sp_dump: out of host memory sorting %lld k-mers", (long long)o.n);
+        }
+    }
     return SP_OK;
+}
+
+// engine 3: the rows the list filter emitted carry dense slots; the API speaks canonical k-mers
+__global__ void __launch_bounds__(256)
+sps_slots_to_keys(unsigned long long *__restrict__ keys, int64_t n, sp_kparams kp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = sp_key_of_slot(keys[i], kp);
 }
 
 // the lists the filter works on: the local chromosomes, or a caller-owned key-range view (sp_sparse_view)
@@ -581,7 +606,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
                      const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
                      double min_freq, double max_freq, double ratio) {
     const int C = sps_C(ctx);
-    if (C > SPS_MAXC) return sp_fail(ctx, SP_EUNSUP, "k > 15: at most %d chromosomes supported (got %d)", SPS_MAXC, C);
+    if (C > SPS_MAXC) return sp_fail(ctx, SP_EUNSUP, "list filter (k > 15, or engine 3): at most %d chromosomes supported (got %d)", SPS_MAXC, C);
     int64_t total = 0;
     for (int c = 0; c < C; c++) total += sps_n(ctx, c);
     ctx->sf_n = total;
@@ -673,6 +698,9 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
         SP_LAUNCH(ctx, "sps_emit_hist", sps_emit, dim3((unsigned)nblk), dim3(SEL_BLOCK), 0, K1, V1, total, C,
                   (const uint8_t *)flags, (uint8_t)2, (const unsigned long long *)blk_h, (unsigned long long *)nullptr,
                   (uint32_t *)nullptr, (unsigned long long *)ctx->b_sf_hist.p);
+    if (M && ctx->list_mode)
+        SP_LAUNCH(ctx, "sps_slots_to_keys", sps_slots_to_keys, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                  (unsigned long long *)ctx->b_sf_keys.p, M, sp_make_kparams(ctx->k));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->filtered = true;
     return SP_OK;

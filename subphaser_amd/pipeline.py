@@ -91,7 +91,7 @@ CLI = [
         (("-max_memory",), dict(type=str, metavar="MEM", default=None)),
         (("-cleanup",), _FLAG),
         (("-overwrite",), _FLAG),
-        (("-engine",), dict(type=int, default=0, help="k-mer counting engine (0 auto, 1 atomic table, 2 LDS radix)")),
+        (("-engine",), dict(type=int, default=0, help="k-mer counting engine (0 auto, 1 atomic table, 2 LDS radix, 3 LDS radix into lists: small genomes)")),
         (("-write_dumps",), dict(help="also write jellyfish-style text dumps {chrom}_{k}.fa", **_FLAG)),
         (("-bootstrap_seed",), dict(type=int, default=None, help="seed of k-means and of the bootstrap resampling")),
     ]),

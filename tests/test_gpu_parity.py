@@ -12,6 +12,15 @@ import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["tables", "lists"])
+def count_engine(request, monkeypatch):
+    """k <= 15 counts live either in byte tables (engines 1 / 2 + the dense filter) or, for small genomes, in sorted
+    (slot, count) lists (engine 3 + the list filter).  engine = 0 picks by table occupancy -- every toy genome of this
+    suite would take the lists -- so the tests that go through the auto engine run once with each, forced."""
+    monkeypatch.setenv("SP_LIST_ENGINE", "1" if request.param == "lists" else "0")
+    return request.param
+
+
 def _rand_seq(rng, n, p_other=0.01, lower=0.1):
     a = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, size=n)].copy()
     m = rng.random_sample(n) < lower
@@ -106,6 +115,56 @@ def test_count_engine2_hot_slots(gpu_ctx, k):
     seqs = [np.concatenate([_rand_seq(rng, 50000), sep, np.frombuffer(b"T" * 18_000_000, np.uint8), sep,
                             np.tile(unit, 70000)]), _rand_seq(rng, 5000)]
     _count_both(gpu_ctx, seqs, k, 2, engine=2)
+
+
+def test_count_engine2_sampled_sizing_and_recount(gpu_ctx, monkeypatch):
+    """Engine 2 lays its partition buckets out from a 1-in-16 stripe sample (round 3).  (a) on ordinary sequence
+    nothing overruns and nothing is recounted; (b) with the slack removed and the multiplier halved (test hooks)
+    buckets do overrun: the chromosome must be recounted from the exact histogram and the dump must still be the
+    oracle's, bit for bit; (c) a local repeat array that the sample cannot see in proportion (a 25-kb array of one
+    13-mer unit, a 300-kb homopolymer) is either absorbed by the slack or recounted -- exact either way; (d)
+    SP_C2_EXACT=1 is the round-2 path."""
+    rng = np.random.RandomState(4242)
+    unit = _rand_seq(rng, 13, 0, 0)
+    plain = [_rand_seq(rng, 3_000_001), _rand_seq(rng, 70_000)]
+    before = gpu_ctx.count_recounts()
+    _count_both(gpu_ctx, plain, 15, 3, engine=2)
+    _count_both(gpu_ctx, plain, 13, 1, engine=2)
+    assert gpu_ctx.count_recounts() == before                       # (a)
+    monkeypatch.setenv("SP_C2_SLACK", "0")
+    monkeypatch.setenv("SP_C2_MULT8", "64")                         # regions half of what the sample predicts
+    _count_both(gpu_ctx, plain, 13, 1, engine=2)
+    _count_both(gpu_ctx, plain, 11, 3, engine=2)
+    assert gpu_ctx.count_recounts() >= before + 2                   # (b) both chromosomes, at least once
+    monkeypatch.delenv("SP_C2_SLACK")
+    monkeypatch.delenv("SP_C2_MULT8")
+    arr = [np.concatenate([_rand_seq(rng, 400_000), np.tile(unit, 2000), _rand_seq(rng, 100_000),
+                           np.frombuffer(b"A" * 300_000, np.uint8), _rand_seq(rng, 9_000), np.tile(unit[::-1], 1500)])]
+    _count_both(gpu_ctx, arr, 15, 3, engine=2)                      # (c)
+    _count_both(gpu_ctx, arr, 12, 1, engine=2)
+    monkeypatch.setenv("SP_C2_EXACT", "1")
+    n = gpu_ctx.count_recounts()
+    _count_both(gpu_ctx, arr, 15, 2, engine=2)                      # (d)
+    assert gpu_ctx.count_recounts() == n
+
+
+@pytest.mark.parametrize("k", [9, 10, 12, 13, 14, 15])
+def test_count_engine3_lists(gpu_ctx, k):
+    """Engine 3 (small genomes): the partition chain ends in (slot, count >= lower) LISTS instead of byte tables.
+    Dumps (converted back to canonical k-mers), lengths and dump sizes against the oracle; hot slots far beyond 255
+    and beyond 16 bits; buckets with more kept slots than the LDS stage holds (k = 9: every slot of a bucket)."""
+    rng = np.random.RandomState(300 + k)
+    unit = _rand_seq(rng, 13, 0, 0)
+    seqs = [_rand_seq(rng, n) for n in (5000, 1_200_001, 64, 333)]
+    seqs.append(np.concatenate([np.frombuffer(b"A" * 300000, np.uint8), _rand_seq(rng, 50000), np.tile(unit, 70000),
+                                np.frombuffer(b"TTTAGGG" * 5000, np.uint8), np.frombuffer(b"N", np.uint8),
+                                np.frombuffer(b"AC" * 100000, np.uint8)]))
+    seqs += [np.frombuffer(b"", np.uint8), np.frombuffer(b"N" * 100, np.uint8)]
+    for lower in (1, 3):
+        out = _count_both(gpu_ctx, seqs, k, lower, engine=3)
+        assert [gpu_ctx.dump_size(i) for i in range(len(seqs))] == [len(kk) for kk, _ in out]
+    with pytest.raises(Exception):
+        gpu_ctx.count(5, 3, 3)            # 2^9 slots: no partition plan
 
 
 def test_count_engine2_unsupported_small_k(gpu_ctx):
@@ -268,15 +327,15 @@ def test_count_rejects_bad_k(gpu_ctx):
     gpu_ctx.count(32, 1)         # the largest supported k
 
 
-def test_toy_dumps(gpu_ctx, golden, toy):
+def test_toy_dumps(gpu_ctx, golden, toy, count_engine):
     pc.check_toy_dumps(gpu_ctx, golden, toy, engine=1)
 
 
-def test_filter_cases(gpu_ctx, golden, toy):
+def test_filter_cases(gpu_ctx, golden, toy, count_engine):
     pc.check_filter_cases(gpu_ctx, golden, toy)
 
 
-def test_filter_vs_oracle_random(gpu_ctx, oracle_ctx):
+def test_filter_vs_oracle_random(gpu_ctx, oracle_ctx, count_engine):
     """Random multi-chromosome genomes, random set structures: matrix rows bit-exact vs the oracle."""
     rng = np.random.RandomState(21)
     k = 11
@@ -316,7 +375,7 @@ def test_filter_vs_oracle_random(gpu_ctx, oracle_ctx):
         assert g[1] > 0
 
 
-def test_filter_near_threshold_screen(gpu_ctx):
+def test_filter_near_threshold_screen(gpu_ctx, count_engine):
     """The fold test is screened in fp32 and decided in fp64 only near the threshold: hand-made count
     tables whose fold sits within 1e-9 .. 1e-3 (relative) of min_fold on both sides, exactly on it, and
     far from it, through the slot-range view (caller-owned tables + caller-given lengths)."""
@@ -533,7 +592,7 @@ def test_byte_table_and_overflow_list(gpu_ctx, engine):
         gpu_ctx.dev_free(d8)
 
 
-def test_filter_errors(gpu_ctx):
+def test_filter_errors(gpu_ctx, count_engine):
     rng = np.random.RandomState(2)
     gpu_ctx.genome_reset(2)
     gpu_ctx.genome_add(0, _rand_seq(rng, 5000))
@@ -550,22 +609,22 @@ def test_filter_errors(gpu_ctx):
         gpu_ctx.filter(*csr1, 2, 1, 1, 1e9, 1)
 
 
-@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("engine", [1, 2, 3])
 @pytest.mark.parametrize("shape", ["wheat", "peanut", "ara"])
 def test_baseline_shapes(gpu_ctx, golden, shape, engine):
     """21 / 7 x 3, 20 / 10 x 2 and 13 comma-grouped chromosomes against reference-generated fixtures (G10)."""
     pc.check_shape(gpu_ctx, golden, shape, engine=engine)
 
 
-def test_dump_roundtrip(gpu_ctx, golden, toy, tmp_path):
+def test_dump_roundtrip(gpu_ctx, golden, toy, tmp_path, count_engine):
     pc.check_dump_roundtrip(gpu_ctx, golden, toy, tmp_path)
 
 
-def test_kmer_mat_text(gpu_ctx, golden, toy):
+def test_kmer_mat_text(gpu_ctx, golden, toy, count_engine):
     pc.check_kmer_mat_text(gpu_ctx, golden, toy)
 
 
-def test_map_cases(gpu_ctx, golden, toy):
+def test_map_cases(gpu_ctx, golden, toy, count_engine):
     pc.check_map_cases(gpu_ctx, golden, toy)
 
 
@@ -581,11 +640,11 @@ def test_map_dict_labels(gpu_ctx, golden, toy):
     pc.check_dict_labels(gpu_ctx, golden, toy)
 
 
-def test_hotpath_stack(gpu_ctx, golden, toy):
+def test_hotpath_stack(gpu_ctx, golden, toy, count_engine):
     pc.check_hotpath_stack(gpu_ctx, golden, toy)
 
 
-def test_pipeline_cli(gpu_ctx, golden, toy, tmp_path):
+def test_pipeline_cli(gpu_ctx, golden, toy, tmp_path, count_engine):
     pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
 
 
@@ -783,7 +842,7 @@ def test_wheat_sized_chromosome_properties_sparse(gpu_ctx, k):
         gpu_ctx.dev_free(d)
 
 
-def test_fuzz_against_oracle(gpu_ctx, oracle_ctx):
+def test_fuzz_against_oracle(gpu_ctx, oracle_ctx, count_engine):
     """150 random cases of tools/fuzz_parity.py (random genomes, k in 1..32, thresholds, engines, labels,
     bin / chunk sizes, set structures): counts, matrix rows, bin counts, feature totals, bit-exact."""
     import importlib.util
@@ -849,7 +908,7 @@ def test_medium_scale_count_filter_map_vs_oracle(gpu_ctx, oracle_ctx, k):
 
 
 @pytest.mark.parametrize("config,scale", [("wheat", 0.003), ("peanut", 0.012), ("ara", 0.08)])
-def test_synth_baseline_shapes_vs_oracle(gpu_ctx, config, scale):
+def test_synth_baseline_shapes_vs_oracle(gpu_ctx, config, scale, count_engine):
     """bench.py's own generator at the BASELINE chromosome / set structures (21 / 7 x 3, 20 / 10 x 2, 13
     comma-grouped), scaled down until the oracle finishes in seconds: HotPath on the HIP context against the
     oracle step by step -- lengths, (n_union, n_rows, n_hist), matrix rows, bins, windows, p-values, calls."""
