@@ -89,7 +89,8 @@ k1_narrow(const uint32_t *__restrict__ tab32, int64_t nslots, uint32_t lower, ui
 // ----------------------------------------------------------------- overflow list: segments -> sorted list
 // exclusive scan of the per-bucket overflow counts (n <= 2^16 buckets; single block)
 __global__ void __launch_bounds__(1024)
-ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/) {
+ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/,
+         unsigned long long *__restrict__ total_out /* number of pairs, or NULL */) {
     __shared__ uint32_t wsum[16];
     const int64_t per = (n + 1023) / 1024;
     int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
@@ -99,7 +100,10 @@ ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__
     for (int64_t i = lo; i < hi; i++) s += seg_cnt[i];
     uint32_t total;
     uint32_t run = sp_block_excl_scan(s, wsum, total);
-    if (threadIdx.x == 0) seg_off[n] = total;
+    if (threadIdx.x == 0) {
+        seg_off[n] = total;
+        if (total_out) *total_out = total;
+    }
     for (int64_t i = lo; i < hi; i++) {
         seg_off[i] = run;
         run += seg_cnt[i];
@@ -326,19 +330,19 @@ kx_lengths(sp_tabref T, int64_t slot_base, int64_t n, uint32_t lower, unsigned l
 
 // Lay the overflow segments a counting kernel left behind out in bucket order (= ascending slot order).
 static int ovf_finalize_to(sp_ctx *ctx, uint2 *out, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
-                           uint32_t *seg_off, int64_t n_buckets) {
-    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
+                           uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total = nullptr) {
+    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off, d_total);
     SP_LAUNCH(ctx, "ovf_place", ovf_place<false>, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base, seg_cnt,
               (const uint32_t *)seg_off, n_buckets, out, (unsigned long long *)nullptr, (uint32_t *)nullptr);
     return SP_OK;
 }
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
-                    uint32_t *seg_off, int64_t n_buckets) {
-    return ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets);
+                    uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total) {
+    return ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets, d_total);
 }
 int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
-                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets) {
-    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off);
+                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total) {
+    SP_LAUNCH(ctx, "ovf_scan", ovf_scan, dim3(1), dim3(1024), 0, seg_cnt, n_buckets, seg_off, d_total);
     SP_LAUNCH(ctx, "ovf_place_list", ovf_place<true>, dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, tmp, seg_base,
               seg_cnt, (const uint32_t *)seg_off, n_buckets, (uint2 *)nullptr, keys, cnts);
     return SP_OK;
@@ -503,7 +507,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         SP_LAUNCH(ctx, "k1_narrow", k1_narrow, dim3(grid2), dim3(256), 0, (const uint32_t *)tab32, nslots,
                   (uint32_t)lower_count, c.d_tab, d_len + 4 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
                   n_buckets);
-        rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets);
+        rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets, nullptr);   // (k1_narrow keeps an exact cursor in d_len[2])
         if (rc) return rc;
     }
     std::vector<unsigned long long> h(4 * C);
@@ -535,10 +539,11 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         ctx->chroms[ci].n_ovf = (int64_t)h[4 * ci + 2];
         if (list_mode) {     // the pairs ARE the dump: n_ovf of them, in ctx->sparse[ci]
             sp_sparse_chrom &o = ctx->sparse[ci];
-            if (ctx->chroms[ci].n_ovf > o.cap || ctx->chroms[ci].n_ovf != ctx->chroms[ci].n_dump)
-                return sp_fail(ctx, SP_ESTATE, "count engine 3: chromosome %zu kept %lld pairs for %lld dump k-mers (capacity %lld)",
+            // (h[.. + 2] is the staging cursor: the segments reserved, an upper bound of the pairs written)
+            if (ctx->chroms[ci].n_ovf > o.cap || ctx->chroms[ci].n_dump > o.cap)
+                return sp_fail(ctx, SP_ESTATE, "count engine 3: chromosome %zu reserved %lld pairs for %lld dump k-mers (capacity %lld)",
                                ci, (long long)ctx->chroms[ci].n_ovf, (long long)ctx->chroms[ci].n_dump, (long long)o.cap);
-            o.n = ctx->chroms[ci].n_ovf;
+            o.n = ctx->chroms[ci].n_dump;
             o.length_sum = ctx->chroms[ci].length_sum;
             ctx->chroms[ci].n_ovf = 0;
             continue;

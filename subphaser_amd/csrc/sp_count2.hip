@@ -424,7 +424,6 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE
     __shared__ unsigned long long red[16];
     __shared__ uint32_t s_nov, s_rank;
-    __shared__ unsigned long long s_base;
     __shared__ uint2 stage[C2_STAGE];
     unsigned long long s = 0, n = 0;
     const uint32_t thr = LIST ? lower : 255u;     // counts from here on become pairs
@@ -515,9 +514,10 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
         __syncthreads();
         const uint32_t nov = s_nov;   // block-uniform
         if (nov) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&out3[2], (unsigned long long)nov);
-            __syncthreads();
-            const unsigned long long base = s_base;
+            // the bucket's segment of the staging list starts at floor(first key / 255): a slot that overflows accounts
+            // for >= 255 keys, the key regions are disjoint, and floor(a / L) + floor(b / L) <= floor((a + b) / L) --
+            // no cursor (one same-address global atomic per bucket: 16 K of them per launch)
+            const unsigned long long base = lo / 255ULL;
             if (nov <= C2_STAGE) {
                 for (uint32_t p = threadIdx.x; p < nov; p += C2_COUNT_THREADS)
                     if (base + p < ovf_cap) ovf_tmp[base + p] = stage[p];
@@ -546,10 +546,152 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
     }
 }
 
+// ---------------------------------------------------------------- c2_count_list (engine 3)
+// Small genomes: a fine bucket of 2^15 slots receives a few thousand keys (1.2 K on a 20-Mb chromosome at k = 15), and
+// clearing + scanning 128 KiB of LDS counters per bucket -- what the table kernel above does -- was the whole cost
+// (0.33 ms per chromosome whatever its length).  Here the work per bucket is O(keys): the keys stay in registers,
+// pass 1 counts them, pass 2 lets every key swap its counter for zero -- the one lane that gets the count back owns
+// the slot, emits (slot, count) if count >= lower, and the counters are clean again for the next bucket.  No table is
+// written.  The pairs of a bucket go to one contiguous segment of the staging list, placed at floor(first key / lower):
+// a kept slot accounts for >= lower keys, the key regions are disjoint and floor(a / L) + floor(b / L) <=
+// floor((a + b) / L) -- no cursor (one same-address global atomic per bucket is 16 K of them per launch: 0.2 ms, and
+// it was most of this kernel).  ovf_scan / ovf_place<SPLIT> then lay the segments out in bucket order, ranked by slot
+// inside a bucket.  Buckets with more keys than the registers hold (C2L_PF quads per thread) read the rest from
+// memory and walk the counters in pass 2.
+// What is left is one memory round trip per bucket (0.14 ms per 20-Mb chromosome): the next bucket's keys are
+// requested one bucket ahead, and deeper register pipelines do not help -- the compiler cannot count the conditional
+// loads and stores in flight and waits for all of them (vmcnt(0)) at the first use; four 512-thread blocks per CU on
+// quarter buckets (32-KiB counters, the keys walked four times) were measured at twice the time
+// (profiles/r03_notes.md).
+#define C2L_DEPTH 2
+#define C2L_PF 4
+#define C2L_MAXB 256      // fine buckets per block at most (the launch sizes the grid accordingly)
+__global__ void __launch_bounds__(C2_COUNT_THREADS)
+c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
+              unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n*/,
+              uint2 *__restrict__ stage, unsigned long long stage_cap, uint32_t *__restrict__ seg_base,
+              uint32_t *__restrict__ seg_cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE
+    __shared__ unsigned long long red[16];
+    __shared__ uint32_t s_nov[2];
+    __shared__ ulonglong2 s_span[C2L_MAXB];
+    unsigned long long s = 0, n = 0;
+    {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < 2) s_nov[threadIdx.x] = 0;
+        // the spans of this block's buckets: one read up front, so that a prefetch is ONE memory round trip (keys)
+        for (int64_t j = threadIdx.x, fbn = blockIdx.x + (int64_t)threadIdx.x * gridDim.x; j < C2L_MAXB && fbn < n_fine;
+             j += C2_COUNT_THREADS, fbn += (int64_t)C2_COUNT_THREADS * gridDim.x)
+            s_span[j] = span[fbn];
+    }
+    __syncthreads();
+    uint2 pf[C2L_DEPTH][C2L_PF];
+    unsigned long long p_lo[C2L_DEPTH], p_hi[C2L_DEPTH];
+    auto issue = [&](int d, int64_t fbn, int64_t j) {      // d is a constant after unrolling: the arrays live in registers
+        p_lo[d] = p_hi[d] = 0;
+        if (fbn >= n_fine) return;
+        const ulonglong2 sp = s_span[j];
+        p_lo[d] = sp.x;
+        p_hi[d] = sp.y;
+        const unsigned long long a0 = sp.x & ~3ULL;            // whole quads from the aligned address below `first`
+        const unsigned long long nq = (sp.y - a0 + 3ULL) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a0);
+#pragma unroll
+        for (int q = 0; q < C2L_PF; q++) {
+            const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
+            if (i < nq) pf[d][q] = p2[i];
+        }
+    };
+    // f(residual) for the valid keys of quad i of the bucket [lo, hi)
+    auto quad = [&](const uint2 v, unsigned long long i, unsigned long long a0, unsigned long long lo, unsigned long long hi,
+                    auto &&f) {
+        const unsigned long long k0 = a0 + 4ULL * i;
+        if (k0 + 0 >= lo && k0 + 0 < hi) f(v.x & 0xffffu);
+        if (k0 + 1 >= lo && k0 + 1 < hi) f(v.x >> 16);
+        if (k0 + 2 >= lo && k0 + 2 < hi) f(v.y & 0xffffu);
+        if (k0 + 3 >= lo && k0 + 3 < hi) f(v.y >> 16);
+    };
+#pragma unroll
+    for (int d = 0; d < C2L_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
+    int par = 0;
+    int64_t j0 = 0;
+    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L_DEPTH * gridDim.x, j0 += C2L_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < C2L_DEPTH; d++) {
+            const int64_t fb = fb0 + (int64_t)d * gridDim.x;
+            if (fb >= n_fine) break;     // block-uniform
+            const unsigned long long lo = p_lo[d], hi = p_hi[d];
+            const unsigned long long a0 = lo & ~3ULL, nq = (hi - a0 + 3ULL) >> 2;
+            const bool in_regs = nq <= (unsigned long long)C2L_PF * C2_COUNT_THREADS;      // block-uniform
+            const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
+            const unsigned long long base = lo / lower;
+            const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a0);
+            auto add = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
+            // ---- pass 1: count
+#pragma unroll
+            for (int q = 0; q < C2L_PF; q++) {
+                const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
+                if (i < nq) quad(pf[d][q], i, a0, lo, hi, add);
+            }
+            if (!in_regs)
+                for (unsigned long long i = threadIdx.x + (unsigned long long)C2L_PF * C2_COUNT_THREADS; i < nq; i += C2_COUNT_THREADS)
+                    quad(p2[i], i, a0, lo, hi, add);
+            sp_barrier_lds();   // (A) counts complete
+            auto emit = [&](uint32_t r, uint32_t c) {
+                if (c >= lower) {
+                    s += c;
+                    n++;
+                    const unsigned long long pos = base + atomicAdd(&s_nov[par], 1u);
+                    if (pos < stage_cap) stage[pos] = make_uint2(slot0 + r, c);
+                }
+            };
+            // ---- pass 2: every key swaps its counter for zero; the lane that gets the count back owns the slot
+            if (in_regs) {
+                auto take = [&](uint32_t r) {
+                    const uint32_t c = atomicExch(&cnt[r], 0u);
+                    if (c) emit(r, c);
+                };
+#pragma unroll
+                for (int q = 0; q < C2L_PF; q++) {
+                    const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
+                    if (i < nq) quad(pf[d][q], i, a0, lo, hi, take);
+                }
+            } else {           // a crowded bucket: walk the counters instead of the keys
+                uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+                for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
+                    const uint4 v = c4[i];
+                    if (v.x | v.y | v.z | v.w) {
+                        c4[i] = make_uint4(0, 0, 0, 0);
+                        emit(4 * i + 0, v.x);
+                        emit(4 * i + 1, v.y);
+                        emit(4 * i + 2, v.z);
+                        emit(4 * i + 3, v.w);
+                    }
+                }
+            }
+            if (threadIdx.x == 0) s_nov[par ^ 1] = 0;     // the other parity's tally was read after the previous (B)
+            sp_barrier_lds();   // (B) counters clean, tally final
+            if (threadIdx.x == 0) {
+                seg_cnt[fb] = s_nov[par];
+                seg_base[fb] = (uint32_t)base;
+            }
+            issue(d, fb + (int64_t)C2L_DEPTH * gridDim.x, j0 + d + C2L_DEPTH);
+            par ^= 1;
+        }
+    }
+    unsigned long long ts = sp_block_sum_u64(s, red);
+    unsigned long long tn = sp_block_sum_u64(n, red);
+    if (threadIdx.x == 0) {
+        if (ts) atomicAdd(&out3[0], ts);
+        if (tn) atomicAdd(&out3[1], tn);
+    }
+}
+
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
-                    uint32_t *seg_off, int64_t n_buckets);   // sp_count.hip
+                    uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total);   // sp_count.hip
 int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
-                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets);
+                          const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total);
 
 bool sp_engine2_supported(int64_t nslots) {
     c2_plan p;
@@ -633,13 +775,17 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     uint8_t *hi1 = (uint8_t *)(ws + o_buf1) + lo1_bytes;
     // the unordered overflow pairs live in the level-1 planes (dead once part2 has run); a LIST run stages every
     // kept slot and gets a buffer of its own
+    // (a bucket's segment starts at floor(its first key / L), L = 255 or lower_count: cap_keys / L pairs at most)
     uint2 *ovf_tmp = (uint2 *)(ws + o_buf1);
-    unsigned long long ovf_cap = (unsigned long long)c.len / 4 + 8;   // pairs that fit in the u16 plane (>= len/255 + 16)
+    unsigned long long ovf_cap = (unsigned long long)(lo1_bytes / 8);
+    if (cap_keys / (size_t)(list ? lower : 255) + C2_FINE >= ((size_t)1 << 32))
+        return sp_fail(ctx, SP_EUNSUP, "count engine 2: a chromosome of %lld bases needs 64-bit segment offsets", (long long)c.len);
     if (list) {
-        int rcl = sp_buf_ensure(ctx, ctx->b_ovfw, (list->cap + 16) * 8);
+        const unsigned long long need = (unsigned long long)(cap_keys / (size_t)lower) + C2_FINE + 16;
+        int rcl = sp_buf_ensure(ctx, ctx->b_ovfw, (int64_t)need * 8);
         if (rcl) return rcl;
         ovf_tmp = (uint2 *)ctx->b_ovfw.p;
-        ovf_cap = (unsigned long long)list->cap;
+        ovf_cap = need;
     }
     // zero ghist .. cursor2 in one memset (they are contiguous)
     SP_HIP(ctx, hipMemsetAsync(ws, 0, zero_bytes, ctx->stream));
@@ -672,15 +818,15 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     SP_LAUNCH(ctx, "c2_spans", c2_spans, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, (const unsigned long long *)off_fine,
               (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3);
     if (list) {
-        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
-        SP_LAUNCH(ctx, "c2_count_list", c2_count<true>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
-                  (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, (uint8_t *)nullptr, d_len4, ovf_tmp, ovf_cap, seg_base,
-                  seg_cnt);
+        if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+        SP_LAUNCH(ctx, "c2_count_list", c2_count_list, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
+                  (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
         return sp_ovf_finalize_split(ctx, (unsigned long long *)list->d_keys, list->d_cnts, ovf_tmp, seg_base, seg_cnt, seg_off,
-                                     (int64_t)nf);
+                                     (int64_t)nf, d_len4 + 2);
     }
     SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
     SP_LAUNCH(ctx, "c2_count", c2_count<false>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
               (int64_t)nf, (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
-    return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf);
+    return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf, d_len4 + 2);
 }

@@ -347,6 +347,15 @@ __device__ __forceinline__ uint32_t sp_tab_count(const sp_tabref &t, int64_t loc
 // overflow lists are produced bucket by bucket (2^15 consecutive slots), see sp_count2.hip / sp_count.hip
 #define SP_OVF_SHIFT 15
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it
+// also drains every global load in flight, so a software pipeline that prefetches the next tile's keys across a
+// barrier pays the full memory round trip at that barrier anyway (the list counter of engine 3 spent 2 us per bucket
+// there).  Use where the threads of a block exchange data through LDS only; the compiler still waits (vmcnt) for a
+// prefetched register before its first use.
+__device__ __forceinline__ void sp_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // wave-level inclusive/exclusive helpers (64 lanes)
 __device__ __forceinline__ int sp_lane() { return threadIdx.x & 63; }
 
