@@ -324,7 +324,7 @@ class Context:
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         ptr, cap = self._pinned.get(tag, (None, 0))
-        if n > cap:
+        if n > cap or ptr is None:       # (a request for zero rows still gets a real buffer)
             if ptr:
                 self.L.sp_host_free(self.h, C.c_void_p(ptr))
             p = C.c_void_p()

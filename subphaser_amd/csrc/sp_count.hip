@@ -195,26 +195,17 @@ dump_count(sp_tabref T, int64_t nslots, uint32_t lower, unsigned long long *__re
 // single-block exclusive scan of n u64 values (n up to a few million)
 __global__ void __launch_bounds__(1024)
 scan_excl_u64(unsigned long long *__restrict__ a, int64_t n, unsigned long long *__restrict__ total) {
-    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long wsum[16];
     const int T = 1024;
     int64_t per = (n + T - 1) / T;
     int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per;
+    if (lo > n) lo = n;
     if (hi > n) hi = n;
     unsigned long long s = 0;
     for (int64_t i = lo; i < hi; i++) s += a[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < T; i++) {
-            unsigned long long v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        if (total) *total = run;
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
+    unsigned long long tot;
+    unsigned long long run = sp_block_excl_scan(s, wsum, tot);
+    if (threadIdx.x == 0 && total) *total = tot;
     for (int64_t i = lo; i < hi; i++) {
         unsigned long long v = a[i];
         a[i] = run;

@@ -602,9 +602,362 @@ static int64_t sps_len(sp_ctx *ctx, int c) {
     return ctx->sv_on ? ctx->fv_lengths[(size_t)c] : ctx->chroms[(size_t)c].length_sum;
 }
 
-int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
-                     const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
-                     double min_freq, double max_freq, double ratio) {
+// ------------------------------------------------------------------ list filter: C-way hash join (round 3)
+// The first list filter concatenated the C sorted lists, sorted the concatenation by key with a device-wide library
+// radix sort and evaluated runs of equal keys: ~220 bytes of HBM traffic per list entry (27 ms per wheat-like pass at
+// k = 17, the worst stage of that line).  The lists are sorted already, so the join needs no global sort:
+//   sps_bounds   cuts the key space into 2^rb equal ranges and records where every list crosses every range edge;
+//   sps_join     one workgroup per range: the C segments (a few hundred entries together) go to LDS, an LDS hash
+//                table groups the entries of equal keys (chain per key, owner = the entry of the lowest chromosome),
+//                the owner rebuilds the row and takes the decision (the shared sp_filter_decide).  Fold-passing
+//                totals go to a staging array at the position the range has in the virtual concatenation (closed
+//                form, no atomics); differential rows -- rare -- go to a row staging area handed out in chunks, each
+//                with its rank inside the range (ascending key).  A range with more than JOIN_T entries is worked
+//                off in rounds of key sub-ranges (pivot = the smallest of the lists' (JOIN_T / C)-th pending keys).
+//   sps_place_*  scan of the per-range tallies, then rows / totals move to their final, key-ordered places.
+// The lists are read once (12 B per entry) plus once for the range edges (8 B).
+#define JOIN_T 1024          // entries per round
+#define JOIN_H 2048          // hash slots
+#define JOIN_BLOCK 256
+#define JOIN_CHUNK 256       // rows handed out per grab of the global row cursor
+struct sps_list {
+    const unsigned long long *keys;
+    const uint32_t *cnts;
+    long long n;
+};
+
+__global__ void __launch_bounds__(256)
+sps_bounds(const sps_list *__restrict__ lists, int shift, long long R, uint32_t *__restrict__ bnd /* C x (R + 1) */) {
+    const sps_list L = lists[blockIdx.y];
+    uint32_t *b = bnd + (size_t)blockIdx.y * (size_t)(R + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L.n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = (long long)(L.keys[i] >> shift);
+        const long long rp = i ? (long long)(L.keys[i - 1] >> shift) : -1;
+        for (long long x = rp + 1; x <= r; x++) b[x] = (uint32_t)i;      // first entry at or beyond the edge of range x
+        if (i == L.n - 1)
+            for (long long x = r + 1; x <= R; x++) b[x] = (uint32_t)L.n;
+    }
+}
+
+struct sps_join_args {
+    int C, shift;
+    long long R;
+    sp_fsets F;
+    const sps_list *lists;
+    const uint32_t *bnd;
+    uint32_t *n_rows, *n_hist;            // per range
+    unsigned long long *hist_stage;       // [total]: fold-passing totals of range r from the range's first entry on
+    unsigned long long *row_cursor;       // rows handed out so far (may exceed row_cap: the surplus is not written)
+    unsigned long long row_cap;
+    unsigned long long *row_keys, *row_tot;   // row staging: key (all ones = unused), tot, rank inside the range, counts
+    uint32_t *row_rank, *row_counts;
+    unsigned long long *n_union;
+    const unsigned long long *chrom_sets;     // per chromosome: bit s set if it belongs to non-singleton set number s
+    int screen;                               // the bit masks are usable (<= 64 non-singleton sets)
+};
+
+// ONE WAVE per key range: a range holds ~100 entries, and a 256-thread workgroup per range spent its time in
+// barriers and in single-thread loops over the C lists (77 ms per wheat-like pass at k = 17 -- twice the sort it
+// replaced).  A wave needs no barriers: lane c owns list c's cursor (pivot, share, offsets by shuffles), the entries
+// are spread over the lanes, LDS traffic of one wave is in order.  Keys are held as residuals below the range's
+// common high bits (RT = u32 when 31 bits suffice).
+#define JW_T 256          // entries per round
+#define JW_H 512          // hash slots at most (2 x entries of the round, rounded up to a power of two, are used)
+#define JW_WAVES 4        // waves (= ranges in flight) per workgroup
+#define JW_Q (JW_T / 64)
+#define JW_ROWS 16        // rows a wave decides at a time
+#define JW_FS 64         // set structure held in LDS up to: sets, units, unit members
+#define JW_FU 128
+#define JW_FC 256
+template <typename RT>
+struct jw_lds {
+    RT Kk[JW_T], Hk[JW_H];
+    uint32_t Vv[JW_T], Hhead[JW_H], Hmin[JW_H];
+    uint16_t Nx[JW_T], Sl[JW_T], RL[JW_T], seg_off[SPS_MAXC + 2];
+    uint8_t Ch[JW_T];
+};
+__device__ __forceinline__ void jw_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ T jw_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long jw_min(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x = __shfl_xor(v, o, 64);
+        v = x < v ? x : v;
+    }
+    return v;
+}
+
+template <typename RT>
+__global__ void __launch_bounds__(64 * JW_WAVES)
+sps_join(sps_join_args A) {
+    __shared__ jw_lds<RT> lds[JW_WAVES];
+    extern __shared__ uint32_t jw_rows[];      // [JW_WAVES][JW_ROWS][C]: rows being decided
+    // the set structure the decision walks: in LDS (a chain of dependent look-ups per unit -- from global memory that
+    // is half a microsecond each and was most of this kernel)
+    __shared__ int32_t s_set_off[JW_FS + 1], s_unit_off[JW_FU + 1], s_unit_chrom[JW_FC];
+    __shared__ double s_unit_den[2 * JW_FU];
+    __shared__ unsigned long long s_csets[SPS_MAXC];
+    const int C = A.C, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    jw_lds<RT> &L = lds[w];
+    sp_fsets F = A.F;
+    {
+        const int n_units = A.F.set_off[A.F.n_sets], n_uc = A.F.unit_off[n_units];
+        if (A.F.n_sets <= JW_FS && n_units <= JW_FU && n_uc <= JW_FC) {
+            for (int i = threadIdx.x; i <= A.F.n_sets; i += blockDim.x) s_set_off[i] = A.F.set_off[i];
+            for (int i = threadIdx.x; i <= n_units; i += blockDim.x) s_unit_off[i] = A.F.unit_off[i];
+            for (int i = threadIdx.x; i < n_uc; i += blockDim.x) s_unit_chrom[i] = A.F.unit_chrom[i];
+            for (int i = threadIdx.x; i < n_units; i += blockDim.x) {
+                s_unit_den[i] = A.F.unit_den[i];
+                s_unit_den[n_units + i] = A.F.unit_inv[i];
+            }
+            F.set_off = s_set_off;
+            F.unit_off = s_unit_off;
+            F.unit_chrom = s_unit_chrom;
+            F.unit_den = s_unit_den;
+            F.unit_inv = s_unit_den + n_units;
+        }
+        for (int i = threadIdx.x; i < C; i += blockDim.x) s_csets[i] = A.chrom_sets[i];
+        __syncthreads();
+    }
+    const RT EMPTY = (RT)~(RT)0;
+    const unsigned long long rmask = A.shift >= 64 ? ~0ULL : ((1ULL << A.shift) - 1ULL);
+    const unsigned long long *my_keys = nullptr;
+    const uint32_t *my_cnts = nullptr;
+    if (lane < C) {
+        my_keys = A.lists[lane].keys;
+        my_cnts = A.lists[lane].cnts;
+    }
+    unsigned long long uni = 0, chunk_pos = 0, chunk_end = 0;     // (the chunk state is wave-uniform)
+    const uint32_t per = JW_T / (uint32_t)C;
+    for (long long r = (long long)blockIdx.x * JW_WAVES + w; r < A.R; r += (long long)gridDim.x * JW_WAVES) {
+        uint32_t cur = 0, endp = 0;
+        if (lane < C) {
+            cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r];
+            endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r + 1];
+        }
+        const unsigned long long hist_pos = jw_sum((unsigned long long)cur);   // the range's place in the virtual concatenation
+        const unsigned long long hi_bits = A.shift >= 64 ? 0ULL : ((unsigned long long)r << A.shift);
+        uint32_t rows_before = 0, hist_before = 0;
+        for (;;) {
+            // ---- the round's share of every list: everything, or everything below the pivot key
+            const uint32_t left = endp - cur;
+            unsigned long long pivot = SPS_SENTINEL;
+            if (jw_sum(left) > JW_T) pivot = jw_min((lane < C && left > per) ? my_keys[cur + per] : SPS_SENTINEL);
+            uint32_t take = left;
+            if (pivot != SPS_SENTINEL && lane < C) {     // entries below the pivot: at most `per` (the per-th is >= pivot)
+                const unsigned long long *kk = my_keys + cur;
+                uint32_t lo = 0, hi = left < per ? left : per;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (kk[mid] < pivot) lo = mid + 1;
+                    else hi = mid;
+                }
+                take = lo;
+            }
+            uint32_t incl = take;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += x;
+            }
+            const uint32_t T = __shfl(incl, 63, 64);                 // <= JW_T by construction
+            const bool more = __any(cur + take < endp);
+            if (lane <= C) L.seg_off[lane] = (uint16_t)(lane < C ? incl - take : T);
+            uint32_t Hn = 64;
+            while (Hn < 2 * T) Hn <<= 1;
+            for (uint32_t i = lane; i < Hn; i += 64) {
+                L.Hk[i] = EMPTY;
+                L.Hhead[i] = 0xFFFFu;
+                L.Hmin[i] = 0xFFFFFFFFu;
+            }
+            jw_fence();
+            // ---- load + hash-insert (chain per key; owner = the entry of the lowest chromosome)
+#pragma unroll
+            for (int q = 0; q < JW_Q; q++) {
+                const uint32_t e = lane + 64 * q;
+                int lo = 0, hi = C;       // list of entry e: last c with seg_off[c] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L.seg_off[mid] <= e) lo = mid;
+                    else hi = mid;
+                }
+                const int c = e < T ? lo : 0;
+                const unsigned long long *kp_ = (const unsigned long long *)__shfl((unsigned long long)my_keys, c, 64);
+                const uint32_t *cp_ = (const uint32_t *)__shfl((unsigned long long)my_cnts, c, 64);
+                const uint32_t cur_c = __shfl(cur, c, 64);
+                if (e < T) {
+                    const size_t i = (size_t)cur_c + (e - L.seg_off[c]);
+                    const RT res = (RT)(kp_[i] & rmask);
+                    L.Kk[e] = res;
+                    L.Vv[e] = cp_[i];
+                    L.Ch[e] = (uint8_t)c;
+                    uint32_t h = (uint32_t)sps_mix((uint64_t)res) & (Hn - 1);
+                    for (;;) {
+                        const RT prev = atomicCAS(&L.Hk[h], EMPTY, res);
+                        if (prev == EMPTY || prev == res) break;
+                        h = (h + 1) & (Hn - 1);
+                    }
+                    L.Sl[e] = (uint16_t)h;
+                    L.Nx[e] = (uint16_t)atomicExch(&L.Hhead[h], e);
+                    atomicMin(&L.Hmin[h], ((uint32_t)c << 16) | e);
+                }
+            }
+            jw_fence();
+            // ---- owners rebuild their row and decide
+            bool is_row[JW_Q], is_hist[JW_Q];
+            unsigned long long tots[JW_Q];
+            uint32_t nrow = 0;
+#pragma unroll
+            for (int q = 0; q < JW_Q; q++) {
+                const uint32_t e = lane + 64 * q;
+                is_row[q] = is_hist[q] = false;
+                tots[q] = 0;
+                bool pending = false;      // an owner that passed the screen and still needs the full decision
+                if (e < T && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) {
+                    uni++;
+                    // screen: a set without any count fails the fold test, so a k-mer present in too few non-singleton
+                    // sets to reach `ratio` is rejected exactly as the full decision would (monotone quotient) -- most
+                    // of the union never builds a row
+                    unsigned long long sets = 0, tot = 0;
+                    for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) {
+                        sets |= s_csets[L.Ch[x]];
+                        tot += L.Vv[x];
+                    }
+                    tots[q] = tot;
+                    pending = !A.screen || !((double)__popcll(sets) / (double)F.n_multi < F.ratio);
+                }
+                // the survivors -- a handful per wave -- rebuild their rows in LDS, JW_ROWS of them at a time (a row in
+                // private memory is scratch = global memory: the decision reads it dozens of times)
+                for (unsigned long long pb = __ballot(pending); pb; pb = __ballot(pending)) {
+                    const int slot = __popcll(pb & ((1ULL << lane) - 1ULL));
+                    if (pending && slot < JW_ROWS) {
+                        uint32_t *row = jw_rows + ((size_t)w * JW_ROWS + slot) * (size_t)C;
+                        for (int c = 0; c < C; c++) row[c] = 0;
+                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) row[L.Ch[x]] = L.Vv[x];
+                        sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tots[q], F, is_row[q], is_hist[q]);
+                        pending = false;
+                    }
+                }
+                // fold-passing totals: range start + tally so far + position inside the round (any order)
+                const unsigned long long bh = __ballot(is_hist[q]);
+                if (is_hist[q]) A.hist_stage[hist_pos + hist_before + __popcll(bh & ((1ULL << lane) - 1ULL))] = tots[q];
+                hist_before += (uint32_t)__popcll(bh);
+                const unsigned long long br = __ballot(is_row[q]);
+                if (is_row[q]) L.RL[nrow + __popcll(br & ((1ULL << lane) - 1ULL))] = (uint16_t)e;
+                nrow += (uint32_t)__popcll(br);
+            }
+            if (nrow) {       // rare: rows to the staging area, ranked by key inside the round
+                jw_fence();
+                if (chunk_pos + nrow > chunk_end) {      // wave-uniform
+                    const unsigned long long grab = nrow > JOIN_CHUNK ? nrow : JOIN_CHUNK;
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(A.row_cursor, grab);
+                    chunk_pos = __shfl(got, 0, 64);
+                    chunk_end = chunk_pos + grab;
+                }
+#pragma unroll
+                for (int q = 0; q < JW_Q; q++) {
+                    if (!is_row[q]) continue;
+                    const uint32_t e = lane + 64 * q;
+                    const RT res = L.Kk[e];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.RL[j]] < res;
+                    const unsigned long long pos = chunk_pos + rank;
+                    if (pos < A.row_cap) {
+                        A.row_keys[pos] = hi_bits | (unsigned long long)res;
+                        A.row_tot[pos] = tots[q];
+                        A.row_rank[pos] = rows_before + rank;
+                        uint32_t *out = A.row_counts + pos * (size_t)C;
+                        for (int c = 0; c < C; c++) out[c] = 0;
+                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) out[L.Ch[x]] = L.Vv[x];
+                    }
+                }
+                chunk_pos += nrow;
+                rows_before += nrow;
+            }
+            jw_fence();
+            if (!more) break;
+            cur += take;
+        }
+        if (lane == 0) {
+            A.n_rows[r] = rows_before;
+            A.n_hist[r] = hist_before;
+        }
+    }
+    uni = jw_sum(uni);
+    if (lane == 0 && uni) atomicAdd(A.n_union, uni);
+}
+
+// per-range tallies -> offsets: block sums, one-block scan of the sums, offsets inside every block
+#define TALLY_CHUNK 4096
+__global__ void __launch_bounds__(256)
+sps_tally_sums(const uint32_t *__restrict__ a, long long n, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long red[16];
+    const long long lo = (long long)blockIdx.x * TALLY_CHUNK, hi = lo + TALLY_CHUNK < n ? lo + TALLY_CHUNK : n;
+    unsigned long long v = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) v += a[i];
+    const unsigned long long t = sp_block_sum_u64(v, red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256)
+sps_tally_apply(const uint32_t *__restrict__ a, long long n, const unsigned long long *__restrict__ boff,
+                const unsigned long long *__restrict__ total, unsigned long long *__restrict__ off /* n + 1 */) {
+    __shared__ unsigned long long wsum[16];
+    const long long lo = (long long)blockIdx.x * TALLY_CHUNK, hi = lo + TALLY_CHUNK < n ? lo + TALLY_CHUNK : n;
+    constexpr int PER = TALLY_CHUNK / 256;
+    const long long t0 = lo + (long long)threadIdx.x * PER;
+    unsigned long long s = 0;
+    for (int j = 0; j < PER; j++)
+        if (t0 + j < hi) s += a[t0 + j];
+    unsigned long long tot;
+    unsigned long long run = boff[blockIdx.x] + sp_block_excl_scan(s, wsum, tot);
+    for (int j = 0; j < PER; j++)
+        if (t0 + j < hi) {
+            off[t0 + j] = run;
+            run += a[t0 + j];
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = *total;
+}
+
+// staged rows -> their final places: offset of the row's range + its rank inside the range (ascending key overall)
+__global__ void __launch_bounds__(256)
+sps_place_rows(const unsigned long long *__restrict__ row_keys, const unsigned long long *__restrict__ row_tot,
+               const uint32_t *__restrict__ row_rank, const uint32_t *__restrict__ row_counts, unsigned long long n_staged,
+               int C, int shift, const unsigned long long *__restrict__ row_off, unsigned long long *__restrict__ out_keys,
+               uint32_t *__restrict__ out_counts, unsigned long long *__restrict__ out_tot) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_staged) return;
+    const unsigned long long key = row_keys[i];
+    if (key == SPS_SENTINEL) return;      // the unused tail of a chunk
+    const unsigned long long pos = row_off[key >> shift] + row_rank[i];
+    out_keys[pos] = key;
+    out_tot[pos] = row_tot[i];
+    for (int c = 0; c < C; c++) out_counts[pos * (size_t)C + c] = row_counts[i * (size_t)C + c];
+}
+
+// fold-passing totals of range r: hist_stage[start of the range ..) -> out[hist_off[r] ..)
+__global__ void __launch_bounds__(256)
+sps_place_hist(const unsigned long long *__restrict__ hist_stage, const uint32_t *__restrict__ bnd, int C, long long R,
+               const uint32_t *__restrict__ n_hist, const unsigned long long *__restrict__ hist_off,
+               unsigned long long *__restrict__ out) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const uint32_t m = n_hist[r];
+    if (!m) return;
+    unsigned long long src = 0;
+    for (int c = 0; c < C; c++) src += bnd[(size_t)c * (size_t)(R + 1) + (size_t)r];
+    const unsigned long long dst = hist_off[r];
+    for (uint32_t j = 0; j < m; j++) out[dst + j] = hist_stage[src + j];
+}
+
+static int sps_filter_sort(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+                           const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
+                           double min_freq, double max_freq, double ratio) {
     const int C = sps_C(ctx);
     if (C > SPS_MAXC) return sp_fail(ctx, SP_EUNSUP, "list filter (k > 15, or engine 3): at most %d chromosomes supported (got %d)", SPS_MAXC, C);
     int64_t total = 0;
@@ -704,6 +1057,186 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->filtered = true;
     return SP_OK;
+}
+
+static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+                           const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
+                           double min_freq, double max_freq, double ratio) {
+    const int C = sps_C(ctx);
+    if (C > SPS_MAXC)
+        return sp_fail(ctx, SP_EUNSUP, "list filter (k > 15, or engine 3): at most %d chromosomes supported (got %d)", SPS_MAXC, C);
+    int64_t total = 0, longest = 0;
+    std::vector<sps_list> hl((size_t)C);
+    for (int c = 0; c < C; c++) {
+        hl[(size_t)c] = sps_list{sps_keys(ctx, c), sps_cnts(ctx, c), (long long)sps_n(ctx, c)};
+        total += sps_n(ctx, c);
+        longest = sps_n(ctx, c) > longest ? sps_n(ctx, c) : longest;
+    }
+    ctx->sf_n = total;
+    ctx->n_union = ctx->n_rows = ctx->n_hist = 0;
+    if (total == 0) {
+        ctx->filtered = true;
+        return SP_OK;
+    }
+    if (longest >= (1LL << 32)) return sp_fail(ctx, SP_EUNSUP, "list filter: a list of 2^32 or more k-mers");
+    // key ranges: 2^rb of them, ~100 entries each (one round of one wave)
+    int bits = 2 * ctx->k;
+    if (ctx->list_mode) {
+        bits = 0;
+        while ((1LL << bits) < ctx->nslots) bits++;
+    }
+    if (bits > 64) bits = 64;
+    int rb = 0;
+    while (rb < bits && rb < 23 && ((int64_t)1 << rb) * 96 < total) rb++;
+    const long long R = 1LL << rb;
+    const int shift = bits - rb;
+    const int n_units = set_off[n_sets], n_uc = unit_off[n_units];
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // b_sp_a: list descriptors | range edges | per-range tallies | offsets      b_sp_b: staging of the totals
+    const size_t o_lists = 0, o_bnd = al((size_t)C * sizeof(sps_list)), o_nr = o_bnd + al((size_t)C * (size_t)(R + 1) * 4),
+                 o_nh = o_nr + al((size_t)R * 4), o_roff = o_nh + al((size_t)R * 4), o_hoff = o_roff + al((size_t)(R + 1) * 8),
+                 o_set = o_hoff + al((size_t)(R + 1) * 8), o_uo = o_set + al((size_t)(n_sets + 1) * 4),
+                 o_uc = o_uo + al((size_t)(n_units + 1) * 4), o_den = o_uc + al((size_t)(n_uc + 1) * 4),
+                 o_small = o_den + al((size_t)n_units * 16), o_cs = o_small + 256, o_bs = o_cs + al((size_t)C * 8),
+                 a_bytes = o_bs + 2 * al((size_t)(R / TALLY_CHUNK + 2) * 8);
+    int rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_b, total * 8 + 64);
+    if (rc) return rc;
+    char *A0 = (char *)ctx->b_sp_a.p;
+    const sps_list *d_lists = (const sps_list *)(A0 + o_lists);
+    uint32_t *bnd = (uint32_t *)(A0 + o_bnd), *n_rows = (uint32_t *)(A0 + o_nr), *n_hist = (uint32_t *)(A0 + o_nh);
+    unsigned long long *row_off = (unsigned long long *)(A0 + o_roff), *hist_off = (unsigned long long *)(A0 + o_hoff),
+                       *small = (unsigned long long *)(A0 + o_small);     // [0] union [1] row cursor [2] M [3] H
+    SP_HIP(ctx, hipMemcpyAsync(A0 + o_lists, hl.data(), (size_t)C * sizeof(sps_list), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(A0 + o_set, set_off, (size_t)(n_sets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(A0 + o_uo, unit_off, (size_t)(n_units + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_uc) SP_HIP(ctx, hipMemcpyAsync(A0 + o_uc, unit_chrom, (size_t)n_uc * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(A0 + o_den, den.data(), (size_t)n_units * 16, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(bnd, 0, (size_t)C * (size_t)(R + 1) * 4, ctx->stream));
+    {
+        int64_t gx = (longest + 255) / 256;
+        if (gx > (int64_t)ctx->n_cu * 16) gx = (int64_t)ctx->n_cu * 16;
+        SP_LAUNCH(ctx, "sps_bounds", sps_bounds, dim3((unsigned)(gx > 0 ? gx : 1), (unsigned)C), dim3(256), 0, d_lists, shift, R, bnd);
+    }
+    sps_join_args A;
+    A.C = C;
+    A.shift = shift;
+    A.R = R;
+    A.F.n_sets = n_sets;
+    A.F.n_multi = 0;
+    for (int st = 0; st < n_sets; st++) A.F.n_multi += (set_off[st + 1] - set_off[st]) > 1;
+    A.F.baseline = baseline;
+    A.F.set_off = (const int32_t *)(A0 + o_set);
+    A.F.unit_off = (const int32_t *)(A0 + o_uo);
+    A.F.unit_chrom = (const int32_t *)(A0 + o_uc);
+    A.F.unit_den = (const double *)(A0 + o_den);
+    A.F.unit_inv = A.F.unit_den + n_units;
+    A.F.min_fold = min_fold;
+    A.F.min_freq = min_freq;
+    A.F.max_freq = max_freq;
+    A.F.ratio = ratio;
+    {   // per chromosome: which non-singleton sets it belongs to (screen of sps_join)
+        std::vector<unsigned long long> cs((size_t)C, 0ULL);
+        int ms = 0;
+        for (int st = 0; st < n_sets; st++) {
+            if (set_off[st + 1] - set_off[st] <= 1) continue;
+            if (ms < 64)
+                for (int u = set_off[st]; u < set_off[st + 1]; u++)
+                    for (int j = unit_off[u]; j < unit_off[u + 1]; j++) cs[(size_t)unit_chrom[j]] |= 1ULL << ms;
+            ms++;
+        }
+        A.screen = ms <= 64 ? 1 : 0;
+        SP_HIP(ctx, hipMemcpyAsync(A0 + o_cs, cs.data(), (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));     // cs goes out of scope
+        A.chrom_sets = (const unsigned long long *)(A0 + o_cs);
+    }
+    A.lists = d_lists;
+    A.bnd = bnd;
+    A.n_rows = n_rows;
+    A.n_hist = n_hist;
+    A.hist_stage = (unsigned long long *)ctx->b_sp_b.p;
+    A.row_cursor = small + 1;
+    A.n_union = small;
+    // differential rows are rare (a fraction of a percent of the union on the BASELINE genomes): the staging area holds
+    // total / 16 rows (at least 2^20); if a filter configuration keeps more, the pass is repeated with what it asked for
+    unsigned long long row_cap = (unsigned long long)(total / 16);
+    if (row_cap < (1ULL << 20)) row_cap = (unsigned long long)(total < (1LL << 20) ? total : (1LL << 20));
+    row_cap += (unsigned long long)ctx->n_cu * 16 * JOIN_CHUNK;       // every resident workgroup may strand one chunk
+    unsigned long long h[4] = {0, 0, 0, 0};
+    for (int attempt = 0;; attempt++) {
+        const size_t row_bytes = 8 + 8 + 4 + (size_t)C * 4;
+        rc = sp_buf_ensure(ctx, ctx->b_sp_c, (int64_t)(al(row_cap * 8) * 2 + al(row_cap * 4) + al(row_cap * (size_t)C * 4) + 64));
+        if (rc) return rc;
+        (void)row_bytes;
+        char *S0 = (char *)ctx->b_sp_c.p;
+        A.row_cap = row_cap;
+        A.row_keys = (unsigned long long *)S0;
+        A.row_tot = (unsigned long long *)(S0 + al(row_cap * 8));
+        A.row_rank = (uint32_t *)(S0 + 2 * al(row_cap * 8));
+        A.row_counts = (uint32_t *)(S0 + 2 * al(row_cap * 8) + al(row_cap * 4));
+        SP_HIP(ctx, hipMemsetAsync(A.row_keys, 0xff, row_cap * 8, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(small, 0, 64, ctx->stream));
+        int64_t grid = (R + JW_WAVES - 1) / JW_WAVES;
+        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+        const size_t row_lds = (size_t)JW_WAVES * JW_ROWS * (size_t)C * 4;     // <= 16 KiB
+        if (shift <= 31)
+            SP_LAUNCH(ctx, "sps_join", sps_join<uint32_t>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
+        else
+            SP_LAUNCH(ctx, "sps_join", sps_join<unsigned long long>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
+        const long long nb = (R + TALLY_CHUNK - 1) / TALLY_CHUNK;
+        unsigned long long *bs_r = (unsigned long long *)(A0 + o_bs), *bs_h = bs_r + (R / TALLY_CHUNK + 2);
+        SP_LAUNCH(ctx, "sps_tally_sums", sps_tally_sums, dim3((unsigned)nb), dim3(256), 0, (const uint32_t *)n_rows, R, bs_r);
+        SP_LAUNCH(ctx, "sps_tally_sums", sps_tally_sums, dim3((unsigned)nb), dim3(256), 0, (const uint32_t *)n_hist, R, bs_h);
+        SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, bs_r, (int64_t)nb, small + 2);
+        SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, bs_h, (int64_t)nb, small + 3);
+        SP_LAUNCH(ctx, "sps_tally_apply", sps_tally_apply, dim3((unsigned)nb), dim3(256), 0, (const uint32_t *)n_rows, R,
+                  (const unsigned long long *)bs_r, (const unsigned long long *)(small + 2), row_off);
+        SP_LAUNCH(ctx, "sps_tally_apply", sps_tally_apply, dim3((unsigned)nb), dim3(256), 0, (const uint32_t *)n_hist, R,
+                  (const unsigned long long *)bs_h, (const unsigned long long *)(small + 3), hist_off);
+        SP_HIP(ctx, hipMemcpyAsync(h, small, 32, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[1] <= row_cap) break;
+        if (attempt) return sp_fail(ctx, SP_ESTATE, "list filter: row staging overran twice (%llu > %llu)", h[1], row_cap);
+        row_cap = h[1] + (unsigned long long)ctx->n_cu * 16 * JOIN_CHUNK;
+    }
+    ctx->n_union = (int64_t)h[0];
+    ctx->n_rows = (int64_t)h[2];
+    ctx->n_hist = (int64_t)h[3];
+    const int64_t M = ctx->n_rows, H = ctx->n_hist;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_keys, (M + 1) * 8);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_counts, (M + 1) * (int64_t)C * 4);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_tot, (M + 1) * 8);
+    if (rc) return rc;
+    rc = sp_buf_ensure(ctx, ctx->b_sf_hist, (H + 1) * 8);
+    if (rc) return rc;
+    if (M)
+        SP_LAUNCH(ctx, "sps_place_rows", sps_place_rows, dim3((unsigned)((h[1] + 255) / 256)), dim3(256), 0,
+                  (const unsigned long long *)A.row_keys, (const unsigned long long *)A.row_tot, (const uint32_t *)A.row_rank,
+                  (const uint32_t *)A.row_counts, h[1], C, shift, (const unsigned long long *)row_off,
+                  (unsigned long long *)ctx->b_sf_keys.p, (uint32_t *)ctx->b_sf_counts.p, (unsigned long long *)ctx->b_sf_tot.p);
+    if (H)
+        SP_LAUNCH(ctx, "sps_place_hist", sps_place_hist, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
+                  (const unsigned long long *)A.hist_stage, (const uint32_t *)bnd, C, R, (const uint32_t *)n_hist,
+                  (const unsigned long long *)hist_off, (unsigned long long *)ctx->b_sf_hist.p);
+    if (M && ctx->list_mode)
+        SP_LAUNCH(ctx, "sps_slots_to_keys", sps_slots_to_keys, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                  (unsigned long long *)ctx->b_sf_keys.p, M, sp_make_kparams(ctx->k));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->filtered = true;
+    return SP_OK;
+}
+
+// SP_LIST_FILTER=sort selects the first implementation (concatenate + library radix sort), kept as a cross-check
+int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
+                     const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
+                     double min_freq, double max_freq, double ratio) {
+    const char *e = getenv("SP_LIST_FILTER");
+    if (e && !strcmp(e, "sort"))
+        return sps_filter_sort(ctx, n_sets, set_off, unit_off, unit_chrom, den, min_fold, baseline, min_freq, max_freq, ratio);
+    return sps_filter_join(ctx, n_sets, set_off, unit_off, unit_chrom, den, min_fold, baseline, min_freq, max_freq, ratio);
 }
 
 int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot) {
