@@ -191,6 +191,14 @@ int sp_stack_windows_dev(sp_ctx *ctx, int64_t bin_size, int64_t chunk_size, int6
  * counts: n_feat x n_sg int64 (whole-feature totals).                      */
 int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64_t n_feat,
                     int64_t *counts);
+/* interval mode: BED-style features over the RESIDENT genome -- what `-custom_features` (__main__.py:509-517;
+ * Seqs.map_kmer3(chunk=False), Seqs.py:228-244) computes from a FASTA of the feature sequences, without uploading
+ * sequence that is already in HBM.  counts[i * n_sg + sg] = number of k-mer starts s with start[i] <= s and
+ * s + k <= end[i] on chromosome chrom[i] whose canonical k-mer is labelled sg (0-based, half-open like BED).
+ * Intervals may overlap or nest.  A labelled k-mer counts as "seen" (sp_labels_hit) only where some interval
+ * contains it -- the same k-mers a FASTA of the features would contain.                                   */
+int sp_map_intervals(sp_ctx *ctx, const int32_t *chrom, const int64_t *start, const int64_t *end, int64_t n,
+                     int64_t *counts);
 /* number of distinct labelled k-mers seen by sp_map_bins/sp_map_features since
  * sp_labels_set (the reference's "mapped kmers" log line, Seqs.py:109-117)  */
 int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit);
@@ -300,11 +308,13 @@ int sp_text_repr(const double *x, int64_t n, char *out, int64_t *off);
  *   SP_COL_STR   data = char blob, off[M + 1]: the string of row i is data[off[i] .. off[i + 1])
  *   SP_COL_I64   data = int64 [M x width], printed in decimal, joined by `join`
  *   SP_COL_F64   data = double [M x width], printed as Python's repr(), joined by `join`
- *   SP_COL_NAME  data = int32 [M] indices into `names` (`width` strings; string j = names[off[j] .. off[j + 1])) */
+ *   SP_COL_NAME  data = int32 [M] indices into `names` (`width` strings; string j = names[off[j] .. off[j + 1]))
+ *   SP_COL_IVAL  data = int64 [M x 3] (name index, start, end), printed `name:start-end` (ids of BED intervals) */
 #define SP_COL_STR 0
 #define SP_COL_I64 1
 #define SP_COL_F64 2
 #define SP_COL_NAME 3
+#define SP_COL_IVAL 4
 typedef struct sp_text_col {
     int kind;
     int width;

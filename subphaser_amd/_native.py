@@ -22,7 +22,7 @@ SYMBOLS = [
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
     "sp_count", "sp_count_range", "sp_count_recounts", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_async", "sp_filter_fetch_wait", "sp_filter_fetch_device", "sp_filter_hist",
-    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_labels_hit",
+    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_map_intervals", "sp_labels_hit",
     "sp_enrich", "sp_enrich_dev", "sp_kmer_ttest",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
@@ -90,6 +90,7 @@ def load():
     L.sp_stack_windows_dev.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
     L.sp_stack_enrich.argtypes = [vp, i64, i64, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp]
     L.sp_map_features.argtypes = [vp, vp, vp, i64, vp]
+    L.sp_map_intervals.argtypes = [vp, vp, vp, vp, i64, vp]
     L.sp_host_alloc.argtypes = [vp, i64, P(vp)]
     L.sp_host_free.argtypes = [vp, vp]
     L.sp_labels_hit.argtypes = [vp, P(i64)]
@@ -234,7 +235,8 @@ def str_blob(strings):
 
 def text_table(fout, n_rows, cols):
     """Tab-separated rows through the library's threaded writer (sp_text_table).  cols: list of
-    ("str", blob, off) | ("i64", array [n x w], join) | ("f64", array [n x w], join) | ("name", idx int32 [n], names).
+    ("str", blob, off) | ("i64", array [n x w], join) | ("f64", array [n x w], join) | ("name", idx int32 [n], names)
+    | ("ival", int64 [n x 3] = name index, start, end, names).
     Returns False when fout has no file descriptor (the caller formats in Python then)."""
     fd = _fd_of(fout)
     if fd is None:
@@ -252,6 +254,11 @@ def text_table(fout, n_rows, cols):
             a = np.ascontiguousarray(col[1], np.int64 if kind == "i64" else np.float64).reshape(n_rows, -1)
             c.kind, c.width, c.join, c.data = (1 if kind == "i64" else 2), max(1, a.shape[1]), col[2].encode(), a.ctypes.data
             keep.append(a)
+        elif kind == "ival":      # (name index, start, end) rows printed `name:start-end`
+            a = np.ascontiguousarray(col[1], np.int64).reshape(n_rows, 3)
+            blob, off = str_blob(col[2])
+            c.kind, c.width, c.join, c.data, c.off, c.names = 4, len(col[2]), b"\t", a.ctypes.data, off.ctypes.data, blob.ctypes.data
+            keep += [a, blob, off]
         elif kind == "name":
             idx = np.ascontiguousarray(col[1], np.int32)
             blob, off = str_blob(col[2])
@@ -664,6 +671,18 @@ class Context:
         n = off.size - 1
         out = np.zeros((n, self.n_sg), np.int64)
         self._ck(self.L.sp_map_features(self.h, _p(cat), _p(off), n, _p(out)))
+        return out
+
+    def map_intervals(self, chrom, start, end):
+        """BED-style intervals over the resident genome: int64 [n, n_sg] counts of labelled k-mer starts s with
+        start <= s and s + k <= end on chromosome index chrom (0-based, half-open) -- sp_map_features' totals for the
+        same sub-sequences, without uploading them."""
+        chrom = np.ascontiguousarray(chrom, np.int32)
+        start = np.ascontiguousarray(start, np.int64)
+        end = np.ascontiguousarray(end, np.int64)
+        assert chrom.size == start.size == end.size
+        out = np.zeros((chrom.size, self.n_sg), np.int64)
+        self._ck(self.L.sp_map_intervals(self.h, _p(chrom), _p(start), _p(end), chrom.size, _p(out)))
         return out
 
     def labels_hit(self):

@@ -137,7 +137,7 @@ struct sp_ctx {
     sp_buf b_wtab, b_enr;   // window table (device) and the enrichment outputs
     sp_buf b_fq;      // global slow queue of the filter
     sp_buf b_fflat;   // flat set tables of the filter (sp_filter.hip)
-    sp_buf b_map, b_mapdesc, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
+    sp_buf b_map, b_mapdesc, b_ival, b_emit, b_fpar, b_win;  // reusable device buffers of sp_map_bins / k3_emit / sp_filter / stack
     bool map_all_valid = false;
     // profiling
     bool prof = false;

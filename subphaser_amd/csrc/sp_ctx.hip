@@ -141,6 +141,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_mapdesc);
+    sp_buf_free(ctx->b_ival);
     sp_buf_free(ctx->b_ptab);
     sp_buf_free(ctx->b_tab32);
     sp_buf_free(ctx->b_ovfw);

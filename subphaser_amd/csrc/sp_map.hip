@@ -410,6 +410,103 @@ k5_map_feat_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm
     }
 }
 
+// ----------------------------------------------------------------- interval mode (BED features over the resident genome)
+// The reference maps `-custom_features` as a FASTA of feature sequences (__main__.py:509-517, Seqs.py:228-244): at
+// wheat scale that is 10 Gb of sequence that is already resident in HBM as the genome.  Intervals need no upload:
+//   kv_cover    marks every k-mer start that lies, with its whole k-mer, inside at least one interval (1 bit per start);
+//   k5_map_mask the usual scan, restricted to covered starts: one 64-bit mask per (unit of 64 starts, subgenome) --
+//               bit j = start 64 u + j carries a k-mer of that subgenome; labelled k-mers are marked "seen" only at
+//               covered starts, exactly the k-mers a feature FASTA would contain;
+//   kv_count    one wave per interval: popcounts of the masks over its units (edge units masked) -> counts[i][sg].
+// Overlapping and nested intervals cost nothing extra, every interval reads only its own units.
+__global__ void __launch_bounds__(256)
+kv_cover(const int32_t *__restrict__ chrom, const int64_t *__restrict__ start, const int64_t *__restrict__ end, int64_t n,
+         int k, const int64_t *__restrict__ ubase /* first unit of every chromosome */, unsigned long long *__restrict__ cov) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wv; i < n; i += nw) {
+        const int64_t a = start[i], b = end[i] - k + 1;     // starts [a, b)
+        if (b <= a) continue;
+        unsigned long long *cw = cov + ubase[chrom[i]];
+        const int64_t u0 = a >> 6, u1 = (b - 1) >> 6;
+        for (int64_t u = u0 + lane; u <= u1; u += 64) {
+            unsigned long long m = ~0ULL;
+            if (u == u0) m &= ~0ULL << (a & 63);
+            if (u == u1 && (b & 63)) m &= (1ULL << (b & 63)) - 1ULL;
+            if (m == ~0ULL) {
+                if (cw[u] != ~0ULL) cw[u] = ~0ULL;     // (plain store of all ones: idempotent, races are benign)
+            } else {
+                atomicOr(&cw[u], m);
+            }
+        }
+    }
+}
+
+template <int ENGINE /* 0 = pair table, 1 = label table */>
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_mask(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+            sp_kparams32 kp, int64_t n_units, int S, uint32_t *__restrict__ ptab, uint8_t *__restrict__ label,
+            const uint32_t *__restrict__ bloom, int bloom_bits, const unsigned long long *__restrict__ cov,
+            unsigned long long *__restrict__ masks /* n_units x S */) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        const unsigned long long cv = cov[u];
+        if (__all(cv == 0ULL)) continue;         // nothing of this wave's 4096 starts lies in a feature
+        if (ENGINE == 0) {
+            unsigned long long m[MAP_PAIR_MAX_SG] = {0, 0, 0, 0, 0, 0, 0};
+            auto hit = [&](int64_t start, int sg) {
+                const unsigned long long bit = 1ULL << (start & 63);
+                if (!(cv & bit)) return false;
+#pragma unroll
+                for (int j = 0; j < MAP_PAIR_MAX_SG; j++) m[j] |= (j == sg) ? bit : 0ULL;
+                return true;
+            };
+            map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+#pragma unroll
+            for (int j = 0; j < MAP_PAIR_MAX_SG; j++)
+                if (j < S) masks[u * S + j] = m[j];
+        } else {
+            map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+                const unsigned long long bit = 1ULL << (start & 63);
+                if (!(cv & bit)) return;
+                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+                const uint32_t l = label[slot];
+                if (l) {
+                    if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
+                    atomicOr(&masks[u * S + ((int)(l & 0x7fu) - 1)], bit);
+                }
+            });
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+kv_count(const int32_t *__restrict__ chrom, const int64_t *__restrict__ start, const int64_t *__restrict__ end, int64_t n,
+         int k, int S, const int64_t *__restrict__ ubase, const unsigned long long *__restrict__ masks,
+         unsigned long long *__restrict__ counts /* n x S */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wv; i < n; i += nw) {
+        const int64_t a = start[i], b = end[i] - k + 1;
+        const int64_t u0 = a >> 6, u1 = b > a ? (b - 1) >> 6 : u0 - 1;
+        const unsigned long long *mk = masks + ubase[chrom[i]] * S;
+        for (int sg = 0; sg < S; sg++) {
+            unsigned long long c = 0;
+            for (int64_t u = u0 + lane; u <= u1; u += 64) {
+                unsigned long long m = mk[u * S + sg];
+                if (u == u0) m &= ~0ULL << (a & 63);
+                if (u == u1 && (b & 63)) m &= (1ULL << (b & 63)) - 1ULL;
+                c += __popcll(m);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0) counts[i * S + sg] = c;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k4_count_seen(const uint8_t *__restrict__ label, int64_t nslots, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long red[16];
@@ -443,6 +540,8 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
 int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units,
                           const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts);
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n);
+int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, const unsigned long long *d_cov,
+                          unsigned long long *d_masks);
 
 // Build the pair filter over the labelled keys (device array, canonical 2-bit keys) at the smallest
 // size whose fill stays below MAP_FILL_MAX.  Shared by the dense and the sparse label paths.
@@ -813,6 +912,72 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
                       S, ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_counts.p);
     }
     SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n_feat * S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int sp_map_intervals(sp_ctx *ctx, const int32_t *chrom, const int64_t *start, const int64_t *end, int64_t n,
+                     int64_t *counts) {
+    if (!ctx || n < 0 || (n > 0 && (!chrom || !start || !end || !counts)))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_intervals: bad arguments");
+    if (!(ctx->sparse_mode ? ctx->d_hkeys != nullptr : ctx->labels_ready))
+        return sp_fail(ctx, SP_EINVAL, "sp_map_intervals: call sp_labels_set first");
+    const int C = (int)ctx->chroms.size(), S = ctx->n_sg, k = ctx->k;
+    for (int64_t i = 0; i < n; i++) {
+        if (chrom[i] < 0 || chrom[i] >= C) return sp_fail(ctx, SP_EINVAL, "sp_map_intervals: interval %lld: chromosome %d out of range", (long long)i, chrom[i]);
+        if (start[i] < 0 || end[i] < start[i] || end[i] > ctx->chroms[(size_t)chrom[i]].len)
+            return sp_fail(ctx, SP_EINVAL, "sp_map_intervals: interval %lld = [%lld, %lld) outside chromosome %d (%lld bases)",
+                           (long long)i, (long long)start[i], (long long)end[i], chrom[i], (long long)ctx->chroms[(size_t)chrom[i]].len);
+    }
+    if (n == 0) return SP_OK;
+    SP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int64_t> ubase((size_t)C + 1, 0);
+    for (int c = 0; c < C; c++) ubase[(size_t)c + 1] = ubase[(size_t)c] + (ctx->chroms[(size_t)c].len + SP_UNIT - 1) / SP_UNIT + 1;
+    const int64_t total_units = ubase[(size_t)C];
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_cov = 0, o_masks = al((size_t)total_units * 8), o_ub = o_masks + al((size_t)total_units * S * 8),
+                 o_ch = o_ub + al((size_t)(C + 1) * 8), o_st = o_ch + al((size_t)n * 4), o_en = o_st + al((size_t)n * 8),
+                 o_cnt = o_en + al((size_t)n * 8), bytes = o_cnt + al((size_t)n * S * 8);
+    int rc = sp_buf_ensure(ctx, ctx->b_ival, (int64_t)bytes);
+    if (rc) return rc;
+    char *B = (char *)ctx->b_ival.p;
+    unsigned long long *d_cov = (unsigned long long *)(B + o_cov), *d_masks = (unsigned long long *)(B + o_masks),
+                       *d_counts = (unsigned long long *)(B + o_cnt);
+    int64_t *d_ub = (int64_t *)(B + o_ub), *d_st = (int64_t *)(B + o_st), *d_en = (int64_t *)(B + o_en);
+    int32_t *d_ch = (int32_t *)(B + o_ch);
+    SP_HIP(ctx, hipMemsetAsync(B, 0, o_ub, ctx->stream));      // coverage + masks
+    SP_HIP(ctx, hipMemcpyAsync(d_ub, ubase.data(), (size_t)(C + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_ch, chrom, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_st, start, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_en, end, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int64_t gw = (n + 3) / 4;       // four intervals (waves) per block
+    if (gw > (int64_t)ctx->n_cu * 32) gw = (int64_t)ctx->n_cu * 32;
+    SP_LAUNCH(ctx, "kv_cover", kv_cover, dim3((unsigned)gw), dim3(256), 0, (const int32_t *)d_ch, (const int64_t *)d_st,
+              (const int64_t *)d_en, n, k, (const int64_t *)d_ub, d_cov);
+    for (int c = 0; c < C; c++) {
+        sp_chrom &ch = ctx->chroms[(size_t)c];
+        const int64_t n_units = (ch.len + SP_UNIT - 1) / SP_UNIT;
+        if (n_units == 0) continue;
+        if (ctx->sparse_mode) {
+            int rcs = sp_sparse_mask_launch(ctx, ch, n_units, S, d_cov + ubase[(size_t)c], d_masks + ubase[(size_t)c] * S);
+            if (rcs) return rcs;
+            continue;
+        }
+        const sp_kparams32 kp = sp_make_kparams32(k);
+        int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+        if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
+        if (ctx->map_engine == 0)
+            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
+                      n_units, S, (uint32_t *)ctx->b_ptab.p, (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
+        else
+            SP_LAUNCH(ctx, "k5_map_mask_lab", k5_map_mask<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm,
+                      kp, n_units, S, (uint32_t *)nullptr, ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
+    }
+    SP_LAUNCH(ctx, "kv_count", kv_count, dim3((unsigned)gw), dim3(256), 0, (const int32_t *)d_ch, (const int64_t *)d_st,
+              (const int64_t *)d_en, n, k, S, (const int64_t *)d_ub, (const unsigned long long *)d_masks, d_counts);
+    SP_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)n * S * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }

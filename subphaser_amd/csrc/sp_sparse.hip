@@ -1335,6 +1335,50 @@ int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_n
     return SP_OK;
 }
 
+// interval mode (sp_map.hip: kv_cover / kv_count): the k > 15 scan that fills the per-unit subgenome masks
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_mask_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units, int S,
+                   unsigned long long *__restrict__ htab, uint64_t mask, const uint32_t *__restrict__ bloom, int bloom_bits,
+                   const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks, int pairs) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        const unsigned long long cv = cov[u];
+        if (__all(cv == 0ULL)) continue;
+        if (pairs) {
+            unsigned long long m[MAP_PAIR_MAX_SG] = {0, 0, 0, 0, 0, 0, 0};
+            map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
+                const unsigned long long bit = 1ULL << (start & 63);
+                if (!(cv & bit)) return false;
+#pragma unroll
+                for (int j = 0; j < MAP_PAIR_MAX_SG; j++) m[j] |= (j == sg) ? bit : 0ULL;
+                return true;
+            });
+#pragma unroll
+            for (int j = 0; j < MAP_PAIR_MAX_SG; j++)
+                if (j < S) masks[u * S + j] = m[j];
+        } else {
+            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                const unsigned long long bit = 1ULL << (start & 63);
+                if (!(cv & bit)) return;
+                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+                if (sg >= 0) atomicOr(&masks[u * S + sg], bit);
+            });
+        }
+    }
+}
+
+int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, const unsigned long long *d_cov,
+                          unsigned long long *d_masks) {
+    const sp_kparams kp = sp_make_kparams(ctx->k);
+    int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
+              (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1),
+              (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks, ctx->map_engine == 0 ? 1 : 0);
+    return SP_OK;
+}
+
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
     if (ctx->map_engine == 0) {
         if (ctx->n_labels > 0)

@@ -191,8 +191,14 @@ extern "C" int sp_text_table(const sp_text_col *cols, int n_cols, int64_t M, int
     if (M < 0 || n_cols < 1 || !cols) return SP_EINVAL;
     for (int c = 0; c < n_cols; c++) {
         const sp_text_col &q = cols[c];
-        if (q.kind < SP_COL_STR || q.kind > SP_COL_NAME || (M > 0 && !q.data)) return SP_EINVAL;
-        if ((q.kind == SP_COL_STR || q.kind == SP_COL_NAME) && !q.off) return SP_EINVAL;
+        if (q.kind < SP_COL_STR || q.kind > SP_COL_IVAL || (M > 0 && !q.data)) return SP_EINVAL;
+        if ((q.kind == SP_COL_STR || q.kind == SP_COL_NAME || q.kind == SP_COL_IVAL) && !q.off) return SP_EINVAL;
+        if (q.kind == SP_COL_IVAL) {
+            if (!q.names || q.width < 1) return SP_EINVAL;
+            const int64_t *iv = (const int64_t *)q.data;
+            for (int64_t i = 0; i < M; i++)
+                if (iv[3 * i] < 0 || iv[3 * i] >= q.width) return SP_EINVAL;
+        }
         if ((q.kind == SP_COL_I64 || q.kind == SP_COL_F64) && q.width < 1) return SP_EINVAL;
         if (q.kind == SP_COL_NAME) {
             if (!q.names || q.width < 1) return SP_EINVAL;
@@ -216,6 +222,17 @@ extern "C" int sp_text_table(const sp_text_col *cols, int n_cols, int64_t M, int
                 case SP_COL_NAME: {
                     const int32_t j = ((const int32_t *)q.data)[i];
                     b.append(q.names + q.off[j], (size_t)(q.off[j + 1] - q.off[j]));
+                    break;
+                }
+                case SP_COL_IVAL: {      // name:start-end
+                    const int64_t *iv = (const int64_t *)q.data + 3 * i;
+                    b.append(q.names + q.off[iv[0]], (size_t)(q.off[iv[0] + 1] - q.off[iv[0]]));
+                    b.push_back(':');
+                    auto r1 = std::to_chars(tmp, tmp + sizeof tmp, (long long)iv[1]);
+                    b.append(tmp, (size_t)(r1.ptr - tmp));
+                    b.push_back('-');
+                    auto r2 = std::to_chars(tmp, tmp + sizeof tmp, (long long)iv[2]);
+                    b.append(tmp, (size_t)(r2.ptr - tmp));
                     break;
                 }
                 case SP_COL_I64: {

@@ -10,6 +10,7 @@ and the Fisher tests -- `.subgenome.bin.count` is written FROM the device arrays
 parsed back (the reference re-reads it with Circos.stack_matrix before it can enrich).
 """
 import argparse
+import io
 import os
 import pickle
 import shutil
@@ -43,7 +44,11 @@ CLI = [
         (("-target",), dict(type=str, metavar="FILE", default=None)),
         (("-sg_assigned",), dict(type=str, metavar="FILE", default=None)),
         (("-sep",), dict(type=str, metavar="STR", default="|")),
-        (("-custom_features",), dict(nargs="+", metavar="FASTA", default=None)),
+        (("-custom_features",), dict(nargs="+", metavar="FASTA|BED", default=None,
+                                     help="feature sets to test for subgenome enrichment: FASTA files of feature sequences "
+                                          "(ids chrom:start-end, as the reference takes them) and / or BED files of "
+                                          "intervals on the target chromosomes (reduced over the resident genome: no "
+                                          "sequence is uploaded)")),
     ]),
     ("Output", None, [
         (("-pre", "-prefix"), dict(dest="prefix", metavar="STR", default=None)),
@@ -216,6 +221,7 @@ class Pipeline:
                 defer=True)
             self._background.append(("chromosome files", waiting.wait,
                                      lambda: mk_ckp(ckp, chromfiles, labels, d_targets, d_size)))
+        self.d_targets = dict(d_targets)      # ids as they are in the input -> labels (BED files may use either)
         # config order, not file order
         where = dict(zip(labels, chromfiles))
         labels = [lab for lab in d_targets.values() if lab in where]
@@ -394,19 +400,46 @@ class Pipeline:
         feat_map = lay.out("custom.bin.count")
         logger.info("feature sets: {}".format(self.custom_features))
         lines = []       # the written lines as arrays: `custom.bin.count` is an output, nothing below parses it back
+        ivals = []       # BED feature sets: (IntervalRows, counts) per file, one row per feature
+        beds = [f for f in self.custom_features if seqs.is_bed(f)]
+        fastas = [f for f in self.custom_features if f not in beds]
         with open(feat_map, "w") as fout:
-            seqs.map_kmer3(self.custom_features, kmer_labels, fout=fout, k=self.k, bin_size=FEATURE_BIN,
-                           sg_names=cl.sg_names, chunk=False, log=False, collect=lines)
+            if fastas or not beds:
+                seqs.map_kmer3(fastas, kmer_labels, fout=fout, k=self.k, bin_size=FEATURE_BIN,
+                               sg_names=cl.sg_names, chunk=False, log=False, collect=lines)
+            if beds:
+                # intervals: a reduction over the genome the GPU already holds; ids are synthesised as chrom:start-end
+                # (what enrich_ltr's id rule expects); BED names may be the ids before or after renaming
+                if fastas:
+                    sub = io.StringIO()
+                    seqs.map_intervals(beds, kmer_labels, {lab: i for i, lab in enumerate(self.labels)}, fout=sub, k=self.k,
+                                       bin_size=FEATURE_BIN, sg_names=cl.sg_names, collect=ivals,
+                                       aliases=dict(getattr(self, "d_targets", None) or {}))
+                    fout.write(sub.getvalue().split("\n", 1)[1])      # one header line per file
+                else:
+                    seqs.map_intervals(beds, kmer_labels, {lab: i for i, lab in enumerate(self.labels)}, fout=fout, k=self.k,
+                                       bin_size=FEATURE_BIN, sg_names=cl.sg_names, collect=ivals,
+                                       aliases=dict(getattr(self, "d_targets", None) or {}))
         logger.info("feature enrichment")
-        names, code = circos.factorize_first([x for part in lines for x in part[0]])
-        ids, counts = circos.stack_arrays(
-            names, code, np.concatenate([part[1] for part in lines]) if lines else np.zeros(0, np.int64),
-            np.concatenate([part[2] for part in lines], axis=0) if lines else np.zeros((0, len(cl.sg_names)), np.int64),
-            window_size=100000000)
+        S = len(cl.sg_names)
+        ids, counts = [], []
+        if lines:
+            names, code = circos.factorize_first([x for part in lines for x in part[0]])
+            ids, counts = circos.stack_arrays(names, code, np.concatenate([part[1] for part in lines]),
+                                              np.concatenate([part[2] for part in lines], axis=0), window_size=100000000)
         feat_enrich = lay.out("custom.enrich")
         with open(feat_enrich, "w") as fout:
-            enriched, _ = stats.enrich_ltr(fout, cl.d_sg, counts, colnames=cl.sg_names, rownames=ids,
-                                           max_pval=self.max_pval)
+            if ivals and not ids:       # intervals only: rows stay arrays end to end (millions of features)
+                rows = seqs.IntervalRows.concat([p_[0] for p_ in ivals])
+                sg_idx, _ = stats.enrich_ltr(fout, cl.d_sg, np.concatenate([p_[1] for p_ in ivals], axis=0),
+                                             colnames=cl.sg_names, rownames=rows, max_pval=self.max_pval, as_arrays=True)
+                enriched = {i: cl.sg_names[j] for i, j in enumerate(sg_idx.tolist()) if j >= 0}
+            else:
+                for rows, cc in ivals:
+                    ids = list(ids) + [(x, 0, 100000000) for x in rows.ids()]
+                    counts = list(counts) + cc.tolist()
+                enriched, _ = stats.enrich_ltr(fout, cl.d_sg, np.asarray(counts, np.int64).reshape(len(ids), S),
+                                               colnames=cl.sg_names, rownames=ids, max_pval=self.max_pval)
         logger.info("wrote {}".format(feat_enrich))
         logger.info("{} significant subgenome-specific features".format(len(enriched)))
         for sg, n in sorted(Counter(enriched.values()).items()):

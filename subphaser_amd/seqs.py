@@ -525,6 +525,166 @@ def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bi
     return mapped_num
 
 
+def is_bed(path):
+    """a feature set given as BED intervals (chrom, start, end[, name ...]) rather than as a FASTA of sequences"""
+    opener = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    with opener(path, "rt") as fh:
+        for line in fh:
+            if not line.strip() or line.startswith(("#", "track", "browser")):
+                continue
+            if line.startswith(">"):
+                return False
+            t = line.split()
+            return len(t) >= 3 and t[1].isdigit() and t[2].isdigit()
+    return False
+
+
+def read_bed(path):
+    """(names list, code int64[n], start int64[n], end int64[n]) of a (gz) BED file -- 0-based, half-open; code[i]
+    indexes names.  Millions of lines: parsed by pandas' C reader when it is importable."""
+    try:
+        import pandas as pd
+        df = pd.read_csv(path, sep=r"\s+", header=None, usecols=[0, 1, 2], comment="#", dtype={0: str, 1: str, 2: str},
+                         engine="c", skip_blank_lines=True, names=["c", "s", "e"])
+        junk = df["c"].str.startswith(("track", "browser"))
+        if junk.any():
+            df = df[~junk]
+        if len(df) and not (df["s"].str.isdigit().all() and df["e"].str.isdigit().all()):
+            bad = df[~(df["s"].str.isdigit() & df["e"].str.isdigit())].iloc[0]
+            raise ValueError("{}: not a BED line: {!r}".format(path, "\t".join(map(str, bad.tolist()))))
+        code, names = pd.factorize(df["c"], sort=False)
+        return list(names), code.astype(np.int64), df["s"].to_numpy().astype(np.int64), df["e"].to_numpy().astype(np.int64)
+    except ImportError:
+        pass
+    opener = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    names, where, code, st, en = [], {}, [], [], []
+    with opener(path, "rt") as fh:
+        for ln, line in enumerate(fh, 1):
+            if not line.strip() or line.startswith(("#", "track", "browser")):
+                continue
+            t = line.split()
+            if len(t) < 3 or not (t[1].isdigit() and t[2].isdigit()):
+                raise ValueError("{}:{}: not a BED line: {!r}".format(path, ln, line.rstrip()))
+            if t[0] not in where:
+                where[t[0]] = len(names)
+                names.append(t[0])
+            code.append(where[t[0]])
+            st.append(int(t[1]))
+            en.append(int(t[2]))
+    return names, np.asarray(code, np.int64), np.asarray(st, np.int64), np.asarray(en, np.int64)
+
+
+class IntervalRows:
+    """The rows of an interval feature set as arrays: row i is `names[code[i]]:start[i]-end[i]`.  Stands in for the
+    list of id strings where millions of ids would only be formatted to be written out again."""
+
+    def __init__(self, names, code, start, end):
+        self.names, self.code = list(names), np.asarray(code, np.int64)
+        self.start, self.end = np.asarray(start, np.int64), np.asarray(end, np.int64)
+
+    def __len__(self):
+        return int(self.code.size)
+
+    def ids(self):
+        return ["%s:%d-%d" % (self.names[c], a, b) for c, a, b in zip(self.code.tolist(), self.start.tolist(), self.end.tolist())]
+
+    def take(self, sel):
+        return IntervalRows(self.names, self.code[sel], self.start[sel], self.end[sel])
+
+    def column(self):
+        """the id column for _native.text_table"""
+        return ("ival", np.stack([self.code, self.start, self.end], axis=1), self.names)
+
+    @staticmethod
+    def concat(parts):
+        names, where, codes = [], {}, []
+        for p_ in parts:
+            remap = np.empty(len(p_.names), np.int64)
+            for j, nm in enumerate(p_.names):
+                if nm not in where:
+                    where[nm] = len(names)
+                    names.append(nm)
+                remap[j] = where[nm]
+            codes.append(remap[p_.code] if len(p_) else p_.code)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)
+        return IntervalRows(names, cat(codes), cat([p_.start for p_ in parts]), cat([p_.end for p_ in parts]))
+
+
+def map_intervals(bedfiles, d_kmers, chrom_index, fout=sys.stdout, k=None, bin_size=10000, sg_names=[], ctx=None,
+                  collect=None, aliases=None):
+    """`-custom_features` given as BED: the intervals are reduced over the genome that is already resident on the GPU
+    (sp_map_intervals) instead of being uploaded as sequence (map_kmer3(chunk=False) on a FASTA of the same
+    sub-sequences writes the same lines, with ids `chrom:start-end`; __main__.py:509-517, Seqs.py:228-244).
+    chrom_index: {chromosome label: index in the context's genome}; aliases: {other name: label} (e.g. the ids
+    before renaming).  Intervals on sequences that are not target chromosomes are skipped, like the records of a
+    feature FASTA that carry no subgenome-specific k-mer.
+    collect: a list that receives, per BED file, (IntervalRows, counts int64 [n, S]) of the features that carry a
+    subgenome-specific k-mer (one row per feature: what stack_matrix makes of the lines)."""
+    ctx = ctx or get_context()
+    labels = _as_labels(d_kmers, sg_names, k)
+    if k is None:
+        k = labels.k
+    sg_names = list(sg_names) if sg_names else labels.sg_names
+    bin_size = int(bin_size)
+    ctx.labels_set(labels.keys, labels.sg_idx, len(sg_names))
+    fout.write("\t".join(["#chrom", "start", "end"] + sg_names) + "\n")
+    aliases = aliases or {}
+    n_seq = mapped_seqs = mapped_num = skipped = 0
+    for bed in bedfiles:
+        names, code, st, en = read_bed(bed)
+        names = [aliases.get(c, c) for c in names]           # chromosome labels from here on (ids, subgenome look-ups)
+        gidx = np.array([chrom_index.get(c, -1) for c in names], np.int64)   # per distinct name
+        idx = gidx[code] if code.size else code
+        keep = np.flatnonzero(idx >= 0)
+        skipped += int(code.size - keep.size)
+        code, idx, st, en = code[keep], idx[keep], st[keep], en[keep]
+        lens = en - st
+        n = int(code.size)
+        if n and bool((lens > bin_size).any()):
+            # a feature longer than one bin is reported per bin, bin j owning the k-mer starts [j * bin, (j + 1) * bin)
+            nb = np.maximum(1, -(-lens // bin_size))
+            piece_of = np.repeat(np.arange(n), nb)
+            j = np.arange(piece_of.size) - np.repeat(np.cumsum(nb) - nb, nb)
+            p_st = st[piece_of] + j * bin_size
+            p_en = np.maximum(np.minimum(p_st + bin_size + (k - 1), en[piece_of]), p_st)
+            pc = ctx.map_intervals(idx[piece_of], p_st, p_en)
+            counts = np.zeros((n, len(sg_names)), np.int64)
+            np.add.at(counts, piece_of, pc)
+            many = nb > 1
+        else:
+            piece_of, j = np.arange(n), np.zeros(n, np.int64)
+            pc = counts = ctx.map_intervals(idx, st, en) if n else np.zeros((0, len(sg_names)), np.int64)
+            many = np.zeros(n, bool)
+        tot = counts.sum(axis=1)
+        n_seq += n
+        mapped_num += int(tot.sum())
+        mapped_seqs += int((tot > 0).sum())
+        feats = IntervalRows(names, code, st, en)
+        rows = np.flatnonzero((tot[piece_of] > 0) & (~many[piece_of] | pc.any(axis=1)))      # the lines, in file order
+        r_feat = piece_of[rows]
+        r_st = (j[rows] * bin_size).astype(np.int64)
+        r_en = np.minimum(r_st + bin_size, lens[r_feat])
+        r_cc = pc[rows]
+        if collect is not None:
+            sel = np.flatnonzero(tot > 0)
+            collect.append((feats.take(sel), counts[sel]))
+        if rows.size and not _native.text_table(fout, rows.size, [feats.take(r_feat).column(), ("i64", r_st, "\t"),
+                                                                  ("i64", r_en, "\t"), ("i64", r_cc, "\t")]):
+            for rid, a, b, cc in zip(feats.take(r_feat).ids(), r_st.tolist(), r_en.tolist(), r_cc.tolist()):
+                fout.write("%s\t%d\t%d\t%s\n" % (rid, a, b, "\t".join(map(str, cc))))
+    logger.info("Processed {} intervals".format(n_seq))
+    if skipped:
+        logger.info("{} intervals lie on sequences that are not target chromosomes: skipped".format(skipped))
+    total = len(labels.keys)
+    if n_seq and total:
+        hit = ctx.labels_hit()
+        logger.info("{} ({:.2%}) intervals contain subgenome-specific kmers".format(mapped_seqs, mapped_seqs / n_seq))
+        logger.info("{:.2%} of {} subgenome-specific kmers are mapped".format(hit / total, total))
+    else:
+        logger.warning("None intervals, please check.")
+    return mapped_num
+
+
 def _write_lines(fout, rid, starts, ends, counts):
     if len(starts) == 0:
         return

@@ -163,11 +163,13 @@ def feature_chroms(ids):
 
 
 def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_ratio=0.5, max_pval=0.05, ctx=None,
-               row_chroms=None, **kargs):
+               row_chroms=None, as_arrays=False, **kargs):
     """Output LTR / custom-feature enrichments (`.ltr.enrich`, `.custom.enrich`; Stats.py:33-73).
     Array code throughout: feature sets have millions of rows (BASELINE config 5); the rows are formatted by the
     library's threaded writer when fout is a real file.  row_chroms: the chromosome of every row when the caller
-    already has it (BED intervals), else it is parsed from the id (`chrom:start-end`)."""
+    already has it, else it is parsed from the id (`chrom:start-end`).  rownames may be a seqs.IntervalRows (BED
+    intervals): the ids are then written straight from its arrays.  as_arrays: return (subgenome index or -1, exchange
+    code) arrays instead of the two {id: ...} dicts."""
     from . import _native
     from .textio import write_chunks
     arr = np.ascontiguousarray(matrix, np.int64)
@@ -186,16 +188,23 @@ def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_rat
     else:
         pvals, argmin, sig, pmin = np.zeros((0, arr.shape[1])), np.zeros(0, np.int64), np.zeros(0, bool), np.zeros(0)
     sig = np.asarray(sig, bool)
-    ids = [r[0] for r in rownames] if n and not isinstance(rownames[0], str) else list(rownames)   # `ltr, *_ = res.rowname`
-    # the reference crashes (AttributeError) on ids that are not chrom:start-end
-    # (Stats.py:42-43); the evident intent is "unknown chromosome"
-    chroms = list(row_chroms) if row_chroms is not None else feature_chroms(ids)
     col_of = {name: j for j, name in enumerate(colnames)}
-    obs_of = {}
-    for c in set(chroms):
+
+    def obs_code(c):
         sg = d_sg.get(c) if c else None
-        obs_of[c] = (col_of.get(sg, len(colnames)) if sg else -1)    # -1: unknown chromosome; len: a name outside colnames
-    obs = np.fromiter((obs_of[c] for c in chroms), np.int64, n)
+        return col_of.get(sg, len(colnames)) if sg else -1    # -1: unknown chromosome; len: a name outside colnames
+    ival = rownames if hasattr(rownames, "column") else None      # seqs.IntervalRows: ids stay arrays
+    if ival is not None:
+        ids = None
+        per_name = np.array([obs_code(c) for c in ival.names], np.int64)
+        obs = per_name[ival.code] if n else np.zeros(0, np.int64)
+    else:
+        ids = [r[0] for r in rownames] if n and not isinstance(rownames[0], str) else list(rownames)   # `ltr, *_ = res.rowname`
+        # the reference crashes (AttributeError) on ids that are not chrom:start-end
+        # (Stats.py:42-43); the evident intent is "unknown chromosome"
+        chroms = list(row_chroms) if row_chroms is not None else feature_chroms(ids)
+        obs_of = {c: obs_code(c) for c in set(chroms)}
+        obs = np.fromiter((obs_of[c] for c in chroms), np.int64, n)
     exp = np.where(sig, argmin, -1)
     # is_exchange(obs, exp): "none" when either side is missing, else "no" / "yes"
     exch_code = np.where((obs < 0) | (exp < 0), 0, np.where(obs == exp, 1, 2)).astype(np.int32)
@@ -209,16 +218,27 @@ def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_rat
     sg_names = colnames + ["None"]
     done = False
     if n:
-        blob, off = _native.str_blob(ids)
-        done = _native.text_table(fout, n, [("str", blob, off), ("name", sg_idx, sg_names), ("f64", pmin, ","),
+        if ival is not None:
+            idcol = ival.column()
+        else:
+            blob, off = _native.str_blob(ids)
+            idcol = ("str", blob, off)
+        done = _native.text_table(fout, n, [idcol, ("name", sg_idx, sg_names), ("f64", pmin, ","),
                                             ("i64", arr, ","), ("name", exch_code, list(_EXCH)), ("f64", qvals, ",")])
     if not done:
+        if ids is None:
+            ids = ival.ids()
+
         def fmt(lo, hi):
             return "".join("%s\t%s\t%s\t%s\t%s\t%s\n" % (ids[i], sg_names[sg_idx[i]], repr(float(pmin[i])),
                                                        ",".join(map(str, arr[i].tolist())), _EXCH[exch_code[i]],
                                                        repr(float(qvals[i])))
                            for i in range(lo, hi))
         write_chunks(fout, n, fmt)
+    if as_arrays:      # millions of rows: (subgenome index or -1, exchange code 0 none / 1 no / 2 yes) instead of two dicts
+        return np.where(sig, argmin, -1), exch_code
+    if ids is None:
+        ids = ival.ids()
     hit = np.flatnonzero(sig)
     d_enriched = {ids[i]: colnames[j] for i, j in zip(hit.tolist(), argmin[hit].tolist())}
     d_exchange = dict(zip(ids, map(_EXCH.__getitem__, exch_code.tolist())))

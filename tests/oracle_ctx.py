@@ -137,6 +137,10 @@ class OracleContext:
         cat = np.asarray(cat, np.uint8)
         return self.map_features([cat[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)])
 
+    def map_intervals(self, chrom, start, end):
+        """sp_map_intervals: the sub-sequences cut out of the resident chromosomes, mapped like features"""
+        return self.map_features([po._ascii(self.seqs[int(c)])[int(a):int(b)] for c, a, b in zip(chrom, start, end)])
+
     def labels_hit(self):
         return int(self.hit.sum())
 

@@ -324,6 +324,51 @@ def check_pipeline_cli(ctx, golden, toy, tmp_path):
     assert (tmpd / "chromosomes" / "A1.fasta").exists()
 
 
+def check_pipeline_cli_bed(ctx, golden, toy, tmp_path):
+    """`-custom_features x.bed`: the features as intervals over the resident genome must give the files the FASTA of
+    the same sub-sequences gives (`.custom.bin.count`, `.custom.enrich` byte for byte), and the `.custom.bin.count`
+    lines must be the reference's (G4) for those features."""
+    import re
+    from subphaser_amd import pipeline, runtime
+    fa = tmp_path / "toy.fa"
+    with open(fa, "w") as f:
+        for lab in toy["labels"]:
+            f.write(">%s\n%s\n" % (lab, toy["seqs"][lab]))
+    cfg = tmp_path / "sg.config"
+    cfg.write_text("\n".join("\t".join(",".join(u) for u in sg) for sg in toy["sgs"]) + "\n")
+    asg = tmp_path / "assigned.tsv"
+    asg.write_text("".join("%s\t%s\n" % kv for kv in toy["sg_assigned"].items()))
+    feats = [(fid, sq) for fid, sq in golden["G4_map_features"]["features"]
+             if re.match(r"(\S+?):(\d+)-(\d+)$", fid) and fid.split(":")[0] in toy["seqs"]]
+    assert len(feats) >= 10
+    ffa, fbed = tmp_path / "features.fa", tmp_path / "features.bed"
+    with open(ffa, "w") as f, open(fbed, "w") as b:
+        b.write("# toy features\ntrack name=toy\n")
+        for fid, sq in feats:
+            c, a, e = re.match(r"(\S+?):(\d+)-(\d+)$", fid).groups()
+            assert toy["seqs"][c][int(a):int(e)] == sq
+            f.write(">%s\n%s\n" % (fid, sq))
+            b.write("%s\t%s\t%s\tfeature_%s\t0\t+\n" % (c, a, e, a))
+        b.write("unplaced_scaffold\t0\t10\n")        # not a target chromosome: skipped
+    res = {}
+    old = runtime._ctx
+    runtime.set_context(ctx)
+    try:
+        for tag, ff in (("fasta", ffa), ("bed", fbed)):
+            out, tmpd = tmp_path / ("out_" + tag), tmp_path / ("tmp_" + tag)
+            pipeline.main(["-i", str(fa), "-c", str(cfg), "-sg_assigned", str(asg), "-q", "30", "-k", str(K), "-o", str(out),
+                           "-tmpdir", str(tmpd), "-window_size", "2500", "-custom_features", str(ff), "-disable_ltr",
+                           "-disable_circos", "-figfmt", "png"])
+            base = out / ("k%d_q30_f2" % K)
+            res[tag] = (open(str(base) + ".custom.bin.count").read(), open(str(base) + ".custom.enrich").read())
+    finally:
+        runtime._ctx = old
+    assert res["bed"][0] == res["fasta"][0]
+    assert res["bed"][1] == res["fasta"][1] and len(res["bed"][1].strip().split("\n")) > 3
+    ref_lines = [l for l in golden["G4_map_features"]["text"].split("\n") if l.split("\t")[0] in dict(feats)]
+    assert res["bed"][0].strip().split("\n")[1:] == ref_lines and len(ref_lines) >= 5
+
+
 def check_long_feature(ctx, golden, toy, tmp_path):
     """A feature longer than the bin size is reported per bin, like a chunk-less chromosome."""
     cl, labels = check_output_kmers(ctx, golden, toy)

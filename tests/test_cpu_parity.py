@@ -166,3 +166,7 @@ def test_circos_tracks_from_bin_counts(golden, tmp_path):
     rf, ef = circos.out_sg_lines(lines, str(tmp_path / "d"))
     assert open(rf).read() == "chrA\t0\t2500\t0.4,0.6\nchrB\t2500\t5000\tnan,nan\n"
     assert open(ef).read() == "chrA\t0\t2500\t1,0,0\nchrB\t2500\t5000\t0,0,1\n"
+
+
+def test_pipeline_cli_bed_features(oracle_ctx, golden, toy, tmp_path):
+    pc.check_pipeline_cli_bed(oracle_ctx, golden, toy, tmp_path)

@@ -648,6 +648,10 @@ def test_pipeline_cli(gpu_ctx, golden, toy, tmp_path, count_engine):
     pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
 
 
+def test_pipeline_cli_bed_features(gpu_ctx, golden, toy, tmp_path):
+    pc.check_pipeline_cli_bed(gpu_ctx, golden, toy, tmp_path)
+
+
 def test_pipeline_cli_background_writers(gpu_ctx, golden, toy, tmp_path, monkeypatch):
     """the same CLI run with every text output forced onto the background writer threads (at toy size they are
     written inline): identical files, checkpoints recorded after the writers"""
@@ -990,9 +994,10 @@ def test_shared_host_segment_copy(gpu_ctx):
         shm.unlink()
 
 
-@pytest.mark.parametrize("k", [15, 17])
-def test_feature_join_at_reduced_scale(gpu_ctx, k):
-    """BASELINE config 5's feature-window join at 1/100 of its size: 20,000 features of U[0.2, 10] kb cut from a
+@pytest.mark.parametrize("k,n_sg", [(15, 2), (17, 2), (21, 2), (15, 9), (17, 9)])
+def test_feature_join_at_reduced_scale(gpu_ctx, k, n_sg):
+    """(k = 21: BASELINE config 5's second k; 9 subgenomes: the label-table / per-k-mer hash engines.)
+    BASELINE config 5's feature-window join at 1/100 of its size: 20,000 features of U[0.2, 10] kb cut from a
     synthetic chromosome (N runs, soft-masked repeats, features that overlap each other), mapped back to back in one
     upload (sp_map_features: k-mers across feature boundaries rejected in the kernel) -- per-feature totals and the
     number of labelled k-mers seen against the oracle, which maps every feature on its own."""
@@ -1010,7 +1015,7 @@ def test_feature_join_at_reduced_scale(gpu_ctx, k):
     gpu_ctx.count(k, 3, 0)
     keys, cnts = gpu_ctx.dump(0)
     sel = np.flatnonzero(cnts >= 40)[::3]                    # labelled: every third k-mer seen >= 40 times
-    lab_keys, lab_sg = keys[sel], (np.arange(sel.size) % 2).astype(np.uint8)
+    lab_keys, lab_sg = keys[sel], (np.arange(sel.size) % n_sg).astype(np.uint8)      # 9 subgenomes: the per-k-mer label engines
     assert lab_keys.size > 1000
     rng = np.random.RandomState(4)
     ln = rng.randint(200, 10001, size=n_feat)
@@ -1018,15 +1023,26 @@ def test_feature_join_at_reduced_scale(gpu_ctx, k):
     st = rng.randint(0, n - 10001, size=n_feat)
     off = np.concatenate(([0], np.cumsum(ln))).astype(np.int64)
     cat = np.concatenate([host[s:s + l] for s, l in zip(st.tolist(), ln.tolist())])
-    gpu_ctx.labels_set(lab_keys, lab_sg, 2)
+    gpu_ctx.labels_set(lab_keys, lab_sg, n_sg)
     got = gpu_ctx.map_features_cat(cat, off)
     octx = OracleContext(nthreads=1)
     octx.k = k
-    octx.labels_set(lab_keys, lab_sg, 2)
+    octx.labels_set(lab_keys, lab_sg, n_sg)
     exp = octx.map_features_cat(cat, off)
     assert got.shape == exp.shape and (got == exp).all()
     assert int(got.sum()) > 10 * n_feat
     assert gpu_ctx.labels_hit() == octx.labels_hit()
+    # the same features as BED intervals over the resident chromosome (sp_map_intervals): no sequence is uploaded;
+    # totals and the set of labelled k-mers seen must equal the FASTA path's
+    gpu_ctx.labels_set(lab_keys, lab_sg, n_sg)
+    iv = gpu_ctx.map_intervals(np.zeros(n_feat, np.int32), st, st + ln)
+    assert iv.shape == exp.shape and (iv == exp).all()
+    assert gpu_ctx.labels_hit() == octx.labels_hit()
+    with pytest.raises(Exception):
+        gpu_ctx.map_intervals([0], [5], [n + 1])            # beyond the chromosome
+    with pytest.raises(Exception):
+        gpu_ctx.map_intervals([1], [0], [10])               # no such chromosome
+    assert gpu_ctx.map_intervals([], [], []).shape == (0, n_sg)
 
 
 def test_kmer_ttest_device_vs_scipy(gpu_ctx):

@@ -41,9 +41,10 @@ print("labels: %d significant k-mers" % len(labels.keys))
 t0 = time.perf_counter()
 rng = np.random.RandomState(4)
 fa = os.path.join(work, "features.fa")
+bed = os.path.join(work, "features.bed")
 per = -(-n_feat // C)
 total_bp = 0
-with open(fa, "wb") as out:
+with open(fa, "wb") as out, open(bed, "wb") as outb:
     for ci, c in enumerate(gen.chroms):
         seq = ctx.dev_to_host(d_ascii[ci], c["length"])
         n = min(per, n_feat - ci * per)
@@ -57,6 +58,7 @@ with open(fa, "wb") as out:
             parts.append(seq[s_:s_ + l_].tobytes())
             parts.append(b"\n")
         out.write(b"".join(parts))
+        outb.write(b"".join(b"%s\t%d\t%d\n" % (c["label"].encode(), s_, s_ + l_) for s_, l_ in zip(st.tolist(), ln.tolist())))
         total_bp += int(ln.sum())
 print("features: %d records, %.2f Gbases, FASTA %.1f MB written in %.1f s"
       % (n_feat, total_bp / 1e9, os.path.getsize(fa) / 1e6, time.perf_counter() - t0))
@@ -81,3 +83,20 @@ print("stack_matrix: %.2f s, %d rows, %d significant" % (t15 - t1, len(bins), le
 print("map_kmer3(chunk=False): %.2f s   stack+enrich_ltr: %.2f s   -> %.3f M features/s, %.3f Gbases/s end to end"
       % (t1 - t0, t2 - t1, n_feat / (t2 - t0) / 1e6, total_bp / (t2 - t0) / 1e9))
 print("outputs: %d + %d bytes" % (os.path.getsize(feat_map), os.path.getsize(os.path.join(work, "custom.enrich"))))
+
+# ---- the same features as BED intervals over the resident genome (sp_map_intervals): no sequence upload
+t0 = time.perf_counter()
+rows_b = []
+with open(os.path.join(work, "custom_bed.bin.count"), "w") as fout:
+    Seqs.map_intervals([bed], labels, {c["label"]: i for i, c in enumerate(gen.chroms)}, fout=fout, k=k, bin_size=10000000,
+                       sg_names=sg_names, ctx=ctx, collect=rows_b)
+t1 = time.perf_counter()
+rows_iv = Seqs.IntervalRows.concat([p_[0] for p_ in rows_b])
+counts_b = np.concatenate([p_[1] for p_ in rows_b], axis=0)
+with open(os.path.join(work, "custom_bed.enrich"), "w") as fout:
+    sg_idx, _ = Stats.enrich_ltr(fout, d_sg, counts_b, colnames=sg_names, rownames=rows_iv, max_pval=0.05, as_arrays=True)
+t2 = time.perf_counter()
+same = len(counts_b) == len(counts) and (np.asarray(counts_b) == np.asarray(counts)).all()
+print("BED intervals: map_intervals %.2f s   enrich_ltr %.2f s   -> %.3f M features/s, %.2f s end to end; %d rows, %d "
+      "significant; per-feature totals equal to the FASTA path: %s"
+      % (t1 - t0, t2 - t1, n_feat / (t2 - t0) / 1e6, t2 - t0, len(rows_iv), int((sg_idx >= 0).sum()), same))
