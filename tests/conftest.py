@@ -23,6 +23,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_k17():
+    """G14: the reference's outputs at k = 17 / 21 (tests/golden/gen_golden_k17.py)"""
+    with gzip.open(os.path.join(HERE, "golden", "golden_k17.json.gz"), "rt") as f:
+        return json.load(f)["G14_shapes_k17_k21"]
+
+
+@pytest.fixture(scope="session")
 def toy():
     from toygenome import make_toy_genome
     return make_toy_genome(seed=7)

@@ -393,12 +393,14 @@ def _sha(txt):
     return hashlib.sha256(txt.encode()).hexdigest()
 
 
-def check_shape(ctx, golden, shape, engine=0):
+def check_shape(ctx, golden, shape, engine=0, k=None, ent=None):
     """Whole path on a toy with the structure of the wheat (21 / 7 x 3), peanut (20 / 10 x 2) or
-    Arabidopsis suecica (13, comma-grouped units) config, against what the imported reference produced."""
+    Arabidopsis suecica (13, comma-grouped units) config, against what the imported reference produced.
+    k / ent: another k-mer length with its own fixture entry (G14: k = 17, 21)."""
     from toygenome import make_shape_genome
+    K = k or globals()["K"]
     tg = make_shape_genome(shape)
-    ent = golden["G10_shapes"][shape]
+    ent = ent or golden["G10_shapes"][shape]
     files = []
     for lab in tg["labels"]:
         path = "/virtual/shape_%s/%s.fasta" % (shape, lab)

@@ -170,3 +170,10 @@ def test_circos_tracks_from_bin_counts(golden, tmp_path):
 
 def test_pipeline_cli_bed_features(oracle_ctx, golden, toy, tmp_path):
     pc.check_pipeline_cli_bed(oracle_ctx, golden, toy, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["wheat_k17", "wheat_k21", "peanut_k17"])
+def test_baseline_shapes_k17_k21(oracle_ctx, golden, golden_k17, name):
+    """G14 pins the oracle (and the host layer) at k = 17 / 21 to the imported reference"""
+    ent = golden_k17[name]
+    pc.check_shape(oracle_ctx, golden, ent["shape"], k=ent["k"], ent=ent)

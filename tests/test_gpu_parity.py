@@ -616,6 +616,15 @@ def test_baseline_shapes(gpu_ctx, golden, shape, engine):
     pc.check_shape(gpu_ctx, golden, shape, engine=engine)
 
 
+@pytest.mark.parametrize("name", ["wheat_k17", "wheat_k21", "peanut_k17"])
+def test_baseline_shapes_k17_k21(gpu_ctx, golden, golden_k17, name):
+    """G14: the same whole-path fixtures, generated by the imported reference at k = 17 and 21 (BASELINE config 5):
+    lists + join filter + hashed pair table against the reference's matrix rows, significant k-mers, `.bin.count`
+    text, windows and enrichment calls."""
+    ent = golden_k17[name]
+    pc.check_shape(gpu_ctx, golden, ent["shape"], k=ent["k"], ent=ent)
+
+
 def test_dump_roundtrip(gpu_ctx, golden, toy, tmp_path, count_engine):
     pc.check_dump_roundtrip(gpu_ctx, golden, toy, tmp_path)
 
@@ -683,6 +692,36 @@ def test_map_vs_oracle_random(gpu_ctx):
     assert (allb[0] == exp).all() and int(nm[0]) == n2
     assert gpu_ctx.labels_hit() == int(hit.sum())
     assert int(got.sum()) == int(cnts[cnts >= 20].astype(np.int64).sum())   # every occurrence mapped once
+
+
+@pytest.mark.parametrize("k,S", [(13, 8), (15, 9), (15, 8), (13, 9)])
+def test_map_label_table_engine_many_subgenomes(gpu_ctx, k, S):
+    """More than 7 subgenomes: the pair table's 3-bit label does not fit, the dense per-k-mer label table
+    (`k5_map_lab`) maps instead.  Bins, n_mapped, labels_hit and the batched entry point against the oracle."""
+    rng = np.random.RandomState(900 + 10 * k + S)
+    unit = _rand_seq(rng, 40, 0, 0)
+    s = np.concatenate([_rand_seq(rng, 120_000), np.tile(unit, 300), _rand_seq(rng, 60_000, p_other=0.05)])
+    s2 = np.concatenate([s[50_000:90_000], _rand_seq(rng, 30_000)])
+    gpu_ctx.genome_reset(2)
+    gpu_ctx.genome_add(0, s)
+    gpu_ctx.genome_add(1, s2)
+    gpu_ctx.count(k, 1, 0)
+    keys, cnts = gpu_ctx.dump(0)
+    sel = keys[(cnts >= 2) | (np.arange(keys.size) % 7 == 0)]       # the repeats + every seventh k-mer
+    assert sel.size > 500
+    sg = (np.arange(sel.size) % S).astype(np.uint8)
+    gpu_ctx.labels_set(sel, sg, S)
+    hit_all = np.zeros(sel.size, bool)
+    for bin_size, chunk in ((10000, 10_000_000), (100, 2000), (333, 1000)):
+        for ci, seq in enumerate((s, s2)):
+            got, n = gpu_ctx.map_bins(ci, bin_size, chunk)
+            exp, hit, n2 = po.map_bins(seq, k, sel, sg, S, bin_size, chunk, nthreads=4)
+            assert got.shape == exp.shape and (got == exp).all() and n == n2, (bin_size, chunk, ci)
+            hit_all |= hit.astype(bool)
+    assert (got.sum(axis=0) > 0).sum() == S          # every subgenome column is exercised
+    allb, nm = gpu_ctx.map_bins_all(333, 1000)
+    assert (allb[1] == exp).all() and int(nm[1]) == n2
+    assert gpu_ctx.labels_hit() == int(hit_all.sum())
 
 
 def test_enrich_bin(gpu_ctx, golden, tmp_path):

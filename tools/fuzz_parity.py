@@ -46,7 +46,7 @@ def run(iters, seed, gpu, ora, verbose=True):
         seqs = [rand_chrom(rng) for _ in range(C)]
         k = int(rng.choice([1, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 19, 21, 24, 27, 31, 32]))
         lower = int(rng.randint(1, 4))
-        engine = int(rng.choice([0, 1, 2])) if k <= 15 else int(rng.choice([0, 1]))
+        engine = int(rng.choice([0, 1, 2, 3])) if k <= 15 else int(rng.choice([0, 1]))      # 3: lists (k >= 9), else falls back
         tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s" % (it, C, k, lower, engine, [len(s) for s in seqs])
         try:
             for ctx in (gpu, ora):
@@ -56,7 +56,7 @@ def run(iters, seed, gpu, ora, verbose=True):
             try:
                 gpu.count(k, lower, engine)
             except ValueError as e:
-                if engine == 2 and "engine" in str(e).lower():
+                if engine in (2, 3) and "engine" in str(e).lower():
                     gpu.count(k, lower, 0)
                 else:
                     raise
@@ -70,7 +70,7 @@ def run(iters, seed, gpu, ora, verbose=True):
             allk = np.unique(np.concatenate([d[0] for d in dumps])) if C else np.empty(0, np.uint64)
             if allk.size:
                 sel = allk[rng.rand(allk.size) < rng.choice([0.02, 0.3, 1.0])]
-                S = int(rng.randint(1, 5))
+                S = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9]))      # > 7: the per-k-mer label engines
                 sg = rng.randint(0, S, size=sel.size).astype(np.uint8)
                 for ctx in (gpu, ora):
                     ctx.labels_set(sel, sg, S)
@@ -81,6 +81,13 @@ def run(iters, seed, gpu, ora, verbose=True):
                 assert gpu.labels_hit() == ora.labels_hit(), "labels_hit"
                 feats = [seqs[rng.randint(0, C)][a:a + int(rng.randint(0, 400))] for a in rng.randint(0, 3000, size=5)]
                 assert (gpu.map_features(feats) == ora.map_features(feats)).all(), "features"
+                iv_c = rng.randint(0, C, size=12)
+                iv_a = np.array([rng.randint(0, len(seqs[c]) + 1) for c in iv_c], np.int64)
+                iv_b = np.array([rng.randint(a, len(seqs[c]) + 1) for c, a in zip(iv_c, iv_a)], np.int64)
+                for ctx in (gpu, ora):
+                    ctx.labels_set(sel, sg, S)
+                gi, oi = gpu.map_intervals(iv_c, iv_a, iv_b), ora.map_intervals(iv_c, iv_a, iv_b)
+                assert (gi == oi).all() and gpu.labels_hit() == ora.labels_hit(), "intervals"
             if C >= 2 and all(int(l) > 0 for l in ora.lengths()):
                 perm = rng.permutation(C).tolist()
                 cut = sorted(rng.choice(range(1, C), size=min(C - 1, rng.randint(1, 3)), replace=False).tolist()) if C > 2 else [1]
