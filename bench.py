@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL process group, table exchange) even with one rank")
+    ap.add_argument("--dist-selfcheck", action="store_true",
+                    help="before the timed run, every rank takes part in one distributed pass over the `small` synthetic "
+                         "genome (9 chromosomes, cut inside chromosomes) and rank 0 compares tallies, lengths, matrix rows, "
+                         "windows and calls with a single-process pass over the same genome")
     ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "1000")))
     return ap.parse_args()
 
@@ -45,8 +49,8 @@ def algorithmic_bytes(kernel, bases, nslots, C, S, extra):
     k = extra.get("k", 15)
     if k > 16 and kernel.startswith("s3_"):
         return 16.25 * bases                      # 0.25 B read + 8 B key read + 4 B counter read + 4 B write per base
-    if kernel.startswith("sps_"):                 # matrix + filter, 64-bit keys: (Kb + 4) B per dumped k-mer + the rows
-        return extra.get("sum_dump", 0) * 12.0 + extra.get("M", 0) * C * 8.0
+    if kernel.startswith("sps_"):                 # matrix + filter over lists: (Kb + 4) B per dumped k-mer + the rows
+        return extra.get("sum_dump", 0) * (12.0 if k > 15 else 8.0) + extra.get("M", 0) * C * 8.0
     if kernel == "k5_map_sparse":
         return 9.25 * bases + extra.get("nbins", 0) * S * 4
     if kernel.startswith("k1_") or kernel.startswith("c2_"):
@@ -95,13 +99,23 @@ def main():
     from subphaser_amd import _native, cluster
     from subphaser_amd.hotpath import HotPath
     from subphaser_amd.synth import SynthGenome
+    rccl_ranks = None
+    if dist is not None:     # how many ranks RCCL really connects: a 1-element all-reduce of ones
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if rccl_ranks != world:
+            raise SystemExit("RCCL all-reduce over %d ranks returned %d" % (world, rccl_ranks))
 
     gen = SynthGenome(args.config, args.scale)
     ctx = _native.Context(local_rank)
     C, S = len(gen.chroms), gen.S
 
+    selfcheck = None
     if dist is not None:
         from subphaser_amd.dist import DistHotPath
+        if args.dist_selfcheck:
+            selfcheck = dist_selfcheck(ctx, dist, torch, args, rank)
         runner = DistHotPath(ctx, gen, dist, torch, k=args.k, engine=args.engine)
     else:
         runner = None
@@ -213,20 +227,26 @@ def main():
     local_bases = sum(pc["stop"] - pc["start"] for pc in pieces)
     extra = dict(nbins=sum(len(x) for x in b.bins) / max(1, len(b.bins)), M=a.n_rows,
                  sum_dump=int(n_dumped), k=args.k)
-    try:    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_summary.py)
-        pmc = "r02_wheat_pmc.json" if args.k == 15 else "r02_wheat_k%d_pmc.json" % args.k      # one table per measured k
-        tj = json.load(open(os.path.join(ROOT, "profiles", pmc)))["kernels"]
-        if not (args.config == "wheat" and world == 1):
-            tj = {}
+    # physical HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_round.sh).  They describe the
+    # kernels as they were when the passes ran: the file carries the hash of csrc/ and the commit, and the numbers are
+    # quoted only while the sources still hash to it -- otherwise `traffic` is null (stale evidence is worse than none)
+    tj, traffic_commit = {}, None
+    try:
+        from subphaser_amd._native import csrc_fingerprint
+        pmc = "r03_wheat_pmc.json" if args.k == 15 else "r03_wheat_k%d_pmc.json" % args.k      # one table per measured k
+        pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+        if args.config == "wheat" and world == 1 and pj.get("csrc_sha16") == csrc_fingerprint():
+            tj, traffic_commit = pj["kernels"], pj.get("commit")
     except (OSError, ValueError, KeyError):
-        tj = {}
+        pass
 
     def price(names, label, per_chrom=True):
         """achieved algorithmic GB/s of one kernel, or of a chain of kernels launched once per chromosome"""
         sts = [prof[n] for n in names if n in prof]
         if not sts:
             return None
-        units = n_local if per_chrom else 1     # a chain runs once per local chromosome, or once per step
+        # a chain runs once per local chromosome, a whole-genome kernel (k5_map since round 3, the filter) once per step
+        units = max(1, int(round(prof[[n for n in names if n in prof][0]]["calls"] / args.steps)))
         per_launch = local_bases / units
         alg = algorithmic_bytes(names[0], per_launch, nslots, C, S, extra)
         if not alg:
@@ -242,11 +262,14 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
 
-    COUNT_CHAIN = [n for n in ("c2_hist_fine", "c2_offsets", "c2_part1", "c2_part2", "c2_count", "ovf_scan", "ovf_place",
-                               "k1_count_atomic", "k1_narrow") if n in prof]
+    COUNT_CHAIN = [n for n in ("c2_hist_sample", "c2_hist_fine", "c2_offsets", "c2_part1", "c2_tiles", "c2_part2", "c2_spans",
+                               "c2_count", "c2_count_list", "ovf_scan", "ovf_place", "ovf_place_list", "k1_count_atomic",
+                               "k1_narrow") if n in prof and prof[n]["calls"] >= args.steps * max(1, n_local)]
     if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
         COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))
-    FILTER_CHAIN = ["k3_eval", "k3_slow"] if args.k <= 15 else sorted(n for n in prof if n.startswith("sps_") and "hash" not in n and "pair" not in n)
+    # byte-table filter, or the list filter (k > 15, and engine 3 on small genomes at k <= 15)
+    FILTER_CHAIN = ["k3_eval", "k3_slow"] if "k3_eval" in prof else \
+        sorted((n for n in prof if n.startswith("sps_") and "hash" not in n and "pair" not in n), key=lambda n: n != "sps_join")
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
     roofline = None
     if dom:
@@ -282,7 +305,10 @@ def main():
                    "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": ("single GPU" if world == 1 else "genome-position-sharded count/map + slot-range-sharded filter x%d" % world)},
-        "roofline": roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
+        "rccl_ranks": rccl_ranks, "dist_selfcheck": selfcheck,
+        "pieces_per_rank": ([{"rank": r_, "pieces": len(p_), "bases": int(sum(e_ - a_ for _, a_, e_ in p_))}
+                             for r_, p_ in enumerate(runner.pieces)] if runner is not None else None),
+        "traffic_commit": traffic_commit, "roofline": roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
                                   for k_, v in (hp if runner is None else runner).wall.items()},
     }
@@ -358,13 +384,128 @@ def cpu_baseline(ctx, gen, d_ascii, kmer_labels, args):
         if gb.shape != ob[0].shape or not (gb == ob[0]).all() or gn != ob[2]:
             raise SystemExit("VERIFY FAILED: bin counts of sample chromosome %d differ from the oracle" % i)
         checked["bins"] += int(gb.shape[0])
-    return {"value": round(bases / total / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
+    jf = jellyfish_leg(seqs, labs, args.k, 3, cores, dumps)
+    return {"value": round(bases / total / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port", "jellyfish": jf,
             "sample": "%s of the %d chromosomes of homoeologous set 1 (%.1f Mbases): "
                       "oracle count (thread-partitioned) %.2fs + matrix/filter %.2fs + map %.2fs"
                       % ("all" if all(len(s) == gen.chroms[i]["length"] for s, i in zip(seqs, idx))
                          else "first %.0f Mb of each" % args.cpu_sample_mb, len(seqs), bases / 1e6, t_count,
                          t_filter, t_map),
             "verified": True, "verified_items": checked}
+
+
+def dist_selfcheck(ctx, dist, torch, args, rank):
+    """One distributed pass over the `small` synthetic genome (9 chromosomes of ~30 Mb: at 8 ranks every rank gets a
+    ~34-Mb slice, so chromosomes are cut and the halo / merge / slot-range code runs) against a single-process pass
+    on rank 0.  Cheap (a fraction of a second) and loud: any difference ends the run with the first mismatch."""
+    import numpy as np
+    from subphaser_amd import cluster
+    from subphaser_amd.dist import DistHotPath
+    from subphaser_amd.hotpath import HotPath
+    from subphaser_amd.synth import SynthGenome
+    g = SynthGenome("small")
+    kw = dict(k=args.k, lower_count=3, min_freq=20)
+
+    def synth(pieces):
+        out = []
+        for pc in pieces:
+            c = g.chroms[pc["chrom"]]
+            n = pc["stop"] - pc["start"]
+            p = ctx.dev_alloc(max(n, 1))
+            ctx.synth_chrom_range(p, c["length"], pc["start"], n, g.seed, c["set_id"], c["sg_id"], g.S, c["chrom_id"], c["exchange"])
+            out.append(p)
+        ctx.sync()
+        return out
+
+    def labels_of(res):
+        class _Mat:
+            pass
+        m = _Mat()
+        m.labels, m.keys, m.k = g.labels, res.keys, args.k
+        m.freqs = res.counts.astype(np.float64) / np.asarray(res.kmer_lengths, np.float64)
+        return cluster.Cluster(m, n_clusters=g.S, sg_assigned=g.sg_assigned).output_kmers(open(os.devnull, "w"), max_pval=0.05)
+
+    runner = DistHotPath(ctx, g, dist, torch, engine=args.engine, **kw)
+    ptrs = synth(runner.local_pieces)
+    a = runner.count_and_filter(ptrs, host_rows_on_all_ranks=True)
+    lab = labels_of(a)
+    b = runner.map_and_enrich(lab, g.S)
+    runner.close()
+    for p in ptrs:
+        ctx.dev_free(p)
+    ok, why = True, ""
+    if rank == 0:
+        whole = [dict(chrom=i, start=0, stop=c["length"]) for i, c in enumerate(g.chroms)]
+        ptrs = synth(whole)
+        hp = HotPath(ctx, g.labels, [c["length"] for c in g.chroms], g.sgs, engine=args.engine if args.k > 15 else 2, **kw)
+        ra = hp.count_and_filter(ptrs, sort=True)
+        rb = hp.map_and_enrich(labels_of(ra), g.S)
+        for p in ptrs:
+            ctx.dev_free(p)
+        o = np.argsort(a.keys, kind="stable")
+        checks = [("tallies", (a.n_union, a.n_rows, a.n_hist) == (ra.n_union, ra.n_rows, ra.n_hist)),
+                  ("lengths", list(map(int, a.kmer_lengths)) == list(map(int, ra.kmer_lengths))),
+                  ("matrix rows", a.n_rows == ra.n_rows and (a.keys[o] == ra.keys).all() and (a.counts[o] == ra.counts).all()),
+                  ("mapped positions", b.n_mapped == rb.n_mapped),
+                  ("window table", b.coords == rb.coords and (b.window_counts == rb.window_counts).all()),
+                  ("calls", (b.sig == rb.sig).all() and (b.argmin == rb.argmin).all()
+                   and bool(np.allclose(b.pvals, rb.pvals, rtol=1e-6, atol=1e-300)))]
+        bad = [n_ for n_, v in checks if not v]
+        ok, why = not bad, ", ".join(bad)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+    dist.broadcast(flag, 0)
+    if not int(flag.item()):
+        raise SystemExit("DIST SELFCHECK FAILED on rank 0: %s differ between the %d-rank pass and the single-process pass"
+                         % (why or "results", dist.get_world_size()))
+    return {"config": "small", "ranks": dist.get_world_size(), "pieces": [len(p) for p in runner.pieces], "ok": True,
+            "compared": ["n_union/n_rows/n_hist", "lengths", "matrix rows", "mapped positions", "window table", "p-values/calls"]}
+
+
+def jellyfish_leg(seqs, labs, k, lower, cores, dumps):
+    """If the `jellyfish` binary is on PATH: the reference's exact count / dump commands (Jellyfish.py:697-699) on the
+    CPU sample, timed, and its dump -- sorted -- compared with the oracle's (which the HIP path has just been verified
+    against): the one route by which the count stage is pinned to jellyfish itself rather than to its definition.
+    jellyfish 2.2.10 is not in this image (SubPhaser.yaml:66): the leg then reports "absent"."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("jellyfish")
+    if not exe:
+        return "absent"
+    tmp = tempfile.mkdtemp(prefix="sp_jf_")
+    try:
+        t_all, same, n_lines = 0.0, True, 0
+        for lab, s, (ok, oc) in zip(labs, seqs, dumps):
+            fa = os.path.join(tmp, lab + ".fasta")
+            with open(fa, "wb") as f:
+                f.write(b">" + lab.encode() + b"\n")
+                f.write(np.asarray(s, np.uint8).tobytes())
+                f.write(b"\n")
+            pre = "%s_%d" % (fa, k)
+            cmd = ('cat {fa} | jellyfish count -t {t} -m {k} -s 100000000  --canonical /dev/stdin -o "{pre}.jf" && '
+                   'jellyfish histo -h 100000 -t {t} -o {pre}.histo {pre}.jf && '
+                   'jellyfish dump -c -o "{pre}.fa" "{pre}.jf" -L {L}').format(fa=fa, t=cores, k=k, pre=pre, L=lower)
+            t0 = time.perf_counter()
+            subprocess.check_call(cmd, shell=True)
+            t_all += time.perf_counter() - t0
+            code = {65: 0, 67: 1, 71: 2, 84: 3}
+            got = {}
+            with open(pre + ".fa") as f:
+                for line in f:
+                    km, c = line.split()
+                    v = 0
+                    for ch in km.encode():
+                        v = (v << 2) | code[ch]
+                    got[v] = int(c)
+            n_lines += len(got)
+            same = same and len(got) == len(ok) and all(got.get(int(a)) == int(b) for a, b in zip(ok.tolist(), oc.tolist()))
+            os.remove(pre + ".jf")
+        bases = sum(len(x) for x in seqs)
+        return {"version": subprocess.check_output([exe, "--version"]).decode().strip(), "count_dump_s": round(t_all, 2),
+                "Gbases_per_s": round(bases / t_all / 1e9, 5), "threads": cores, "dump_kmers": n_lines,
+                "dumps_equal_oracle_and_hip": bool(same)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

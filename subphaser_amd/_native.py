@@ -32,6 +32,19 @@ SYMBOLS = [
 ]
 
 
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources: profiles/*_pmc.json are stamped with it, and bench.py
+    quotes their measured HBM traffic only while the sources are the ones that were profiled"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 class NativeError(RuntimeError):
     """HIP/runtime failure inside libsubphaser_hip.so."""
 

@@ -221,6 +221,10 @@ class DistHotPath:
                     self.dummy8 = t.zeros((self.world, self.chunk), dtype=t.uint8, device=self.device)
                 send = self.dummy8
             if self.world > 1:
+                # the exchange must move every slot of the table exactly once: world equal slices that cover it
+                assert send.numel() == self.world * self.chunk == self.recv8[i].numel() and self.world * self.chunk >= self.nslots, \
+                    "all_to_all_single: %d send / %d recv bytes for %d ranks x %d slots (table: %d slots)" % (
+                        send.numel(), self.recv8[i].numel(), self.world, self.chunk, self.nslots)
                 works.append(dist.all_to_all_single(self.recv8[i].view(-1), send.reshape(-1), async_op=True))
         tt = self._t("count(+exchange issue)", tt)
         # overflow pairs of every piece to every rank (small: counts >= 255 are rare)
@@ -452,6 +456,13 @@ class DistHotPath:
         tt = self._t("split+export", tt)
         if W > 1:
             keys_recv, cnts_recv = self._buf("kr", n_recv, t.int64), self._buf("cr", n_recv, t.int32)
+            # uneven splits: what this rank sends / receives must add up to its buffers, and over all ranks to the same total
+            assert int(sum(send_counts.tolist())) == n_send and int(sum(recv_counts.tolist())) == n_recv, \
+                "all_to_all_single splits: send %s != %d or recv %s != %d" % (send_counts.tolist(), n_send, recv_counts.tolist(), n_recv)
+            chk = t.tensor([n_send, -n_recv], dtype=t.int64, device=self.device)
+            dist.all_reduce(chk)
+            assert int(chk[0].item()) == -int(chk[1].item()), "key-range exchange: %d keys sent, %d expected by the receivers" % (
+                int(chk[0].item()), -int(chk[1].item()))
             dist.all_to_all_single(keys_recv[:n_recv], keys_send[:n_send], recv_counts.tolist(), send_counts.tolist())
             dist.all_to_all_single(cnts_recv[:n_recv], cnts_send[:n_send], recv_counts.tolist(), send_counts.tolist())
         else:

@@ -410,3 +410,54 @@ def test_output_kmers_group_larger_than_kernel_limit():
             if b.mean() > a.mean():
                 a, b = b, a
             assert np.isclose(float(p), st.ttest_ind(a, b)[1], rtol=1e-9, atol=1e-300)
+
+
+def test_bench_jellyfish_leg(tmp_path, monkeypatch):
+    """bench.py's cpu_baseline leg runs the reference's exact jellyfish commands (Jellyfish.py:697-699) when the
+    binary exists and diffs its dump with the oracle's; this image has none -> "absent".  With a stand-in executable
+    that answers `count` / `histo` / `dump` from the oracle, the leg must parse the dump and report equality."""
+    import importlib.util
+    import stat
+    import sys
+    import numpy as np
+    import pyoracle as po
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(2)
+    seqs = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)] for _ in range(2)]
+    seqs[0] = np.concatenate([seqs[0], seqs[0][:1500]])
+    k, L = 15, 2
+    dumps = [po.count(s, k, L) for s in seqs]
+    monkeypatch.setenv("PATH", str(tmp_path / "nobin"))
+    assert bench.jellyfish_leg(seqs, ["c0", "c1"], k, L, 2, dumps) == "absent"
+    fake = tmp_path / "bin" / "jellyfish"
+    fake.parent.mkdir()
+    fake.write_text("""#!%s
+import sys
+sys.path.insert(0, %r)
+import numpy as np, pyoracle as po
+a = sys.argv[1:]
+if a[0] == "--version":
+    print("jellyfish stand-in 0.0")
+elif a[0] == "count":
+    k = int(a[a.index("-m") + 1]); out = a[a.index("-o") + 1]
+    seq = "".join(l.strip() for l in sys.stdin if not l.startswith(">"))
+    open(out, "w").write("%%d\\n%%s" %% (k, seq))
+elif a[0] == "histo":
+    open(a[a.index("-o") + 1], "w").write("")
+elif a[0] == "dump":
+    jf = [x for x in a[1:] if x.endswith(".jf")][0]
+    k, seq = open(jf).read().split("\\n", 1)
+    keys, cnts = po.count(np.frombuffer(seq.encode(), np.uint8), int(k), int(a[a.index("-L") + 1]))
+    order = np.random.default_rng(1).permutation(len(keys))       # hash order, like the real dump
+    with open(a[a.index("-o") + 1], "w") as f:
+        for i in order:
+            f.write("%%s %%d\\n" %% (po.decode(int(keys[i]), int(k)), int(cnts[i])))
+""" % (sys.executable, os.path.join(ROOT, "oracle")))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + "/usr/bin:/bin")
+    r = bench.jellyfish_leg(seqs, ["c0", "c1"], k, L, 2, dumps)
+    assert r["dumps_equal_oracle_and_hip"] is True and r["dump_kmers"] == sum(len(d[0]) for d in dumps) > 0
+    bad = [(d[0], d[1] + 1) for d in dumps]
+    assert bench.jellyfish_leg(seqs, ["c0", "c1"], k, L, 2, bad)["dumps_equal_oracle_and_hip"] is False

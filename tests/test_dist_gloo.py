@@ -146,3 +146,31 @@ def test_two_rank_overflow_lists_over_gloo(tmp_path):
 def test_eight_rank_wheat_shape_over_gloo(tmp_path):
     """21 chromosomes / 7 sets x 3 (the wheat structure) on 8 ranks: seven chromosomes are cut"""
     _spawn(tmp_path, 8, 9, shape="wheat")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_wheat_shape_two_and_four_ranks_over_gloo(tmp_path, world):
+    """the wheat structure at the other rank counts the driver's scaling run uses (N = 1, 2, 4, 8)"""
+    _spawn(tmp_path, world, 9, shape="wheat")
+
+
+def test_plan_pieces_wheat_every_rank_count():
+    """position plan of the wheat-like genome at N = 1, 2, 4, 8: every base owned exactly once, cuts inside a
+    chromosome on multiples of the chunk size, slices balanced to within one chunk"""
+    from subphaser_amd.dist import plan_pieces
+    from subphaser_amd.synth import SynthGenome
+    lens = [c["length"] for c in SynthGenome("wheat").chroms]
+    align = 10_000_000
+    for n in (1, 2, 4, 8):
+        plan = plan_pieces(lens, n, align)
+        assert len(plan) == n
+        cover = [[] for _ in lens]
+        for pieces in plan:
+            for c, a, b in pieces:
+                assert 0 <= a < b <= lens[c] and (a % align == 0) and (b % align == 0 or b == lens[c])
+                cover[c].append((a, b))
+        for c, iv in enumerate(cover):
+            iv.sort()
+            assert iv[0][0] == 0 and iv[-1][1] == lens[c] and all(x[1] == y[0] for x, y in zip(iv, iv[1:]))
+        loads = [sum(b - a for _, a, b in pieces) for pieces in plan]
+        assert max(loads) - min(loads) <= 2 * align, (n, loads)

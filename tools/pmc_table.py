@@ -8,7 +8,10 @@ usage: pmc_table.py <csv>... > table.json"""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 GATHER = ("k5_map", "k5_map_lab", "k5_map_sparse", "k5_map_feat", "k5_map_feat_sparse")
 
@@ -38,7 +41,10 @@ def main(paths):
         if "TCC_HIT_sum" in ent and ent["TCC_HIT_sum"] + ent.get("TCC_MISS_sum", 0) > 0:
             ent["l2_hit_rate"] = ent["TCC_HIT_sum"] / (ent["TCC_HIT_sum"] + ent["TCC_MISS_sum"])
         out[k] = ent
-    json.dump({"unit": "per launch (averages over the launches of one bench step)", "kernels": out}, sys.stdout,
+    from subphaser_amd._native import csrc_fingerprint
+    json.dump({"unit": "per launch (averages over the launches of one bench step)", "kernels": out,
+               # what was profiled: bench.py drops `traffic` when the kernel sources no longer hash to this
+               "csrc_sha16": csrc_fingerprint(), "commit": os.environ.get("SP_COMMIT", "unknown")}, sys.stdout,
               indent=1, sort_keys=True)
 
 
