@@ -660,6 +660,148 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const unsigned long long *__restri
     if (threadIdx.x == 0 && tot) atomicAdd(len_sum, tot);
 }
 
+// ---------------------------------------------------------------- s3_final_hash (k >= 18)
+// Residuals wider than 16 bits cannot take the bitmap finish, and round 2 left the job to a register-resident block
+// radix sort (a library block primitive inside s3_final_small / s3_final: 254 of 476 ms per wheat-like pass at
+// k = 21).  But the OUTPUT of a fine bucket is tiny: only residuals with count >= lower_count survive, and on a real
+// genome most k-mers of a bucket occur once.  So nothing is sorted that does not have to be:
+//   stage 1  every key bumps one of 4096 LDS counters chosen by a hash (a counting Bloom filter with one hash): a key
+//            whose counter stays below lower_count cannot have lower_count copies -- it is dropped, unsorted, uncounted;
+//   stage 2  the survivors (true repeats + a few per cent of colliding singletons) are counted exactly in a small
+//            open-addressing table that reuses the counters' LDS;
+//   emit     table entries with count >= lower_count -- a few dozen per bucket -- are ranked by residual among
+//            themselves (quadratic in THEIR number) and written in ascending order.
+// Buckets above 2048 keys (repeat families) skip stage 1 and stream straight into the table: many copies of few
+// residuals.  A bucket with more distinct survivors than the table takes (S3H_CAP) is handed to s3_final
+// (kept[] = S3_BM_PUNT), which still sorts.
+#define S3H_COUNTERS 4096
+#define S3H_SLOTS 2048
+#define S3H_CAP 1536            // distinct residuals the table accepts
+#define S3H_PER 8               // keys per thread held in registers: buckets up to 2048 keys are read once
+template <typename KR2>
+struct s3h_lds {
+    union {
+        uint32_t c1[S3H_COUNTERS];
+        struct {
+            KR2 key[S3H_SLOTS];
+            uint32_t cnt[S3H_SLOTS];
+        } t;
+    } u;
+    KR2 lk[S3H_CAP + S3_SORT_THREADS];
+    uint32_t lc[S3H_CAP + S3_SORT_THREADS];
+    uint32_t n_distinct, n_kept, abort_;
+    unsigned long long red[16];
+};
+__device__ __forceinline__ uint32_t s3h_hash2(unsigned long long v) {
+    v ^= v >> 31;
+    v *= 0xD6E8FEB86659FD93ULL;
+    return (uint32_t)(v >> 37);
+}
+
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+              uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
+              unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+    __shared__ s3h_lds<KR2> L;
+    const KR2 EMPTY = (KR2)~(KR2)0;
+    const int tid = threadIdx.x;
+    unsigned long long lsum = 0;
+    // exact count of one key in the table; false when the table is closed (too many distinct residuals)
+    auto insert = [&](KR2 key) {
+        uint32_t h = s3h_hash2((unsigned long long)key) & (S3H_SLOTS - 1);
+        for (;;) {
+            const KR2 prev = atomicCAS(&L.u.t.key[h], EMPTY, key);
+            if (prev == key) break;
+            if (prev == EMPTY) {
+                if (atomicAdd(&L.n_distinct, 1u) >= S3H_CAP) L.abort_ = 1;
+                break;
+            }
+            h = (h + 1) & (S3H_SLOTS - 1);
+        }
+        atomicAdd(&L.u.t.cnt[h], 1u);
+    };
+    for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
+        const unsigned long long o = off_fine[bucket];
+        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        if (n64 == 0 || n64 > S3_BM_NMAX) {
+            if (tid == 0) kept[bucket] = n64 ? S3_BM_PUNT : 0ULL;
+            continue;
+        }
+        const uint32_t n = (uint32_t)n64;
+        const KR2 *seg = buf2 + o;
+        const bool in_regs = n <= S3_SORT_THREADS * S3H_PER;      // block-uniform
+        KR2 mine[S3H_PER];
+        uint32_t alive = 0;      // bit j: mine[j] survived stage 1
+        __syncthreads();         // the previous bucket's readers of L are done
+        if (tid == 0) L.n_distinct = L.n_kept = L.abort_ = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < S3H_PER; j++) {
+                const uint32_t i = tid + j * S3_SORT_THREADS;
+                if (i < n) mine[j] = seg[i];
+            }
+            for (int i = tid; i < S3H_COUNTERS; i += S3_SORT_THREADS) L.u.c1[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < S3H_PER; j++)
+                if (tid + j * S3_SORT_THREADS < n) atomicAdd(&L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)], 1u);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < S3H_PER; j++)
+                if (tid + j * S3_SORT_THREADS < n && L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)] >= lower)
+                    alive |= 1u << j;
+            __syncthreads();     // every flag is taken: the counters' memory becomes the table
+        }
+        for (int i = tid; i < S3H_SLOTS; i += S3_SORT_THREADS) {
+            L.u.t.key[i] = EMPTY;
+            L.u.t.cnt[i] = 0;
+        }
+        __syncthreads();
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < S3H_PER; j++)
+                if ((alive >> j) & 1u) {
+                    if (L.abort_) break;
+                    insert(mine[j]);
+                }
+        } else {
+            for (uint32_t i = tid; i < n; i += S3_SORT_THREADS) {
+                if (L.abort_) break;
+                insert(seg[i]);
+            }
+        }
+        __syncthreads();
+        if (L.abort_) {          // block-uniform after the barrier
+            if (tid == 0) kept[bucket] = S3_BM_PUNT;
+            continue;
+        }
+        // ---- the kept entries: a short list, ranked by residual
+        for (int i = tid; i < S3H_SLOTS; i += S3_SORT_THREADS) {
+            const uint32_t c = L.u.t.cnt[i];
+            if (c >= lower) {
+                const uint32_t at = atomicAdd(&L.n_kept, 1u);
+                L.lk[at] = L.u.t.key[i];
+                L.lc[at] = c;
+                lsum += c;
+            }
+        }
+        __syncthreads();
+        const uint32_t m = L.n_kept;
+        for (uint32_t i = tid; i < m; i += S3_SORT_THREADS) {
+            const KR2 key = L.lk[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; j++) rank += L.lk[j] < key;
+            tmp_keys[o + rank] = key;
+            tmp_cnts[o + rank] = L.lc[i];
+        }
+        if (tid == 0) kept[bucket] = m;
+    }
+    __syncthreads();
+    const unsigned long long tot = sp_block_sum_u64(lsum, L.red);
+    if (tid == 0 && tot) atomicAdd(len_sum, tot);
+}
+
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
 s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned long long *__restrict__ off_fine,
@@ -1042,9 +1184,16 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
               (const unsigned long long *)d_of, d_c2, buf2);
     int64_t g4 = n_fine < (int64_t)ctx->n_cu * 64 ? n_fine : (int64_t)ctx->n_cu * 64;
     const bool bitmap = P.R2 <= S3_BM_MAXBITS && sizeof(KR2) == 4;      // k = 16, 17
+    // k >= 18: hashed pre-count + exact table of the survivors (SP_S3_FINAL=sort: the block radix sort of round 2)
+    const char *env_fin = getenv("SP_S3_FINAL");
+    const bool use_hash = !bitmap && !(env_fin && !strcmp(env_fin, "sort"));
     if (bitmap)
         SP_LAUNCH(ctx, "s3_final_bitmap", s3_final_bitmap<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS),
                   (size_t)(P.R2 > 5 ? 1 << (P.R2 - 5) : 1) * 6 + (size_t)S3_BM_CAP * 4,
+                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  d_kp, d_small + 2);
+    else if (use_hash)
+        SP_LAUNCH(ctx, "s3_final_hash", s3_final_hash<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
                   (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
     else
@@ -1054,7 +1203,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
               (KR2 *)buf1, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
               d_small + 1, (unsigned long long)big_cap, d_small + 2,
-              bitmap ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP);
+              (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP);
     unsigned long long n_big = 0;
     SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
