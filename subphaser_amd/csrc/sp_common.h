@@ -124,6 +124,18 @@ struct sp_ctx {
     void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
     int64_t ws2_bytes = 0;
     sp_buf b_tab32, b_ovfw;      // engine 1: u32 scratch table; overflow staging (unordered pairs + per-bucket index)
+    // Small genomes: the partition chain of a 20-Mb chromosome is ten launches of a few tens of microseconds that do
+    // not fill the chip; chromosomes are counted on SP_LANES streams side by side, each with its own workspace.
+    struct lane_t {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void *d_ws2 = nullptr;
+        int64_t ws2_bytes = 0;
+        sp_buf b_ovfw;
+    };
+    lane_t lanes[3];             // lanes 1..3 (lane 0 = the context's own stream and buffers above)
+    lane_t *lane = nullptr;      // the auxiliary lane the engine-2 chain is being issued on, or NULL
+    hipEvent_t lane_go = nullptr;
     // sparse engine (k = 16..32)
     bool sparse_mode = false;
     bool list_mode = false;     // k <= 15, engine 3: per-chromosome sorted (SLOT, count) lists in `sparse`, no byte tables;

@@ -432,6 +432,25 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     const char *env_exact = getenv("SP_C2_EXACT");      // "1": size the buckets from the full histogram (round-2 path)
     const bool sized_by_sample = !(env_exact && env_exact[0] == '1');
     std::vector<char> by_engine2(C, 0);
+    // small genomes (engine 3): count chromosomes on up to three more streams side by side (SP_LANES=0: one stream)
+    int n_lanes = 0;
+    if (list_mode && C > 1) {
+        const char *el = getenv("SP_LANES");
+        n_lanes = el ? atoi(el) : 3;
+        if (n_lanes > 3) n_lanes = 3;
+        if (n_lanes < 0) n_lanes = 0;
+        for (int l = 0; l < n_lanes; l++) {
+            if (!ctx->lanes[l].stream) {
+                SP_HIP(ctx, hipStreamCreateWithFlags(&ctx->lanes[l].stream, hipStreamNonBlocking));
+                SP_HIP(ctx, hipEventCreateWithFlags(&ctx->lanes[l].done, hipEventDisableTiming));
+            }
+        }
+        if (n_lanes && !ctx->lane_go) SP_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_go, hipEventDisableTiming));
+        if (n_lanes) {      // the lanes start after what is queued on the main stream (packing, the memset above)
+            SP_HIP(ctx, hipEventRecord(ctx->lane_go, ctx->stream));
+            for (int l = 0; l < n_lanes; l++) SP_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lane_go, 0));
+        }
+    }
     for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
         sp_chrom &c = ctx->chroms[ci];
         if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
@@ -453,7 +472,16 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                 SP_HIP(ctx, hipMalloc(&o.d_cnts, (size_t)(need + 1) * 4));
                 o.cap = need;
             }
+            // lanes: chromosome ci on stream ci % (1 + lanes in use); lane 0 is the context's own stream
+            sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
+            hipStream_t main_stream = ctx->stream;
+            if (ln) {
+                ctx->lane = ln;
+                ctx->stream = ln->stream;
+            }
             rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, &o);
+            ctx->lane = nullptr;
+            ctx->stream = main_stream;
             if (rc) return rc;
             by_engine2[ci] = 1;
             continue;
@@ -500,6 +528,10 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                   n_buckets);
         rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets, nullptr);   // (k1_narrow keeps an exact cursor in d_len[2])
         if (rc) return rc;
+    }
+    for (int l = 0; l < n_lanes; l++) {      // the main stream goes on when every lane is done
+        SP_HIP(ctx, hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].stream));
+        SP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[l].done, 0));
     }
     std::vector<unsigned long long> h(4 * C);
     SP_HIP(ctx, hipMemcpyAsync(h.data(), d_len, 4 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost,

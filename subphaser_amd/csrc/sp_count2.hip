@@ -753,17 +753,20 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
     size_t total = o_sego + al((nf + 1) * 4);
-    if ((int64_t)total > ctx->ws2_bytes) {
-        if (ctx->d_ws2) {
+    void *&d_ws2 = ctx->lane ? ctx->lane->d_ws2 : ctx->d_ws2;           // this lane's workspace (sp_common.h)
+    int64_t &ws2_bytes = ctx->lane ? ctx->lane->ws2_bytes : ctx->ws2_bytes;
+    sp_buf &b_ovfw = ctx->lane ? ctx->lane->b_ovfw : ctx->b_ovfw;
+    if ((int64_t)total > ws2_bytes) {
+        if (d_ws2) {
             SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            SP_HIP(ctx, hipFree(ctx->d_ws2));
-            ctx->d_ws2 = nullptr;
-            ctx->ws2_bytes = 0;
+            SP_HIP(ctx, hipFree(d_ws2));
+            d_ws2 = nullptr;
+            ws2_bytes = 0;
         }
-        SP_HIP(ctx, hipMalloc(&ctx->d_ws2, total));
-        ctx->ws2_bytes = (int64_t)total;
+        SP_HIP(ctx, hipMalloc(&d_ws2, total));
+        ws2_bytes = (int64_t)total;
     }
-    char *ws = (char *)ctx->d_ws2;
+    char *ws = (char *)d_ws2;
     unsigned long long *ghist = (unsigned long long *)(ws + o_ghist);
     unsigned long long *off_fine = (unsigned long long *)(ws + o_offf);
     unsigned long long *off1 = (unsigned long long *)(ws + o_off1);
@@ -782,9 +785,9 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
         return sp_fail(ctx, SP_EUNSUP, "count engine 2: a chromosome of %lld bases needs 64-bit segment offsets", (long long)c.len);
     if (list) {
         const unsigned long long need = (unsigned long long)(cap_keys / (size_t)lower) + C2_FINE + 16;
-        int rcl = sp_buf_ensure(ctx, ctx->b_ovfw, (int64_t)need * 8);
+        int rcl = sp_buf_ensure(ctx, b_ovfw, (int64_t)need * 8);
         if (rcl) return rcl;
-        ovf_tmp = (uint2 *)ctx->b_ovfw.p;
+        ovf_tmp = (uint2 *)b_ovfw.p;
         ovf_cap = need;
     }
     // zero ghist .. cursor2 in one memset (they are contiguous)

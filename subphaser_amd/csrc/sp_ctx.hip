@@ -139,6 +139,13 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     if (ctx->d_bloom) hipFree(ctx->d_bloom);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->d_ws2) hipFree(ctx->d_ws2);
+    for (auto &ln : ctx->lanes) {
+        if (ln.d_ws2) hipFree(ln.d_ws2);
+        sp_buf_free(ln.b_ovfw);
+        if (ln.done) hipEventDestroy(ln.done);
+        if (ln.stream) hipStreamDestroy(ln.stream);
+    }
+    if (ctx->lane_go) hipEventDestroy(ctx->lane_go);
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_mapdesc);
     sp_buf_free(ctx->b_ival);
