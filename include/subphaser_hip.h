@@ -68,7 +68,7 @@ int sp_genome_unpack(sp_ctx *ctx, int chrom, uint8_t *ascii_out, int64_t len);
  * canonical k-mer counts, kept when count >= lower_count (`jellyfish dump -L`).
  * engine: 0 = auto, 1 = global-atomic table, 2 = LDS radix-partition counter (byte tables), 3 = the same partition
  * chain ending in per-chromosome (slot, count) LISTS -- no byte tables; what auto picks for small genomes, where a
- * chromosome fills less than 1/8 of its dense table (k <= 15 with 2^17..2^31 slots, <= 64 chromosomes, whole-genome
+ * chromosome fills less than 1/3 of its dense table (k <= 15 with 2^17..2^31 slots, <= 64 chromosomes, whole-genome
  * sp_count calls only; sp_table_overflow / sp_filter_view / the table exchange are byte-table interfaces). */
 int sp_count(sp_ctx *ctx, int k, int lower_count, int engine);
 /* same for chromosomes [first, last) only (k <= 15): lets a multi-GPU caller ship the finished

@@ -374,10 +374,12 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     ctx->sparse_mode = false;
     const sp_kparams kp = sp_make_kparams(k);
     const int64_t nslots = sp_dense_slots(k);
-    // Engine choice by table occupancy.  A chromosome fills at most len / nslots of its dense table; below 1/8 (the
-    // Arabidopsis-like 20-Mb chromosomes at k = 15: 4 %) writing 512 MiB per chromosome and streaming all of them
-    // through the filter is most of the pass, so the counts are kept as LISTS of (slot, count >= lower) pairs in
-    // ascending slot order instead (engine 3: the same partition chain, c2_count<LIST>), joined by the list filter.
+    // Engine choice by table occupancy.  A chromosome fills at most len / nslots of its dense table; below 1/3 (the
+    // Arabidopsis-like 20-Mb chromosomes at k = 15: 4 %, the peanut-like 128-Mb ones: 24 %) clearing, writing and
+    // streaming 512 MiB per chromosome through the filter costs more than it saves, so the counts are kept as LISTS of
+    // (slot, count >= lower) pairs in ascending slot order instead (engine 3: the same partition chain ending in
+    // c2_count_list), joined by the list filter.  Measured per pass: Arabidopsis-like 13.0 -> 6.3 ms, peanut-like
+    // 35.8 -> 31.6 ms; a wheat-like chromosome (670 Mb: more k-mers than slots) stays on byte tables.
     // Whole-genome calls on library-owned tables only (the multi-GPU table exchange needs the byte tables).
     bool list_mode = false;
     {
@@ -395,7 +397,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                                                "library-owned tables and at most 64 chromosomes");
             list_mode = true;
         } else if (engine == 0 && possible) {
-            list_mode = (env3 && env3[0] == '1') || (!(env3 && env3[0] == '0') && longest > 0 && longest * 8 < nslots);
+            list_mode = (env3 && env3[0] == '1') || (!(env3 && env3[0] == '0') && longest > 0 && longest * 3 < nslots);
         }
     }
     // a new k invalidates old tables
