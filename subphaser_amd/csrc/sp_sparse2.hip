@@ -679,8 +679,8 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const unsigned long long *__restri
 #define S3H_CAP 1536            // distinct residuals the table accepts
 #define S3H_PER 8               // keys per thread held in registers: buckets up to 2048 keys are read once
 template <typename KR2>
-struct s3h_lds {
-    union {
+struct __attribute__((aligned(16))) s3h_lds {
+    union __attribute__((aligned(16))) {
         uint32_t c1[S3H_COUNTERS];
         struct {
             KR2 key[S3H_SLOTS];
@@ -741,7 +741,10 @@ s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict
                 const uint32_t i = tid + j * S3_SORT_THREADS;
                 if (i < n) mine[j] = seg[i];
             }
-            for (int i = tid; i < S3H_COUNTERS; i += S3_SORT_THREADS) L.u.c1[i] = 0;
+            {       // 16-byte LDS stores: a quarter of the instructions (the kernel is LDS-issue-bound, not latency-bound)
+                uint4 *z = reinterpret_cast<uint4 *>(L.u.c1);
+                for (int i = tid; i < S3H_COUNTERS / 4; i += S3_SORT_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+            }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < S3H_PER; j++)
@@ -753,9 +756,10 @@ s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict
                     alive |= 1u << j;
             __syncthreads();     // every flag is taken: the counters' memory becomes the table
         }
-        for (int i = tid; i < S3H_SLOTS; i += S3_SORT_THREADS) {
-            L.u.t.key[i] = EMPTY;
-            L.u.t.cnt[i] = 0;
+        {
+            uint4 *zk = reinterpret_cast<uint4 *>(L.u.t.key), *zc = reinterpret_cast<uint4 *>(L.u.t.cnt);
+            for (int i = tid; i < (int)(S3H_SLOTS * sizeof(KR2) / 16); i += S3_SORT_THREADS) zk[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (int i = tid; i < S3H_SLOTS / 4; i += S3_SORT_THREADS) zc[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
         if (in_regs) {
@@ -777,13 +781,18 @@ s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict
             continue;
         }
         // ---- the kept entries: a short list, ranked by residual
-        for (int i = tid; i < S3H_SLOTS; i += S3_SORT_THREADS) {
-            const uint32_t c = L.u.t.cnt[i];
-            if (c >= lower) {
-                const uint32_t at = atomicAdd(&L.n_kept, 1u);
-                L.lk[at] = L.u.t.key[i];
-                L.lc[at] = c;
-                lsum += c;
+        for (int i4 = tid; i4 < S3H_SLOTS / 4; i4 += S3_SORT_THREADS) {
+            const uint4 c4 = reinterpret_cast<const uint4 *>(L.u.t.cnt)[i4];
+            const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t c = cc[q];
+                if (c >= lower) {
+                    const uint32_t at = atomicAdd(&L.n_kept, 1u);
+                    L.lk[at] = L.u.t.key[4 * i4 + q];
+                    L.lc[at] = c;
+                    lsum += c;
+                }
             }
         }
         __syncthreads();
