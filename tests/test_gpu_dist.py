@@ -123,3 +123,32 @@ def test_two_processes_one_gpu_overflow_lists(gpu_ctx, tmp_path):
 def test_two_processes_one_gpu_key_range(gpu_ctx, tmp_path):
     """k = 17: sorted (k-mer, count) lists, splitters, uneven all_to_all of key-range pieces"""
     _spawn(tmp_path, 2, 17)
+
+
+def test_bench_line_single_and_forced_dist(tmp_path):
+    """bench.py end to end on the `small` genome: the JSON contract (metric / value / roofline / cpu_baseline with the
+    jellyfish leg / verified), then the multi-GPU code path through RCCL with one rank (`--force-dist`) including
+    `--dist-selfcheck` -- the checks the first 8-GPU lease will rely on (rccl_ranks, pieces_per_rank, selfcheck ok)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample-mb", "5"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "stage_roofline", "traffic_commit"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified"] is True and d["unit"] == "Gbases/s"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["traffic"] is None
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["jellyfish"] in ("absent",) or isinstance(d["cpu_baseline"]["jellyfish"], dict)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--force-dist", "--dist-selfcheck"], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d2["rccl_ranks"] == 1 and d2["dist_selfcheck"]["ok"] is True and d2["pieces_per_rank"][0]["rank"] == 0
+    assert d2["pieces_per_rank"][0]["bases"] > 0 and d2["config"]["differential_kmers"] == d["config"]["differential_kmers"]
+    assert d2["config"]["mapped_positions"] == d["config"]["mapped_positions"]
