@@ -410,11 +410,6 @@ c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
 #define C2_PF 8         // prefetched 8-byte loads per thread (32 K keys per block: most of an average bucket)
 #endif
 #define C2_STAGE 1024   // overflow pairs staged in LDS per bucket (8 KiB next to the 128 KiB of counters)
-// LIST = true (engine 3, small genomes): no table at all -- EVERY slot with count >= lower becomes a (slot, count)
-// pair of the same segment protocol, i.e. the chromosome's dump as a list in ascending slot order.  A 20-Mb
-// chromosome fills 4 % of the 2^29 slots at k = 15: writing and re-reading 512 MiB of zeros per chromosome was 8 of
-// the 13 ms of an Arabidopsis-like pass.
-template <bool LIST>
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span /* [first, last) key of every fine bucket */,
          int64_t n_fine, uint32_t lower, uint8_t *__restrict__ tab,
@@ -426,7 +421,7 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
     __shared__ uint32_t s_nov, s_rank;
     __shared__ uint2 stage[C2_STAGE];
     unsigned long long s = 0, n = 0;
-    const uint32_t thr = LIST ? lower : 255u;     // counts from here on become pairs
+    const uint32_t thr = 255u;     // counts from here on go to the overflow list
     // Software pipeline over the buckets a block processes: the first C2_PF x 4 keys per thread of the NEXT
     // bucket are loaded while this bucket's counters are written out and cleared (one block per CU: nothing else
     // would hide those round trips; the kernel ran at 2.5 TB/s of its 4.6).
@@ -494,7 +489,7 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
             atomicAdd(&cnt[buf2[t]], 1u);
         prefetch(fb + gridDim.x);   // in flight across the write-out below and the next clear
         __syncthreads();
-        uint32_t *t32 = LIST ? nullptr : reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
             const uint4 v = c4[i];
             const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
@@ -509,7 +504,7 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
                 }
                 packed |= (c < 255u ? c : 255u) << (8 * j);
             }
-            if (!LIST) t32[i] = packed;
+            t32[i] = packed;
         }
         __syncthreads();
         const uint32_t nov = s_nov;   // block-uniform
@@ -776,7 +771,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     uint32_t *seg_base = (uint32_t *)(ws + o_segb), *seg_cnt = (uint32_t *)(ws + o_segc), *seg_off = (uint32_t *)(ws + o_sego);
     uint16_t *lo1 = (uint16_t *)(ws + o_buf1);                         // level-1 records: 3 bytes per key in two planes
     uint8_t *hi1 = (uint8_t *)(ws + o_buf1) + lo1_bytes;
-    // the unordered overflow pairs live in the level-1 planes (dead once part2 has run); a LIST run stages every
+    // the unordered overflow pairs live in the level-1 planes (dead once part2 has run); an engine-3 (list) run stages every
     // kept slot and gets a buffer of its own
     // (a bucket's segment starts at floor(its first key / L), L = 255 or lower_count: cap_keys / L pairs at most)
     uint2 *ovf_tmp = (uint2 *)(ws + o_buf1);
@@ -828,8 +823,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
         return sp_ovf_finalize_split(ctx, (unsigned long long *)list->d_keys, list->d_cnts, ovf_tmp, seg_base, seg_cnt, seg_off,
                                      (int64_t)nf, d_len4 + 2);
     }
-    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
-    SP_LAUNCH(ctx, "c2_count", c2_count<false>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
+    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+    SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
               (int64_t)nf, (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
     return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf, d_len4 + 2);
 }
