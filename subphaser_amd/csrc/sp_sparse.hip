@@ -1088,6 +1088,7 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
     if (bits > 64) bits = 64;
     int rb = 0;
     while (rb < bits && rb < 23 && ((int64_t)1 << rb) * 96 < total) rb++;
+    if (bits - rb > 63) rb = bits - 63;      // k = 32 and a handful of k-mers: `key >> 64` is not a shift (fuzz case k32_join)
     const long long R = 1LL << rb;
     const int shift = bits - rb;
     const int n_units = set_off[n_sets], n_uc = unit_off[n_units];

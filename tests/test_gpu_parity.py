@@ -227,6 +227,33 @@ def test_count_sparse_engine_hot_buckets(gpu_ctx):
     _count_both(gpu_ctx, seqs, k, 3, 0)
 
 
+def test_list_filter_handful_of_kmers(gpu_ctx, oracle_ctx):
+    """A fuzz find of round 3 (tools/fuzz_parity.py seed 9301, iteration 47): k = 32 and lists of 2 and 1 k-mers.  The
+    join filter cut the 64-bit key space into ONE range, i.e. shifted keys right by 64 -- not a shift on the device --
+    and wrote range edges out of bounds.  Also: the same lists through every k that leaves the key space 64 - 2k
+    bits short of a machine word."""
+    from subphaser_amd.config import sets_to_csr
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz_case_k32_join.npz"))
+    seqs = [d["s0"], d["s1"]]
+    for k, lower in ((32, 3), (32, 1), (31, 3), (24, 2), (17, 3)):
+        for ctx in (gpu_ctx, oracle_ctx):
+            ctx.genome_reset(2)
+            for i, s in enumerate(seqs):
+                ctx.genome_add(i, s)
+            ctx.count(k, lower)
+        assert gpu_ctx.lengths().tolist() == oracle_ctx.lengths().tolist()
+        csr = sets_to_csr([[[0], [1]]], [0, 1])
+        res = []
+        for ctx in (gpu_ctx, oracle_ctx):
+            nu, nr, nh = ctx.filter(*csr, 1.5, -1, 3.0, 1e9, 1.0)
+            keys, counts, freqs, tot = ctx.filter_fetch(nr)
+            res.append((nu, nr, nh, keys, counts, freqs, tot, np.sort(ctx.filter_hist(nh))))
+        g, o = res
+        assert g[:3] == o[:3], (k, lower, g[:3], o[:3])
+        for a, b in zip(g[3:], o[3:]):
+            assert a.shape == b.shape and (a == b).all(), (k, lower)
+
+
 @pytest.mark.parametrize("map_engine", ["pairs", "per-kmer"])
 @pytest.mark.parametrize("k", [17, 21, 32])
 def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkeypatch):

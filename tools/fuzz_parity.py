@@ -38,6 +38,11 @@ def rand_chrom(rng):
             b = rng.randint(0, max(1, n - m)); s[a:a + min(m, n - a)] = s[b:b + min(m, n - a)]
     return s
 
+def _tr(what):
+    if os.environ.get("SP_FUZZ_TRACE"):
+        print("   " + what, file=sys.stderr, flush=True)
+
+
 def run(iters, seed, gpu, ora, verbose=True):
     rng = np.random.RandomState(seed)
     bad = 0
@@ -48,11 +53,14 @@ def run(iters, seed, gpu, ora, verbose=True):
         lower = int(rng.randint(1, 4))
         engine = int(rng.choice([0, 1, 2, 3])) if k <= 15 else int(rng.choice([0, 1]))      # 3: lists (k >= 9), else falls back
         tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s" % (it, C, k, lower, engine, [len(s) for s in seqs])
+        if os.environ.get("SP_FUZZ_TRACE"):      # a GPU fault kills the process: leave the case on stderr first
+            print(tag, file=sys.stderr, flush=True)
         try:
             for ctx in (gpu, ora):
                 ctx.genome_reset(C)
                 for i, s in enumerate(seqs):
                     ctx.genome_add(i, s)
+            _tr("count")
             try:
                 gpu.count(k, lower, engine)
             except ValueError as e:
@@ -62,6 +70,7 @@ def run(iters, seed, gpu, ora, verbose=True):
                     raise
             ora.count(k, lower)
             assert gpu.lengths().tolist() == ora.lengths().tolist(), "lengths"
+            _tr("dump")
             dumps = []
             for i in range(C):
                 gk, gc = gpu.dump(i); ok, oc = ora.dump(i)
@@ -72,13 +81,16 @@ def run(iters, seed, gpu, ora, verbose=True):
                 sel = allk[rng.rand(allk.size) < rng.choice([0.02, 0.3, 1.0])]
                 S = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9]))      # > 7: the per-k-mer label engines
                 sg = rng.randint(0, S, size=sel.size).astype(np.uint8)
+                _tr("labels S=%d n=%d" % (S, sel.size))
                 for ctx in (gpu, ora):
                     ctx.labels_set(sel, sg, S)
+                _tr("map_bins")
                 for i in range(C):
                     bs = int(rng.choice([1, 7, 100, 10000])); ch = int(rng.choice([0, 50, 1000, 10_000_000]))
                     g, gn = gpu.map_bins(i, bs, ch); o, on = ora.map_bins(i, bs, ch)
                     assert g.shape == o.shape and (g == o).all() and gn == on, "map %d bin=%d chunk=%d" % (i, bs, ch)
                 assert gpu.labels_hit() == ora.labels_hit(), "labels_hit"
+                _tr("features")
                 feats = [seqs[rng.randint(0, C)][a:a + int(rng.randint(0, 400))] for a in rng.randint(0, 3000, size=5)]
                 assert (gpu.map_features(feats) == ora.map_features(feats)).all(), "features"
                 iv_c = rng.randint(0, C, size=12)
@@ -86,6 +98,7 @@ def run(iters, seed, gpu, ora, verbose=True):
                 iv_b = np.array([rng.randint(a, len(seqs[c]) + 1) for c, a in zip(iv_c, iv_a)], np.int64)
                 for ctx in (gpu, ora):
                     ctx.labels_set(sel, sg, S)
+                _tr("intervals")
                 gi, oi = gpu.map_intervals(iv_c, iv_a, iv_b), ora.map_intervals(iv_c, iv_a, iv_b)
                 assert (gi == oi).all() and gpu.labels_hit() == ora.labels_hit(), "intervals"
             if C >= 2 and all(int(l) > 0 for l in ora.lengths()):
@@ -96,6 +109,7 @@ def run(iters, seed, gpu, ora, verbose=True):
                 args = (float(rng.choice([1.0, 1.5, 2.0, 3.0])), int(rng.choice([1, -1])), float(rng.choice([1, 3, 20])), 1e9,
                         float(rng.choice([0.5, 1.0])))
                 csr = sets_to_csr(sgs, list(range(C)))
+                _tr("filter %s %s" % (sgs, args))
                 res = []
                 for ctx in (gpu, ora):
                     try:
