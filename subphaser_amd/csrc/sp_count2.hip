@@ -385,7 +385,7 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
 // cost 3.8 ms per wheat-like pass).  A bucket that outgrew its region (estimate mode) raises the flag.
 __global__ void __launch_bounds__(256)
 c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
-         ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag) {
+         ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag, uint32_t list_div) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_fine) return;
     const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
@@ -394,7 +394,10 @@ c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
         n = cap;
         atomicAdd(flag, 1ULL);
     }
-    span[f] = make_ulonglong2(lo, lo + n);
+    // engine 2: [first, last) key.  Engine 3 (list_div = lower_count): first key, then {number of keys, the bucket's
+    // segment base floor(first / lower_count)} as two 32-bit halves -- the 64-bit division by a run-time divisor was a
+    // third of c2_count_list's instructions when every wave of the workgroup did it per bucket
+    span[f] = list_div ? make_ulonglong2(lo, (n & 0xffffffffULL) | ((lo / list_div) << 32)) : make_ulonglong2(lo, lo + n);
 }
 
 // ---------------------------------------------------------------- c2_count
@@ -558,8 +561,12 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
 // loads and stores in flight and waits for all of them (vmcnt(0)) at the first use; four 512-thread blocks per CU on
 // quarter buckets (32-KiB counters, the keys walked four times) were measured at twice the time
 // (profiles/r03_notes.md).
-#define C2L_DEPTH 2
-#define C2L_PF 4
+#ifndef C2L_DEPTH
+#define C2L_DEPTH 4      // buckets per group (one memory round trip per group)
+#endif
+#ifndef C2L_PF
+#define C2L_PF 2         // 8-byte loads per thread and bucket held in registers (8 K keys per bucket)
+#endif
 #define C2L_MAXB 256      // fine buckets per block at most (the launch sizes the grid accordingly)
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
@@ -581,98 +588,185 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
             s_span[j] = span[fbn];
     }
     __syncthreads();
+    // per prefetched bucket: aligned address of its first quad, offset of the first key in that quad (0..3), number of
+    // keys, segment base.  Everything inside a bucket is 32-bit arithmetic (a region holds < 2^32 keys: host check).
     uint2 pf[C2L_DEPTH][C2L_PF];
-    unsigned long long p_lo[C2L_DEPTH], p_hi[C2L_DEPTH];
+    unsigned long long p_a0[C2L_DEPTH];
+    uint32_t p_off[C2L_DEPTH], p_n[C2L_DEPTH], p_base[C2L_DEPTH];
     auto issue = [&](int d, int64_t fbn, int64_t j) {      // d is a constant after unrolling: the arrays live in registers
-        p_lo[d] = p_hi[d] = 0;
+        p_a0[d] = 0;
+        p_off[d] = p_n[d] = p_base[d] = 0;
         if (fbn >= n_fine) return;
         const ulonglong2 sp = s_span[j];
-        p_lo[d] = sp.x;
-        p_hi[d] = sp.y;
-        const unsigned long long a0 = sp.x & ~3ULL;            // whole quads from the aligned address below `first`
-        const unsigned long long nq = (sp.y - a0 + 3ULL) >> 2;
-        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a0);
+        p_a0[d] = sp.x & ~3ULL;            // whole quads from the aligned address below the first key
+        p_off[d] = (uint32_t)(sp.x & 3ULL);
+        p_n[d] = (uint32_t)sp.y;
+        p_base[d] = (uint32_t)(sp.y >> 32);
+        const uint32_t nq = (p_off[d] + p_n[d] + 3u) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + p_a0[d]);
 #pragma unroll
         for (int q = 0; q < C2L_PF; q++) {
-            const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nq) pf[d][q] = p2[i];
         }
     };
-    // f(residual) for the valid keys of quad i of the bucket [lo, hi)
-    auto quad = [&](const uint2 v, unsigned long long i, unsigned long long a0, unsigned long long lo, unsigned long long hi,
-                    auto &&f) {
-        const unsigned long long k0 = a0 + 4ULL * i;
-        if (k0 + 0 >= lo && k0 + 0 < hi) f(v.x & 0xffffu);
-        if (k0 + 1 >= lo && k0 + 1 < hi) f(v.x >> 16);
-        if (k0 + 2 >= lo && k0 + 2 < hi) f(v.y & 0xffffu);
-        if (k0 + 3 >= lo && k0 + 3 < hi) f(v.y >> 16);
+    // f(residual) for the valid keys of quad i of a bucket whose keys are [off, end) counted from its first quad
+    auto quad = [&](const uint2 v, uint32_t i, uint32_t off, uint32_t end, auto &&f) {
+        const uint32_t k0 = 4u * i;
+        if (k0 + 0 >= off && k0 + 0 < end) f(v.x & 0xffffu);
+        if (k0 + 1 >= off && k0 + 1 < end) f(v.x >> 16);
+        if (k0 + 2 >= off && k0 + 2 < end) f(v.y & 0xffffu);
+        if (k0 + 3 >= off && k0 + 3 < end) f(v.y >> 16);
     };
 #pragma unroll
     for (int d = 0; d < C2L_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
     int par = 0;
     int64_t j0 = 0;
+    // one bucket, full 32-bit counters (any size)
+    uint2 cur[C2L_DEPTH][C2L_PF];
+    unsigned long long c_a0[C2L_DEPTH];
+    uint32_t c_off[C2L_DEPTH], c_n[C2L_DEPTH], c_base[C2L_DEPTH];
+    auto single = [&](int d, int64_t fb) {
+        const uint32_t off = c_off[d], end = c_off[d] + c_n[d], nq = (end + 3u) >> 2;
+        const bool in_regs = nq <= (uint32_t)C2L_PF * C2_COUNT_THREADS;      // block-uniform
+        const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
+        const unsigned long long base = c_base[d];
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + c_a0[d]);
+        auto add = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
+        // ---- pass 1: count
+#pragma unroll
+        for (int q = 0; q < C2L_PF; q++) {
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
+            if (i < nq) quad(cur[d][q], i, off, end, add);
+        }
+        if (!in_regs)
+            for (uint32_t i = threadIdx.x + (uint32_t)C2L_PF * C2_COUNT_THREADS; i < nq; i += C2_COUNT_THREADS)
+                quad(p2[i], i, off, end, add);
+        sp_barrier_lds();   // (A) counts complete
+        auto emit = [&](uint32_t r, uint32_t c) {
+            if (c >= lower) {
+                s += c;
+                n++;
+                const unsigned long long pos = base + atomicAdd(&s_nov[par], 1u);
+                if (pos < stage_cap) stage[pos] = make_uint2(slot0 + r, c);
+            }
+        };
+        // ---- pass 2: every key swaps its counter for zero; the lane that gets the count back owns the slot
+        if (in_regs) {
+            auto take = [&](uint32_t r) {
+                const uint32_t c = atomicExch(&cnt[r], 0u);
+                if (c) emit(r, c);
+            };
+#pragma unroll
+            for (int q = 0; q < C2L_PF; q++) {
+                const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
+                if (i < nq) quad(cur[d][q], i, off, end, take);
+            }
+        } else {           // a crowded bucket: walk the counters instead of the keys
+            uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+            for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
+                const uint4 v = c4[i];
+                if (v.x | v.y | v.z | v.w) {
+                    c4[i] = make_uint4(0, 0, 0, 0);
+                    emit(4 * i + 0, v.x);
+                    emit(4 * i + 1, v.y);
+                    emit(4 * i + 2, v.z);
+                    emit(4 * i + 3, v.w);
+                }
+            }
+        }
+        if (threadIdx.x == 0) s_nov[par ^ 1] = 0;     // the other parity's tally was read after the previous (B)
+        sp_barrier_lds();   // (B) counters clean, tally final
+        if (threadIdx.x == 0) {
+            seg_cnt[fb] = s_nov[par];
+            seg_base[fb] = (uint32_t)base;
+        }
+        par ^= 1;
+    };
+    // TWO buckets of fewer than 65536 keys at once: they share the counters, 16 bits each (a count cannot exceed the
+    // number of keys of its bucket, so neither half carries into the other; pass 2 clears its own half with an atomic
+    // AND).  The chain of dependent LDS round trips and the two barriers are paid once per PAIR.
+    auto pair = [&](int d, int64_t fbA, int64_t fbB) {
+        const uint32_t offA = c_off[d], endA = c_off[d] + c_n[d], nqA = (endA + 3u) >> 2;
+        const uint32_t offB = c_off[d + 1], endB = c_off[d + 1] + c_n[d + 1], nqB = (endB + 3u) >> 2;
+        const uint32_t slotA = (uint32_t)(fbA * C2_FINE), slotB = (uint32_t)(fbB * C2_FINE);
+        const unsigned long long baseA = c_base[d], baseB = c_base[d + 1];
+        auto addA = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
+        auto addB = [&](uint32_t r) { atomicAdd(&cnt[r], 0x10000u); };
+#pragma unroll
+        for (int q = 0; q < C2L_PF; q++) {
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
+            if (i < nqA) quad(cur[d][q], i, offA, endA, addA);
+            if (i < nqB) quad(cur[d + 1][q], i, offB, endB, addB);
+        }
+        sp_barrier_lds();   // (A) counts complete
+        // tallies: the low half of s_nov[par] counts A's pairs, the high half B's
+        auto takeA = [&](uint32_t r) {
+            const uint32_t c = atomicAnd(&cnt[r], 0xffff0000u) & 0xffffu;
+            if (c >= lower) {      // (c != 0: this lane owns the slot)
+                s += c;
+                n++;
+                const unsigned long long pos = baseA + (atomicAdd(&s_nov[par], 1u) & 0xffffu);
+                if (pos < stage_cap) stage[pos] = make_uint2(slotA + r, c);
+            }
+        };
+        auto takeB = [&](uint32_t r) {
+            const uint32_t c = atomicAnd(&cnt[r], 0x0000ffffu) >> 16;
+            if (c >= lower) {
+                s += c;
+                n++;
+                const unsigned long long pos = baseB + (atomicAdd(&s_nov[par], 0x10000u) >> 16);
+                if (pos < stage_cap) stage[pos] = make_uint2(slotB + r, c);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < C2L_PF; q++) {
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
+            if (i < nqA) quad(cur[d][q], i, offA, endA, takeA);
+            if (i < nqB) quad(cur[d + 1][q], i, offB, endB, takeB);
+        }
+        if (threadIdx.x == 0) s_nov[par ^ 1] = 0;
+        sp_barrier_lds();   // (B) counters clean, tallies final
+        if (threadIdx.x == 0) {
+            const uint32_t t = s_nov[par];
+            seg_cnt[fbA] = t & 0xffffu;
+            seg_base[fbA] = (uint32_t)baseA;
+            seg_cnt[fbB] = t >> 16;
+            seg_base[fbB] = (uint32_t)baseB;
+        }
+        par ^= 1;
+    };
+    static_assert(C2L_DEPTH % 2 == 0, "buckets are taken in pairs");
+    // A GROUP of C2L_DEPTH buckets per iteration.  Their keys move to `cur` FIRST (the compiler waits for every load in
+    // flight at the first use of a loaded register -- vmcnt(0): it cannot count the conditional loads), THEN the loads
+    // of the next group are issued, THEN the group is processed bucket by bucket: the wait at the top of the next
+    // iteration finds loads that are a whole group old, and one memory round trip is paid per group, not per bucket
+    // (per bucket, issued after the work: 1.75 ms per Arabidopsis-like pass; copy-issue-work: 1.49; groups of 4: see
+    // profiles/r03_notes.md).
     for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L_DEPTH * gridDim.x, j0 += C2L_DEPTH) {
 #pragma unroll
         for (int d = 0; d < C2L_DEPTH; d++) {
-            const int64_t fb = fb0 + (int64_t)d * gridDim.x;
-            if (fb >= n_fine) break;     // block-uniform
-            const unsigned long long lo = p_lo[d], hi = p_hi[d];
-            const unsigned long long a0 = lo & ~3ULL, nq = (hi - a0 + 3ULL) >> 2;
-            const bool in_regs = nq <= (unsigned long long)C2L_PF * C2_COUNT_THREADS;      // block-uniform
-            const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
-            const unsigned long long base = lo / lower;
-            const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a0);
-            auto add = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
-            // ---- pass 1: count
 #pragma unroll
-            for (int q = 0; q < C2L_PF; q++) {
-                const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
-                if (i < nq) quad(pf[d][q], i, a0, lo, hi, add);
-            }
-            if (!in_regs)
-                for (unsigned long long i = threadIdx.x + (unsigned long long)C2L_PF * C2_COUNT_THREADS; i < nq; i += C2_COUNT_THREADS)
-                    quad(p2[i], i, a0, lo, hi, add);
-            sp_barrier_lds();   // (A) counts complete
-            auto emit = [&](uint32_t r, uint32_t c) {
-                if (c >= lower) {
-                    s += c;
-                    n++;
-                    const unsigned long long pos = base + atomicAdd(&s_nov[par], 1u);
-                    if (pos < stage_cap) stage[pos] = make_uint2(slot0 + r, c);
-                }
-            };
-            // ---- pass 2: every key swaps its counter for zero; the lane that gets the count back owns the slot
-            if (in_regs) {
-                auto take = [&](uint32_t r) {
-                    const uint32_t c = atomicExch(&cnt[r], 0u);
-                    if (c) emit(r, c);
-                };
+            for (int q = 0; q < C2L_PF; q++) cur[d][q] = pf[d][q];
+            c_a0[d] = p_a0[d];
+            c_off[d] = p_off[d];
+            c_n[d] = p_n[d];
+            c_base[d] = p_base[d];
+        }
 #pragma unroll
-                for (int q = 0; q < C2L_PF; q++) {
-                    const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS;
-                    if (i < nq) quad(pf[d][q], i, a0, lo, hi, take);
-                }
-            } else {           // a crowded bucket: walk the counters instead of the keys
-                uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
-                for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
-                    const uint4 v = c4[i];
-                    if (v.x | v.y | v.z | v.w) {
-                        c4[i] = make_uint4(0, 0, 0, 0);
-                        emit(4 * i + 0, v.x);
-                        emit(4 * i + 1, v.y);
-                        emit(4 * i + 2, v.z);
-                        emit(4 * i + 3, v.w);
-                    }
-                }
+        for (int d = 0; d < C2L_DEPTH; d++)
+            issue(d, fb0 + (int64_t)(d + C2L_DEPTH) * gridDim.x, j0 + d + C2L_DEPTH);
+#pragma unroll
+        for (int d = 0; d < C2L_DEPTH; d += 2) {
+            const int64_t fbA = fb0 + (int64_t)d * gridDim.x, fbB = fbA + gridDim.x;
+            if (fbA >= n_fine) break;           // block-uniform
+            const uint32_t lim = (uint32_t)C2L_PF * C2_COUNT_THREADS * 4u - 8u;
+            if (fbB < n_fine && c_n[d] < 65536u && c_n[d + 1] < 65536u && c_n[d] <= lim && c_n[d + 1] <= lim) {
+                pair(d, fbA, fbB);
+            } else {
+                single(d, fbA);
+                if (fbB < n_fine) single(d + 1, fbB);
             }
-            if (threadIdx.x == 0) s_nov[par ^ 1] = 0;     // the other parity's tally was read after the previous (B)
-            sp_barrier_lds();   // (B) counters clean, tally final
-            if (threadIdx.x == 0) {
-                seg_cnt[fb] = s_nov[par];
-                seg_base[fb] = (uint32_t)base;
-            }
-            issue(d, fb + (int64_t)C2L_DEPTH * gridDim.x, j0 + d + C2L_DEPTH);
-            par ^= 1;
         }
     }
     unsigned long long ts = sp_block_sum_u64(s, red);
@@ -776,6 +870,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     // (a bucket's segment starts at floor(its first key / L), L = 255 or lower_count: cap_keys / L pairs at most)
     uint2 *ovf_tmp = (uint2 *)(ws + o_buf1);
     unsigned long long ovf_cap = (unsigned long long)(lo1_bytes / 8);
+    if (list && c.len >= (1LL << 32) - 16)
+        return sp_fail(ctx, SP_EUNSUP, "count engine 3: a chromosome of %lld bases (32-bit positions inside a bucket)", (long long)c.len);
     if (cap_keys / (size_t)(list ? lower : 255) + C2_FINE >= ((size_t)1 << 32))
         return sp_fail(ctx, SP_EUNSUP, "count engine 2: a chromosome of %lld bases needs 64-bit segment offsets", (long long)c.len);
     if (list) {
@@ -814,7 +910,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
     ulonglong2 *span = (ulonglong2 *)(ws + o_span);
     SP_LAUNCH(ctx, "c2_spans", c2_spans, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, (const unsigned long long *)off_fine,
-              (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3);
+              (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3, (uint32_t)(list ? lower : 0));
     if (list) {
         if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
         SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
