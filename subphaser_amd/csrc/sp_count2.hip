@@ -233,14 +233,29 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     __shared__ unsigned long long delta[C2_MAXF];
     __shared__ uint32_t keys[C2_P1_KEYS];
     const int sh = 32 - 2 * kp.k;
+    // the words of the NEXT tile's unit travel while this tile is sorted and written (copy to working registers, issue
+    // the next loads, then work: loads issued after the work are waited for in full at the next use -- r03_notes.md)
+    sp_words32 p_x;
+    uint32_t p_nm0 = 0, p_nm1 = 0;
+    auto fetch = [&](int64_t t) {
+        const int64_t u = t * C2_P1_THREADS + threadIdx.x;
+        if (t < n_tiles && u < n_units) {
+            p_nm0 = nm[u];              // (u * 32) >> 5
+            p_nm1 = nm[u + 1];
+            p_x = sp_load_words32(pk, pm, u * C2_P1_UNIT);
+        }
+    };
+    fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (threadIdx.x < F1) hist[threadIdx.x] = 0;
-        __syncthreads();
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
+        const sp_words32 x = p_x;
+        const uint32_t c_nm0 = p_nm0, c_nm1 = p_nm1;
+        fetch(tile + gridDim.x);
+        __syncthreads();
         uint32_t slot[32], rank[32], ok = 0;
         if (u < n_units) {
-            ok = ~(uint32_t)sp_bad_starts64(nm, u * C2_P1_UNIT, kp.k);
-            const sp_words32 x = sp_load_words32(pk, pm, u * C2_P1_UNIT);
+            ok = ~(uint32_t)sp_bad_from_words64((uint64_t)c_nm0 | ((uint64_t)c_nm1 << 32), kp.k);
             auto f = [&](int j, uint32_t V, uint32_t W) {
                 slot[j] = kp.odd ? sp_slot_of32_t<true>(V >> sh, ~W & kp.kmask, kp)
                                  : sp_slot_of32_t<false>(V >> sh, ~W & kp.kmask, kp);

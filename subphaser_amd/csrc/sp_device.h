@@ -177,6 +177,17 @@ __device__ __forceinline__ void sp_scan_unit64(const uint32_t *__restrict__ pk, 
 
 // bit j of the result: the w bases s0+j .. s0+j+w-1 are all valid (w <= 32; s0 a multiple of 32).
 // `shift1`: answer for windows starting one base later (s0+j+1 ..), used for the shared (k-1)-mer.
+__device__ __forceinline__ uint64_t sp_bad_from_words64(uint64_t inv, int w) {
+    if (w <= 0) return 0;
+    uint64_t e = inv;
+    int have = 1;
+    while (have * 2 <= w) {
+        e |= e >> have;
+        have *= 2;
+    }
+    if (have < w) e |= e >> (w - have);
+    return e;   // bit j: an invalid base in [s0+j, s0+j+w)
+}
 __device__ __forceinline__ uint64_t sp_bad_starts64(const uint32_t *__restrict__ nm, int64_t s0, int w) {
     const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     if (w <= 0) return 0;

@@ -155,8 +155,24 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     __shared__ uint32_t head[THREADS];      // tile positions / 32 = THREADS words
     __shared__ uint16_t hpre[THREADS];
     const uint64_t rmask = (R1 >= 64) ? ~0ULL : ((1ULL << R1) - 1ULL);
+    // the NEXT tile's unit (validity words + both packed streams) travels while this tile is sorted and written: copy
+    // to working registers, issue the next loads, then work (profiles/r03_notes.md)
+    sp_words64 p_x;
+    uint32_t p_nm0 = 0, p_nm1 = 0;
+    auto fetch = [&](int64_t t) {
+        const int64_t u = t * THREADS + threadIdx.x;
+        if (t < n_tiles && u < n_units) {
+            p_nm0 = nm[u];              // (u * 32) >> 5
+            p_nm1 = nm[u + 1];
+            p_x = sp_load_words64(pk, pm, u * S3_P1_UNIT);
+        }
+    };
+    fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
+        const sp_words64 x = p_x;
+        const uint32_t c_nm0 = p_nm0, c_nm1 = p_nm1;
+        fetch(tile + gridDim.x);
         __syncthreads();
         // ONE scan: the unit's 32 canonical keys stay in registers (the 64-KiB tile leaves one block per CU, so
         // registers are plentiful); the rank inside the bucket run is what the histogram atomic returns
@@ -164,9 +180,8 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         uint64_t key[32];
         uint32_t rank[32], ok = 0;
         if (u < n_units) {
-            ok = ~(uint32_t)sp_bad_starts64(nm, u * S3_P1_UNIT, kp.k);
+            ok = ~(uint32_t)sp_bad_from_words64((uint64_t)c_nm0 | ((uint64_t)c_nm1 << 32), kp.k);
             if (ok) {
-                const sp_words64 x = sp_load_words64(pk, pm, u * S3_P1_UNIT);
                 sp_scan32_keys64(x, kp, [&](int j, uint64_t fwd, uint64_t rc) {
                     key[j] = fwd < rc ? fwd : rc;
                     if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[key[j] >> R1], 1u);
