@@ -257,7 +257,7 @@ template <typename KR1>
 __global__ void __launch_bounds__(S3_P2_THREADS)
 s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
-         unsigned long long *__restrict__ hist2 /* F1 * F2 */) {
+         unsigned long long *__restrict__ hist2 /* F1 * F2 */, int sample /* 1: two rows of 16 of every tile */) {
     __shared__ uint32_t lh[S3_MAXF];
     __shared__ int s_b;
     const unsigned long long n_tiles = tile_start[F1];
@@ -282,6 +282,16 @@ s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
             __syncthreads();
         }
         const unsigned long long base = off1[cb] + (tile - tile_start[cb]) * S3_P2_KEYS, end = off1[cb + 1];
+        if (sample) {       // one 64-key group in eight, from every row of every tile: wave (tile mod 8) reads its slices
+            if ((int)(threadIdx.x >> 6) == (int)(tile & 7ULL)) {
+#pragma unroll
+                for (int j = 0; j < S3_P2_PER; j++) {
+                    const unsigned long long idx = base + (unsigned long long)j * S3_P2_THREADS + threadIdx.x;
+                    if (idx < end) atomicAdd(&lh[(uint32_t)(buf1[idx] >> R2) & mask2], 1u);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < S3_P2_PER; j++) {
             const unsigned long long idx = base + (unsigned long long)j * S3_P2_THREADS + threadIdx.x;
@@ -293,6 +303,41 @@ s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
         const uint32_t v = lh[i];
         if (v) atomicAdd(&hist2[(size_t)cb * F2 + i], (unsigned long long)v);
     }
+}
+
+// Round 3: level-2 regions from a SAMPLE.  s3_hist2 reads one 64-key group in eight of every row of every tile (an
+// eighth of the level-1 buffer in 256-byte pieces: 17 -> 5 ms per wheat-like pass; whole rows of 512 keys were cheaper
+// still but missed the ~2 K-key chunks in which a tandem array reaches a bucket, and the 30 K-key telomere buckets of the
+// wheat-like genome overran their regions on most chromosomes); s3_caps turns a sampled count s into a capacity 10 s + 8 ceil(7 sqrt(s)) +
+// S3_CAP_SLACK (1.25 x the estimate, seven standard deviations of it, and a constant -- memory is plentiful), the scan of the capacities lays the regions out, s3_part2 drops what does not fit and s3_spans -- which
+// also turns the cursors, updated by atomics, into plainly stored {offset, size} records for the kernels that follow --
+// raises a flag; the chromosome is then counted again with exact sizes (sample = 0), so results never depend on the
+// estimate.
+#ifndef S3_CAP_SLACK
+#define S3_CAP_SLACK 1024ULL
+#endif
+#define S3_DROP (~0ULL)
+static_assert(S3_P2_THREADS == 512, "the sample takes one of the eight waves of a tile row");
+#define S3_CAP_MULT 10ULL         // x sampled count (the sample is an eighth: 1.25 x the estimate)
+__global__ void __launch_bounds__(256)
+s3_caps(unsigned long long *__restrict__ hist2, int64_t n_fine, unsigned long long mult, unsigned long long slack) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fine) return;
+    const unsigned long long s = hist2[f];
+    hist2[f] = mult * s + 8ULL * (unsigned long long)ceilf(7.0f * sqrtf((float)s)) + slack;
+}
+__global__ void __launch_bounds__(256)
+s3_spans(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
+         ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fine) return;
+    const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
+    unsigned long long n = cursor2[f];
+    if (n > cap) {
+        n = cap;
+        atomicAdd(flag, 1ULL);
+    }
+    span[f] = make_ulonglong2(lo, n);
 }
 
 // ---------------------------------------------------------------- s3_part2
@@ -354,7 +399,9 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
             if (d < F2) {
                 const uint32_t c = hist[d];
                 const size_t fine = (size_t)b1 * F2 + d;
-                g[q] = off_fine[fine] + (c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL);
+                const unsigned long long o0 = off_fine[fine], at = c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL;
+                // (sampled sizes: a run that does not fit its region is dropped, s3_spans raises the flag)
+                g[q] = at + c <= off_fine[fine + 1] - o0 ? o0 + at : S3_DROP;
             }
         }
         nnext = 0;
@@ -363,7 +410,7 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
 #pragma unroll
         for (int q = 0; q < (S3_MAXF + S3_P2_THREADS - 1) / S3_P2_THREADS; q++) {
             const int d = threadIdx.x + q * S3_P2_THREADS;
-            if (d < F2) gdelta[d] = g[q] - start[d];
+            if (d < F2) gdelta[d] = g[q] == S3_DROP ? S3_DROP : g[q] - start[d];
         }
 #pragma unroll
         for (int j = 0; j < S3_P2_PER; j++)
@@ -371,7 +418,8 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
         __syncthreads();   // (D)
         for (uint32_t i = threadIdx.x; i < total; i += S3_P2_THREADS) {
             const KR1 kk = keys[i];
-            buf2[gdelta[(uint32_t)(kk >> R2) & mask2] + i] = (KR2)((uint64_t)kk & rmask);
+            const unsigned long long gd = gdelta[(uint32_t)(kk >> R2) & mask2];
+            if (gd != S3_DROP) buf2[gd + i] = (KR2)((uint64_t)kk & rmask);
         }
         p ^= 1;
     }
@@ -491,7 +539,7 @@ __device__ __forceinline__ uint32_t s3_sort_segment(const KR2 *__restrict__ seg,
 // light kernel: buckets of <= 1024 residuals (4 per thread, ~14 KB of LDS: many blocks per CU)
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
-s3_final_small(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+s3_final_small(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
                uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
                unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
     // size classes: a 200-key bucket must not pay for a padded 2048-key sort
@@ -504,8 +552,8 @@ s3_final_small(const KR2 *__restrict__ buf2, const unsigned long long *__restric
     __shared__ unsigned long long red[16];
     unsigned long long lsum = 0;
     for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
-        const unsigned long long o = off_fine[bucket];
-        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        const ulonglong2 sp_ = span[bucket];
+        const unsigned long long o = sp_.x, n64 = sp_.y;
         if (n64 > S3_SMALL_CAP) continue;            // the heavy kernel's
         if (n64 == 0) {
             if (threadIdx.x == 0) kept[bucket] = 0;
@@ -569,7 +617,7 @@ __device__ __forceinline__ uint32_t s3_scan_reg(uint32_t v, uint32_t *wsum /* >=
 
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
-s3_final_bitmap(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
                 uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
                 unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm_lds[];   // bm[nw] | cnt[S3_BM_CAP] | pre[nw] (u16)
@@ -589,8 +637,9 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const unsigned long long *__restri
     auto fetch = [&](int64_t b) {
         p_n = 0;
         if (b >= n_fine) return;
-        p_o = off_fine[b];
-        p_n = off_fine[b + 1] - p_o;
+        const ulonglong2 sp_ = span[b];
+        p_o = sp_.x;
+        p_n = sp_.y;
         if (p_n > S3_BM_NMAX) return;
 #pragma unroll
         for (int j = 0; j < S3_BM_PER; j++) {
@@ -715,7 +764,7 @@ __device__ __forceinline__ uint32_t s3h_hash2(unsigned long long v) {
 
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
-s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ off_fine, int64_t n_fine, int R2,
+s3_final_hash(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
               uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
               unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
     __shared__ s3h_lds<KR2> L;
@@ -737,8 +786,8 @@ s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict
         atomicAdd(&L.u.t.cnt[h], 1u);
     };
     for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
-        const unsigned long long o = off_fine[bucket];
-        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        const ulonglong2 sp_ = span[bucket];
+        const unsigned long long o = sp_.x, n64 = sp_.y;
         if (n64 == 0 || n64 > S3_BM_NMAX) {
             if (tid == 0) kept[bucket] = n64 ? S3_BM_PUNT : 0ULL;
             continue;
@@ -828,7 +877,7 @@ s3_final_hash(const KR2 *__restrict__ buf2, const unsigned long long *__restrict
 
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
-s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned long long *__restrict__ off_fine,
+s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglong2 *__restrict__ span,
          int64_t n_fine, int R2, uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
          unsigned long long *__restrict__ kept, unsigned long long *__restrict__ big_list,
          unsigned long long *__restrict__ n_big, unsigned long long big_cap, unsigned long long *__restrict__ len_sum,
@@ -837,8 +886,8 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned
     __shared__ s3_final_lds<KR2> L;
     unsigned long long lsum = 0;
     for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
-        const unsigned long long o = off_fine[bucket];
-        const unsigned long long n64 = off_fine[bucket + 1] - o;
+        const ulonglong2 sp_ = span[bucket];
+        const unsigned long long o = sp_.x, n64 = sp_.y;
         if (light_cap == S3_BM_PUNT ? kept[bucket] != S3_BM_PUNT : n64 <= light_cap) continue;   // the light kernel's
         if (n64 <= S3_SORT_CAP) {
             const uint32_t nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
@@ -1010,13 +1059,13 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const unsigned
 // end of its run by binary search, runs >= lower are kept in order.
 template <typename KR2>
 __global__ void __launch_bounds__(256)
-s3_big_rle(const KR2 *__restrict__ sorted, const unsigned long long *__restrict__ big, const unsigned long long *__restrict__ off_fine,
+s3_big_rle(const KR2 *__restrict__ sorted, const unsigned long long *__restrict__ big, const ulonglong2 *__restrict__ span,
            uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts, unsigned long long *__restrict__ kept,
            unsigned long long *__restrict__ len_sum) {
     __shared__ uint32_t lds[16];
     __shared__ unsigned long long red[16];
     const unsigned long long b = big[blockIdx.x];
-    const unsigned long long o = off_fine[b], n = off_fine[b + 1] - o;
+    const unsigned long long o = span[b].x, n = span[b].y;
     const KR2 *s = sorted + o;
     unsigned long long w = 0, lsum = 0;
     for (unsigned long long base = 0; base < n; base += 256) {
@@ -1056,7 +1105,7 @@ s3_big_rle(const KR2 *__restrict__ sorted, const unsigned long long *__restrict_
 template <typename KR2>
 __global__ void __launch_bounds__(256)
 s3_gather(const KR2 *__restrict__ tmp_keys, const uint32_t *__restrict__ tmp_cnts,
-          const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ kept_excl,
+          const ulonglong2 *__restrict__ span, const unsigned long long *__restrict__ kept_excl,
           const unsigned long long *__restrict__ kept_tot, int64_t n_fine, int R2,
           unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_cnts) {
     // one wave per fine bucket
@@ -1066,7 +1115,7 @@ s3_gather(const KR2 *__restrict__ tmp_keys, const uint32_t *__restrict__ tmp_cnt
     for (int64_t b = wave; b < n_fine; b += n_waves) {
         const unsigned long long w0 = kept_excl[b];
         const unsigned long long n = ((b + 1 < n_fine) ? kept_excl[b + 1] : *kept_tot) - w0;
-        const unsigned long long o = off_fine[b];
+        const unsigned long long o = span[b].x;
         const unsigned long long hi = (R2 >= 64) ? 0ULL : ((unsigned long long)b << R2);
         for (unsigned long long i = lane; i < n; i += 64) {
             out_keys[w0 + i] = hi | (unsigned long long)tmp_keys[o + i];
@@ -1138,7 +1187,7 @@ static int s3_scan(sp_ctx *ctx, unsigned long long *a, int64_t n, unsigned long 
 // ================================================================== host side
 template <typename KR1, typename KR2>
 static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_plan &P, const sp_kparams &kp,
-                          int lower) {
+                          int lower, bool exact, bool *overran) {
     const int64_t len = c.len;
     const int64_t n_fine = (int64_t)P.F1 * P.F2;
     // small arrays: hist1 / off1 [F1+1], cursor1 [F1], tile_start [F1+1], hist2 -> off_fine [n_fine+1],
@@ -1146,7 +1195,8 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     const size_t big_cap = 1 << 16;
     const size_t o_h1 = 0, o_c1 = o_h1 + (size_t)(P.F1 + 1) * 8, o_ts = o_c1 + (size_t)P.F1 * 8,
                  o_of = o_ts + (size_t)(P.F1 + 1) * 8, o_c2 = o_of + (size_t)(n_fine + 1) * 8,
-                 o_kp = o_c2 + (size_t)n_fine * 8, o_big = o_kp + (size_t)(n_fine + 1) * 8,
+                 o_kp = o_c2 + (size_t)n_fine * 8, o_span = o_kp + (size_t)(n_fine + 1) * 8,
+                 o_big = o_span + (size_t)n_fine * 16,
                  o_small = o_big + big_cap * 8, o_bsum = o_small + 256, small_bytes = o_bsum + 1024 * 8;
     int rc = sp_buf_ensure(ctx, ctx->b_s3_small, (int64_t)small_bytes);
     if (rc) return rc;
@@ -1156,7 +1206,8 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
                        *d_c2 = (unsigned long long *)(S + o_c2), *d_kp = (unsigned long long *)(S + o_kp),
                        *d_big = (unsigned long long *)(S + o_big), *d_small = (unsigned long long *)(S + o_small),
                        *d_bsum = (unsigned long long *)(S + o_bsum);
-    // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total
+    ulonglong2 *d_span = (ulonglong2 *)(S + o_span);
+    // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total, [5] sum of the region capacities, [6] overrun flag
     SP_HIP(ctx, hipMemsetAsync(S, 0, small_bytes, ctx->stream));
     const int64_t n_units64 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;      // (units of 32 starts since the direct-window scan)
     int64_t grid = (n_units64 + 255) / 256;
@@ -1172,12 +1223,27 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     out.length_sum = 0;
     if (nv == 0) return SP_OK;
     if (nv >= (1ULL << 32)) return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
-    rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)nv * (int64_t)sizeof(KR1) + 64);
+    // keys the level-2 regions can hold: nv exactly (exact = sizes from the full histogram) or a bound on the sum of
+    // the sampled capacities -- full tiles contribute exactly an eighth of their keys to the sample, the last tile of a
+    // level-1 bucket at most two rows; sum of sqrt <= sqrt(n * sum)
+    unsigned long long cap_tot = nv;
+    if (!exact) {
+        const double s_max = (double)nv / 8.0 + (double)P.F1 * 64.0 * S3_P2_PER;
+        cap_tot = (unsigned long long)(10.0 * s_max + 8.0 * (7.0 * sqrt((double)n_fine * s_max) + (double)n_fine) +
+                                       (double)S3_CAP_SLACK * (double)n_fine) + 4096ULL;
+        if (cap_tot >= (1ULL << 32)) {      // 32-bit positions in the library sort of the hot buckets: exact sizes instead
+            exact = true;
+            cap_tot = nv;
+        }
+    }
+    *overran = false;
+    const size_t a_bytes = (size_t)nv * sizeof(KR1) > (size_t)cap_tot * sizeof(KR2) ? (size_t)nv * sizeof(KR1) : (size_t)cap_tot * sizeof(KR2);
+    rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes + 64);      // level-1 records, later the finish kernels' scratch (region-indexed)
     if (rc) return rc;
-    rc = sp_buf_ensure(ctx, ctx->b_sp_b, (int64_t)nv * (int64_t)sizeof(KR2) + 64);
+    rc = sp_buf_ensure(ctx, ctx->b_sp_b, (int64_t)cap_tot * (int64_t)sizeof(KR2) + 64);
     if (rc) return rc;
-    const size_t tk_bytes = ((size_t)nv * sizeof(KR2) + 63) & ~(size_t)63;
-    rc = sp_buf_ensure(ctx, ctx->b_sp_c, (int64_t)(tk_bytes + (size_t)nv * 4 + 64));
+    const size_t tk_bytes = ((size_t)cap_tot * sizeof(KR2) + 63) & ~(size_t)63;
+    rc = sp_buf_ensure(ctx, ctx->b_sp_c, (int64_t)(tk_bytes + (size_t)cap_tot * 4 + 64));
     if (rc) return rc;
     KR1 *buf1 = (KR1 *)ctx->b_sp_a.p;
     KR2 *buf2 = (KR2 *)ctx->b_sp_b.p;
@@ -1198,14 +1264,21 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, P.F1, d_ts);
     const int64_t est_tiles = (int64_t)(nv / S3_P2_KEYS) + P.F1 + 1;
     int64_t g2 = est_tiles < (int64_t)ctx->n_cu * 8 ? est_tiles : (int64_t)ctx->n_cu * 8;
-    SP_LAUNCH(ctx, "s3_hist2", s3_hist2<KR1>, dim3((unsigned)g2), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
-              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2, d_of);
+    SP_LAUNCH(ctx, exact ? "s3_hist2" : "s3_hist2_sample", s3_hist2<KR1>, dim3((unsigned)g2), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
+              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2, d_of, exact ? 0 : 1);
+    if (!exact) {
+        const char *em = getenv("SP_S3_MULT"), *es = getenv("SP_S3_SLACK");      // test hooks (force overruns)
+        SP_LAUNCH(ctx, "s3_caps", s3_caps, dim3((unsigned)((n_fine + 255) / 256)), dim3(256), 0, d_of, n_fine,
+                  em ? (unsigned long long)atoll(em) : S3_CAP_MULT, es ? (unsigned long long)atoll(es) : S3_CAP_SLACK);
+    }
     rc = s3_scan(ctx, d_of, n_fine + 1, d_small + 5, d_bsum);
     if (rc) return rc;
     int64_t g3 = est_tiles < (int64_t)ctx->n_cu * 16 ? est_tiles : (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "s3_part2", (s3_part2<KR1, KR2>), dim3((unsigned)g3), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
               (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
               (const unsigned long long *)d_of, d_c2, buf2);
+    SP_LAUNCH(ctx, "s3_spans", s3_spans, dim3((unsigned)((n_fine + 255) / 256)), dim3(256), 0, (const unsigned long long *)d_of,
+              (const unsigned long long *)d_c2, n_fine, d_span, d_small + 6);
     int64_t g4 = n_fine < (int64_t)ctx->n_cu * 64 ? n_fine : (int64_t)ctx->n_cu * 64;
     const bool bitmap = P.R2 <= S3_BM_MAXBITS && sizeof(KR2) == 4;      // k = 16, 17
     // k >= 18: hashed pre-count + exact table of the survivors (SP_S3_FINAL=sort: the block radix sort of round 2)
@@ -1214,48 +1287,56 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     if (bitmap)
         SP_LAUNCH(ctx, "s3_final_bitmap", s3_final_bitmap<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS),
                   (size_t)(P.R2 > 5 ? 1 << (P.R2 - 5) : 1) * 6 + (size_t)S3_BM_CAP * 4,
-                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
     else if (use_hash)
         SP_LAUNCH(ctx, "s3_final_hash", s3_final_hash<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
-                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
     else
         SP_LAUNCH(ctx, "s3_final_small", s3_final_small<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
-                  (const KR2 *)buf2, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
     SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
-              (KR2 *)buf1, (const unsigned long long *)d_of, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
+              (KR2 *)buf1, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
               d_small + 1, (unsigned long long)big_cap, d_small + 2,
               (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP);
-    unsigned long long n_big = 0;
+    unsigned long long n_big = 0, h_flag = 0;
     SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(&h_flag, d_small + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_flag) {      // a region overran (keys were dropped): the caller counts the chromosome again with exact sizes
+        *overran = true;
+        out.n = 0;
+        out.length_sum = 0;
+        return SP_OK;
+    }
     if (n_big > big_cap) return sp_fail(ctx, SP_EUNSUP, "k > 15: %llu oversized k-mer buckets", n_big);
     if (n_big) {   // hot keys: buckets beyond one workgroup -- ONE segmented device sort, then one block per bucket
-        std::vector<unsigned long long> big((size_t)n_big), offs((size_t)n_fine + 1), seg(2 * (size_t)n_big);
+        std::vector<unsigned long long> big((size_t)n_big), seg(2 * (size_t)n_big);
+        std::vector<ulonglong2> spans((size_t)n_fine);
         SP_HIP(ctx, hipMemcpy(big.data(), d_big, (size_t)n_big * 8, hipMemcpyDeviceToHost));
-        SP_HIP(ctx, hipMemcpy(offs.data(), d_of, (size_t)(n_fine + 1) * 8, hipMemcpyDeviceToHost));
+        SP_HIP(ctx, hipMemcpy(spans.data(), d_span, (size_t)n_fine * 16, hipMemcpyDeviceToHost));
         for (size_t bi = 0; bi < (size_t)n_big; bi++) {
-            seg[bi] = offs[(size_t)big[bi]];
-            seg[(size_t)n_big + bi] = offs[(size_t)big[bi] + 1];
+            seg[bi] = spans[(size_t)big[bi]].x;
+            seg[(size_t)n_big + bi] = spans[(size_t)big[bi]].x + spans[(size_t)big[bi]].y;
         }
-        KR2 *srt = (KR2 *)buf1;      // the level-1 buffer is free by now and holds nv keys of at least this width
+        KR2 *srt = (KR2 *)buf1;      // the level-1 buffer is free by now and holds every region (a_bytes above)
         size_t tb = 0;
         const unsigned long long *nul = nullptr;
-        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, (const KR2 *)buf2, srt, (unsigned int)nv, (unsigned int)n_big,
+        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, (const KR2 *)buf2, srt, (unsigned int)cap_tot, (unsigned int)n_big,
                                                        nul, nul, 0u, (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
         const size_t seg_bytes = 2 * (size_t)n_big * 8;
         rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)(tb + seg_bytes + 512));
         if (rc) return rc;
         unsigned long long *d_seg = (unsigned long long *)((char *)ctx->b_sp_tmp.p + ((tb + 255) & ~(size_t)255));
         SP_HIP(ctx, hipMemcpyAsync(d_seg, seg.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(ctx->b_sp_tmp.p, tb, (const KR2 *)buf2, srt, (unsigned int)nv,
+        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(ctx->b_sp_tmp.p, tb, (const KR2 *)buf2, srt, (unsigned int)cap_tot,
                                                        (unsigned int)n_big, (const unsigned long long *)d_seg,
                                                        (const unsigned long long *)(d_seg + n_big), 0u,
                                                        (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
         SP_LAUNCH(ctx, "s3_big_rle", s3_big_rle<KR2>, dim3((unsigned)n_big), dim3(256), 0, (const KR2 *)srt,
-                  (const unsigned long long *)d_big, (const unsigned long long *)d_of, (uint32_t)lower, tmp_keys, tmp_cnts,
+                  (const unsigned long long *)d_big, (const ulonglong2 *)d_span, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `seg` (pageable) must outlive the copy
     }
@@ -1281,7 +1362,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
         int64_t g5 = (n_fine * 64 + 255) / 256;
         if (g5 > (int64_t)ctx->n_cu * 32) g5 = (int64_t)ctx->n_cu * 32;
         SP_LAUNCH(ctx, "s3_gather", s3_gather<KR2>, dim3((unsigned)g5), dim3(256), 0, (const KR2 *)tmp_keys,
-                  (const uint32_t *)tmp_cnts, (const unsigned long long *)d_of, (const unsigned long long *)d_kp,
+                  (const uint32_t *)tmp_cnts, (const ulonglong2 *)d_span, (const unsigned long long *)d_kp,
                   (const unsigned long long *)(d_small + 3), n_fine, P.R2, (unsigned long long *)out.d_keys, out.d_cnts);
     }
     return SP_OK;
@@ -1295,6 +1376,7 @@ int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
     }
     const sp_kparams kp = sp_make_kparams(k);
     const s3_plan P = s3_make_plan(k);
+    const char *env_exact = getenv("SP_S3_EXACT");      // "1": level-2 regions from the full histogram (the round-2 path)
     for (size_t ci = 0; ci < C; ci++) {
         sp_chrom &c = ctx->chroms[ci];
         sp_sparse_chrom &o = ctx->sparse[ci];
@@ -1303,10 +1385,19 @@ int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
         c.length_sum = 0;
         c.n_dump = 0;
         if (c.len <= 0) continue;
-        int rc;
-        if (!P.wide1) rc = s3_count_chrom<uint32_t, uint32_t>(ctx, c, o, P, kp, lower);
-        else if (!P.wide2) rc = s3_count_chrom<unsigned long long, uint32_t>(ctx, c, o, P, kp, lower);
-        else rc = s3_count_chrom<unsigned long long, unsigned long long>(ctx, c, o, P, kp, lower);
+        int rc = SP_OK;
+        bool exact = env_exact && env_exact[0] == '1';
+        for (int attempt = 0; attempt < 2; attempt++) {      // sampled region sizes first, exact ones if a region overran
+            bool overran = false;
+            if (!P.wide1) rc = s3_count_chrom<uint32_t, uint32_t>(ctx, c, o, P, kp, lower, exact, &overran);
+            else if (!P.wide2) rc = s3_count_chrom<unsigned long long, uint32_t>(ctx, c, o, P, kp, lower, exact, &overran);
+            else rc = s3_count_chrom<unsigned long long, unsigned long long>(ctx, c, o, P, kp, lower, exact, &overran);
+            if (rc || !overran) break;
+            if (exact) return sp_fail(ctx, SP_ESTATE, "k > 15: a bucket overran a region of its exact size");
+            exact = true;
+            ctx->c2_recounts++;
+            if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] k > 15: chromosome %zu recounted with exact bucket sizes\n", ci);
+        }
         if (rc) return rc;
         c.length_sum = o.length_sum;
         c.n_dump = o.n;

@@ -192,6 +192,31 @@ def test_count_sparse_engine(gpu_ctx, k, engine):
     _count_both(gpu_ctx, seqs, k, 3, engine)
 
 
+def test_count_sparse_engine_sampled_sizing_and_recount(gpu_ctx, monkeypatch):
+    """k > 15 (round 3): the level-2 regions are laid out from a 1-in-8 sample of the level-1 buffer.  (a) sampled sizes
+    on plain + repeat-rich sequence: exact results; (b) regions forced far too small (test hooks): keys are dropped, the
+    flag goes up, the chromosome is counted again from the exact histogram -- same results, recounts reported;
+    (c) SP_S3_EXACT=1 (the round-2 path) never recounts."""
+    rng = np.random.RandomState(77)
+    unit = _rand_seq(rng, 31, 0, 0)
+    seqs = [np.concatenate([_rand_seq(rng, 300_000), np.tile(unit, 3000), _rand_seq(rng, 50_000)]), _rand_seq(rng, 180_000)]
+    before = gpu_ctx.count_recounts()
+    for k in (16, 17, 21, 32):
+        _count_both(gpu_ctx, seqs, k, 2, 0)
+    assert gpu_ctx.count_recounts() == before                       # (a)
+    monkeypatch.setenv("SP_S3_MULT", "2")
+    monkeypatch.setenv("SP_S3_SLACK", "0")
+    for k in (17, 21, 32):
+        _count_both(gpu_ctx, seqs, k, 1, 0)
+    assert gpu_ctx.count_recounts() >= before + 3                   # (b)
+    monkeypatch.delenv("SP_S3_MULT")
+    monkeypatch.delenv("SP_S3_SLACK")
+    monkeypatch.setenv("SP_S3_EXACT", "1")
+    n = gpu_ctx.count_recounts()
+    _count_both(gpu_ctx, seqs, 17, 3, 0)                            # (c)
+    assert gpu_ctx.count_recounts() == n
+
+
 def test_count_sparse_engine_hot_buckets(gpu_ctx):
     """Buckets beyond one workgroup's sort capacity (a k-mer repeated > 4096 times, and many distinct keys
     sharing the 18-19 partition bits) take the device-wide fallback of the MSD engine."""
