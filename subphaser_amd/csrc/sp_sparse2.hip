@@ -122,18 +122,41 @@ __device__ __forceinline__ uint32_t s3_scan_reg_t(uint32_t v, uint32_t *wsum /* 
     return base + incl - v;
 }
 
+// Round 3: the level-1 regions, too, come from a sample: s3_hist1 scans ONE STRIPE of 64 units (2048 starts) IN 16,
+// rotating through the groups like engine 2's sampler; a level-1 bucket receives ~40 K sampled keys of a wheat-sized
+// chromosome, so the estimate is good to a fraction of a per cent and the capacity s * 16 * 33/32 + slack wastes
+// nothing to speak of.  Runs that do not fit land in a trash area behind the regions, s3_tiles raises the flag and
+// the chromosome is counted again from the exact histograms.
+#define S3_STRIPE 64
+#define S3_SAMPLE_SHIFT 4
+#define S3_SAMPLE_MIN_LEN (1LL << 24)     // shorter chromosomes: exact level-1 histogram (and the key count with it)
+__device__ __forceinline__ int64_t s3_sample_unit(int64_t j, int sample_shift) {
+    if (sample_shift == 0) return j;
+    const int64_t g = j / S3_STRIPE;
+    const int64_t phase = (g * 7 + (g >> 4)) & ((1 << sample_shift) - 1);
+    return ((g << sample_shift) + phase) * S3_STRIPE + (j % S3_STRIPE);
+}
+__global__ void __launch_bounds__(1024)
+s3_caps1(unsigned long long *__restrict__ hist1, int F1, unsigned long long mult32, unsigned long long slack) {
+    const int b = threadIdx.x;
+    if (b < F1) hist1[b] = ((hist1[b] << S3_SAMPLE_SHIFT) * mult32) / 32ULL + slack;
+}
 // ---------------------------------------------------------------- s3_hist1
 __global__ void __launch_bounds__(256)
 s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-         int64_t n_units /* of 32 starts */, sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ ghist) {
+         int64_t n_units /* of 32 starts */, int64_t n_visit, int sample_shift, sp_kparams kp, int R1, int F1,
+         unsigned long long *__restrict__ ghist) {
     __shared__ uint32_t lh[S3_MAXF];
     for (int i = threadIdx.x; i < F1; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_visit; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = s3_sample_unit(j, sample_shift);
+        if (u >= n_units) continue;
         sp_scan32_valid64(pk, pm, nm, u * S3_P1_UNIT, kp, [&](int64_t, uint64_t fwd, uint64_t rc) {
             const uint64_t key = fwd < rc ? fwd : rc;
             atomicAdd(&lh[key >> R1], 1u);
         });
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < F1; i += blockDim.x) {
         const uint32_t v = lh[i];
@@ -148,11 +171,14 @@ template <typename KR1, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
          int64_t n_units /* of 32 starts */, sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ cursor1, KR1 *__restrict__ buf1,
-         int64_t n_tiles) {
+         int64_t n_tiles, const unsigned long long *__restrict__ off1 /* F1+1: where the regions start */, uint32_t trash) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     KR1 *keys = reinterpret_cast<KR1 *>(s3_lds);                        // [THREADS * 32]
     __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], delta[S3_MAXF], wsum[THREADS / 64];
     __shared__ uint32_t head[THREADS];      // tile positions / 32 = THREADS words
+    __shared__ uint32_t lim[S3_MAXF];       // end of every bucket's region (read once per workgroup)
+    for (int b = threadIdx.x; b < F1; b += THREADS) lim[b] = (uint32_t)off1[b + 1];
+    __syncthreads();
     __shared__ uint16_t hpre[THREADS];
     const uint64_t rmask = (R1 >= 64) ? ~0ULL : ((1ULL << R1) - 1ULL);
     // the NEXT tile's unit (validity words + both packed streams) travels while this tile is sorted and written: copy
@@ -213,7 +239,9 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
             if (hist[b]) {       // (the placement cursor = the run's length)
                 const uint32_t p0 = start[b];
                 const uint32_t r = (uint32_t)hpre[p0 >> 5] + (uint32_t)__popc(head[p0 >> 5] & ((1u << (p0 & 31)) - 1u));
-                delta[r] = gbase[b] - p0;
+                // (sampled regions: a run that does not fit goes to the trash area behind them; s3_tiles sees the cursor)
+                const uint32_t at = gbase[b];
+                delta[r] = ((unsigned long long)at + hist[b] <= (unsigned long long)lim[b] ? at : trash) - p0;
             }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += THREADS) {
@@ -224,18 +252,32 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     }
 }
 
-// tile bookkeeping shared by hist2 / part2: level-1 bucket b owns keys [off1[b], off1[b+1]) of buf1 and
-// tiles [tile_start[b], tile_start[b+1]) of S3_P2_KEYS keys
+// tile bookkeeping shared by hist2 / part2: level-1 bucket b owns keys [off1[b], end1[b]) of buf1 (what part1's cursor
+// says it wrote; the region may be larger) and tiles [tile_start[b], tile_start[b+1]) of S3_P2_KEYS keys.  Also the
+// number of keys of the chromosome and the overrun flag.  (One thread walked the 1024 buckets until round 3: 95 us.)
 __global__ void __launch_bounds__(1024)
-s3_tiles(const unsigned long long *__restrict__ hist1_excl /* F1+1: exclusive scan */, int F1,
-         unsigned long long *__restrict__ tile_start /* F1+1 */) {
-    if (threadIdx.x == 0) {
-        unsigned long long tiles = 0;
-        for (int b = 0; b < F1; b++) {
-            tile_start[b] = tiles;
-            tiles += (hist1_excl[b + 1] - hist1_excl[b] + S3_P2_KEYS - 1) / S3_P2_KEYS;
+s3_tiles(const unsigned long long *__restrict__ off1 /* F1+1 */, const unsigned long long *__restrict__ cursor1, int F1,
+         unsigned long long *__restrict__ tile_start /* F1+1 */, unsigned long long *__restrict__ end1 /* F1 */,
+         unsigned long long *__restrict__ n_keys, unsigned long long *__restrict__ flag) {
+    __shared__ unsigned long long lds[16];
+    const int b = threadIdx.x;
+    unsigned long long n = 0;
+    if (b < F1) {
+        const unsigned long long lo = off1[b], cap = off1[b + 1] - lo;
+        n = cursor1[b] - lo;
+        if (n > cap) {
+            n = cap;
+            atomicAdd(flag, 1ULL);
         }
-        tile_start[F1] = tiles;
+        end1[b] = lo + n;
+    }
+    unsigned long long tot_tiles, tot_keys;
+    const unsigned long long t0 = sp_block_excl_scan<unsigned long long>((n + S3_P2_KEYS - 1) / S3_P2_KEYS, lds, tot_tiles);
+    sp_block_excl_scan<unsigned long long>(n, lds, tot_keys);
+    if (b < F1) tile_start[b] = t0;
+    if (b == 0) {
+        tile_start[F1] = tot_tiles;
+        *n_keys = tot_keys;
     }
 }
 
@@ -255,7 +297,7 @@ __device__ __forceinline__ int s3_bucket_of(const unsigned long long *__restrict
 // LDS; it is flushed when the bucket changes.
 template <typename KR1>
 __global__ void __launch_bounds__(S3_P2_THREADS)
-s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1, const unsigned long long *__restrict__ end1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
          unsigned long long *__restrict__ hist2 /* F1 * F2 */, int sample /* 1: two rows of 16 of every tile */) {
     __shared__ uint32_t lh[S3_MAXF];
@@ -281,7 +323,7 @@ s3_hist2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
             while (tile >= tile_start[cb + 1]) cb++;
             __syncthreads();
         }
-        const unsigned long long base = off1[cb] + (tile - tile_start[cb]) * S3_P2_KEYS, end = off1[cb + 1];
+        const unsigned long long base = off1[cb] + (tile - tile_start[cb]) * S3_P2_KEYS, end = end1[cb];
         if (sample) {       // one 64-key group in eight, from every row of every tile: wave (tile mod 8) reads its slices
             if ((int)(threadIdx.x >> 6) == (int)(tile & 7ULL)) {
 #pragma unroll
@@ -343,7 +385,7 @@ s3_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
 // ---------------------------------------------------------------- s3_part2
 template <typename KR1, typename KR2>
 __global__ void __launch_bounds__(S3_P2_THREADS)
-s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1,
+s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ off1, const unsigned long long *__restrict__ end1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int R2,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2,
          KR2 *__restrict__ buf2) {
@@ -363,7 +405,7 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
     KR1 nxt[S3_P2_PER];
     int nnext = 0;
     auto fetch = [&](int nb, unsigned long long t) {
-        const unsigned long long base = off1[nb] + (t - tile_start[nb]) * S3_P2_KEYS, end = off1[nb + 1];
+        const unsigned long long base = off1[nb] + (t - tile_start[nb]) * S3_P2_KEYS, end = end1[nb];
         nnext = 0;
 #pragma unroll
         for (int j = 0; j < S3_P2_PER; j++) {
@@ -1185,6 +1227,9 @@ static int s3_scan(sp_ctx *ctx, unsigned long long *a, int64_t n, unsigned long 
 }
 
 // ================================================================== host side
+#ifndef S3_P1T32
+#define S3_P1T32 512
+#endif
 template <typename KR1, typename KR2>
 static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_plan &P, const sp_kparams &kp,
                           int lower, bool exact, bool *overran) {
@@ -1193,7 +1238,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     // small arrays: hist1 / off1 [F1+1], cursor1 [F1], tile_start [F1+1], hist2 -> off_fine [n_fine+1],
     // cursor2 [n_fine], kept [n_fine+1], big list, counters
     const size_t big_cap = 1 << 16;
-    const size_t o_h1 = 0, o_c1 = o_h1 + (size_t)(P.F1 + 1) * 8, o_ts = o_c1 + (size_t)P.F1 * 8,
+    const size_t o_h1 = 0, o_c1 = o_h1 + (size_t)(P.F1 + 1) * 8, o_e1 = o_c1 + (size_t)P.F1 * 8, o_ts = o_e1 + (size_t)P.F1 * 8,
                  o_of = o_ts + (size_t)(P.F1 + 1) * 8, o_c2 = o_of + (size_t)(n_fine + 1) * 8,
                  o_kp = o_c2 + (size_t)n_fine * 8, o_span = o_kp + (size_t)(n_fine + 1) * 8,
                  o_big = o_span + (size_t)n_fine * 16,
@@ -1202,7 +1247,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     if (rc) return rc;
     char *S = (char *)ctx->b_s3_small.p;
     unsigned long long *d_h1 = (unsigned long long *)(S + o_h1), *d_c1 = (unsigned long long *)(S + o_c1),
-                       *d_ts = (unsigned long long *)(S + o_ts), *d_of = (unsigned long long *)(S + o_of),
+                       *d_e1 = (unsigned long long *)(S + o_e1), *d_ts = (unsigned long long *)(S + o_ts), *d_of = (unsigned long long *)(S + o_of),
                        *d_c2 = (unsigned long long *)(S + o_c2), *d_kp = (unsigned long long *)(S + o_kp),
                        *d_big = (unsigned long long *)(S + o_big), *d_small = (unsigned long long *)(S + o_small),
                        *d_bsum = (unsigned long long *)(S + o_bsum);
@@ -1210,19 +1255,41 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total, [5] sum of the region capacities, [6] overrun flag
     SP_HIP(ctx, hipMemsetAsync(S, 0, small_bytes, ctx->stream));
     const int64_t n_units64 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;      // (units of 32 starts since the direct-window scan)
-    int64_t grid = (n_units64 + 255) / 256;
-    if (grid > (int64_t)ctx->n_cu * 8) grid = (int64_t)ctx->n_cu * 8;
-    SP_LAUNCH(ctx, "s3_hist1", s3_hist1, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_pm, c.d_nm, n_units64, kp, P.R1, P.F1,
-              d_h1);
+    // level 1: regions from a 1-in-16 stripe sample (long chromosomes) or from the full histogram
+    const bool sample1 = !exact && len >= S3_SAMPLE_MIN_LEN;
+    const int64_t n_stripes = (n_units64 + S3_STRIPE - 1) / S3_STRIPE;
+    const int64_t n_visit = sample1 ? ((n_stripes + (1 << S3_SAMPLE_SHIFT) - 1) >> S3_SAMPLE_SHIFT) * S3_STRIPE : n_units64;
+    int64_t grid = (n_visit + 255) / 256;
+    const int64_t hist_blocks = sample1 ? (int64_t)ctx->n_cu : (int64_t)ctx->n_cu * 8;
+    if (grid > hist_blocks) grid = hist_blocks;
+    if (grid < 1) grid = 1;
+    SP_LAUNCH(ctx, sample1 ? "s3_hist1_sample" : "s3_hist1", s3_hist1, dim3((unsigned)grid), dim3(256), 0, c.d_pk, c.d_pm, c.d_nm,
+              n_units64, n_visit, sample1 ? S3_SAMPLE_SHIFT : 0, kp, P.R1, P.F1, d_h1);
+    unsigned long long slack1 = 0;
+    if (sample1) {
+        const char *es1 = getenv("SP_S3_SLACK1"), *em1 = getenv("SP_S3_MULT1");      // test hooks (force level-1 overruns)
+        slack1 = es1 ? (unsigned long long)atoll(es1) : 8192ULL + (unsigned long long)(len >> 16);   // (wide regions slow part1 down: 35 % slack cost 40 %)
+        SP_LAUNCH(ctx, "s3_caps1", s3_caps1, dim3(1), dim3(1024), 0, d_h1, P.F1, em1 ? (unsigned long long)atoll(em1) : 33ULL, slack1);
+    }
     SP_LAUNCH(ctx, "scan_excl_u64", scan_excl_u64, dim3(1), dim3(1024), 0, d_h1, (int64_t)P.F1 + 1, d_small);
-    unsigned long long nv = 0;
-    SP_HIP(ctx, hipMemcpyAsync(&nv, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_c1, d_h1, (size_t)P.F1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // keys of the chromosome: read back when the histogram was exact; a bound (every start) when it was sampled --
+    // nothing below needs more than a bound, and the chain loses a host synchronisation
+    unsigned long long nv = (unsigned long long)len, cap1 = 0;
+    if (!sample1) {
+        SP_HIP(ctx, hipMemcpyAsync(&nv, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        cap1 = nv;
+    } else {
+        // the sample sees at most n_visit * 32 k-mers
+        cap1 = (((unsigned long long)n_visit * S3_P1_UNIT) << S3_SAMPLE_SHIFT) * 33ULL / 32ULL + (unsigned long long)P.F1 * slack1;
+    }
     out.n = 0;
     out.length_sum = 0;
+    *overran = false;
     if (nv == 0) return SP_OK;
-    if (nv >= (1ULL << 32)) return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
+    if (nv >= (1ULL << 32) - (1ULL << 20) || cap1 >= (1ULL << 32) - (1ULL << 20))
+        return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
     // keys the level-2 regions can hold: nv exactly (exact = sizes from the full histogram) or a bound on the sum of
     // the sampled capacities -- full tiles contribute exactly an eighth of their keys to the sample, the last tile of a
     // level-1 bucket at most two rows; sum of sqrt <= sqrt(n * sum)
@@ -1236,8 +1303,9 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
             cap_tot = nv;
         }
     }
-    *overran = false;
-    const size_t a_bytes = (size_t)nv * sizeof(KR1) > (size_t)cap_tot * sizeof(KR2) ? (size_t)nv * sizeof(KR1) : (size_t)cap_tot * sizeof(KR2);
+    constexpr int P1T_ = sizeof(KR1) == 4 ? S3_P1T32 : 256;
+    const size_t l1_entries = (size_t)cap1 + (size_t)P1T_ * S3_P1_UNIT + 64;      // regions + the trash area of one tile
+    const size_t a_bytes = l1_entries * sizeof(KR1) > (size_t)cap_tot * sizeof(KR2) ? l1_entries * sizeof(KR1) : (size_t)cap_tot * sizeof(KR2);
     rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes + 64);      // level-1 records, later the finish kernels' scratch (region-indexed)
     if (rc) return rc;
     rc = sp_buf_ensure(ctx, ctx->b_sp_b, (int64_t)cap_tot * (int64_t)sizeof(KR2) + 64);
@@ -1250,9 +1318,6 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     KR2 *tmp_keys = (KR2 *)ctx->b_sp_c.p;
     uint32_t *tmp_cnts = (uint32_t *)((char *)ctx->b_sp_c.p + tk_bytes);
 
-#ifndef S3_P1T32
-#define S3_P1T32 512
-#endif
     constexpr int P1T = sizeof(KR1) == 4 ? S3_P1T32 : 256;
     const int64_t n_units32 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;
     const int64_t n_tiles1 = (n_units32 + P1T - 1) / P1T;
@@ -1260,12 +1325,14 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     const size_t lds1 = (size_t)P1T * S3_P1_UNIT * sizeof(KR1);
     SP_HIP(ctx, hipFuncSetAttribute((const void *)s3_part1<KR1, P1T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     SP_LAUNCH(ctx, "s3_part1", (s3_part1<KR1, P1T>), dim3((unsigned)g1), dim3(P1T), lds1, c.d_pk, c.d_pm, c.d_nm, n_units32, kp,
-              P.R1, P.F1, d_c1, buf1, n_tiles1);
-    SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, P.F1, d_ts);
+              P.R1, P.F1, d_c1, buf1, n_tiles1, (const unsigned long long *)d_h1, (uint32_t)cap1);
+    SP_LAUNCH(ctx, "s3_tiles", s3_tiles, dim3(1), dim3(1024), 0, (const unsigned long long *)d_h1, (const unsigned long long *)d_c1,
+              P.F1, d_ts, d_e1, d_small + 7, d_small + 6);
     const int64_t est_tiles = (int64_t)(nv / S3_P2_KEYS) + P.F1 + 1;
     int64_t g2 = est_tiles < (int64_t)ctx->n_cu * 8 ? est_tiles : (int64_t)ctx->n_cu * 8;
     SP_LAUNCH(ctx, exact ? "s3_hist2" : "s3_hist2_sample", s3_hist2<KR1>, dim3((unsigned)g2), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
-              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2, d_of, exact ? 0 : 1);
+              (const unsigned long long *)d_h1, (const unsigned long long *)d_e1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
+              d_of, exact ? 0 : 1);
     if (!exact) {
         const char *em = getenv("SP_S3_MULT"), *es = getenv("SP_S3_SLACK");      // test hooks (force overruns)
         SP_LAUNCH(ctx, "s3_caps", s3_caps, dim3((unsigned)((n_fine + 255) / 256)), dim3(256), 0, d_of, n_fine,
@@ -1275,7 +1342,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     if (rc) return rc;
     int64_t g3 = est_tiles < (int64_t)ctx->n_cu * 16 ? est_tiles : (int64_t)ctx->n_cu * 16;
     SP_LAUNCH(ctx, "s3_part2", (s3_part2<KR1, KR2>), dim3((unsigned)g3), dim3(S3_P2_THREADS), 0, (const KR1 *)buf1,
-              (const unsigned long long *)d_h1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
+              (const unsigned long long *)d_h1, (const unsigned long long *)d_e1, (const unsigned long long *)d_ts, P.F1, P.F2, P.R2,
               (const unsigned long long *)d_of, d_c2, buf2);
     SP_LAUNCH(ctx, "s3_spans", s3_spans, dim3((unsigned)((n_fine + 255) / 256)), dim3(256), 0, (const unsigned long long *)d_of,
               (const unsigned long long *)d_c2, n_fine, d_span, d_small + 6);

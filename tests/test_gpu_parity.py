@@ -211,6 +211,19 @@ def test_count_sparse_engine_sampled_sizing_and_recount(gpu_ctx, monkeypatch):
     assert gpu_ctx.count_recounts() >= before + 3                   # (b)
     monkeypatch.delenv("SP_S3_MULT")
     monkeypatch.delenv("SP_S3_SLACK")
+    # level 1 is sampled on chromosomes of 2^24 bases or more: plain, then with regions half the estimate
+    big = [np.concatenate([_rand_seq(rng, 9_000_000), np.tile(unit, 200_000), _rand_seq(rng, 2_000_000),
+                           np.frombuffer(b"N" * 5000, np.uint8), _rand_seq(rng, 300_000)])]
+    assert big[0].size >= 1 << 24
+    n0 = gpu_ctx.count_recounts()
+    _count_both(gpu_ctx, big, 17, 3, 0)
+    assert gpu_ctx.count_recounts() == n0
+    monkeypatch.setenv("SP_S3_MULT1", "16")
+    monkeypatch.setenv("SP_S3_SLACK1", "0")
+    _count_both(gpu_ctx, big, 21, 3, 0)
+    assert gpu_ctx.count_recounts() == n0 + 1
+    monkeypatch.delenv("SP_S3_MULT1")
+    monkeypatch.delenv("SP_S3_SLACK1")
     monkeypatch.setenv("SP_S3_EXACT", "1")
     n = gpu_ctx.count_recounts()
     _count_both(gpu_ctx, seqs, 17, 3, 0)                            # (c)
