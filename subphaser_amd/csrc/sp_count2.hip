@@ -405,8 +405,8 @@ c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
     if (f >= n_fine) return;
     const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
     unsigned long long n = cursor2[f];
-    if (n > cap) {
-        n = cap;
+    if (n > cap) {      // a dropped run leaves part of the region unwritten: nobody may read it (the chromosome is recounted)
+        n = 0;
         atomicAdd(flag, 1ULL);
     }
     // engine 2: [first, last) key.  Engine 3 (list_div = lower_count): first key, then {number of keys, the bucket's

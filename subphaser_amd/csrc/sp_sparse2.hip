@@ -375,8 +375,8 @@ s3_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
     if (f >= n_fine) return;
     const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
     unsigned long long n = cursor2[f];
-    if (n > cap) {
-        n = cap;
+    if (n > cap) {      // a dropped run leaves part of the region unwritten: nobody may read it (the chromosome is recounted)
+        n = 0;
         atomicAdd(flag, 1ULL);
     }
     span[f] = make_ulonglong2(lo, n);
@@ -495,12 +495,38 @@ struct s3_sort_lds {
 #define S3_HASH_SLOTS 2048                       // LDS hash table of the hot-key path
 #define S3_HASH_MAX (S3_HASH_SLOTS * 3 / 4)      // distinct residuals it accepts
 
+// (s3_final_hash's table -- described at the kernel below -- is also what s3_final counts its pieces with)
+#define S3H_COUNTERS 4096
+#define S3H_SLOTS 2048
+#define S3H_CAP 1536            // distinct residuals the table accepts
+#define S3H_PER 8               // keys per thread held in registers: buckets up to 2048 keys are read once
+template <typename KR2>
+struct __attribute__((aligned(16))) s3h_lds {
+    union __attribute__((aligned(16))) {
+        uint32_t c1[S3H_COUNTERS];
+        struct {
+            KR2 key[S3H_SLOTS];
+            uint32_t cnt[S3H_SLOTS];
+        } t;
+    } u;
+    KR2 lk[S3H_CAP + S3_SORT_THREADS];
+    uint32_t lc[S3H_CAP + S3_SORT_THREADS];
+    uint32_t n_distinct, n_kept, abort_;
+    unsigned long long red[16];
+};
+__device__ __forceinline__ uint32_t s3h_hash2(unsigned long long v) {
+    v ^= v >> 31;
+    v *= 0xD6E8FEB86659FD93ULL;
+    return (uint32_t)(v >> 37);
+}
+
 template <typename KR2>
 struct s3_final_lds {
     union {
         s3_sort_lds<KR2, S3_SORT_PER> q;     // also the hot-key path's (key, count) staging
         s3_sort_lds<KR2, 4> q4;
         s3_sort_lds<KR2, 2> q2;
+        s3h_lds<KR2> h;                      // pieces counted instead of sorted (k >= 18)
     };
     union {
         uint32_t direct[1 << S3_DIRECT_BITS];
@@ -634,6 +660,13 @@ s3_final_small(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span
 #define S3_BM_NMAX (1u << 22)   // keys per bucket it is willing to stream (hot buckets: few distinct, many copies)
 #define S3_BM_PER 8             // keys per thread prefetched into registers (buckets up to 2048 keys never re-read)
 #define S3_BM_PUNT (~0ULL)      // kept[bucket] value that hands the bucket to s3_final
+// ... and the bucket goes on the punt list s3_final walks (thread 0 of the workgroup; round 3: s3_final used to look at
+// kept[] of all 2^19 buckets, 32 per workgroup with two dependent loads each -- most of its time)
+__device__ __forceinline__ void s3_punt(unsigned long long *__restrict__ kept, int64_t bucket, uint32_t *__restrict__ punt_list,
+                                        unsigned long long *__restrict__ n_punt) {
+    kept[bucket] = S3_BM_PUNT;
+    punt_list[atomicAdd(n_punt, 1ULL)] = (uint32_t)bucket;
+}
 
 // exclusive prefix of v over the block (value in a register); *total = block sum.  Ends with a barrier.
 __device__ __forceinline__ uint32_t s3_scan_reg(uint32_t v, uint32_t *wsum /* >= THREADS/64 */, uint32_t *total) {
@@ -661,7 +694,8 @@ template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
 s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
                 uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
-                unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+                unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum,
+                uint32_t *__restrict__ punt_list, unsigned long long *__restrict__ n_punt) {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm_lds[];   // bm[nw] | cnt[S3_BM_CAP] | pre[nw] (u16)
     __shared__ uint32_t ws1[S3_SORT_THREADS / 64], ws2[S3_SORT_THREADS / 64];
     __shared__ unsigned long long red[16];
@@ -697,7 +731,10 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ spa
         for (int j = 0; j < S3_BM_PER; j++) key[j] = p_key[j];
         fetch(bucket + gridDim.x);
         if (n64 == 0 || n64 > S3_BM_NMAX) {
-            if (threadIdx.x == 0) kept[bucket] = n64 ? S3_BM_PUNT : 0ULL;
+            if (threadIdx.x == 0) {
+                if (n64) s3_punt(kept, bucket, punt_list, n_punt);
+                else kept[bucket] = 0ULL;
+            }
             continue;
         }
         const uint32_t n = (uint32_t)n64;
@@ -717,7 +754,7 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ spa
         uint32_t distinct;
         const uint32_t first = s3_scan_reg(mine, ws1, &distinct);   // rank of this thread's first distinct residual
         if (distinct > S3_BM_CAP) {                                 // block-uniform
-            if (threadIdx.x == 0) kept[bucket] = S3_BM_PUNT;
+            if (threadIdx.x == 0) s3_punt(kept, bucket, punt_list, n_punt);
             __syncthreads();
             continue;
         }
@@ -780,137 +817,143 @@ s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ spa
 // Buckets above 2048 keys (repeat families) skip stage 1 and stream straight into the table: many copies of few
 // residuals.  A bucket with more distinct survivors than the table takes (S3H_CAP) is handed to s3_final
 // (kept[] = S3_BM_PUNT), which still sorts.
-#define S3H_COUNTERS 4096
-#define S3H_SLOTS 2048
-#define S3H_CAP 1536            // distinct residuals the table accepts
-#define S3H_PER 8               // keys per thread held in registers: buckets up to 2048 keys are read once
+
+// exact count of one key in the table; the table closes (abort_) when it has taken S3H_CAP distinct residuals
 template <typename KR2>
-struct __attribute__((aligned(16))) s3h_lds {
-    union __attribute__((aligned(16))) {
-        uint32_t c1[S3H_COUNTERS];
-        struct {
-            KR2 key[S3H_SLOTS];
-            uint32_t cnt[S3H_SLOTS];
-        } t;
-    } u;
-    KR2 lk[S3H_CAP + S3_SORT_THREADS];
-    uint32_t lc[S3H_CAP + S3_SORT_THREADS];
-    uint32_t n_distinct, n_kept, abort_;
-    unsigned long long red[16];
-};
-__device__ __forceinline__ uint32_t s3h_hash2(unsigned long long v) {
-    v ^= v >> 31;
-    v *= 0xD6E8FEB86659FD93ULL;
-    return (uint32_t)(v >> 37);
+__device__ __forceinline__ void s3h_insert(s3h_lds<KR2> &L, KR2 key) {
+    const KR2 EMPTY = (KR2)~(KR2)0;
+    uint32_t h = s3h_hash2((unsigned long long)key) & (S3H_SLOTS - 1);
+    for (;;) {
+        const KR2 prev = atomicCAS(&L.u.t.key[h], EMPTY, key);
+        if (prev == key) break;
+        if (prev == EMPTY) {
+            if (atomicAdd(&L.n_distinct, 1u) >= S3H_CAP) L.abort_ = 1;
+            break;
+        }
+        h = (h + 1) & (S3H_SLOTS - 1);
+    }
+    atomicAdd(&L.u.t.cnt[h], 1u);
+}
+// the kept entries of the table: a short list, ranked by residual, written at out_*[0 ..); returns their number
+template <typename KR2>
+__device__ __forceinline__ uint32_t s3h_emit(s3h_lds<KR2> &L, uint32_t lower, KR2 *__restrict__ out_keys,
+                                             uint32_t *__restrict__ out_cnts, unsigned long long &lsum) {
+    const int tid = threadIdx.x;
+    for (int i4 = tid; i4 < S3H_SLOTS / 4; i4 += S3_SORT_THREADS) {
+        const uint4 c4 = reinterpret_cast<const uint4 *>(L.u.t.cnt)[i4];
+        const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t c = cc[q];
+            if (c >= lower) {
+                const uint32_t at = atomicAdd(&L.n_kept, 1u);
+                L.lk[at] = L.u.t.key[4 * i4 + q];
+                L.lc[at] = c;
+                lsum += c;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t m = L.n_kept;
+    for (uint32_t i = tid; i < m; i += S3_SORT_THREADS) {
+        const KR2 key = L.lk[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) rank += L.lk[j] < key;
+        out_keys[rank] = key;
+        out_cnts[rank] = L.lc[i];
+    }
+    return m;
+}
+__device__ __forceinline__ void s3h_clear_table_words(uint4 *zk, int nk16, uint4 *zc, int nc16) {
+    for (int i = threadIdx.x; i < nk16; i += S3_SORT_THREADS) zk[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int i = threadIdx.x; i < nc16; i += S3_SORT_THREADS) zc[i] = make_uint4(0, 0, 0, 0);
+}
+// One segment of at most S3_SORT_THREADS * S3H_PER residuals through both stages (all threads of the workgroup).
+// Returns the number of kept (residual, count) pairs written at out_*[0 ..) in ascending order, or ~0u when more
+// distinct survivors turn up than the table takes (the caller sorts the segment instead; lsum is untouched then).
+template <typename KR2>
+__device__ __forceinline__ uint32_t s3h_segment(const KR2 *__restrict__ seg, uint32_t n, uint32_t lower, s3h_lds<KR2> &L,
+                                                KR2 *__restrict__ out_keys, uint32_t *__restrict__ out_cnts,
+                                                unsigned long long &lsum) {
+    const int tid = threadIdx.x;
+    KR2 mine[S3H_PER];
+    uint32_t alive = 0;      // bit j: mine[j] survived stage 1
+    __syncthreads();         // the previous readers of L are done
+    if (tid == 0) L.n_distinct = L.n_kept = L.abort_ = 0;
+#pragma unroll
+    for (int j = 0; j < S3H_PER; j++) {
+        const uint32_t i = tid + j * S3_SORT_THREADS;
+        if (i < n) mine[j] = seg[i];
+    }
+    {       // 16-byte LDS stores: a quarter of the instructions (the kernel is LDS-issue-bound, not latency-bound)
+        uint4 *z = reinterpret_cast<uint4 *>(L.u.c1);
+        for (int i = tid; i < S3H_COUNTERS / 4; i += S3_SORT_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < S3H_PER; j++)
+        if (tid + j * S3_SORT_THREADS < n) atomicAdd(&L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)], 1u);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < S3H_PER; j++)
+        if (tid + j * S3_SORT_THREADS < n && L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)] >= lower)
+            alive |= 1u << j;
+    __syncthreads();     // every flag is taken: the counters' memory becomes the table
+    s3h_clear_table_words(reinterpret_cast<uint4 *>(L.u.t.key), (int)(S3H_SLOTS * sizeof(KR2) / 16),
+                          reinterpret_cast<uint4 *>(L.u.t.cnt), S3H_SLOTS / 4);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < S3H_PER; j++)
+        if ((alive >> j) & 1u) {
+            if (L.abort_) break;
+            s3h_insert(L, mine[j]);
+        }
+    __syncthreads();
+    if (L.abort_) return ~0u;          // block-uniform after the barrier
+    return s3h_emit(L, lower, out_keys, out_cnts, lsum);
 }
 
 template <typename KR2>
 __global__ void __launch_bounds__(S3_SORT_THREADS)
 s3_final_hash(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
               uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
-              unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+              unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum,
+              uint32_t *__restrict__ punt_list, unsigned long long *__restrict__ n_punt) {
     __shared__ s3h_lds<KR2> L;
-    const KR2 EMPTY = (KR2)~(KR2)0;
     const int tid = threadIdx.x;
     unsigned long long lsum = 0;
-    // exact count of one key in the table; false when the table is closed (too many distinct residuals)
-    auto insert = [&](KR2 key) {
-        uint32_t h = s3h_hash2((unsigned long long)key) & (S3H_SLOTS - 1);
-        for (;;) {
-            const KR2 prev = atomicCAS(&L.u.t.key[h], EMPTY, key);
-            if (prev == key) break;
-            if (prev == EMPTY) {
-                if (atomicAdd(&L.n_distinct, 1u) >= S3H_CAP) L.abort_ = 1;
-                break;
-            }
-            h = (h + 1) & (S3H_SLOTS - 1);
-        }
-        atomicAdd(&L.u.t.cnt[h], 1u);
-    };
     for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
         const ulonglong2 sp_ = span[bucket];
         const unsigned long long o = sp_.x, n64 = sp_.y;
         if (n64 == 0 || n64 > S3_BM_NMAX) {
-            if (tid == 0) kept[bucket] = n64 ? S3_BM_PUNT : 0ULL;
+            if (tid == 0) {
+                if (n64) s3_punt(kept, bucket, punt_list, n_punt);
+                else kept[bucket] = 0ULL;
+            }
             continue;
         }
         const uint32_t n = (uint32_t)n64;
         const KR2 *seg = buf2 + o;
-        const bool in_regs = n <= S3_SORT_THREADS * S3H_PER;      // block-uniform
-        KR2 mine[S3H_PER];
-        uint32_t alive = 0;      // bit j: mine[j] survived stage 1
-        __syncthreads();         // the previous bucket's readers of L are done
-        if (tid == 0) L.n_distinct = L.n_kept = L.abort_ = 0;
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < S3H_PER; j++) {
-                const uint32_t i = tid + j * S3_SORT_THREADS;
-                if (i < n) mine[j] = seg[i];
-            }
-            {       // 16-byte LDS stores: a quarter of the instructions (the kernel is LDS-issue-bound, not latency-bound)
-                uint4 *z = reinterpret_cast<uint4 *>(L.u.c1);
-                for (int i = tid; i < S3H_COUNTERS / 4; i += S3_SORT_THREADS) z[i] = make_uint4(0, 0, 0, 0);
-            }
+        uint32_t m;
+        if (n <= S3_SORT_THREADS * S3H_PER) {      // block-uniform: both stages, the keys in registers
+            m = s3h_segment<KR2>(seg, n, lower, L, tmp_keys + o, tmp_cnts + o, lsum);
+        } else {                                   // a repeat family: many copies of few residuals, straight into the table
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < S3H_PER; j++)
-                if (tid + j * S3_SORT_THREADS < n) atomicAdd(&L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)], 1u);
+            if (tid == 0) L.n_distinct = L.n_kept = L.abort_ = 0;
+            s3h_clear_table_words(reinterpret_cast<uint4 *>(L.u.t.key), (int)(S3H_SLOTS * sizeof(KR2) / 16),
+                                  reinterpret_cast<uint4 *>(L.u.t.cnt), S3H_SLOTS / 4);
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < S3H_PER; j++)
-                if (tid + j * S3_SORT_THREADS < n && L.u.c1[s3_hash((unsigned long long)mine[j]) & (S3H_COUNTERS - 1)] >= lower)
-                    alive |= 1u << j;
-            __syncthreads();     // every flag is taken: the counters' memory becomes the table
-        }
-        {
-            uint4 *zk = reinterpret_cast<uint4 *>(L.u.t.key), *zc = reinterpret_cast<uint4 *>(L.u.t.cnt);
-            for (int i = tid; i < (int)(S3H_SLOTS * sizeof(KR2) / 16); i += S3_SORT_THREADS) zk[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-            for (int i = tid; i < S3H_SLOTS / 4; i += S3_SORT_THREADS) zc[i] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < S3H_PER; j++)
-                if ((alive >> j) & 1u) {
-                    if (L.abort_) break;
-                    insert(mine[j]);
-                }
-        } else {
             for (uint32_t i = tid; i < n; i += S3_SORT_THREADS) {
                 if (L.abort_) break;
-                insert(seg[i]);
+                s3h_insert(L, seg[i]);
             }
+            __syncthreads();
+            m = L.abort_ ? ~0u : s3h_emit(L, lower, tmp_keys + o, tmp_cnts + o, lsum);
         }
-        __syncthreads();
-        if (L.abort_) {          // block-uniform after the barrier
-            if (tid == 0) kept[bucket] = S3_BM_PUNT;
-            continue;
+        if (tid == 0) {
+            if (m == ~0u) s3_punt(kept, bucket, punt_list, n_punt);
+            else kept[bucket] = (unsigned long long)m;
         }
-        // ---- the kept entries: a short list, ranked by residual
-        for (int i4 = tid; i4 < S3H_SLOTS / 4; i4 += S3_SORT_THREADS) {
-            const uint4 c4 = reinterpret_cast<const uint4 *>(L.u.t.cnt)[i4];
-            const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t c = cc[q];
-                if (c >= lower) {
-                    const uint32_t at = atomicAdd(&L.n_kept, 1u);
-                    L.lk[at] = L.u.t.key[4 * i4 + q];
-                    L.lc[at] = c;
-                    lsum += c;
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t m = L.n_kept;
-        for (uint32_t i = tid; i < m; i += S3_SORT_THREADS) {
-            const KR2 key = L.lk[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < m; j++) rank += L.lk[j] < key;
-            tmp_keys[o + rank] = key;
-            tmp_cnts[o + rank] = L.lc[i];
-        }
-        if (tid == 0) kept[bucket] = m;
     }
     __syncthreads();
     const unsigned long long tot = sp_block_sum_u64(lsum, L.red);
@@ -924,13 +967,19 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
          unsigned long long *__restrict__ kept, unsigned long long *__restrict__ big_list,
          unsigned long long *__restrict__ n_big, unsigned long long big_cap, unsigned long long *__restrict__ len_sum,
          unsigned long long light_cap /* buckets up to this size were the light kernel's; S3_BM_PUNT: the ones
-                                         the bitmap kernel marked in kept[] */) {
+                                         the bitmap kernel marked in kept[] */,
+         int hash_pieces /* k >= 18: count the pieces of a split bucket like s3_final_hash does, sort only on abort */,
+         const uint32_t *__restrict__ punt_list, const unsigned long long *__restrict__ n_punt) {
     __shared__ s3_final_lds<KR2> L;
     unsigned long long lsum = 0;
-    for (int64_t bucket = blockIdx.x; bucket < n_fine; bucket += gridDim.x) {
+    // punt mode: the listed buckets; else (the round-2 sort kernels, SP_S3_FINAL=sort) every bucket above light_cap
+    const bool listed = light_cap == S3_BM_PUNT;
+    const int64_t n_work = listed ? (int64_t)*n_punt : n_fine;
+    for (int64_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int64_t bucket = listed ? (int64_t)punt_list[wi] : wi;
         const ulonglong2 sp_ = span[bucket];
         const unsigned long long o = sp_.x, n64 = sp_.y;
-        if (light_cap == S3_BM_PUNT ? kept[bucket] != S3_BM_PUNT : n64 <= light_cap) continue;   // the light kernel's
+        if (!listed && n64 <= light_cap) continue;   // the light kernel's
         if (n64 <= S3_SORT_CAP) {
             const uint32_t nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
             if (threadIdx.x == 0) kept[bucket] = nk;
@@ -948,16 +997,33 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
             const KR2 rem_mask = (rem >= (int)(8 * sizeof(KR2))) ? (KR2)~(KR2)0 : (KR2)(((KR2)1 << rem) - 1);
             for (int i = threadIdx.x; i < nsub; i += S3_SORT_THREADS) L.sub_cnt[i] = 0;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += S3_SORT_THREADS) atomicAdd(&L.sub_cnt[(uint32_t)(buf2[o + i] >> rem)], 1u);
+            // (eight loads in flight per thread: with one, a 64 K-key bucket was 256 serialized round trips per pass and
+            // the split alone 18 of this kernel's 37 ms per wheat-like pass at k = 21)
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * S3_SORT_THREADS) {
+                KR2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n) v[q] = buf2[o + i0 + q * S3_SORT_THREADS];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n) atomicAdd(&L.sub_cnt[(uint32_t)(v[q] >> rem)], 1u);
+            }
             __syncthreads();
             const uint32_t tot = s3_block_scan<S3_SORT_THREADS>(L.sub_cnt, L.sub_off, nsub, L.q.wsum);
             if (threadIdx.x == 0) L.sub_off[nsub] = tot;
             for (int i = threadIdx.x; i < nsub; i += S3_SORT_THREADS) L.sub_cnt[i] = 0;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += S3_SORT_THREADS) {
-                const KR2 v = buf2[o + i];
-                const uint32_t d = (uint32_t)(v >> rem);
-                scratch[o + L.sub_off[d] + atomicAdd(&L.sub_cnt[d], 1u)] = v;
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * S3_SORT_THREADS) {
+                KR2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n) v[q] = buf2[o + i0 + q * S3_SORT_THREADS];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n) {
+                        const uint32_t d = (uint32_t)(v[q] >> rem);
+                        scratch[o + L.sub_off[d] + atomicAdd(&L.sub_cnt[d], 1u)] = v[q];
+                    }
             }
             __threadfence_block();
             __syncthreads();
@@ -966,7 +1032,16 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
                 if (m == 0) continue;
                 const KR2 *seg = scratch + o + so;
                 const KR2 hi = (rem >= (int)(8 * sizeof(KR2))) ? (KR2)0 : (KR2)((KR2)d << rem);
-                if (m <= S3_SORT_CAP) {
+                uint32_t nkh = ~0u;
+                if (hash_pieces && m <= S3_SORT_THREADS * S3H_PER) {
+                    // round 3: a 64 K-key bucket was ~30 block radix sorts in a row inside ONE workgroup -- the long pole
+                    // of this kernel; its pieces go through the hashed pre-count + exact table instead
+                    nkh = s3h_segment<KR2>(seg, m, lower, L.h, tmp_keys + o + w, tmp_cnts + o + w, bsum);
+                    __syncthreads();
+                }
+                if (nkh != ~0u) {
+                    w += nkh;
+                } else if (m <= S3_SORT_CAP) {
                     // the pieces hold full residuals; sort on the remaining bits only
                     if (m <= 2 * S3_SORT_THREADS)
                         w += s3_sort_segment<KR2, 2>(seg, m, rem, lower, L.q2, tmp_keys + o + w, tmp_cnts + o + w, bsum);
@@ -1241,7 +1316,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     const size_t o_h1 = 0, o_c1 = o_h1 + (size_t)(P.F1 + 1) * 8, o_e1 = o_c1 + (size_t)P.F1 * 8, o_ts = o_e1 + (size_t)P.F1 * 8,
                  o_of = o_ts + (size_t)(P.F1 + 1) * 8, o_c2 = o_of + (size_t)(n_fine + 1) * 8,
                  o_kp = o_c2 + (size_t)n_fine * 8, o_span = o_kp + (size_t)(n_fine + 1) * 8,
-                 o_big = o_span + (size_t)n_fine * 16,
+                 o_pl = o_span + (size_t)n_fine * 16, o_big = o_pl + (((size_t)n_fine * 4 + 15) & ~(size_t)15),
                  o_small = o_big + big_cap * 8, o_bsum = o_small + 256, small_bytes = o_bsum + 1024 * 8;
     int rc = sp_buf_ensure(ctx, ctx->b_s3_small, (int64_t)small_bytes);
     if (rc) return rc;
@@ -1252,6 +1327,7 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
                        *d_big = (unsigned long long *)(S + o_big), *d_small = (unsigned long long *)(S + o_small),
                        *d_bsum = (unsigned long long *)(S + o_bsum);
     ulonglong2 *d_span = (ulonglong2 *)(S + o_span);
+    uint32_t *d_pl = (uint32_t *)(S + o_pl);      // buckets handed to s3_final; their number in d_small[8]
     // d_small: [0] total keys, [1] n_big, [2] length sum, [3] kept total, [5] sum of the region capacities, [6] overrun flag
     SP_HIP(ctx, hipMemsetAsync(S, 0, small_bytes, ctx->stream));
     const int64_t n_units64 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;      // (units of 32 starts since the direct-window scan)
@@ -1355,19 +1431,21 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
         SP_LAUNCH(ctx, "s3_final_bitmap", s3_final_bitmap<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS),
                   (size_t)(P.R2 > 5 ? 1 << (P.R2 - 5) : 1) * 6 + (size_t)S3_BM_CAP * 4,
                   (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
-                  d_kp, d_small + 2);
+                  d_kp, d_small + 2, d_pl, d_small + 8);
     else if (use_hash)
         SP_LAUNCH(ctx, "s3_final_hash", s3_final_hash<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
                   (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
-                  d_kp, d_small + 2);
+                  d_kp, d_small + 2, d_pl, d_small + 8);
     else
         SP_LAUNCH(ctx, "s3_final_small", s3_final_small<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0,
                   (const KR2 *)buf2, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts,
                   d_kp, d_small + 2);
-    SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
+    const int64_t g4f = (bitmap || use_hash) ? ((int64_t)ctx->n_cu * 8 < g4 ? (int64_t)ctx->n_cu * 8 : g4) : g4;   // punt mode: the listed buckets only
+    SP_LAUNCH(ctx, "s3_final", s3_final<KR2>, dim3((unsigned)g4f), dim3(S3_SORT_THREADS), 0, (const KR2 *)buf2,
               (KR2 *)buf1, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
               d_small + 1, (unsigned long long)big_cap, d_small + 2,
-              (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP);
+              (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP, use_hash ? 1 : 0, (const uint32_t *)d_pl,
+              (const unsigned long long *)(d_small + 8));
     unsigned long long n_big = 0, h_flag = 0;
     SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(&h_flag, d_small + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
