@@ -1,5 +1,5 @@
 set -u
-export SP_COMMIT=a2fc366
+export SP_COMMIT=61e9496
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r03_final_pytest_gpu.txt
 bash tools/pmc_round.sh r03_wheat > /dev/null 2>&1
