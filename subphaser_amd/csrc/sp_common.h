@@ -133,7 +133,8 @@ struct sp_ctx {
         int64_t ws2_bytes = 0;
         sp_buf b_ovfw;
     };
-    lane_t lanes[3];             // lanes 1..3 (lane 0 = the context's own stream and buffers above)
+#define SP_MAX_LANES 7
+    lane_t lanes[SP_MAX_LANES];  // lanes 1..7 (lane 0 = the context's own stream and buffers above)
     lane_t *lane = nullptr;      // the auxiliary lane the engine-2 chain is being issued on, or NULL
     hipEvent_t lane_go = nullptr;
     // sparse engine (k = 16..32)

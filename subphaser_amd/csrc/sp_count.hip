@@ -435,11 +435,15 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     const bool sized_by_sample = !(env_exact && env_exact[0] == '1');
     std::vector<char> by_engine2(C, 0);
     // small genomes (engine 3): count chromosomes on up to three more streams side by side (SP_LANES=0: one stream)
+    // Byte tables (engine 2, whole-genome calls): ONE more stream.  A chromosome's chain has five single-workgroup
+    // kernels (sample histogram, offsets, tile starts, overflow scan / place: ~0.15 ms of a 3-ms chain during which
+    // the chip idles); with two chains side by side they run next to the neighbour's partition kernels.
     int n_lanes = 0;
-    if (list_mode && C > 1) {
-        const char *el = getenv("SP_LANES");
+    const bool dense_lanes = !list_mode && C > 1 && first == 0 && last == (int)C && engine != 1;
+    if ((list_mode && C > 1) || dense_lanes) {
+        const char *el = getenv(list_mode ? "SP_LANES" : "SP_LANES_DENSE");
         n_lanes = el ? atoi(el) : 3;
-        if (n_lanes > 3) n_lanes = 3;
+        if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
         if (n_lanes < 0) n_lanes = 0;
         for (int l = 0; l < n_lanes; l++) {
             if (!ctx->lanes[l].stream) {
@@ -453,83 +457,103 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             for (int l = 0; l < n_lanes; l++) SP_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lane_go, 0));
         }
     }
-    for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
-        sp_chrom &c = ctx->chroms[ci];
-        if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
-        if (list_mode) {
-            sp_sparse_chrom &o = ctx->sparse[ci];
-            o.n = 0;
-            o.length_sum = 0;
-            // every kept slot accounts for >= lower k-mer occurrences (and there are at most nslots of them)
-            int64_t need = c.len / lower_count + 16;
-            if (need > nslots) need = nslots;
-            if (need > o.cap) {
-                SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (o.d_keys) hipFree(o.d_keys);
-                if (o.d_cnts) hipFree(o.d_cnts);
-                o.d_keys = nullptr;
-                o.d_cnts = nullptr;
-                o.cap = 0;
-                SP_HIP(ctx, hipMalloc(&o.d_keys, (size_t)(need + 1) * 8));
-                SP_HIP(ctx, hipMalloc(&o.d_cnts, (size_t)(need + 1) * 4));
-                o.cap = need;
+    // (a lambda: an error return inside must not leave the other lanes' kernels running on the shared scratch)
+    auto count_all = [&]() -> int {
+        for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
+            sp_chrom &c = ctx->chroms[ci];
+            if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
+            if (list_mode) {
+                sp_sparse_chrom &o = ctx->sparse[ci];
+                o.n = 0;
+                o.length_sum = 0;
+                // every kept slot accounts for >= lower k-mer occurrences (and there are at most nslots of them)
+                int64_t need = c.len / lower_count + 16;
+                if (need > nslots) need = nslots;
+                if (need > o.cap) {
+                    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (o.d_keys) hipFree(o.d_keys);
+                    if (o.d_cnts) hipFree(o.d_cnts);
+                    o.d_keys = nullptr;
+                    o.d_cnts = nullptr;
+                    o.cap = 0;
+                    SP_HIP(ctx, hipMalloc(&o.d_keys, (size_t)(need + 1) * 8));
+                    SP_HIP(ctx, hipMalloc(&o.d_cnts, (size_t)(need + 1) * 4));
+                    o.cap = need;
+                }
+                // lanes: chromosome ci on stream ci % (1 + lanes in use); lane 0 is the context's own stream
+                sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
+                hipStream_t main_stream = ctx->stream;
+                if (ln) {
+                    ctx->lane = ln;
+                    ctx->stream = ln->stream;
+                }
+                rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, &o);
+                ctx->lane = nullptr;
+                ctx->stream = main_stream;
+                if (rc) return rc;
+                by_engine2[ci] = 1;
+                continue;
             }
-            // lanes: chromosome ci on stream ci % (1 + lanes in use); lane 0 is the context's own stream
-            sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
-            hipStream_t main_stream = ctx->stream;
-            if (ln) {
-                ctx->lane = ln;
-                ctx->stream = ln->stream;
+            if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots));
+            // every overflow pair accounts for >= 255 k-mer occurrences
+            const int64_t need_ovf = c.len / 255 + 16;
+            if (need_ovf > c.cap_ovf) {
+                if (c.d_ovf) {
+                    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    hipFree(c.d_ovf);
+                    c.d_ovf = nullptr;
+                }
+                SP_HIP(ctx, hipMalloc(&c.d_ovf, (size_t)need_ovf * sizeof(uint2)));
+                c.cap_ovf = need_ovf;
             }
-            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, &o);
-            ctx->lane = nullptr;
-            ctx->stream = main_stream;
+            int eng = engine;
+            if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
+            if (eng == 2) {
+                sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
+                hipStream_t main_stream = ctx->stream;
+                if (ln) {
+                    ctx->lane = ln;
+                    ctx->stream = ln->stream;
+                }
+                rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, nullptr);
+                ctx->lane = nullptr;
+                ctx->stream = main_stream;
+                if (rc) return rc;
+                by_engine2[ci] = 1;
+                continue;
+            }
+            // engine 1: global atomics into a u32 scratch table, then one pass to the byte table
+            const int64_t n_buckets = (nslots + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT;
+            rc = sp_buf_ensure(ctx, ctx->b_tab32, nslots * 4);
             if (rc) return rc;
-            by_engine2[ci] = 1;
-            continue;
-        }
-        if (!c.d_tab) SP_HIP(ctx, hipMalloc(&c.d_tab, (size_t)nslots));
-        // every overflow pair accounts for >= 255 k-mer occurrences
-        const int64_t need_ovf = c.len / 255 + 16;
-        if (need_ovf > c.cap_ovf) {
-            if (c.d_ovf) {
-                SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                hipFree(c.d_ovf);
-                c.d_ovf = nullptr;
-            }
-            SP_HIP(ctx, hipMalloc(&c.d_ovf, (size_t)need_ovf * sizeof(uint2)));
-            c.cap_ovf = need_ovf;
-        }
-        int eng = engine;
-        if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
-        if (eng == 2) {
-            rc = sp_count_engine2(ctx, c, kp, lower_count, d_len + 4 * ci, !sized_by_sample, nullptr);
+            rc = sp_buf_ensure(ctx, ctx->b_ovfw, need_ovf * 8 + (3 * n_buckets + 1) * 4 + 256);
             if (rc) return rc;
-            by_engine2[ci] = 1;
-            continue;
+            uint32_t *tab32 = (uint32_t *)ctx->b_tab32.p;
+            uint2 *ovf_tmp = (uint2 *)ctx->b_ovfw.p;
+            uint32_t *seg_base = (uint32_t *)(ovf_tmp + need_ovf), *seg_cnt = seg_base + n_buckets, *seg_off = seg_cnt + n_buckets;
+            SP_HIP(ctx, hipMemsetAsync(tab32, 0, (size_t)nslots * sizeof(uint32_t), ctx->stream));
+            int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
+            if (n_units > 0) {
+                int grid = grid_for(ctx, n_units, 256, 16);
+                SP_LAUNCH(ctx, "k1_count_atomic", k1_count_atomic, dim3(grid), dim3(256), 0, c.d_pk, c.d_nm,
+                          n_units, sp_make_kparams32(k), tab32);
+            }
+            int grid2 = (int)(n_buckets < (int64_t)ctx->n_cu * 8 ? n_buckets : (int64_t)ctx->n_cu * 8);
+            SP_LAUNCH(ctx, "k1_narrow", k1_narrow, dim3(grid2), dim3(256), 0, (const uint32_t *)tab32, nslots,
+                      (uint32_t)lower_count, c.d_tab, d_len + 4 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
+                      n_buckets);
+            rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets, nullptr);   // (k1_narrow keeps an exact cursor in d_len[2])
+            if (rc) return rc;
         }
-        // engine 1: global atomics into a u32 scratch table, then one pass to the byte table
-        const int64_t n_buckets = (nslots + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT;
-        rc = sp_buf_ensure(ctx, ctx->b_tab32, nslots * 4);
-        if (rc) return rc;
-        rc = sp_buf_ensure(ctx, ctx->b_ovfw, need_ovf * 8 + (3 * n_buckets + 1) * 4 + 256);
-        if (rc) return rc;
-        uint32_t *tab32 = (uint32_t *)ctx->b_tab32.p;
-        uint2 *ovf_tmp = (uint2 *)ctx->b_ovfw.p;
-        uint32_t *seg_base = (uint32_t *)(ovf_tmp + need_ovf), *seg_cnt = seg_base + n_buckets, *seg_off = seg_cnt + n_buckets;
-        SP_HIP(ctx, hipMemsetAsync(tab32, 0, (size_t)nslots * sizeof(uint32_t), ctx->stream));
-        int64_t n_units = (c.len + SP_UNIT - 1) / SP_UNIT;
-        if (n_units > 0) {
-            int grid = grid_for(ctx, n_units, 256, 16);
-            SP_LAUNCH(ctx, "k1_count_atomic", k1_count_atomic, dim3(grid), dim3(256), 0, c.d_pk, c.d_nm,
-                      n_units, sp_make_kparams32(k), tab32);
-        }
-        int grid2 = (int)(n_buckets < (int64_t)ctx->n_cu * 8 ? n_buckets : (int64_t)ctx->n_cu * 8);
-        SP_LAUNCH(ctx, "k1_narrow", k1_narrow, dim3(grid2), dim3(256), 0, (const uint32_t *)tab32, nslots,
-                  (uint32_t)lower_count, c.d_tab, d_len + 4 * ci, ovf_tmp, (unsigned long long)need_ovf, seg_base, seg_cnt,
-                  n_buckets);
-        rc = sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, n_buckets, nullptr);   // (k1_narrow keeps an exact cursor in d_len[2])
-        if (rc) return rc;
+        return SP_OK;
+    };
+    rc = count_all();
+    if (rc) {
+        const std::string msg = ctx->err;
+        for (int l = 0; l < n_lanes; l++) hipStreamSynchronize(ctx->lanes[l].stream);
+        hipStreamSynchronize(ctx->stream);
+        ctx->err = msg;
+        return rc;
     }
     for (int l = 0; l < n_lanes; l++) {      // the main stream goes on when every lane is done
         SP_HIP(ctx, hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].stream));

@@ -41,9 +41,30 @@
 #define C2_P2_PER 24
 #endif
 #define C2_TILE_KEYS (C2_P2_THREADS * C2_P2_PER)  // keys per part2 tile
+#ifndef C2_P2_SPREAD
+#define C2_P2_SPREAD 128              // part2 tile order: concurrently processed tiles lie n_tiles / 128 apart
+#endif
 #define C2_HIST_THREADS 512
-#define C2_MAXF 256                   // max fan-out per level
+#define C2_MAXF 128                   // max fan-out per level (k <= 15: at most 2^29 slots = 7 + 7 + 15 bits)
 #define C2_DROP (~0ULL)               // delta / gbase of a run that does not fit its region (estimate mode)
+// Records travel in QUADS (round 4).  A bucket run written by one tile is padded to a multiple of four records, so that
+// the copy-out of both partition kernels handles four consecutive records per lane: one 16-byte LDS read, one look-up
+// of the run's base, one 8-byte (+ one 4-byte) global store -- a quarter of the vector-memory instructions of the
+// one-record-per-lane form, which issued a 2-byte and a 1-byte store per key and was bound by exactly that (the
+// address path takes a wave-instruction's lanes four per clock whatever their width).  A pad record is all ones: a
+// level-1 record carries at most 22 slot bits in 24, a residual 15 bits in 16.
+#define C2_INVALID1 0xFFFFFFu
+#define C2_INVALID2 0xFFFFu
+#define C2_PADS (3 * C2_MAXF)         // pad records one tile can add at most
+// Cursors (round 4, tools/ubench_frag.hip).  Returning atomics on ONE cache line serialise: 128 cursors packed into
+// 1 KiB held a 40 K-tile partition pass at 0.88 ms whatever it wrote; one cursor per 128-byte line 0.52 ms; eight
+// sub-cursors per bucket on a line each 0.29 ms.  So every cursor owns a line, and a level-1 bucket is cut into
+// C2_SPLIT sub-regions with a cursor each: tile t appends to sub-region t mod C2_SPLIT (a static, even deal of the
+// tiles; with the blocks of a launch dealt round-robin to the XCDs, usually also a deal by L2).  Downstream a
+// sub-region is just a level-1 "bucket" of its own: V1 = F1 * C2_SPLIT of them.
+#define C2_SPLIT 8
+#define C2_CSTRIDE 16                 // cursor stride in 8-byte words
+#define C2_MAXV (C2_MAXF * C2_SPLIT)
 
 struct c2_plan {
     int T;        // log2(nslots)
@@ -61,7 +82,7 @@ static bool c2_make_plan(int64_t nslots, c2_plan &p) {
     p.T = T;
     p.B1 = (R + 1) / 2;
     p.B2 = R / 2;
-    if (p.B1 > 8 || p.B2 > 8) return false;
+    if (p.B1 > 7 || p.B2 > 7) return false;
     p.F1 = 1 << p.B1;
     p.F2 = 1 << p.B2;
     p.n_fine = (int64_t)p.F1 * p.F2;
@@ -104,93 +125,108 @@ c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
     }
 }
 
-// Region layout from the fine histogram (n_fine <= 65536): cap(f) = ghist[f] (exact mode: mult = 1, slack = 0) or
-// ghist[f] * mult / 8 + slack rounded up to a multiple of 4 (estimate mode).  off_fine[n_fine + 1] = exclusive
-// scan of the capacities = where every fine bucket's residuals start in buf2; off1[b] = where level-1 bucket b
-// starts in the level-1 planes (sum of its fine capacities, rounded up to a multiple of 4 keys so that part2 can
-// read runs with 8- and 4-byte loads).  Sizes and tile starts come later, from part1's cursors (c2_tiles).
+// Region layout from the fine histogram (n_fine <= 16384).  cap(f) = ghist[f] (exact mode: mult = 1, slack = 0) or
+// ghist[f] * mult / 8 + slack (estimate mode), plus the pad records the bucket can receive (three per part2 tile of its
+// level-1 bucket at most), rounded up to a multiple of 4.  off_fine[n_fine + 1] = exclusive scan of the capacities =
+// where every fine bucket's residuals start in buf2; off1[b] = where level-1 bucket b starts in the level-1 planes
+// (its own bound + three pad records per part1 tile, a multiple of 4).  Sizes and tile starts come later, from
+// part1's cursors (c2_tiles).
 __global__ void __launch_bounds__(1024)
 c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2, unsigned long long mult8,
-           unsigned long long mult8_1, unsigned long long slack, unsigned long long slack1, unsigned long long *__restrict__ off_fine,
-           unsigned long long *__restrict__ off1 /* F1 + 1 starts */) {
+           unsigned long long mult8_1, unsigned long long slack, unsigned long long slack1, unsigned long long pad1,
+           int split /* C2_SPLIT, or 1: everything into sub-region 0 (exact mode) */, unsigned long long sslack,
+           unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1 /* F1 * C2_SPLIT + 1 starts */) {
     __shared__ unsigned long long wsum[16];
     const int T = 1024;
+    const bool exact = !slack && mult8 == 8ULL;
     int per = (n_fine + T - 1) / T;
     int lo = threadIdx.x * per, hi = lo + per;
     if (lo > n_fine) lo = n_fine;
     if (hi > n_fine) hi = n_fine;
+    // level-1 bucket boundaries are thread boundaries (F2 and the per-thread count are powers of two, F2 the larger)
+    __shared__ unsigned long long cap_at[C2_MAXF + 1], raw_at[C2_MAXF + 1], bcap[C2_MAXF], padf[C2_MAXF];
+    unsigned long long raw = 0;
+    for (int i = lo; i < hi; i++) raw += ghist[i];
+    unsigned long long total, total_raw;
+    const unsigned long long raw0 = sp_block_excl_scan(raw, wsum, total_raw);
+    if (lo < n_fine && lo % F2 == 0) raw_at[lo / F2] = raw0;
+    if (threadIdx.x == 0) raw_at[F1] = total_raw;
+    __syncthreads();
+    // level-1 regions: a level-1 bucket is the union of F2 fine buckets and its relative sampling error is that much
+    // smaller, so it gets its own, tighter, bound (estimate x 33/32 + slack1) instead of the sum of the fine regions
+    // (the span of the level-1 planes is what part1's scattered bursts pay for: 22.7 -> 23.6 ms at 2.4x)
+    if (threadIdx.x < F1) {
+        const int b = threadIdx.x;
+        const unsigned long long h = raw_at[b + 1] - raw_at[b];
+        bcap[b] = (exact ? h : (h * mult8_1 + 7ULL) / 8ULL + slack1) + pad1;
+        padf[b] = 3ULL * ((bcap[b] + C2_TILE_KEYS - 1) / C2_TILE_KEYS + 1ULL);   // part2 tiles of the bucket, at most
+    }
+    __syncthreads();
     auto cap = [&](int i) -> unsigned long long {
         const unsigned long long h = ghist[i];
-        if (!slack && mult8 == 8ULL) return h;
-        return ((h * mult8 + 7ULL) / 8ULL + slack + 3ULL) & ~3ULL;
+        return ((exact ? h : (h * mult8 + 7ULL) / 8ULL + slack) + padf[i / F2] + 3ULL) & ~3ULL;
     };
-    unsigned long long s = 0, raw = 0;
-    for (int i = lo; i < hi; i++) {
-        s += cap(i);
-        raw += ghist[i];
-    }
-    unsigned long long total, total_raw;
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; i++) s += cap(i);
     unsigned long long run = sp_block_excl_scan(s, wsum, total);
-    const unsigned long long raw0 = sp_block_excl_scan(raw, wsum, total_raw);
-    // level-1 bucket boundaries are thread boundaries (F2 and the per-thread count are powers of two, F2 the larger)
-    __shared__ unsigned long long cap_at[C2_MAXF + 1], raw_at[C2_MAXF + 1];
-    if (lo < n_fine && lo % F2 == 0) {
-        cap_at[lo / F2] = run;
-        raw_at[lo / F2] = raw0;
-    }
+    if (lo < n_fine && lo % F2 == 0) cap_at[lo / F2] = run;
     if (threadIdx.x == 0) {
         off_fine[n_fine] = total;
         cap_at[F1] = total;
-        raw_at[F1] = total_raw;
     }
     for (int i = lo; i < hi; i++) {
         off_fine[i] = run;
         run += cap(i);
     }
     __syncthreads();
-    // level-1 regions: a level-1 bucket is the union of F2 fine buckets and its relative sampling error is that much
-    // smaller, so it gets its own, tighter, bound (estimate x 33/32 + slack1) instead of the sum of the fine regions
-    // (the span of the level-1 planes is what part1's scattered bursts pay for: 22.7 -> 23.6 ms at 2.4x)
-    __shared__ unsigned long long bcap[C2_MAXF];
     if (threadIdx.x < F1) {
-        const int b = threadIdx.x;
-        const unsigned long long h = raw_at[b + 1] - raw_at[b], sum_fine = cap_at[b + 1] - cap_at[b];
-        bcap[b] = (!slack && mult8 == 8ULL) ? h : (h * mult8_1 + 7ULL) / 8ULL + slack1;
-        if (bcap[b] > sum_fine) bcap[b] = sum_fine;
+        unsigned long long mine = bcap[threadIdx.x];
+        const unsigned long long sum_fine = cap_at[threadIdx.x + 1] - cap_at[threadIdx.x];
+        if (!exact && mine > sum_fine) mine = sum_fine;   // (more keys than that overrun level 2 anyway)
+        bcap[threadIdx.x] = mine;
     }
     __syncthreads();
     {
-        const unsigned long long mine = threadIdx.x < F1 ? (bcap[threadIdx.x] + 3ULL) & ~3ULL : 0ULL;
+        // sub-regions: an eighth of the bucket's bound each + their own slack (a local array of one repeat shorter
+        // than a tile lands in ONE sub-region)
+        const int V1 = F1 * C2_SPLIT;
+        unsigned long long mine = 0;
+        if ((int)threadIdx.x < V1) {
+            const unsigned long long cb = bcap[threadIdx.x / C2_SPLIT];
+            if (split > 1) mine = (cb + C2_SPLIT - 1) / C2_SPLIT + sslack;
+            else mine = (threadIdx.x % C2_SPLIT) ? 0ULL : cb;
+            mine = (mine + 3ULL) & ~3ULL;
+        }
         unsigned long long tot1;
         const unsigned long long o = sp_block_excl_scan(mine, wsum, tot1);
-        if (threadIdx.x < F1) off1[threadIdx.x] = o;
-        if (threadIdx.x == 0) off1[F1] = tot1;
+        if ((int)threadIdx.x < V1) off1[threadIdx.x] = o;
+        if (threadIdx.x == 0) off1[V1] = tot1;
     }
 }
 
-// After part1: the exact level-1 bucket sizes are its cursors.  off1[F1 + 1 + b] = end of the keys of bucket b,
-// tile_start[] = first part2 tile of every bucket.  A bucket that outgrew its region (estimate mode only) had its
+// After part1: the exact sizes of the level-1 sub-regions are its cursors.  off1[V1 + 1 + b] = end of the keys of
+// sub-region b, tile_start[] = first part2 tile of every sub-region.  A bucket that outgrew its region (estimate mode only) had its
 // surplus runs dropped by part1: the flag makes the host count the chromosome again with exact sizes.
-__global__ void __launch_bounds__(C2_MAXF)
-c2_tiles(const unsigned long long *__restrict__ cursor1, int F1, unsigned long long *__restrict__ off1,
-         unsigned long long *__restrict__ tile_start /* F1 + 1 */, unsigned long long *__restrict__ flag) {
-    __shared__ unsigned long long tcount[C2_MAXF];
+__global__ void __launch_bounds__(C2_MAXV)
+c2_tiles(const unsigned long long *__restrict__ cursor1, int V1, unsigned long long *__restrict__ off1,
+         unsigned long long *__restrict__ tile_start /* V1 + 1 */, unsigned long long *__restrict__ flag) {
     const int b = threadIdx.x;
-    if (b < F1) {
-        unsigned long long n = cursor1[b];
+    unsigned long long tc = 0;
+    if (b < V1) {
+        unsigned long long n = cursor1[(size_t)b * C2_CSTRIDE];
         const unsigned long long cap = off1[b + 1] - off1[b];
         if (n > cap) {
             n = cap;
             atomicAdd(flag, 1ULL);
         }
-        off1[F1 + 1 + b] = off1[b] + n;
-        tcount[b] = (n + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
+        off1[V1 + 1 + b] = off1[b] + n;
+        tc = (n + C2_TILE_KEYS - 1) / C2_TILE_KEYS;
     }
     __shared__ unsigned long long wsum[16];
     unsigned long long tot;
-    const unsigned long long t0 = sp_block_excl_scan(b < F1 ? tcount[b] : 0ULL, wsum, tot);
-    if (b < F1) tile_start[b] = t0;
-    if (b == 0) tile_start[F1] = tot;
+    const unsigned long long t0 = sp_block_excl_scan(tc, wsum, tot);
+    if (b < V1) tile_start[b] = t0;
+    if (b == 0) tile_start[V1] = tot;
 }
 
 // block-wide exclusive scan of hist[0..F) (F <= 256 <= blockDim) -> start[]; returns total
@@ -222,17 +258,23 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 // LDS counting sort of a 16 K-key tile on the top B1 slot bits.  The tile's 32 slots per thread stay in registers
 // (two blocks per CU leave 128 VGPRs per thread); the rank inside the bucket run is what the tile-histogram atomic
 // returns; the run's global position is reserved with one global atomic per (tile, bucket) -- the order of the keys
-// inside a level-1 bucket is irrelevant downstream; the copy-out reads one key and ONE table entry
-// (delta[b] = global base of the run - its LDS start, so that out index = delta[b] + i).
+// inside a level-1 bucket is irrelevant downstream.  Runs are padded to whole quads (C2_INVALID1 records) in LDS and
+// in the bucket's region alike, and the copy-out moves a quad per lane: one 16-byte LDS read, ONE table entry
+// (delta[b] = global base of the run - its LDS start, so that out index = delta[b] + i), an 8-byte store to the u16
+// plane and a 4-byte store to the u8 plane.  LDS word of a record: bucket << 24 | its remaining T - B1 slot bits.
+__device__ __forceinline__ uint32_t c2_pack_lo(uint32_t a, uint32_t b) {   // low halves of a and b
+    return __builtin_amdgcn_perm(b, a, 0x05040100u);
+}
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-          int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift1 /* T-B1 */, int F1,
+          int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift1 /* T-B1 */, int F1, int split,
           const unsigned long long *__restrict__ off1, unsigned long long *__restrict__ cursor1, int64_t n_tiles,
           uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], wsum[4];
     __shared__ unsigned long long delta[C2_MAXF];
-    __shared__ uint32_t keys[C2_P1_KEYS];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[C2_P1_KEYS + C2_PADS];
     const int sh = 32 - 2 * kp.k;
+    const uint32_t mask1 = (1u << shift1) - 1u;
     // the words of the NEXT tile's unit travel while this tile is sorted and written (copy to working registers, issue
     // the next loads, then work: loads issued after the work are waited for in full at the next use -- r03_notes.md)
     sp_words32 p_x;
@@ -266,27 +308,39 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         __syncthreads();
         unsigned long long g = 0;
         bool fits = true;
+        uint32_t c = 0;
         if (threadIdx.x < F1) {
-            const uint32_t c = hist[threadIdx.x];
-            const unsigned long long at = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c) : 0ULL;
-            g = off1[threadIdx.x] + at;
+            c = hist[threadIdx.x];
+            const uint32_t cpad = (c + 3u) & ~3u;
+            hist[threadIdx.x] = cpad;     // (own entry: the scan below reads it from this thread)
+            const int vb = (int)threadIdx.x * C2_SPLIT + (split > 1 ? (int)(tile & (C2_SPLIT - 1)) : 0);
+            const unsigned long long at = c ? atomicAdd(&cursor1[(size_t)vb * C2_CSTRIDE], (unsigned long long)cpad) : 0ULL;
+            g = off1[vb] + at;
             // estimate mode: a run that does not fit its bucket's region is dropped (c2_tiles sees the cursor and
             // raises the flag; the chromosome is then counted again from the exact histogram)
-            fits = at + c <= off1[threadIdx.x + 1] - off1[threadIdx.x];
+            fits = at + cpad <= off1[vb + 1] - off1[vb];
         }
         const uint32_t total = c2_scan_F(hist, start, F1, wsum);
-        if (threadIdx.x < F1) delta[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;
+        if (threadIdx.x < F1) {
+            delta[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;
+            for (uint32_t i = c; i < ((c + 3u) & ~3u); i++) keys[start[threadIdx.x] + i] = ((uint32_t)threadIdx.x << 24) | C2_INVALID1;
+        }
 #pragma unroll
         for (int j = 0; j < 32; j++)
-            if ((ok >> j) & 1u) keys[start[slot[j] >> shift1] + rank[j]] = slot[j];
+            if ((ok >> j) & 1u) {
+                const uint32_t b = slot[j] >> shift1;
+                keys[start[b] + rank[j]] = (b << 24) | (slot[j] & mask1);
+            }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += C2_P1_THREADS) {
-            const uint32_t s = keys[i];
-            const unsigned long long d = delta[s >> shift1];
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P1_THREADS) {
+            const uint4 v = k4[q];
+            const unsigned long long d = delta[v.x >> 24];
             if (d == C2_DROP) continue;
-            const unsigned long long o = d + i;
-            lo1[o] = (uint16_t)s;
-            hi1[o] = (uint8_t)(s >> 16);
+            const unsigned long long o = d + 4ULL * q;      // a multiple of 4: region starts, reservations and LDS starts are
+            *reinterpret_cast<uint2 *>(lo1 + o) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
+            *reinterpret_cast<uint32_t *>(hi1 + o) = c2_pack_lo(__builtin_amdgcn_perm(v.y, v.x, 0x0c0c0602u),
+                                                                __builtin_amdgcn_perm(v.w, v.z, 0x0c0c0602u));
         }
         __syncthreads();
     }
@@ -309,17 +363,24 @@ __device__ __forceinline__ int c2_bucket_of(const unsigned long long *__restrict
 
 __global__ void __launch_bounds__(C2_P2_THREADS)
 c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
-         const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2 /* B3 */,
+         const unsigned long long *__restrict__ tile_start, int F1 /* sub-regions of level 1 */, int F2, int shift2 /* B3 */,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
          uint16_t *__restrict__ buf2) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], wsum[4];
     __shared__ unsigned long long gbase[C2_MAXF];
-    __shared__ uint32_t keys[C2_TILE_KEYS];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[C2_TILE_KEYS + C2_PADS];
     __shared__ int s_bucket[2];
     const unsigned long long n_tiles = tile_start[F1];
     const uint32_t mask2 = (uint32_t)F2 - 1u;
-    unsigned long long tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+    // Tile ORDER: the blocks that run at the same time take tiles that lie n_tiles / C2_P2_SPREAD apart, i.e. in
+    // different level-1 buckets, so that their cursor atomics go to different fine buckets' cursors (in bucket order
+    // every resident block hammered the same F2 lines).  A bijection of [0, n_tiles): the last n_tiles mod SPREAD
+    // tiles stay where they are.
+    const unsigned long long perm_q = n_tiles / C2_P2_SPREAD, perm_n = perm_q * C2_P2_SPREAD;
+    auto tile_of = [&](unsigned long long t) { return t < perm_n ? (t % C2_P2_SPREAD) * perm_q + t / C2_P2_SPREAD : t; };
+    unsigned long long it = blockIdx.x;
+    if (it >= n_tiles) return;
+    unsigned long long tile = tile_of(it);
     if (threadIdx.x == 0) s_bucket[0] = c2_bucket_of(tile_start, F1, tile);
     __syncthreads();
     static_assert(C2_P2_PER % 4 == 0, "part2 reads its keys four at a time");
@@ -333,18 +394,17 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const unsigned long long idx = base + ((unsigned long long)g * C2_P2_THREADS + threadIdx.x) * 4ULL;
-            if (idx < end) {
+            if (idx < end) {     // (bucket sizes are multiples of 4: whole quads)
                 nlo[g] = *reinterpret_cast<const uint2 *>(lo1 + idx);
                 nhi[g] = *reinterpret_cast<const uint32_t *>(hi1 + idx);
-                const unsigned long long left = end - idx;
-                nnext = 4 * g + (left < 4ULL ? (int)left : 4);
+                nnext = 4 * g + 4;
             }
         }
     };
     fetch(s_bucket[0], tile - tile_start[s_bucket[0]]);
     int p = 0;
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int b1 = s_bucket[p];
+    for (; it < n_tiles; it += gridDim.x) {
+        const int b1 = s_bucket[p] / C2_SPLIT;
         uint32_t my[C2_P2_PER];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -354,24 +414,28 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
             my[4 * g + 3] = (nlo[g].y >> 16) | ((nhi[g] >> 24) << 16);
         }
         const int nmine = nnext;
-        const unsigned long long ntile = tile + gridDim.x;
+        const bool more = it + gridDim.x < n_tiles;
+        const unsigned long long ntile = more ? tile_of(it + gridDim.x) : n_tiles;
         if (threadIdx.x < F2) hist[threadIdx.x] = 0;
         if (threadIdx.x == 0 && ntile < n_tiles) s_bucket[p ^ 1] = c2_bucket_of(tile_start, F1, ntile);
         __syncthreads();  // (A) also: the previous tile's copy-out has finished reading keys/start/gbase
         uint32_t rank[C2_P2_PER];   // position of the key inside its bucket run = what the counting atomic returns
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++)
-            if (j < nmine) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
+            if (j < nmine && my[j] != C2_INVALID1) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
         __syncthreads();  // (B)
         unsigned long long g = 0;
         bool fits = true;
+        uint32_t c = 0;
         if (threadIdx.x < F2) {  // reserve the output ranges now; the result is needed only after the scan
-            const uint32_t c = hist[threadIdx.x];
+            c = hist[threadIdx.x];
+            const uint32_t cpad = (c + 3u) & ~3u;
+            hist[threadIdx.x] = cpad;     // (own entry: the scan below reads it from this thread)
             const size_t fine = (size_t)b1 * F2 + threadIdx.x;
             const unsigned long long o0 = off_fine[fine];
-            const unsigned long long at = c ? atomicAdd(&cursor2[fine], (unsigned long long)c) : 0ULL;
+            const unsigned long long at = c ? atomicAdd(&cursor2[fine * C2_CSTRIDE], (unsigned long long)cpad) : 0ULL;
             g = o0 + at;
-            fits = at + c <= off_fine[fine + 1] - o0;    // estimate mode: see part1; c2_count raises the flag
+            fits = at + cpad <= off_fine[fine + 1] - o0;    // estimate mode: see part1; c2_spans raises the flag
         }
         nnext = 0;
         if (ntile < n_tiles) {  // next tile's keys: in flight across the rest of this iteration
@@ -379,16 +443,24 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
             fetch(nb, ntile - tile_start[nb]);
         }
         const uint32_t total = c2_scan_F(hist, start, F2, wsum);
-        if (threadIdx.x < F2) gbase[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;   // out index = gbase[b] + LDS index
+        if (threadIdx.x < F2) {
+            gbase[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;   // out index = gbase[b] + LDS index
+            for (uint32_t i = c; i < ((c + 3u) & ~3u); i++) keys[start[threadIdx.x] + i] = ((uint32_t)threadIdx.x << 16) | C2_INVALID2;
+        }
         __syncthreads();  // (C)
 #pragma unroll
         for (int j = 0; j < C2_P2_PER; j++)
-            if (j < nmine) keys[start[(my[j] >> shift2) & mask2] + rank[j]] = my[j];
+            if (j < nmine && my[j] != C2_INVALID1) {
+                const uint32_t b = (my[j] >> shift2) & mask2;
+                keys[start[b] + rank[j]] = (b << 16) | (my[j] & (C2_FINE - 1));
+            }
         __syncthreads();  // (D)
-        for (uint32_t i = threadIdx.x; i < total; i += C2_P2_THREADS) {
-            const uint32_t s = keys[i];
-            const unsigned long long gb = gbase[(s >> shift2) & mask2];
-            if (gb != C2_DROP) buf2[gb + i] = (uint16_t)(s & (C2_FINE - 1));
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P2_THREADS) {
+            const uint4 v = k4[q];
+            const unsigned long long gb = gbase[v.x >> 16];
+            if (gb != C2_DROP)
+                *reinterpret_cast<uint2 *>(buf2 + gb + 4ULL * q) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
         }
         p ^= 1;
     }
@@ -404,7 +476,7 @@ c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_fine) return;
     const unsigned long long lo = off_fine[f], cap = off_fine[f + 1] - lo;
-    unsigned long long n = cursor2[f];
+    unsigned long long n = cursor2[(size_t)f * C2_CSTRIDE];
     if (n > cap) {      // a dropped run leaves part of the region unwritten: nobody may read it (the chromosome is recounted)
         n = 0;
         atomicAdd(flag, 1ULL);
@@ -470,16 +542,18 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
         // 8-byte aligned body: four u16 keys per load
         unsigned long long a = (lo + 3ULL) & ~3ULL;
         if (a > hi) a = hi;
-        for (unsigned long long i = lo + threadIdx.x; i < a; i += C2_COUNT_THREADS) atomicAdd(&cnt[buf2[i]], 1u);
+        // (a pad record, 0xFFFF, adds zero to the last counter: no branch)
+        auto add = [&](uint32_t r) { atomicAdd(&cnt[r & (C2_FINE - 1)], (r >> C2_B3) ^ 1u); };
+        for (unsigned long long i = lo + threadIdx.x; i < a; i += C2_COUNT_THREADS) add(buf2[i]);
         const unsigned long long n4 = (hi - a) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + a);
 #pragma unroll
         for (int q = 0; q < C2_PF; q++) {   // the prefetched part of the body
             if (threadIdx.x + (unsigned long long)q * C2_COUNT_THREADS < n4) {
-                atomicAdd(&cnt[pf[q].x & 0xffffu], 1u);
-                atomicAdd(&cnt[pf[q].x >> 16], 1u);
-                atomicAdd(&cnt[pf[q].y & 0xffffu], 1u);
-                atomicAdd(&cnt[pf[q].y >> 16], 1u);
+                add(pf[q].x & 0xffffu);
+                add(pf[q].x >> 16);
+                add(pf[q].y & 0xffffu);
+                add(pf[q].y >> 16);
             }
         }
         // the rest: four independent 8-byte loads in flight per lane, then the 16 LDS atomics
@@ -490,21 +564,20 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
             for (int q = 0; q < 4; q++) v[q] = p2[i + (unsigned long long)q * C2_COUNT_THREADS];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                atomicAdd(&cnt[v[q].x & 0xffffu], 1u);
-                atomicAdd(&cnt[v[q].x >> 16], 1u);
-                atomicAdd(&cnt[v[q].y & 0xffffu], 1u);
-                atomicAdd(&cnt[v[q].y >> 16], 1u);
+                add(v[q].x & 0xffffu);
+                add(v[q].x >> 16);
+                add(v[q].y & 0xffffu);
+                add(v[q].y >> 16);
             }
         }
         for (; i < n4; i += C2_COUNT_THREADS) {
             uint2 v = p2[i];
-            atomicAdd(&cnt[v.x & 0xffffu], 1u);
-            atomicAdd(&cnt[v.x >> 16], 1u);
-            atomicAdd(&cnt[v.y & 0xffffu], 1u);
-            atomicAdd(&cnt[v.y >> 16], 1u);
+            add(v.x & 0xffffu);
+            add(v.x >> 16);
+            add(v.y & 0xffffu);
+            add(v.y >> 16);
         }
-        for (unsigned long long t = a + (n4 << 2) + threadIdx.x; t < hi; t += C2_COUNT_THREADS)
-            atomicAdd(&cnt[buf2[t]], 1u);
+        for (unsigned long long t = a + (n4 << 2) + threadIdx.x; t < hi; t += C2_COUNT_THREADS) add(buf2[t]);
         prefetch(fb + gridDim.x);   // in flight across the write-out below and the next clear
         __syncthreads();
         uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
@@ -628,10 +701,11 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
     // f(residual) for the valid keys of quad i of a bucket whose keys are [off, end) counted from its first quad
     auto quad = [&](const uint2 v, uint32_t i, uint32_t off, uint32_t end, auto &&f) {
         const uint32_t k0 = 4u * i;
-        if (k0 + 0 >= off && k0 + 0 < end) f(v.x & 0xffffu);
-        if (k0 + 1 >= off && k0 + 1 < end) f(v.x >> 16);
-        if (k0 + 2 >= off && k0 + 2 < end) f(v.y & 0xffffu);
-        if (k0 + 3 >= off && k0 + 3 < end) f(v.y >> 16);
+        // (pad records, 0xFFFF, are skipped: bit 15 is set in no residual)
+        if (k0 + 0 >= off && k0 + 0 < end && !(v.x & 0x8000u)) f(v.x & 0xffffu);
+        if (k0 + 1 >= off && k0 + 1 < end && !(v.x & 0x80000000u)) f(v.x >> 16);
+        if (k0 + 2 >= off && k0 + 2 < end && !(v.y & 0x8000u)) f(v.y & 0xffffu);
+        if (k0 + 3 >= off && k0 + 3 < end && !(v.y & 0x80000000u)) f(v.y >> 16);
     };
 #pragma unroll
     for (int d = 0; d < C2L_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
@@ -835,25 +909,37 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     const unsigned long long mult8_1 = (exact || env_mult) ? mult8 : (unsigned long long)(33 << (C2_SAMPLE_SHIFT - 2));   // x 1 1/32
     const int64_t n_stripes = (n_units32 + C2_STRIPE - 1) / C2_STRIPE;
     const int64_t n_visit = exact ? n_units32 : ((n_stripes + (1 << C2_SAMPLE_SHIFT) - 1) >> C2_SAMPLE_SHIFT) * C2_STRIPE;
-    // keys the regions can hold at most (a rigorous bound: the sample sees at most n_visit * 32 k-mers)
-    const size_t cap_keys = exact ? (size_t)c.len + 4 * nf
-                                  : (size_t)(((unsigned long long)n_visit * C2_P1_UNIT * mult8 + 7) / 8) + nf * (size_t)(slack + 4);
+    // keys the regions can hold at most (rigorous bounds: the sample sees at most n_visit * 32 k-mers).  Pad records:
+    // three per (part1 tile, level-1 bucket) and per (part2 tile, fine bucket) at most -- c2_offsets adds the same terms.
+    const unsigned long long pad1 = 3ULL * (unsigned long long)n_tiles + 3ULL * C2_SPLIT;
+    // estimate mode: C2_SPLIT sub-regions per level-1 bucket, a quarter of the bucket's slack each; exact mode: one
+    const int split = exact ? 1 : C2_SPLIT;
+    const unsigned long long sslack = exact ? 0ULL : slack1 / 4;
+    const int V1 = P.F1 * C2_SPLIT;
+    const size_t cap_keys1 = (exact ? (size_t)c.len : (size_t)(((unsigned long long)n_visit * C2_P1_UNIT * mult8_1 + 7) / 8) +
+                                                          (size_t)P.F1 * (size_t)slack1) + (size_t)P.F1 * (size_t)(pad1 + 4) +
+                             (size_t)V1 * (size_t)(sslack + 8);
+    const size_t tiles2_max = cap_keys1 / C2_TILE_KEYS + 2 * (size_t)V1;
+    const size_t cap_keys2 = (exact ? (size_t)c.len + 4 * nf
+                                    : (size_t)(((unsigned long long)n_visit * C2_P1_UNIT * mult8 + 7) / 8) + nf * (size_t)(slack + 4)) +
+                             3 * (size_t)P.F2 * tiles2_max;
+    const size_t cap_keys = cap_keys1 > cap_keys2 ? cap_keys1 : cap_keys2;
     // workspace: ghist | off_fine | off1 | tile_start | cursor1 | cursor2 | level-1 planes (3 B / key) | buf2 (u16 / key)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_ghist = 0;
     size_t o_offf = o_ghist + al(nf * 8);
     size_t o_off1 = o_offf + al((nf + 1) * 8);
-    size_t o_tile = o_off1 + al((size_t)(P.F1 + 1) * 16);       // level-1 starts, then ends
-    size_t o_cur1 = o_tile + al((size_t)(P.F1 + 1) * 8);
-    size_t o_cur2 = o_cur1 + al((size_t)P.F1 * 8);
-    size_t o_tcnt = o_cur2 + al(nf * 8);        // end of the zeroed head of the workspace
+    size_t o_tile = o_off1 + al((size_t)(V1 + 1) * 16);         // level-1 sub-region starts, then ends
+    size_t o_cur1 = o_tile + al((size_t)(V1 + 1) * 8);
+    size_t o_cur2 = o_cur1 + al((size_t)V1 * 8 * C2_CSTRIDE);   // (every cursor on a cache line of its own)
+    size_t o_tcnt = o_cur2 + al(nf * 8 * C2_CSTRIDE);           // end of the zeroed head of the workspace
     size_t o_span = o_tcnt;
     o_tcnt = o_span + al(nf * 16);              // (the spans are written before they are read: not zeroed)
     const size_t zero_bytes = o_span;
-    const size_t lo1_bytes = al(cap_keys * 2 + 64 + (size_t)P.F1 * 8);
+    const size_t lo1_bytes = al(cap_keys1 * 2 + 64 + (size_t)V1 * 8);
     size_t o_buf1 = o_tcnt;
-    size_t o_buf2 = o_buf1 + lo1_bytes + al(cap_keys + 64 + (size_t)P.F1 * 4);
-    size_t o_segb = o_buf2 + al(cap_keys * 2 + 64);               // overflow segments: base, count, offsets per fine bucket
+    size_t o_buf2 = o_buf1 + lo1_bytes + al(cap_keys1 + 64 + (size_t)V1 * 4);
+    size_t o_segb = o_buf2 + al(cap_keys2 * 2 + 64);               // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
     size_t total = o_sego + al((nf + 1) * 4);
@@ -910,17 +996,17 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
         SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
     SP_LAUNCH(ctx, exact ? "c2_hist_fine" : "c2_hist_sample", c2_hist_fine, dim3(grid_hist), dim3(C2_P1_THREADS), sh_hist,
               c.d_pk, c.d_pm, c.d_nm, n_units32, n_visit, sample_shift, kp32, C2_B3, (int)nf, ghist);
-    SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, mult8, mult8_1, slack, slack1, off_fine,
-              off1);
+    SP_LAUNCH(ctx, "c2_offsets", c2_offsets, dim3(1), dim3(1024), 0, ghist, (int)nf, P.F1, P.F2, mult8, mult8_1, slack, slack1, pad1,
+              split, sslack, off_fine, off1);
     SP_LAUNCH(ctx, "c2_part1", c2_part1, dim3(grid_scan), dim3(C2_P1_THREADS), 0, c.d_pk, c.d_pm, c.d_nm, n_units32,
-              kp32, P.T - P.B1, P.F1, off1, cur1, n_tiles, lo1, hi1);
-    SP_LAUNCH(ctx, "c2_tiles", c2_tiles, dim3(1), dim3(C2_MAXF), 0, (const unsigned long long *)cur1, P.F1, off1, tile_start,
+              kp32, P.T - P.B1, P.F1, split, off1, cur1, n_tiles, lo1, hi1);
+    SP_LAUNCH(ctx, "c2_tiles", c2_tiles, dim3(1), dim3(C2_MAXV), 0, (const unsigned long long *)cur1, V1, off1, tile_start,
               d_len4 + 3);
     // part2 grid: enough blocks to cover the tiles (tile count lives on the device; over-provision)
-    int64_t max_tiles2 = (c.len + C2_TILE_KEYS - 1) / C2_TILE_KEYS + P.F1;
+    int64_t max_tiles2 = (int64_t)tiles2_max;
     int grid2 = (int)(max_tiles2 < (int64_t)ctx->n_cu * 8 ? max_tiles2 : (int64_t)ctx->n_cu * 8);
     SP_LAUNCH(ctx, "c2_part2", c2_part2, dim3(grid2), dim3(C2_P2_THREADS), 0, (const uint16_t *)lo1, (const uint8_t *)hi1, off1,
-              tile_start, P.F1,
+              tile_start, V1,
               P.F2, C2_B3, off_fine, cur2, buf2);
     int gridc = (int)((int64_t)nf < (int64_t)ctx->n_cu ? (int64_t)nf : (int64_t)ctx->n_cu);
     ulonglong2 *span = (ulonglong2 *)(ws + o_span);
