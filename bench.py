@@ -39,9 +39,22 @@ def parse():
     ap.add_argument("--dist-selfcheck", action="store_true",
                     help="before the timed run, every rank takes part in one distributed pass over the `small` synthetic "
                          "genome (9 chromosomes, cut inside chromosomes) and rank 0 compares tallies, lengths, matrix rows, "
-                         "windows and calls with a single-process pass over the same genome")
+                         "windows and calls with a single-process pass over the same genome.  ON BY DEFAULT with more than "
+                         "one rank (the line then carries dist_selfcheck.ok); this flag turns it on for --force-dist runs")
+    ap.add_argument("--no-dist-selfcheck", action="store_true", help="skip the self-check of a multi-rank run")
     ap.add_argument("--cpu-sample-mb", type=float, default=float(os.environ.get("SP_CPU_SAMPLE_MB", "1000")))
     return ap.parse_args()
+
+
+# host wall-clock phases of DistHotPath that contain a collective (reported per rank as `exchange_ms_per_rank`)
+EXCHANGE_KEYS = ["count(+exchange issue)", "exchange wait", "exchange+lengths", "merge+lengths", "rows to shared host memory",
+                 "gather rows", "windows all-reduce+enrich"]
+
+
+def want_selfcheck(args, world):
+    """A run with more than one rank validates its own collectives before anything is timed unless told not to: the
+    driver's `bench.py --gpus N --steps K --warmup W` passes no extra flag, and its line must carry dist_selfcheck.ok."""
+    return bool(args.dist_selfcheck or (world > 1 and not args.no_dist_selfcheck))
 
 
 def algorithmic_bytes(kernel, bases, nslots, C, S, extra):
@@ -114,7 +127,7 @@ def main():
     selfcheck = None
     if dist is not None:
         from subphaser_amd.dist import DistHotPath
-        if args.dist_selfcheck:
+        if want_selfcheck(args, world):
             selfcheck = dist_selfcheck(ctx, dist, torch, args, rank)
         runner = DistHotPath(ctx, gen, dist, torch, k=args.k, engine=args.engine)
     else:
@@ -199,6 +212,14 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     gbases = gen.total_bases / (dt / args.steps) / 1e9
+    # what every rank spent waiting for / issuing the table (or key-range) exchange and the other collectives
+    rank_wall = None
+    if runner is not None:
+        mine = torch.tensor([runner.wall.get(k_, 0.0) / args.steps * 1e3 for k_ in EXCHANGE_KEYS], dtype=torch.float64, device="cuda")
+        allw = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allw, mine)
+        rank_wall = [{"rank": r_, **{k_: round(float(v_), 3) for k_, v_ in zip(EXCHANGE_KEYS, w_.tolist()) if v_}}
+                     for r_, w_ in enumerate(allw)]
 
     # sum over chromosomes of D_c = distinct k-mers with count >= L (the lines of the jellyfish dumps)
     n_dumped = sum(ctx.dump_size(i) for i in range(len(pieces)))
@@ -308,7 +329,7 @@ def main():
                    "engine": args.engine, "differential_kmers": int(a.n_rows), "union_kmers": int(a.n_union),
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": ("single GPU" if world == 1 else "genome-position-sharded count/map + slot-range-sharded filter x%d" % world)},
-        "rccl_ranks": rccl_ranks, "dist_selfcheck": selfcheck,
+        "rccl_ranks": rccl_ranks, "dist_selfcheck": selfcheck, "exchange_ms_per_rank": rank_wall,
         "pieces_per_rank": ([{"rank": r_, "pieces": len(p_), "bases": int(sum(e_ - a_ for _, a_, e_ in p_))}
                              for r_, p_ in enumerate(runner.pieces)] if runner is not None else None),
         "traffic_commit": traffic_commit, "roofline": roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),

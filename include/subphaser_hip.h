@@ -164,6 +164,10 @@ int sp_filter_hist(sp_ctx *ctx, uint64_t *tot, int64_t cap);
  * reported on two lines like the reference does.
  * slot_counts: nslots x n_sg int32 (overwritten).                          */
 int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg);
+/* the same with `keys` and `sg` already in DEVICE memory (e.g. the rows Cluster.output_kmers selected, kept where
+ * sp_kmer_ttest tested them: Cluster.py:186-194 hands the reference's d_kmers dict to Seqs.map_kmer3 in memory too):
+ * no host round trip; labels >= n_sg are detected on the device (SP_EINVAL)                                   */
+int sp_labels_set_device(sp_ctx *ctx, const uint64_t *d_keys, const uint8_t *d_sg, int64_t n, int n_sg);
 int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots);
 int sp_map_bins(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int32_t *slot_counts,
                 int64_t nslots, int64_t *n_mapped);

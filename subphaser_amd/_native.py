@@ -22,7 +22,7 @@ SYMBOLS = [
     "sp_genome_reset", "sp_genome_add", "sp_genome_add_device", "sp_genome_len", "sp_genome_unpack",
     "sp_count", "sp_count_range", "sp_count_recounts", "sp_nslots", "sp_tables_bind", "sp_table_overflow", "sp_table_merge", "sp_table_lengths", "sp_lengths", "sp_dump_size", "sp_dump",
     "sp_filter_view", "sp_filter", "sp_filter_fetch", "sp_filter_fetch_async", "sp_filter_fetch_wait", "sp_filter_fetch_device", "sp_filter_hist",
-    "sp_labels_set", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_map_intervals", "sp_labels_hit",
+    "sp_labels_set", "sp_labels_set_device", "sp_map_nslots", "sp_map_bins", "sp_map_bins_all", "sp_stack_windows", "sp_stack_windows_dev", "sp_stack_enrich", "sp_map_features", "sp_map_intervals", "sp_labels_hit",
     "sp_enrich", "sp_enrich_dev", "sp_kmer_ttest",
     "sp_sparse_sizes", "sp_sparse_sample", "sp_sparse_split", "sp_sparse_export", "sp_sparse_view",
     "sp_prof_enable", "sp_prof_reset", "sp_prof_report",
@@ -96,6 +96,7 @@ def load():
     L.sp_filter_fetch_wait.argtypes = [vp]
     L.sp_filter_hist.argtypes = [vp, vp, i64]
     L.sp_labels_set.argtypes = [vp, vp, vp, i64, ci]
+    L.sp_labels_set_device.argtypes = [vp, vp, vp, i64, ci]
     L.sp_map_nslots.argtypes = [vp, ci, i64, i64, P(i64)]
     L.sp_map_bins.argtypes = [vp, ci, i64, i64, vp, i64, P(i64)]
     L.sp_map_bins_all.argtypes = [vp, i64, i64, vp, vp, vp]
@@ -588,6 +589,19 @@ class Context:
         assert keys.size == sg.size
         self._ck(self.L.sp_labels_set(self.h, _p(keys), _p(sg), keys.size, int(n_sg)))
         self.n_sg = int(n_sg)
+
+    def labels_set_device(self, d_keys, d_sg, n, n_sg):
+        """keys (uint64) and labels (uint8) already in device memory (KmerLabels.on_device)"""
+        self._ck(self.L.sp_labels_set_device(self.h, C.c_void_p(int(d_keys)), C.c_void_p(int(d_sg)), int(n), int(n_sg)))
+        self.n_sg = int(n_sg)
+
+    def labels_set_from(self, labels, n_sg):
+        """a KmerLabels object: through its device copy when it offers one"""
+        if hasattr(labels, "on_device"):
+            d_keys, d_sg = labels.on_device(self)
+            self.labels_set_device(d_keys, d_sg, len(labels.keys), n_sg)
+        else:
+            self.labels_set(labels.keys, labels.sg_idx, n_sg)
 
     def map_nslots(self, chrom, bin_size, chunk_size):
         n = C.c_int64()

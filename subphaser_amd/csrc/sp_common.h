@@ -112,6 +112,12 @@ struct sp_ctx {
     sp_buf b_ptab, b_labkeys;    // pair table (sp_map.hip: 4^(k-1) x u32) and the labelled keys it was built from
     int ptab_k = 0;              // k the pair table currently holds a label set for (0: not built / unknown state)
     int64_t ptab_n = 0;          // number of keys of that set (still in b_labkeys): sp_labels_set un-builds them
+    sp_buf b_lflags;             // device flags of sp_labels_set (sp_map.hip)
+    int64_t bloom_last_n = -1;   // label count and size of the pair filter sp_map_filter_build chose last (same count: same size, no fill check)
+    int bloom_last_bits = 0, bloom_last_k = 0;
+    sp_buf b_ctab, b_covf;       // compact pair table (S <= 3: buckets of two tagged entries) and its overflow table (sp_map.h)
+    int ct_bb = 0;               // bucket bits of the compact table the current label set lives in (0: the direct table)
+    uint32_t ct_ovf_mask = 0;
     int map_engine = 0;          // 0 = pair table (S <= 7), 1 = label table
     bool labels_ready = false;
     uint32_t *d_bloom = nullptr; // L2-resident pair filter over hashed (k-1)-mers (sp_map.hip), 2^bloom_bits bits

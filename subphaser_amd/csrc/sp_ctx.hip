@@ -150,6 +150,9 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_mapdesc);
     sp_buf_free(ctx->b_ival);
     sp_buf_free(ctx->b_ptab);
+    sp_buf_free(ctx->b_lflags);
+    sp_buf_free(ctx->b_ctab);
+    sp_buf_free(ctx->b_covf);
     sp_buf_free(ctx->b_tab32);
     sp_buf_free(ctx->b_ovfw);
     sp_buf_free(ctx->b_labkeys);

@@ -75,6 +75,7 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [R][TS] bytes | queue u16[TS] | slow queue u16[TS] | bitmaps u32[2][TS/32] | lists
     __shared__ unsigned long long red[16];
     __shared__ uint32_t s_qn, s_q2n, s_q3n;
+    __shared__ unsigned long long s_gq0;
     const int TS = P.TS, R = P.R;
     constexpr int RMAX = NCH > 0 ? 8 * NCH : 1;
     const int32_t *__restrict__ rowdesc = P.rowdesc;   // padded with zeros to a multiple of 8 (and at least 32)
@@ -314,11 +315,16 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         {
             const uint32_t q2n = s_q2n;
             const int EW = 1 + (R + 3) / 4;
-            if (threadIdx.x == 0) s_q3n = 0;
+            // ONE reservation per tile, not one returning same-address atomic per slow slot
+            if (threadIdx.x == 0) {
+                s_q3n = 0;
+                s_gq0 = (P.gq && q2n) ? atomicAdd(P.gq_n, (unsigned long long)q2n) : ~0ULL;
+            }
             __syncthreads();
+            const unsigned long long gq0 = s_gq0;
             for (uint32_t q = threadIdx.x; q < q2n; q += F_BLOCK) {
                 const int sl = (int)queue2[q];
-                const unsigned long long pos = P.gq ? atomicAdd(P.gq_n, 1ULL) : ~0ULL;
+                const unsigned long long pos = gq0 == ~0ULL ? ~0ULL : gq0 + q;
                 if (pos < P.gq_cap) {
                     uint32_t *e = P.gq + pos * EW;
                     e[0] = (uint32_t)(base + sl);

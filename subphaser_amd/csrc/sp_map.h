@@ -53,6 +53,9 @@ __device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, c
 #ifndef MAP_BATCH
 #define MAP_BATCH 4     // pairs whose probes / gathers are in flight together (16 pairs per 32-start unit)
 #endif
+#ifndef MAP_BATCH_COMPACT
+#define MAP_BATCH_COMPACT 2   // with the compact table (8-byte bucket loads, more live registers per pair): 2: 46.0, 4: 47.1, 8: 59.8 ms
+#endif
 
 struct map_pair_loc {
     uint32_t idx;   // canonical (k-1)-mer
@@ -77,6 +80,74 @@ __host__ __device__ __forceinline__ map_pair_loc map_pair_loc_suffix(uint64_t o,
     if (x <= xc) { r.idx = (uint32_t)x; r.field = (int)b; }           // b + x
     else { r.idx = (uint32_t)xc; r.field = 7 - (int)b; }              // rc: rc(x) + comp(b)
     return r;
+}
+
+// ----------------------------------------------------------------- compact exact pair table (S <= 3, round 4)
+// The direct pair table is 4^(k-1) words (1 GiB at k = 15) for a few million used entries, and every gather from it
+// leaves the chip's caches (54 G/s).  With the gathers confined to <= 128 MB the same kernel ran 43-44 instead of
+// 50.8 ms per wheat-like pass (profiles/r03_notes.md): the 256-MB Infinity Cache serves them.  The tagged
+// open-addressing table of round 3 lost that again to its probe loops.  This one answers with ONE 8-byte load and no
+// loop: 2^bb buckets of two 32-bit entries; the canonical (k-1)-mer x goes through a BIJECTIVE mix of its 2(k-1) bits,
+// the top bb bits of the mix choose the bucket, the remaining tb <= 7 bits are the entry's tag -- bucket and tag
+// determine x, so a tag match is an exact match.  Entry: tag << 25 | overflow flag << 24 | eight 3-bit fields (label
+// 1..3 in the low two bits, "seen" in the third; the field order of the direct table).  0 = empty (an entry has at
+// least one label).  A key that finds both entries of its bucket taken goes to a small open-addressing overflow table
+// of {x + 1, fields} words and raises the flag in the bucket's first entry: only a look-up that matches neither
+// entry of a flagged bucket (about one in a thousand at the load chosen) probes further.
+#define MAP_CT_FIELD 3
+#define MAP_CT_ANY 0x6DB6DBu          // the label bits of all eight fields
+#define MAP_CT_PAYLOAD 0xFFFFFFu
+#define MAP_CT_OVF (1u << 24)
+#define MAP_CT_MAX_TAG_BITS 7
+struct map_ptab {
+    uint32_t *direct;                 // 4^(k-1) words, 4-bit fields (S <= 7), or NULL
+    uint2 *buckets;                   // compact table
+    unsigned long long *ovf;          // overflow table: (x + 1) << 32 | fields, 0 = empty
+    uint32_t ovf_mask;                // its size - 1
+    int kb, tb;                       // key bits 2(k-1), tag bits
+};
+__host__ __device__ __forceinline__ uint32_t map_ct_mix(uint32_t x, int kb) {
+    const uint32_t m = kb >= 32 ? 0xFFFFFFFFu : ((1u << kb) - 1u);
+    uint32_t h = (x * 0x9E3779B1u) & m;        // odd multiplier: a bijection of the kb-bit values
+    h ^= h >> ((kb + 1) / 2);                  // xorshift by at least half the width: an involution-like bijection
+    h = (h * 0x85EBCA6Bu) & m;
+    h ^= h >> ((kb + 1) / 2);
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t map_ct_ovf_home(uint32_t x) { return (x * 0xC2B2AE35u) >> 7; }
+// look x up: the eight fields (0: absent) and where they live (for the "seen" mark): bucket * 2 + entry, or
+// 0x80000000 | overflow slot
+struct map_ct_hit {
+    uint32_t fields, loc;
+};
+__device__ __forceinline__ map_ct_hit map_ct_lookup(const map_ptab &T, uint32_t x, bool want) {
+    map_ct_hit r;
+    r.fields = 0;
+    r.loc = 0;
+    const uint32_t h = map_ct_mix(x, T.kb), b = h >> T.tb, tag = h & ((1u << T.tb) - 1u);
+    uint2 e = make_uint2(0u, 0u);
+    if (want) e = T.buckets[b];
+    const bool m0 = (e.x >> 25) == tag && (e.x & MAP_CT_PAYLOAD), m1 = (e.y >> 25) == tag && (e.y & MAP_CT_PAYLOAD);
+    r.fields = m0 ? (e.x & MAP_CT_PAYLOAD) : (m1 ? (e.y & MAP_CT_PAYLOAD) : 0u);
+    r.loc = 2u * b + (m1 ? 1u : 0u);
+    if (!m0 && !m1 && (e.x & MAP_CT_OVF)) {        // rare: the bucket overflowed and x is in neither entry
+        uint32_t i = map_ct_ovf_home(x) & T.ovf_mask;
+        for (;;) {
+            const unsigned long long o = T.ovf[i];
+            if (o == 0ULL) break;
+            if ((uint32_t)(o >> 32) == x + 1u) {
+                r.fields = (uint32_t)o & MAP_CT_PAYLOAD;
+                r.loc = 0x80000000u | i;
+                break;
+            }
+            i = (i + 1u) & T.ovf_mask;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ void map_ct_mark(const map_ptab &T, uint32_t loc, uint32_t bits) {
+    if (loc & 0x80000000u) atomicOr(&T.ovf[loc & 0x7fffffffu], (unsigned long long)bits);
+    else atomicOr(reinterpret_cast<uint32_t *>(T.buckets) + loc, bits);
 }
 
 // ----------------------------------------------------------------- K5

@@ -123,13 +123,84 @@ k4_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, cons
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
+// ----------------------------------------------------------------- K4c: compact pair table (sp_map.h), S <= 3
+// insert-or-find x, then OR the field in.  Both entries of a bucket are tried in order and never freed, so two threads
+// that insert the same x meet in the same entry; a bucket with two foreign entries raises its overflow flag and the
+// key goes to the overflow table (linear probing; *fail is set when that table is full -- the host then falls back
+// to the direct table).
+__device__ __forceinline__ void map_ct_insert(const map_ptab &T, uint32_t x, uint32_t bits, unsigned long long *fail) {
+    const uint32_t h = map_ct_mix(x, T.kb), b = h >> T.tb, tag = h & ((1u << T.tb) - 1u);
+    uint32_t *e = reinterpret_cast<uint32_t *>(T.buckets + b);
+    const uint32_t fresh = (tag << 25) | bits;
+    for (int i = 0; i < 2; i++) {
+        const uint32_t old = atomicCAS(&e[i], 0u, fresh);
+        if (old == 0u) return;
+        if ((old >> 25) == tag && (old & MAP_CT_PAYLOAD)) {
+            atomicOr(&e[i], bits);
+            return;
+        }
+    }
+    atomicOr(&e[0], MAP_CT_OVF);
+    const unsigned long long mine = ((unsigned long long)(x + 1u) << 32) | bits;
+    uint32_t i = map_ct_ovf_home(x) & T.ovf_mask;
+    for (uint32_t probes = 0; probes <= T.ovf_mask; probes++) {
+        const unsigned long long old = atomicCAS(&T.ovf[i], 0ULL, mine);
+        if (old == 0ULL) {
+            atomicAdd(fail + 1, 1ULL);      // (statistics: keys in the overflow table)
+            return;
+        }
+        if ((uint32_t)(old >> 32) == x + 1u) {
+            atomicOr(&T.ovf[i], (unsigned long long)bits);
+            return;
+        }
+        i = (i + 1u) & T.ovf_mask;
+    }
+    atomicAdd(fail, 1ULL);
+}
+__global__ void __launch_bounds__(256)
+k4_ctab_build(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n, int k, map_ptab T,
+              unsigned long long *__restrict__ fail) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i], r = sp_revcomp(key, k);
+    const uint32_t l = 1u + sg[i];
+    const map_pair_loc a = map_pair_loc_prefix(key, k), b = map_pair_loc_suffix(key, k);
+    const map_pair_loc c = map_pair_loc_prefix(r, k), d = map_pair_loc_suffix(r, k);
+    map_ct_insert(T, a.idx, l << (MAP_CT_FIELD * a.field), fail);
+    map_ct_insert(T, b.idx, l << (MAP_CT_FIELD * b.field), fail);
+    // (the reverse complement leads to the same two fields unless a (k-1)-mer is its own reverse complement)
+    if (c.idx != b.idx || c.field != b.field) map_ct_insert(T, c.idx, l << (MAP_CT_FIELD * c.field), fail);
+    if (d.idx != a.idx || d.field != a.field) map_ct_insert(T, d.idx, l << (MAP_CT_FIELD * d.field), fail);
+}
+__global__ void __launch_bounds__(256)
+k4_ctab_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, map_ptab T, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i], r = sp_revcomp(key, k);
+        const map_pair_loc L[4] = {map_pair_loc_prefix(key, k), map_pair_loc_suffix(key, k), map_pair_loc_prefix(r, k),
+                                   map_pair_loc_suffix(r, k)};
+        uint32_t seen = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) seen |= (map_ct_lookup(T, L[j].idx, true).fields >> (MAP_CT_FIELD * L[j].field)) & 4u;
+        c += seen ? 1 : 0;
+    }
+    unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
 // Walk the 32 starts [s0, s0+32) pair by pair: ONE filter probe per pair, ONE pair-table gather per
 // candidate pair; hit(start, sg) for every valid start that carries a labelled k-mer.  k <= 15.
-template <typename F>
+// COMPACT: the exact table is the compact one (3-bit fields, one 8-byte bucket load), else the direct one (4-bit fields).
+template <bool COMPACT, typename F>
 __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                 const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
                                                 const uint32_t *__restrict__ bloom, int nbits,
-                                                uint32_t *__restrict__ ptab, F &&hit) {
+                                                const map_ptab &T, F &&hit) {
+    constexpr int FW = COMPACT ? MAP_CT_FIELD : 4;
+    constexpr uint32_t LBL = COMPACT ? 3u : 7u, SEEN = COMPACT ? 4u : 8u, FMASK = COMPACT ? 7u : 15u;
+    constexpr uint32_t ANY = COMPACT ? MAP_CT_ANY : 0x77777777u;
+    constexpr int BATCH = COMPACT ? MAP_BATCH_COMPACT : MAP_BATCH;
     const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
     const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
@@ -143,10 +214,10 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
     // the latency of the scan -> probe -> gather chain (168 G L2 requests/s at 24 waves per CU against the ~270 G/s
     // the chip serves).
 #pragma unroll
-    for (int g = 0; g < 16; g += MAP_BATCH) {
-        uint32_t V[MAP_BATCH], canon[MAP_BATCH], fw[MAP_BATCH], want[MAP_BATCH], wd[MAP_BATCH], e[MAP_BATCH];
+    for (int g = 0; g < 16; g += BATCH) {
+        uint32_t V[BATCH], canon[BATCH], fw[BATCH], want[BATCH], wd[BATCH], e[BATCH], loc[BATCH];
 #pragma unroll
-        for (int q = 0; q < MAP_BATCH; q++) {
+        for (int q = 0; q < BATCH; q++) {
             const int j = 2 * (g + q);
             V[q] = sp_win_msb_at(x, j);
             const uint32_t W = sp_win_lsb_at(x, j);
@@ -159,20 +230,33 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < MAP_BATCH; q++) e[q] = ((wd[q] & want[q]) == want[q]) ? ptab[canon[q]] : 0u;
+        for (int q = 0; q < BATCH; q++) {
+            const bool cand = (wd[q] & want[q]) == want[q];
+            if (COMPACT) {
+                const map_ct_hit r = map_ct_lookup(T, canon[q], cand);
+                e[q] = r.fields;
+                loc[q] = r.loc;
+            } else {
+                e[q] = cand ? T.direct[canon[q]] : 0u;
+                loc[q] = canon[q];
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < MAP_BATCH; q++) {
-            if (!(e[q] & 0x77777777u)) continue;
+        for (int q = 0; q < BATCH; q++) {
+            if (!(e[q] & ANY)) continue;
             const int j = 2 * (g + q);
             const uint32_t b0 = V[q] >> 30, b1 = (V[q] >> sh1) & 3u;
             const int f0 = fw[q] ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
             const int f1 = fw[q] ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
-            const uint32_t v0 = ((ok_k >> j) & 1u) ? (e[q] >> (4 * f0)) & 15u : 0u;
-            const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e[q] >> (4 * f1)) & 15u : 0u;
+            const uint32_t v0 = ((ok_k >> j) & 1u) ? (e[q] >> (FW * f0)) & FMASK : 0u;
+            const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e[q] >> (FW * f1)) & FMASK : 0u;
             uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
-            if ((v0 & 7u) && hit(s0 + j, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
-            if ((v1 & 7u) && hit(s0 + j + 1, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
-            if (mark) atomicOr(&ptab[canon[q]], mark);         // "seen": first touch only
+            if ((v0 & LBL) && hit(s0 + j, (int)(v0 & LBL) - 1) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+            if ((v1 & LBL) && hit(s0 + j + 1, (int)(v1 & LBL) - 1) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+            if (mark) {                                        // "seen": first touch only
+                if (COMPACT) map_ct_mark(T, loc[q], mark);
+                else atomicOr(&T.direct[loc[q]], mark);
+            }
         }
     }
 }
@@ -190,9 +274,10 @@ struct map_chrom_desc {
     unsigned long long *n_mapped;
 };
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, sp_kparams32 kp, sp_map_params P,
-       uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
+       map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
     unsigned long long mapped = 0;
@@ -251,8 +336,8 @@ k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, s
                 acc += 1ULL << (8 * sg);
                 return true;
             };
-            map_pair_scan32(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-            map_pair_scan32(D.pk, D.pm, D.nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32<COMPACT>(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32<COMPACT>(D.pk, D.pm, D.nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
             flush();
         }
         if (P.use_lds) {
@@ -270,6 +355,18 @@ k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, s
     flush_mapped();
 }
 
+// the exact pair table the current label set lives in (compact when ctx->ct_bb != 0)
+static map_ptab map_ptab_of(const sp_ctx *ctx) {
+    map_ptab T;
+    T.direct = ctx->ct_bb ? nullptr : (uint32_t *)ctx->b_ptab.p;
+    T.buckets = ctx->ct_bb ? (uint2 *)ctx->b_ctab.p : nullptr;
+    T.ovf = (unsigned long long *)ctx->b_covf.p;
+    T.ovf_mask = ctx->ct_ovf_mask;
+    T.kb = 2 * (ctx->k - 1);
+    T.tb = T.kb - ctx->ct_bb;
+    return T;
+}
+
 // descriptors of the chromosomes [first, first + n) -> device, then the one launch
 static int map_launch_dense(sp_ctx *ctx, const std::vector<map_chrom_desc> &hd, int64_t n_ranges, const sp_map_params &P) {
     if (n_ranges <= 0) return SP_OK;
@@ -281,8 +378,13 @@ static int map_launch_dense(sp_ctx *ctx, const std::vector<map_chrom_desc> &hd, 
     const sp_kparams32 kp = sp_make_kparams32(ctx->k);
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-    SP_LAUNCH(ctx, "k5_map", k5_map, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
-              (int)hd.size(), n_ranges, kp, P, (uint32_t *)ctx->b_ptab.p, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+    const map_ptab T = map_ptab_of(ctx);
+    if (T.buckets)
+        SP_LAUNCH(ctx, "k5_map", k5_map<true>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+                  (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+    else
+        SP_LAUNCH(ctx, "k5_map", k5_map<false>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+                  (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
     return SP_OK;
 }
 
@@ -366,10 +468,11 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
     atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
             sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
-            uint32_t *__restrict__ ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
+            map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
             unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -382,8 +485,8 @@ k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, co
             atomicAdd(&counts[cur.f * S + sg], 1ULL);
             return true;
         };
-        map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-        map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+        map_pair_scan32<COMPACT>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+        map_pair_scan32<COMPACT>(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
     }
 }
 
@@ -442,10 +545,10 @@ kv_cover(const int32_t *__restrict__ chrom, const int64_t *__restrict__ start, c
     }
 }
 
-template <int ENGINE /* 0 = pair table, 1 = label table */>
+template <int ENGINE /* 0 = direct pair table, 1 = label table, 2 = compact pair table */>
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_mask(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-            sp_kparams32 kp, int64_t n_units, int S, uint32_t *__restrict__ ptab, uint8_t *__restrict__ label,
+            sp_kparams32 kp, int64_t n_units, int S, map_ptab ptab, uint8_t *__restrict__ label,
             const uint32_t *__restrict__ bloom, int bloom_bits, const unsigned long long *__restrict__ cov,
             unsigned long long *__restrict__ masks /* n_units x S */) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,7 +556,7 @@ k5_map_mask(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, co
     for (; u < n_units; u += stride) {
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;         // nothing of this wave's 4096 starts lies in a feature
-        if (ENGINE == 0) {
+        if (ENGINE != 1) {
             unsigned long long m[MAP_PAIR_MAX_SG] = {0, 0, 0, 0, 0, 0, 0};
             auto hit = [&](int64_t start, int sg) {
                 const unsigned long long bit = 1ULL << (start & 63);
@@ -462,8 +565,8 @@ k5_map_mask(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, co
                 for (int j = 0; j < MAP_PAIR_MAX_SG; j++) m[j] |= (j == sg) ? bit : 0ULL;
                 return true;
             };
-            map_pair_scan32(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-            map_pair_scan32(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32<ENGINE == 2>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
+            map_pair_scan32<ENGINE == 2>(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
 #pragma unroll
             for (int j = 0; j < MAP_PAIR_MAX_SG; j++)
                 if (j < S) masks[u * S + j] = m[j];
@@ -535,7 +638,19 @@ static int64_t map_nslots_host(int64_t len, int64_t bin_size, int64_t chunk_size
     return nb + nch;
 }
 
-int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n);          // sp_sparse.hip
+int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, bool on_device);   // sp_sparse.hip
+
+// labels handed over in device memory: the largest one, for the `label < n_sg` check the host does on host arrays
+__global__ void __launch_bounds__(256)
+k4_label_max(const uint8_t *__restrict__ sg, int64_t n, unsigned int *__restrict__ out) {
+    unsigned int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = sg[i] > m ? sg[i] : m;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int x = __shfl_down(m, o, 64);
+        m = x > m ? x : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *d_counts, unsigned long long *d_n);
 int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units,
                           const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts);
@@ -549,6 +664,11 @@ int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n
     if (!ctx->d_bloom) SP_HIP(ctx, hipMalloc(&ctx->d_bloom, ((size_t)1 << MAP_BLOOM_MAX_BITS) / 8 + 64));   // + fill counter
     int bits = MAP_BLOOM_MIN_BITS;
     while (bits < MAP_BLOOM_MAX_BITS - 1 && ((int64_t)1 << bits) < 6 * n) bits++;
+    // The size is a speed heuristic (fill <= MAP_FILL_MAX), never a matter of correctness: a label set of the size of
+    // the previous one (the same set, pass after pass, in a pipeline that re-maps) takes the size chosen then without
+    // measuring the fill again -- the measurement is a device -> host round trip per candidate size.
+    const bool cached = n > 0 && n == ctx->bloom_last_n && ctx->k == ctx->bloom_last_k && ctx->bloom_last_bits >= bits;
+    if (cached) bits = ctx->bloom_last_bits;
     unsigned long long *d_small = (unsigned long long *)((char *)ctx->d_bloom + ((size_t)1 << MAP_BLOOM_MAX_BITS) / 8);
     for (;;) {
         const size_t bytes = ((size_t)1 << bits) / 8;
@@ -557,7 +677,7 @@ int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n
         if (n == 0) break;
         SP_LAUNCH(ctx, "k4_pair_filter", k4_pair_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, n,
                   ctx->k, ctx->d_bloom, bits);
-        if (bits >= MAP_BLOOM_MAX_BITS) break;
+        if (bits >= MAP_BLOOM_MAX_BITS || cached) break;
         SP_HIP(ctx, hipMemsetAsync(d_small, 0, 8, ctx->stream));
         SP_LAUNCH(ctx, "k4_filter_fill", k4_filter_fill, dim3(256), dim3(256), 0, (const uint32_t *)ctx->d_bloom,
                   (int64_t)(bytes / 4), d_small);
@@ -569,61 +689,124 @@ int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n
         if (fill <= MAP_FILL_MAX) break;
         bits++;
     }
+    ctx->bloom_last_n = n;
+    ctx->bloom_last_bits = bits;
+    ctx->bloom_last_k = ctx->k;
     return SP_OK;
 }
 
 extern "C" {
 
-int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg) {
+static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg, bool on_device) {
     if (!ctx || n < 0 || (n > 0 && (!keys || !sg)) || n_sg < 1 || n_sg > 126)
         return sp_fail(ctx, SP_EINVAL, "sp_labels_set: bad arguments");
     if (ctx->k <= 0 || (ctx->nslots <= 0 && !ctx->sparse_mode))
         return sp_fail(ctx, SP_EINVAL, "sp_labels_set: call sp_count first (it fixes k)");
     SP_HIP(ctx, hipSetDevice(ctx->device));
-    {
+    // device flags of this call: [0] largest label (device hand-over), [2] compact table: overflow table full,
+    // [3] keys in the overflow table.  Read back ONCE, at the end.
+    int rcfl = sp_buf_ensure(ctx, ctx->b_lflags, 64);
+    if (rcfl) return rcfl;
+    unsigned long long *d_flags = (unsigned long long *)ctx->b_lflags.p;
+    SP_HIP(ctx, hipMemsetAsync(d_flags, 0, 64, ctx->stream));
+    if (on_device && n > 0) {
+        SP_LAUNCH(ctx, "k4_label_max", k4_label_max, dim3((unsigned)(n < 65536 ? 1 : ctx->n_cu)), dim3(256), 0, sg, n, (unsigned int *)d_flags);
+    } else {
         uint8_t mx = 0;     // (a reduction the compiler vectorises; an early-exit loop over 2 M labels took 1 ms)
         for (int64_t i = 0; i < n; i++) mx = sg[i] > mx ? sg[i] : mx;
         if (n > 0 && mx >= n_sg) return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)mx, n_sg);
     }
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto label_check = [&]() -> int {      // after a synchronisation of the stream
+        if (!(on_device && n > 0)) return SP_OK;
+        unsigned long long hf = 0;
+        SP_HIP(ctx, hipMemcpy(&hf, d_flags, 8, hipMemcpyDeviceToHost));
+        if ((int)(unsigned int)hf >= n_sg) {
+            ctx->labels_ready = false;
+            return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)(unsigned int)hf, n_sg);
+        }
+        return SP_OK;
+    };
     if (ctx->sparse_mode) {
         ctx->n_sg = n_sg;
         ctx->n_labels = n;
-        return sp_sparse_labels_set(ctx, keys, sg, n);
+        int rcs = sp_sparse_labels_set(ctx, keys, sg, n, on_device);
+        if (rcs) return rcs;
+        return label_check();
     }
     const char *eng = getenv("SP_MAP_ENGINE");
     ctx->map_engine = (n_sg > MAP_PAIR_MAX_SG || (eng && eng[0] == '1')) ? 1 : 0;
     ctx->n_sg = n_sg;
     ctx->labels_ready = false;
     const int64_t entries = 1LL << (2 * (ctx->k - 1));
-    // the pair table of the previous label set (same k, same buffer) is un-built key by key instead of memset
+    // Compact table (sp_map.h) when the labels fit 2-bit fields, the direct table is beyond every cache and the
+    // compact one is at least four times smaller: 2^bb buckets >= SP_CTAB_FACTOR (default 3) x n, tag bits <= 7.
+    ctx->ct_bb = 0;
+    bool compact = false;
+    int bb = 10;
+    {
+        const char *env_ct = getenv("SP_CTAB");           // "0": never (cross-check), "1": whenever the tag fits
+        const char *env_f = getenv("SP_CTAB_FACTOR");
+        const int64_t factor = env_f && atoll(env_f) > 0 ? atoll(env_f) : 3;
+        const int kb = 2 * (ctx->k - 1);
+        while (bb < 30 && ((int64_t)1 << bb) < factor * (n > 0 ? n : 1)) bb++;
+        if (bb < kb - MAP_CT_MAX_TAG_BITS) bb = kb - MAP_CT_MAX_TAG_BITS;
+        const bool fits = ctx->map_engine == 0 && n_sg <= 3 && kb >= 2 && bb <= kb && bb <= 28;
+        const bool forced = env_ct && env_ct[0] == '1';
+        compact = fits && !(env_ct && env_ct[0] == '0') &&
+                  (forced || (entries * 4 > (64LL << 20) && ((int64_t)8 << bb) * 4 <= entries * 4));
+    }
+    // direct table: the previous label set (same k, same buffer) is un-built key by key instead of memset -- while its
+    // keys are still in b_labkeys
     bool table_clean = false;
-    if (ctx->map_engine == 0 && ctx->ptab_k == ctx->k && ctx->b_ptab.p && ctx->b_ptab.cap >= entries * 4) {
+    if (!compact && ctx->map_engine == 0 && ctx->ptab_k == ctx->k && ctx->b_ptab.p && ctx->b_ptab.cap >= entries * 4) {
         if (ctx->ptab_n > 0)
             SP_LAUNCH(ctx, "k4_pair_clear", k4_pair_clear, dim3((unsigned)((ctx->ptab_n + 255) / 256)), dim3(256), 0,
                       (const unsigned long long *)ctx->b_labkeys.p, ctx->ptab_n, ctx->k, (uint32_t *)ctx->b_ptab.p);
         table_clean = true;
     }
-    ctx->ptab_k = 0;
+    ctx->ptab_k = 0;      // (from here on the direct table is in an unknown state unless it is rebuilt below)
     ctx->ptab_n = 0;
     ctx->n_labels = n;
     int rcb = sp_buf_ensure(ctx, ctx->b_labkeys, (n > 0 ? n : 1) * 9);
     if (rcb) return rcb;
     unsigned long long *d_keys = (unsigned long long *)ctx->b_labkeys.p;
     uint8_t *d_sg = (uint8_t *)(d_keys + (n > 0 ? n : 1));
-    if (n > 0) {
-        SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0 && (const void *)keys != (const void *)d_keys) {
+        SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, kind, ctx->stream));
+        SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, kind, ctx->stream));
     }
-    if (ctx->map_engine == 0) {
-        rcb = sp_buf_ensure(ctx, ctx->b_ptab, entries * 4);
+    if (compact) {
+        const int64_t nb = (int64_t)1 << bb;
+        int64_t ovf_n = 4096;
+        while (ovf_n < n / 2) ovf_n <<= 1;
+        rcb = sp_buf_ensure(ctx, ctx->b_ctab, nb * 8);
         if (rcb) return rcb;
+        rcb = sp_buf_ensure(ctx, ctx->b_covf, ovf_n * 8);
+        if (rcb) return rcb;
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_ctab.p, 0, (size_t)nb * 8, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_covf.p, 0, (size_t)ovf_n * 8, ctx->stream));
+        ctx->ct_bb = bb;
+        ctx->ct_ovf_mask = (uint32_t)(ovf_n - 1);
+        if (n > 0)
+            SP_LAUNCH(ctx, "k4_ctab_build", k4_ctab_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                      (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, map_ptab_of(ctx), d_flags + 2);
+    }
+    auto build_direct = [&]() -> int {
+        int rc2 = sp_buf_ensure(ctx, ctx->b_ptab, entries * 4);
+        if (rc2) return rc2;
         if (!table_clean) SP_HIP(ctx, hipMemsetAsync(ctx->b_ptab.p, 0, (size_t)entries * 4, ctx->stream));
         if (n > 0)
             SP_LAUNCH(ctx, "k4_pair_table", k4_pair_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                       (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, (uint32_t *)ctx->b_ptab.p);
         ctx->ptab_k = ctx->k;
         ctx->ptab_n = n;
-    } else {
+        return SP_OK;
+    };
+    if (ctx->map_engine == 0 && !compact) {
+        rcb = build_direct();
+        if (rcb) return rcb;
+    } else if (ctx->map_engine != 0) {
         if (!ctx->d_label) SP_HIP(ctx, hipMalloc(&ctx->d_label, (size_t)ctx->nslots));
         SP_HIP(ctx, hipMemsetAsync(ctx->d_label, 0, (size_t)ctx->nslots, ctx->stream));
         if (n > 0) {
@@ -633,9 +816,34 @@ int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t 
         }
     }
     const int rcf = sp_map_filter_build(ctx, n > 0 ? d_keys : nullptr, n);
+    if (rcf) return rcf;
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (rcf == SP_OK) ctx->labels_ready = true;
-    return rcf;
+    int rcl = label_check();
+    if (rcl) return rcl;
+    if (compact && n > 0) {
+        unsigned long long hf[2] = {0, 0};
+        SP_HIP(ctx, hipMemcpy(hf, d_flags + 2, 16, hipMemcpyDeviceToHost));
+        if (getenv("SP_DEBUG_FILTER"))
+            fprintf(stderr, "[sp] compact pair table: 2^%d buckets, %llu entries in the overflow table (%lld labelled k-mers)\n",
+                    bb, hf[1], (long long)n);
+        if (hf[0]) {          // overflow table full (adversarial key sets only): the direct table takes over
+            ctx->ct_bb = 0;
+            table_clean = false;
+            rcb = build_direct();
+            if (rcb) return rcb;
+            SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    ctx->labels_ready = true;
+    return SP_OK;
+}
+
+int sp_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, int n_sg) {
+    return labels_set_impl(ctx, keys, sg, n, n_sg, false);
+}
+
+int sp_labels_set_device(sp_ctx *ctx, const uint64_t *d_keys, const uint8_t *d_sg, int64_t n, int n_sg) {
+    return labels_set_impl(ctx, d_keys, d_sg, n, n_sg, true);
 }
 
 int sp_map_nslots(sp_ctx *ctx, int chrom, int64_t bin_size, int64_t chunk_size, int64_t *nslots) {
@@ -901,10 +1109,15 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        if (ctx->map_engine == 0)
-            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+        if (ctx->map_engine == 0 && ctx->ct_bb)
+            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat<true>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
                       (const uint32_t *)(d_pk.p + 2 * nmw), (const uint32_t *)d_nm.p, kp, n_units,
-                      (const int64_t *)d_foff.p, n_feat, S, (uint32_t *)ctx->b_ptab.p, (const uint32_t *)ctx->d_bloom,
+                      (const int64_t *)d_foff.p, n_feat, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom,
+                      ctx->bloom_bits, d_counts.p);
+        else if (ctx->map_engine == 0)
+            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat<false>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+                      (const uint32_t *)(d_pk.p + 2 * nmw), (const uint32_t *)d_nm.p, kp, n_units,
+                      (const int64_t *)d_foff.p, n_feat, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom,
                       ctx->bloom_bits, d_counts.p);
         else
             SP_LAUNCH(ctx, "k5_map_feat_lab", k5_map_feat_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0,
@@ -966,13 +1179,17 @@ int sp_map_intervals(sp_ctx *ctx, const int32_t *chrom, const int64_t *start, co
         const sp_kparams32 kp = sp_make_kparams32(k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        if (ctx->map_engine == 0)
+        if (ctx->map_engine == 0 && ctx->ct_bb)
+            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<2>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
+                      n_units, S, map_ptab_of(ctx), (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
+        else if (ctx->map_engine == 0)
             SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
-                      n_units, S, (uint32_t *)ctx->b_ptab.p, (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      n_units, S, map_ptab_of(ctx), (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
         else
             SP_LAUNCH(ctx, "k5_map_mask_lab", k5_map_mask<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm,
-                      kp, n_units, S, (uint32_t *)nullptr, ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      kp, n_units, S, map_ptab_of(ctx), ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
     }
     SP_LAUNCH(ctx, "kv_count", kv_count, dim3((unsigned)gw), dim3(256), 0, (const int32_t *)d_ch, (const int64_t *)d_st,
@@ -996,7 +1213,10 @@ int sp_labels_hit(sp_ctx *ctx, int64_t *n_hit) {
         if (rcs) return rcs;
     } else {
         if (ctx->map_engine == 0) {
-            if (ctx->n_labels > 0)
+            if (ctx->n_labels > 0 && ctx->ct_bb)
+                SP_LAUNCH(ctx, "k4_ctab_seen", k4_ctab_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
+                          (const unsigned long long *)ctx->b_labkeys.p, ctx->n_labels, ctx->k, map_ptab_of(ctx), d_n.p);
+            else if (ctx->n_labels > 0)
                 SP_LAUNCH(ctx, "k4_pair_seen", k4_pair_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
                           (const unsigned long long *)ctx->b_labkeys.p, ctx->n_labels, ctx->k,
                           (const uint32_t *)ctx->b_ptab.p, d_n.p);

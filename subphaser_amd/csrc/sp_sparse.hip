@@ -1268,7 +1268,7 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
 
 int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n);   // sp_map.hip
 
-int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n) {
+int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, bool on_device) {
     // <= 7 subgenomes: the pair-keyed table (one look-up per candidate PAIR of starts); else one entry per k-mer
     const char *eng = getenv("SP_MAP_ENGINE");
     ctx->map_engine = (ctx->n_sg > 7 || (eng && eng[0] == '1')) ? 1 : 0;
@@ -1298,8 +1298,9 @@ int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, i
     if (rcb) return rcb;
     unsigned long long *d_keys = (unsigned long long *)ctx->b_labkeys.p;
     uint8_t *d_sg = (uint8_t *)(d_keys + n);
-    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, kind, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, kind, ctx->stream));
     if (pairs)
         SP_LAUNCH(ctx, "sps_pair_insert", sps_pair_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                   (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, (unsigned long long *)ctx->d_hkeys,

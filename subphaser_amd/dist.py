@@ -511,7 +511,7 @@ class DistHotPath:
         self._fence()
         r.bins, r.n_mapped = [], 0
         if mine:
-            ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
+            ctx.labels_set_from(kmer_labels, n_sg)
             all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
             r.bins = all_slots
             r.n_mapped = int(n_mapped.sum())

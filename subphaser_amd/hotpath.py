@@ -92,7 +92,7 @@ class HotPath:
         """K4 labels -> K5 bin map -> window stack -> K6 enrichment."""
         ctx = self.ctx
         t = time.perf_counter()
-        ctx.labels_set(kmer_labels.keys, kmer_labels.sg_idx, n_sg)
+        ctx.labels_set_from(kmer_labels, n_sg)
         t = self._t("labels_set", t)
         r = HotPathResult()
         all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)

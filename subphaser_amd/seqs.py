@@ -376,6 +376,38 @@ class KmerLabels:
     def __len__(self):           # the reference's dict holds both orientations
         return 2 * len(self.keys)
 
+    # The labelled rows were tested on the device (Cluster.output_kmers -> sp_kmer_ttest); `on_device(ctx)` keeps a
+    # device copy of (keys, sg_idx) for the context, made on first use, so that every later map stage hands the set
+    # over with sp_labels_set_device instead of 9 bytes per k-mer of pageable host memory (2.2 of the 2.9 ms
+    # `labels_set` cost per wheat-like pass).  The copy dies with the object or the context.
+    _dev = None
+
+    def on_device(self, ctx):
+        if self._dev is None or self._dev[0] is not ctx or not ctx.h:
+            self.release_device()
+            n = len(self.keys)
+            d_keys = ctx.dev_alloc(max(n, 1) * 8)
+            d_sg = ctx.dev_alloc(max(n, 1))
+            if n:
+                ctx.host_to_dev(d_keys, self.keys)
+                ctx.host_to_dev(d_sg, self.sg_idx)
+            self._dev = (ctx, d_keys, d_sg)
+        return self._dev[1], self._dev[2]
+
+    def release_device(self):
+        if self._dev is not None:
+            ctx, d_keys, d_sg = self._dev
+            self._dev = None
+            if ctx.h:
+                ctx.dev_free(d_keys)
+                ctx.dev_free(d_sg)
+
+    def __del__(self):
+        try:
+            self.release_device()
+        except Exception:
+            pass
+
     def values(self):
         for i in self.sg_idx:
             yield self.sg_names[i]

@@ -75,6 +75,9 @@ class OracleContext:
         self.n_sg = n_sg
         self.hit = np.zeros(len(self.lab_keys), np.uint8)
 
+    def labels_set_from(self, labels, n_sg):       # (the oracle has no device: the host arrays)
+        self.labels_set(labels.keys, labels.sg_idx, n_sg)
+
     def map_nslots(self, i, bin_size, chunk_size):
         return po.n_slots(self.seqs[i].size, bin_size, chunk_size, self.k)
 

@@ -412,6 +412,26 @@ def test_output_kmers_group_larger_than_kernel_limit():
             assert np.isclose(float(p), st.ttest_ind(a, b)[1], rtol=1e-9, atol=1e-300)
 
 
+def test_bench_selfchecks_multi_rank_runs_by_default(monkeypatch):
+    """`bench.py --gpus N --steps K --warmup W` (what the driver runs) must validate its collectives without extra
+    flags: the self-check is on whenever there is more than one rank, off for one rank unless asked for."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def parse(argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+        return bench.parse()
+    assert bench.want_selfcheck(parse(["--gpus", "8", "--steps", "20", "--warmup", "5"]), 8) is True
+    assert bench.want_selfcheck(parse(["--gpus", "2"]), 2) is True
+    assert bench.want_selfcheck(parse(["--gpus", "8", "--no-dist-selfcheck"]), 8) is False
+    assert bench.want_selfcheck(parse([]), 1) is False
+    assert bench.want_selfcheck(parse(["--force-dist", "--dist-selfcheck"]), 1) is True
+    assert "exchange wait" in bench.EXCHANGE_KEYS and "exchange+lengths" in bench.EXCHANGE_KEYS
+
+
 def test_bench_jellyfish_leg(tmp_path, monkeypatch):
     """bench.py's cpu_baseline leg runs the reference's exact jellyfish commands (Jellyfish.py:697-699) when the
     binary exists and diffs its dump with the oracle's; this image has none -> "absent".  With a stand-in executable

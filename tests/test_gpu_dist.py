@@ -150,5 +150,6 @@ def test_bench_line_single_and_forced_dist(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     d2 = json.loads(out.stdout.strip().splitlines()[-1])
     assert d2["rccl_ranks"] == 1 and d2["dist_selfcheck"]["ok"] is True and d2["pieces_per_rank"][0]["rank"] == 0
+    assert d2["exchange_ms_per_rank"][0]["rank"] == 0 and d2["exchange_ms_per_rank"][0]["exchange wait"] >= 0
     assert d2["pieces_per_rank"][0]["bases"] > 0 and d2["config"]["differential_kmers"] == d["config"]["differential_kmers"]
     assert d2["config"]["mapped_positions"] == d["config"]["mapped_positions"]

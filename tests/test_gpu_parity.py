@@ -759,6 +759,76 @@ def test_map_vs_oracle_random(gpu_ctx):
     assert int(got.sum()) == int(cnts[cnts >= 20].astype(np.int64).sum())   # every occurrence mapped once
 
 
+@pytest.mark.parametrize("k", [13, 15, 21])
+def test_labels_set_device(gpu_ctx, k):
+    """sp_labels_set_device (the label set handed over in device memory, KmerLabels.on_device) maps exactly like
+    sp_labels_set; a label >= n_sg is caught on the device."""
+    from subphaser_amd.seqs import KmerLabels
+    rng = np.random.RandomState(77 + k)
+    s = np.concatenate([_rand_seq(rng, 60_000), np.tile(_rand_seq(rng, 300, 0, 0), 30)])
+    gpu_ctx.genome_reset(1)
+    gpu_ctx.genome_add(0, s)
+    gpu_ctx.count(k, 1, 0)
+    keys, cnts = gpu_ctx.dump(0)
+    sel = keys[(cnts >= 2) | (rng.rand(keys.size) < 0.2)]
+    sg = (np.arange(sel.size) % 3).astype(np.uint8)
+    gpu_ctx.labels_set(sel, sg, 3)
+    exp, n_exp = gpu_ctx.map_bins(0, 777, 5000)
+    hit_exp = gpu_ctx.labels_hit()
+    lab = KmerLabels(sel, sg, ["A", "B", "C"], k)
+    gpu_ctx.labels_set(sel[:3], sg[:3], 3)            # something else in between
+    gpu_ctx.labels_set_from(lab, 3)
+    got, n = gpu_ctx.map_bins(0, 777, 5000)
+    assert (got == exp).all() and n == n_exp and gpu_ctx.labels_hit() == hit_exp
+    oref, _, n2 = po.map_bins(s, k, sel, sg, 3, 777, 5000, nthreads=2)
+    assert (got == oref).all() and n == n2
+    d_keys, d_sg = lab.on_device(gpu_ctx)
+    with pytest.raises(ValueError, match="label 2 >= n_sg 2"):
+        gpu_ctx.labels_set_device(d_keys, d_sg, sel.size, 2)
+    lab.release_device()
+
+
+@pytest.mark.parametrize("k", [2, 5, 9, 13, 14, 15])
+@pytest.mark.parametrize("mode", ["compact", "compact-crowded", "direct"])
+def test_map_compact_pair_table(gpu_ctx, monkeypatch, k, mode):
+    """The compact exact pair table (S <= 3: buckets of two tagged entries + overflow table, sp_map.h) against the
+    oracle and against the direct table: forced on at every k (tag bits 0..7), with a load that sends many keys to the
+    overflow table, with palindromic (k-1)-mers, N runs, both strands; bins, n_mapped, labels_hit, features and BED
+    intervals go through the same look-up."""
+    monkeypatch.setenv("SP_CTAB", "0" if mode == "direct" else "1")
+    if mode == "compact-crowded":
+        monkeypatch.setenv("SP_CTAB_FACTOR", "1")      # ~2 keys per bucket of two: a fifth of the keys overflow
+    rng = np.random.RandomState(4100 + k)
+    pal = np.frombuffer(b"ACGTACGTACGTACGTACGTAATTAATTAATTAATTGGCCGGCCGGCC", dtype=np.uint8)
+    s = np.concatenate([_rand_seq(rng, 90_000, 0.01, 0.1), np.tile(pal, 40), _rand_seq(rng, 30_000)])
+    s2 = np.concatenate([s[20_000:50_000][::-1].copy(), np.tile(pal, 10), _rand_seq(rng, 20_000)])
+    gpu_ctx.genome_reset(2)
+    gpu_ctx.genome_add(0, s)
+    gpu_ctx.genome_add(1, s2)
+    gpu_ctx.count(k, 1, 1)
+    keys, cnts = gpu_ctx.dump(0)
+    sel = keys[(cnts >= 2) | (rng.rand(keys.size) < 0.4)]
+    assert sel.size
+    for S in (1, 2, 3):
+        sg = (np.arange(sel.size) % S).astype(np.uint8)
+        gpu_ctx.labels_set(sel, sg, S)
+        hit_all = np.zeros(sel.size, bool)
+        for bin_size, chunk in ((1000, 10_000), (7, 0)):
+            for ci, seq in enumerate((s, s2)):
+                got, n = gpu_ctx.map_bins(ci, bin_size, chunk)
+                exp, hit, n2 = po.map_bins(seq, k, sel, sg, S, bin_size, chunk, nthreads=4)
+                assert got.shape == exp.shape and (got == exp).all() and n == n2, (S, bin_size, chunk, ci)
+                hit_all |= hit.astype(bool)
+        assert gpu_ctx.labels_hit() == int(hit_all.sum())
+    # a second, smaller label set over the same context: nothing of the first one may survive
+    sel2 = sel[::5]
+    sg2 = (np.arange(sel2.size) % 3).astype(np.uint8)
+    gpu_ctx.labels_set(sel2, sg2, 3)
+    got, n = gpu_ctx.map_bins(0, 500, 0)
+    exp, hit, n2 = po.map_bins(s, k, sel2, sg2, 3, 500, 0, nthreads=4)
+    assert (got == exp).all() and n == n2 and gpu_ctx.labels_hit() == int(hit.sum())
+
+
 @pytest.mark.parametrize("k,S", [(13, 8), (15, 9), (15, 8), (13, 9)])
 def test_map_label_table_engine_many_subgenomes(gpu_ctx, k, S):
     """More than 7 subgenomes: the pair table's 3-bit label does not fit, the dense per-k-mer label table
