@@ -28,6 +28,8 @@ struct sp_chrom {
     int64_t n_ovf = 0, cap_ovf = 0;
     int64_t length_sum = 0;    // sum of counts >= lower_count
     int64_t n_dump = 0;        // number of k-mers with count >= lower_count
+    hipEvent_t ev_packed = nullptr;   // recorded behind this chromosome's pack kernel: a counting lane waits for it, not for
+                                      // the packing of the chromosomes after it
 };
 #define SP_PAD_WORDS 8
 
@@ -112,6 +114,7 @@ struct sp_ctx {
     sp_buf b_ptab, b_labkeys;    // pair table (sp_map.hip: 4^(k-1) x u32) and the labelled keys it was built from
     int ptab_k = 0;              // k the pair table currently holds a label set for (0: not built / unknown state)
     int64_t ptab_n = 0;          // number of keys of that set (still in b_labkeys): sp_labels_set un-builds them
+    unsigned long long *h_lflags = nullptr;   // page-locked twin of b_lflags, written by k4_flags_out
     sp_buf b_lflags;             // device flags of sp_labels_set (sp_map.hip)
     int64_t bloom_last_n = -1;   // label count and size of the pair filter sp_map_filter_build chose last (same count: same size, no fill check)
     int bloom_last_bits = 0, bloom_last_k = 0;
@@ -129,6 +132,7 @@ struct sp_ctx {
     int64_t scratch_bytes = 0;
     void *d_ws2 = nullptr;       // engine-2 workspace (histograms, offsets, key buffers)
     int64_t ws2_bytes = 0;
+    sp_buf b_cntlen;             // sp_count's per-chromosome tallies (sum, n, overflow pairs, overrun flag)
     sp_buf b_tab32, b_ovfw;      // engine 1: u32 scratch table; overflow staging (unordered pairs + per-bucket index)
     // Small genomes: the partition chain of a 20-Mb chromosome is ten launches of a few tens of microseconds that do
     // not fill the chip; chromosomes are counted on SP_LANES streams side by side, each with its own workspace.

@@ -425,24 +425,27 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         sp_sparse_release(ctx);
         ctx->sparse.assign(C, sp_sparse_chrom());
     }
-    void *scr = nullptr;
-    int rc = sp_scratch(ctx, (int64_t)(4 * C * sizeof(unsigned long long)), &scr);
+    // per chromosome: sum, n (counts >= lower), overflow pairs, engine 2's region-overrun flag (a buffer of its own: the
+    // lanes below clear their entries on their own streams, next to whatever the main stream still runs)
+    int rc = sp_buf_ensure(ctx, ctx->b_cntlen, (int64_t)(4 * C * sizeof(unsigned long long)));
     if (rc) return rc;
-    // per chromosome: sum, n (counts >= lower), overflow pairs, engine 2's region-overrun flag
-    unsigned long long *d_len = (unsigned long long *)scr;
-    SP_HIP(ctx, hipMemsetAsync(d_len, 0, 4 * C * sizeof(unsigned long long), ctx->stream));
+    unsigned long long *d_len = (unsigned long long *)ctx->b_cntlen.p;
     const char *env_exact = getenv("SP_C2_EXACT");      // "1": size the buckets from the full histogram (round-2 path)
     const bool sized_by_sample = !(env_exact && env_exact[0] == '1');
     std::vector<char> by_engine2(C, 0);
     // small genomes (engine 3): count chromosomes on up to three more streams side by side (SP_LANES=0: one stream)
-    // Byte tables (engine 2, whole-genome calls): ONE more stream.  A chromosome's chain has five single-workgroup
-    // kernels (sample histogram, offsets, tile starts, overflow scan / place: ~0.15 ms of a 3-ms chain during which
-    // the chip idles); with two chains side by side they run next to the neighbour's partition kernels.
+    // Byte tables (engine 2, whole-genome calls): the chains run on SP_LANES_DENSE + 1 auxiliary streams (default 4)
+    // and NOT on the context's stream.  A chromosome's chain has five single-workgroup kernels (sample histogram,
+    // offsets, tile starts, overflow scan / place: ~0.15 ms of a 3-ms chain during which the chip idles) and its big
+    // kernels are bound by different things; side by side they fill each other's gaps (130.5 -> 120.5 ms per
+    // wheat-like pass).  A lane waits for ITS chromosome's pack kernel only (sp_chrom::ev_packed), so counting starts
+    // while the context's stream is still packing the chromosomes behind it.
     int n_lanes = 0;
     const bool dense_lanes = !list_mode && C > 1 && first == 0 && last == (int)C && engine != 1;
     if ((list_mode && C > 1) || dense_lanes) {
         const char *el = getenv(list_mode ? "SP_LANES" : "SP_LANES_DENSE");
         n_lanes = el ? atoi(el) : 3;
+        if (dense_lanes && n_lanes > 0) n_lanes++;       // (the context's stream takes no chain)
         if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
         if (n_lanes < 0) n_lanes = 0;
         for (int l = 0; l < n_lanes; l++) {
@@ -452,7 +455,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             }
         }
         if (n_lanes && !ctx->lane_go) SP_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_go, hipEventDisableTiming));
-        if (n_lanes) {      // the lanes start after what is queued on the main stream (packing, the memset above)
+        if (n_lanes && list_mode) {      // the lanes start after what is queued on the main stream (packing)
             SP_HIP(ctx, hipEventRecord(ctx->lane_go, ctx->stream));
             for (int l = 0; l < n_lanes; l++) SP_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lane_go, 0));
         }
@@ -483,7 +486,8 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                 // lanes: chromosome ci on stream ci % (1 + lanes in use); lane 0 is the context's own stream
                 sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
                 hipStream_t main_stream = ctx->stream;
-                if (ln) {
+                SP_HIP(ctx, hipMemsetAsync(d_len + 4 * ci, 0, 4 * sizeof(unsigned long long), ln ? ln->stream : main_stream));
+                if (ln) {       // (no early return between here and the restore below)
                     ctx->lane = ln;
                     ctx->stream = ln->stream;
                 }
@@ -509,9 +513,12 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             int eng = engine;
             if (eng == 0) eng = (sp_engine2_supported(nslots) && c.len >= (1 << 22)) ? 2 : 1;
             if (eng == 2) {
-                sp_ctx::lane_t *ln = (n_lanes > 0 && ci % (size_t)(n_lanes + 1)) ? &ctx->lanes[ci % (size_t)(n_lanes + 1) - 1] : nullptr;
+                // (byte tables: the auxiliary streams only; each waits for its chromosome's pack kernel)
+                sp_ctx::lane_t *ln = n_lanes > 0 ? &ctx->lanes[ci % (size_t)n_lanes] : nullptr;
                 hipStream_t main_stream = ctx->stream;
-                if (ln) {
+                if (ln && c.ev_packed) SP_HIP(ctx, hipStreamWaitEvent(ln->stream, c.ev_packed, 0));
+                SP_HIP(ctx, hipMemsetAsync(d_len + 4 * ci, 0, 4 * sizeof(unsigned long long), ln ? ln->stream : main_stream));
+                if (ln) {       // (no early return between here and the restore below)
                     ctx->lane = ln;
                     ctx->stream = ln->stream;
                 }
@@ -523,6 +530,7 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                 continue;
             }
             // engine 1: global atomics into a u32 scratch table, then one pass to the byte table
+            SP_HIP(ctx, hipMemsetAsync(d_len + 4 * ci, 0, 4 * sizeof(unsigned long long), ctx->stream));
             const int64_t n_buckets = (nslots + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT;
             rc = sp_buf_ensure(ctx, ctx->b_tab32, nslots * 4);
             if (rc) return rc;

@@ -114,6 +114,7 @@ static void free_chrom(sp_chrom &c) {
     if (c.d_nm) hipFree(c.d_nm);
     if (c.d_tab && !c.tab_external) hipFree(c.d_tab);
     if (c.d_ovf) hipFree(c.d_ovf);
+    if (c.ev_packed) hipEventDestroy(c.ev_packed);
     c = sp_chrom();
 }
 
@@ -151,6 +152,8 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     sp_buf_free(ctx->b_ival);
     sp_buf_free(ctx->b_ptab);
     sp_buf_free(ctx->b_lflags);
+    if (ctx->h_lflags) hipHostFree(ctx->h_lflags);
+    sp_buf_free(ctx->b_cntlen);
     sp_buf_free(ctx->b_ctab);
     sp_buf_free(ctx->b_covf);
     sp_buf_free(ctx->b_tab32);
@@ -291,6 +294,8 @@ static int genome_add_impl(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64
     if (blocks < 1) blocks = 1;
     SP_LAUNCH(ctx, "k0_pack", k0_pack, dim3((unsigned)blocks), dim3(256), 0, d_ascii, len, c.d_pk,
               c.d_pm, c.d_nm, nmw);
+    if (!c.ev_packed) SP_HIP(ctx, hipEventCreateWithFlags(&c.ev_packed, hipEventDisableTiming));
+    SP_HIP(ctx, hipEventRecord(c.ev_packed, ctx->stream));
     ctx->counted = false;
     return SP_OK;
 }

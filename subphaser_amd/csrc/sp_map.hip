@@ -640,6 +640,12 @@ static int64_t map_nslots_host(int64_t len, int64_t bin_size, int64_t chunk_size
 
 int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, bool on_device);   // sp_sparse.hip
 
+// the flags of one sp_labels_set call -> page-locked host memory the kernel writes directly: a hipMemcpy of 32 bytes
+// would queue on the copy engine behind the matrix rows that are still travelling to the host (2 ms per pass)
+__global__ void k4_flags_out(const unsigned long long *__restrict__ d_flags, unsigned long long *__restrict__ h_flags) {
+    if (threadIdx.x < 4) h_flags[threadIdx.x] = d_flags[threadIdx.x];
+}
+
 // labels handed over in device memory: the largest one, for the `label < n_sg` check the host does on host arrays
 __global__ void __launch_bounds__(256)
 k4_label_max(const uint8_t *__restrict__ sg, int64_t n, unsigned int *__restrict__ out) {
@@ -717,10 +723,10 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
         if (n > 0 && mx >= n_sg) return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)mx, n_sg);
     }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    auto label_check = [&]() -> int {      // after a synchronisation of the stream
+    if (!ctx->h_lflags) SP_HIP(ctx, hipHostMalloc((void **)&ctx->h_lflags, 64, hipHostMallocDefault));
+    auto label_check = [&]() -> int {      // after k4_flags_out and a synchronisation of the stream
         if (!(on_device && n > 0)) return SP_OK;
-        unsigned long long hf = 0;
-        SP_HIP(ctx, hipMemcpy(&hf, d_flags, 8, hipMemcpyDeviceToHost));
+        const unsigned long long hf = ctx->h_lflags[0];
         if ((int)(unsigned int)hf >= n_sg) {
             ctx->labels_ready = false;
             return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)(unsigned int)hf, n_sg);
@@ -732,6 +738,8 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
         ctx->n_labels = n;
         int rcs = sp_sparse_labels_set(ctx, keys, sg, n, on_device);
         if (rcs) return rcs;
+        SP_LAUNCH(ctx, "k4_flags_out", k4_flags_out, dim3(1), dim3(64), 0, (const unsigned long long *)d_flags, ctx->h_lflags);
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return label_check();
     }
     const char *eng = getenv("SP_MAP_ENGINE");
@@ -817,12 +825,12 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
     }
     const int rcf = sp_map_filter_build(ctx, n > 0 ? d_keys : nullptr, n);
     if (rcf) return rcf;
+    SP_LAUNCH(ctx, "k4_flags_out", k4_flags_out, dim3(1), dim3(64), 0, (const unsigned long long *)d_flags, ctx->h_lflags);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rcl = label_check();
     if (rcl) return rcl;
     if (compact && n > 0) {
-        unsigned long long hf[2] = {0, 0};
-        SP_HIP(ctx, hipMemcpy(hf, d_flags + 2, 16, hipMemcpyDeviceToHost));
+        const unsigned long long hf[2] = {ctx->h_lflags[2], ctx->h_lflags[3]};
         if (getenv("SP_DEBUG_FILTER"))
             fprintf(stderr, "[sp] compact pair table: 2^%d buckets, %llu entries in the overflow table (%lld labelled k-mers)\n",
                     bb, hf[1], (long long)n);

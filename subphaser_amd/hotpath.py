@@ -68,9 +68,9 @@ class HotPath:
         t = self._t("genome_reset", t)
         for i, (ptr, n) in enumerate(zip(d_ascii, self.lengths)):
             ctx.genome_add_device(i, ptr, n)
-        t = self._t("pack", t)
+        # (no synchronisation here: the counting lanes start on the chromosomes that are packed already)
         ctx.count(self.k, self.lower_count, self.engine)
-        t = self._t("count", t)
+        t = self._t("pack+count", t)
         r = HotPathResult()
         r.kmer_lengths = ctx.lengths()
         r.n_union, r.n_rows, r.n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
