@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-bash tools/ab_round.sh "l3|||" "l2||SP_LANES_DENSE=2|" "l4||SP_LANES_DENSE=4|"
-python - <<P
-import json
-for n in ("l3","l2","l4"):
-    d=json.loads(open("gpurun_out/ab_%s.json"%n).read().strip().splitlines()[-1])
-    print(n, d["host_wall_ms_per_step"])
-P
+timeout 1200 python -m pytest tests -m gpu -x -q -k "sparse or k17 or medium or feature_join or baseline_shapes" 2>&1 | tail -3
+V=subphaser_amd/lib/variants
+bash tools/ab_round.sh "k17prev|$V/lib_prev.so||-k 17" "k17new|||-k 17" "k21prev|$V/lib_prev.so||-k 21" "k21new|||-k 21"
