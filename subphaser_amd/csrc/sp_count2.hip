@@ -32,7 +32,7 @@
 #define C2_P1_UNIT 32
 #define C2_P1_KEYS (C2_P1_THREADS * C2_P1_UNIT)   // starts (<= keys) per part1 tile
 #ifndef C2_P2_THREADS
-#define C2_P2_THREADS 512             // part2 tile = threads x keys per thread.  Round 1 (software pipeline): 512 x 8 -> 1.37 ms per
+#define C2_P2_THREADS 256             // (round 4, after the cursor fix: 256 x 24: 0.861 ms, 512 x 24: 0.897, 512 x 16: 0.990, 768 x 16: 1.20) part2 tile = threads x keys per thread.  Round 1 (software pipeline): 512 x 8 -> 1.37 ms per
                                       // 667-Mb chromosome, 768 x 12 -> 1.22.  Round 2 (rank from the histogram atomic, one table read
                                       // in the copy-out): 768 x 12 1.21, 768 x 16 1.31, 768 x 20 1.25, 1024 x 12 1.23, 1024 x 16 1.17,
                                       // 512 x 24 1.16 (adopted: 12 K-key tiles, 288-byte runs, three blocks per CU)
@@ -518,7 +518,8 @@ c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long lo
 #define C2_STAGE 1024   // overflow pairs staged in LDS per bucket (8 KiB next to the 128 KiB of counters)
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span /* [first, last) key of every fine bucket */,
-         int64_t n_fine, uint32_t lower, uint8_t *__restrict__ tab,
+         int64_t n_fine, const uint32_t *__restrict__ list /* the buckets to count (c2_count16 left them), or NULL: all */,
+         const unsigned long long *__restrict__ n_list, uint32_t lower, uint8_t *__restrict__ tab,
          unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[2]=overflow cursor,[3]=region-overrun flag*/,
          uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap, uint32_t *__restrict__ seg_base,
          uint32_t *__restrict__ seg_cnt) {
@@ -533,9 +534,10 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
     // would hide those round trips; the kernel ran at 2.5 TB/s of its 4.6).
     uint2 pf[C2_PF];
     unsigned long long pf_lo = 0, pf_hi = 0;
-    auto prefetch = [&](int64_t fbn) {
-        if (fbn >= n_fine) return;
-        const ulonglong2 d = span[fbn];      // one 16-byte load: where the bucket's keys lie (c2_spans)
+    const int64_t n_it = list ? (int64_t)*n_list : n_fine;       // buckets to visit
+    auto prefetch = [&](int64_t itn) {
+        if (itn >= n_it) return;
+        const ulonglong2 d = span[list ? (int64_t)list[itn] : itn];      // one 16-byte load: where the bucket's keys lie (c2_spans)
         pf_lo = d.x;
         pf_hi = d.y;
         unsigned long long a = (pf_lo + 3ULL) & ~3ULL;
@@ -549,7 +551,8 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
         }
     };
     prefetch(blockIdx.x);
-    for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
+    for (int64_t it = blockIdx.x; it < n_it; it += gridDim.x) {
+        const int64_t fb = list ? (int64_t)list[it] : it;
         uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_nov = s_rank = 0;
@@ -594,7 +597,7 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
             add(v.y >> 16);
         }
         for (unsigned long long t = a + (n4 << 2) + threadIdx.x; t < hi; t += C2_COUNT_THREADS) add(buf2[t]);
-        prefetch(fb + gridDim.x);   // in flight across the write-out below and the next clear
+        prefetch(it + gridDim.x);   // in flight across the write-out below and the next clear
         __syncthreads();
         uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 4; i += C2_COUNT_THREADS) {
@@ -638,6 +641,123 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
             if (threadIdx.x == 0) seg_base[fb] = (uint32_t)base;
         }
         if (threadIdx.x == 0) seg_cnt[fb] = nov;
+        __syncthreads();
+    }
+    unsigned long long ts = sp_block_sum_u64(s, red);
+    unsigned long long tn = sp_block_sum_u64(n, red);
+    if (threadIdx.x == 0) {
+        if (ts) atomicAdd(&out3[0], ts);
+        if (tn) atomicAdd(&out3[1], tn);
+    }
+}
+
+// ---------------------------------------------------------------- c2_count16 (round 4)
+// c2_count holds ONE 1024-thread block per CU (128 KiB of counters) whose phases -- count, write out + clear -- run one
+// after the other with nothing else resident to fill the CU.  A fine bucket that receives fewer than 65536 records
+// cannot push any counter past 16 bits, so its counters are packed two to a word (64 KiB): two blocks per CU, one
+// counting while the other writes out.  Buckets with more records (repeat-rich ones) are put on a list for c2_count.
+// Same outputs: byte table, overflow segments (at most 257 slots of such a bucket reach 255: they always fit the
+// stage), tallies.  The write-out clears the counters it has read.
+#ifndef C2_C16_THREADS
+#define C2_C16_THREADS 512
+#endif
+#ifndef C2_C16_PF
+#define C2_C16_PF 8
+#endif
+__global__ void __launch_bounds__(C2_C16_THREADS)
+c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
+           uint8_t *__restrict__ tab, unsigned long long *__restrict__ out3, uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap,
+           uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ big_list,
+           unsigned long long *__restrict__ n_big) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[C2_FINE / 2];      // two 16-bit counters per word
+    __shared__ unsigned long long red[16];
+    __shared__ uint32_t s_nov;
+    __shared__ uint2 stage[512];
+    unsigned long long s = 0, n = 0;
+    uint2 pf[C2_C16_PF];
+    unsigned long long pf_lo = 0, pf_hi = 0;
+    auto prefetch = [&](int64_t fbn) {
+        if (fbn >= n_fine) return;
+        const ulonglong2 d = span[fbn];
+        pf_lo = d.x;                             // (a multiple of 4 records, like the size: whole quads)
+        pf_hi = d.y;
+        if (pf_hi - pf_lo >= 65536ULL) return;   // not ours: no loads
+        const unsigned long long n4 = (pf_hi - pf_lo) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + pf_lo);
+#pragma unroll
+        for (int q = 0; q < C2_C16_PF; q++) {
+            const unsigned long long i = threadIdx.x + (unsigned long long)q * C2_C16_THREADS;
+            if (i < n4) pf[q] = p2[i];
+        }
+    };
+    {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) s_nov = 0;
+    }
+    prefetch(blockIdx.x);
+    __syncthreads();
+    // a record adds 1 to its half of the word; a pad record (0xFFFF) adds 0 to the last word
+    auto add = [&](uint32_t r) { atomicAdd(&cnt[(r & (C2_FINE - 1)) >> 1], ((r >> C2_B3) ^ 1u) << (16u * (r & 1u))); };
+    for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
+        const unsigned long long lo = pf_lo, hi = pf_hi;
+        if (hi - lo >= 65536ULL) {               // block-uniform: c2_count takes this bucket
+            if (threadIdx.x == 0) big_list[atomicAdd(n_big, 1ULL)] = (uint32_t)fb;
+            prefetch(fb + gridDim.x);
+            continue;
+        }
+        const unsigned long long n4 = (hi - lo) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + lo);
+#pragma unroll
+        for (int q = 0; q < C2_C16_PF; q++) {
+            if (threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
+                add(pf[q].x & 0xffffu);
+                add(pf[q].x >> 16);
+                add(pf[q].y & 0xffffu);
+                add(pf[q].y >> 16);
+            }
+        }
+        for (unsigned long long i = threadIdx.x + (unsigned long long)C2_C16_PF * C2_C16_THREADS; i < n4; i += C2_C16_THREADS) {
+            const uint2 v = p2[i];
+            add(v.x & 0xffffu);
+            add(v.x >> 16);
+            add(v.y & 0xffffu);
+            add(v.y >> 16);
+        }
+        prefetch(fb + gridDim.x);   // in flight across the write-out below
+        __syncthreads();
+        // write-out: 8 slots per 16-byte LDS read -> 8 table bytes; the words are cleared for the next bucket
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        uint2 *t64 = reinterpret_cast<uint2 *>(tab + fb * C2_FINE);
+        for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) {
+            const uint4 v = c4[i];
+            c4[i] = make_uint4(0, 0, 0, 0);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t c = (w4[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                if (c >= lower) { s += c; n++; }
+                if (c >= 255u) {
+                    const uint32_t pos = atomicAdd(&s_nov, 1u);
+                    if (pos < 512u) stage[pos] = make_uint2((uint32_t)(fb * C2_FINE + 8 * i + j), c);
+                }
+                packed[j >> 2] |= (c < 255u ? c : 255u) << (8 * (j & 3));
+            }
+            t64[i] = make_uint2(packed[0], packed[1]);
+        }
+        __syncthreads();
+        const uint32_t nov = s_nov;   // block-uniform; < 65536 / 255 + 1 <= 257
+        if (nov) {
+            const unsigned long long base = lo / 255ULL;     // (c2_count: the segment's closed-form place)
+            for (uint32_t p = threadIdx.x; p < nov; p += C2_C16_THREADS)
+                if (base + p < ovf_cap) ovf_tmp[base + p] = stage[p];
+            if (threadIdx.x == 0) seg_base[fb] = (uint32_t)base;
+        }
+        if (threadIdx.x == 0) {
+            seg_cnt[fb] = nov;
+            s_nov = 0;
+        }
         __syncthreads();
     }
     unsigned long long ts = sp_block_sum_u64(s, red);
@@ -958,7 +1078,8 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_segb = o_buf2 + al(cap_keys2 * 2 + 64);               // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
-    size_t total = o_sego + al((nf + 1) * 4);
+    size_t o_bigl = o_sego + al((nf + 1) * 4);                    // buckets c2_count16 leaves to c2_count
+    size_t total = o_bigl + al(nf * 4);
     void *&d_ws2 = ctx->lane ? ctx->lane->d_ws2 : ctx->d_ws2;           // this lane's workspace (sp_common.h)
     int64_t &ws2_bytes = ctx->lane ? ctx->lane->ws2_bytes : ctx->ws2_bytes;
     sp_buf &b_ovfw = ctx->lane ? ctx->lane->b_ovfw : ctx->b_ovfw;
@@ -1037,7 +1158,21 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
                                      (int64_t)nf, d_len4 + 2);
     }
     SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
-    SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
-              (int64_t)nf, (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+    const char *env16 = getenv("SP_C2_COUNT16");      // "0": every bucket through the 32-bit counters (cross-check)
+    if (env16 && env16[0] == '0') {
+        SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
+                  (int64_t)nf, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, (uint32_t)lower, c.d_tab, d_len4,
+                  ovf_tmp, ovf_cap, seg_base, seg_cnt);
+    } else {
+        uint32_t *big_list = (uint32_t *)(ws + o_bigl);
+        unsigned long long *n_big = ghist;      // (the histogram is dead by now; its first word was zeroed with the head... re-zero)
+        SP_HIP(ctx, hipMemsetAsync(n_big, 0, 8, ctx->stream));
+        int grid16 = (int)((int64_t)nf < (int64_t)ctx->n_cu * 2 ? (int64_t)nf : (int64_t)ctx->n_cu * 2);
+        SP_LAUNCH(ctx, "c2_count16", c2_count16, dim3(grid16), dim3(C2_C16_THREADS), 0, buf2, (const ulonglong2 *)span, (int64_t)nf,
+                  (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt, big_list, n_big);
+        SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
+                  (int64_t)nf, (const uint32_t *)big_list, (const unsigned long long *)n_big, (uint32_t)lower, c.d_tab, d_len4,
+                  ovf_tmp, ovf_cap, seg_base, seg_cnt);
+    }
     return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf, d_len4 + 2);
 }
