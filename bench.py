@@ -254,10 +254,15 @@ def main():
     tj, traffic_commit = {}, None
     try:
         from subphaser_amd._native import csrc_fingerprint
-        pmc = "r03_wheat_pmc.json" if args.k == 15 else "r03_wheat_k%d_pmc.json" % args.k      # one table per measured k
-        pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))
-        if args.config == "wheat" and world == 1 and pj.get("csrc_sha16") == csrc_fingerprint():
-            tj, traffic_commit = pj["kernels"], pj.get("commit")
+        # one table per measured (genome, k): profiles/r04_wheat_pmc.json, r04_wheat_k17_pmc.json, r04_peanut_pmc.json ...
+        pmc = "%s_pmc.json" % args.config if args.k == 15 else "%s_k%d_pmc.json" % (args.config, args.k)
+        for rnd in ("r04", "r03"):
+            path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, pmc))
+            if os.path.exists(path):
+                pj = json.load(open(path))
+                if world == 1 and pj.get("csrc_sha16") == csrc_fingerprint():
+                    tj, traffic_commit = pj["kernels"], pj.get("commit")
+                break
     except (OSError, ValueError, KeyError):
         pass
 
@@ -267,16 +272,24 @@ def main():
         if not sts:
             return None
         # a chain runs once per local chromosome, a whole-genome kernel (k5_map since round 3, the filter) once per step
-        units = max(1, int(round(prof[[n for n in names if n in prof][0]]["calls"] / args.steps)))
+        # (a chain holds kernels launched several times per chromosome -- scans -- and some launched only where needed:
+        # the unit is the chromosome whenever any of them runs at least once per chromosome)
+        most = max(prof[n]["calls"] for n in names if n in prof) / args.steps
+        units = (n_local if most >= n_local else max(1, int(round(most)))) if per_chrom else 1
         per_launch = local_bases / units
         alg = algorithmic_bytes(names[0], per_launch, nslots, C, S, extra)
         if not alg:
             return None
-        avg_s = sum(st["ms"] for st in sts) / args.steps / units / 1e3     # HIP-event time of one pass of the chain
+        avg_ev = sum(st["ms"] for st in sts) / args.steps / units / 1e3    # HIP-event time of one pass of the chain
+        # chains that run side by side on several streams (round 4): the events of one chain also clock the time it
+        # shares the chip with its neighbours, so the duration that prices the chain is its share of the stage's wall
+        # time (lane_scale = stage wall / sum of the stage's event times); both are on the line
+        avg_s = avg_ev * (lane_scale if names[0] in LANE_KERNELS else 1.0)
         traffic = None
         # the profiler's labels -> the kernel symbols rocprofv3 reports (one kernel launched under two labels)
         sym = {"c2_hist_sample": "c2_hist_fine", "ovf_place_list": "ovf_place", "k5_map_mask_lab": "k5_map_mask",
-               "sps_emit_hist": "sps_emit", "k3_emit_hist": "k3_emit"}
+               "sps_emit_hist": "sps_emit", "k3_emit_hist": "k3_emit", "s3_hist1_sample": "s3_hist1",
+               "s3_hist2_sample": "s3_hist2"}
         if tj and all(sym.get(n, n) in tj for n in names if n in prof):
             # PMC bytes are per launch; launches per pass of the chain come from THIS run's launch counts
             traffic = int(sum((tj[sym.get(n, n)].get("read_bytes", 0) + tj[sym.get(n, n)].get("write_bytes", 0))
@@ -284,17 +297,27 @@ def main():
         ach = alg / avg_s
         return {"bound": "hbm", "kernel": label, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic,
-                "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg)}
+                "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": int(alg),
+                **({"avg_launch_ms_events": round(avg_ev * 1e3, 4), "lane_scale": round(lane_scale, 4)}
+                   if names[0] in LANE_KERNELS and lane_scale != 1.0 else {})}
 
     COUNT_CHAIN = [n for n in ("c2_hist_sample", "c2_hist_fine", "c2_offsets", "c2_part1", "c2_tiles", "c2_part2", "c2_spans",
-                               "c2_count", "c2_count_list", "ovf_scan", "ovf_place", "ovf_place_list", "k1_count_atomic",
+                               "c2_count16", "c2_count", "c2_count_list", "ovf_scan", "ovf_place", "ovf_place_list", "k1_count_atomic",
                                "k1_narrow") if n in prof and prof[n]["calls"] >= args.steps * max(1, n_local)]
     if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
         COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))
     # byte-table filter, or the list filter (k > 15, and engine 3 on small genomes at k <= 15)
     FILTER_CHAIN = ["k3_eval", "k3_slow"] if "k3_eval" in prof else \
         sorted((n for n in prof if n.startswith("sps_") and "hash" not in n and "pair" not in n), key=lambda n: n != "sps_join")
-    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    # k <= 15, one process: pack + count chains overlap on up to four streams (sp_count's lanes)
+    LANE_KERNELS, lane_scale = set(), 1.0
+    wall_pc = (hp.wall.get("pack+count", 0.0) / args.steps * 1e3) if runner is None else 0.0
+    if args.k <= 15 and wall_pc > 0:
+        lk = [n for n in COUNT_CHAIN + ["k0_pack"] if n in prof]
+        ev = sum(prof[n]["ms"] for n in lk) / args.steps
+        if ev > 0 and wall_pc / ev < 0.9:
+            LANE_KERNELS, lane_scale = set(lk), wall_pc / ev
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"] * (lane_scale if kv[0] in LANE_KERNELS else 1.0)) if prof else None
     roofline = None
     if dom:
         name = dom[0]

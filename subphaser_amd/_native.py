@@ -247,6 +247,14 @@ def str_blob(strings):
     return np.frombuffer(b"".join(enc) or b"\0", np.uint8), off
 
 
+def write_chunks(fout, n_rows, format_rows, chunk=50000):
+    """Fallback of the threaded text writers below for targets that are not real files (StringIO, wrapped stdout):
+    format_rows(lo, hi) -> str for rows [lo, hi), written to fout in order, in this process (a process that owns a
+    HIP context must not fork worker pools: DESIGN.md section 7b)."""
+    for lo in range(0, max(0, n_rows), chunk):
+        fout.write(format_rows(lo, min(lo + chunk, n_rows)))
+
+
 def text_table(fout, n_rows, cols):
     """Tab-separated rows through the library's threaded writer (sp_text_table).  cols: list of
     ("str", blob, off) | ("i64", array [n x w], join) | ("f64", array [n x w], join) | ("name", idx int32 [n], names)

@@ -19,7 +19,7 @@ from . import _native
 from . import kmer as kmerlib
 from .runtime import logger
 from .seqs import KmerLabels
-from .textio import write_chunks
+from ._native import write_chunks
 
 
 def load_matrix(datafile):

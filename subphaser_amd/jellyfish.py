@@ -18,7 +18,7 @@ from . import kmer as kmerlib
 from .config import sets_to_csr
 from .runtime import get_context, logger
 from .seqs import load_chromfile
-from .textio import write_chunks
+from ._native import write_chunks
 
 
 class KmerDump(str):

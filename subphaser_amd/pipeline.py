@@ -430,8 +430,9 @@ class Pipeline:
         feat_enrich = lay.out("custom.enrich")
         with open(feat_enrich, "w") as fout:
             if ivals and not ids:       # intervals only: rows stay arrays end to end (millions of features)
-                rows = seqs.IntervalRows.concat([p_[0] for p_ in ivals])
-                sg_idx, _ = stats.enrich_ltr(fout, cl.d_sg, np.concatenate([p_[1] for p_ in ivals], axis=0),
+                rows, rcounts = seqs.IntervalRows.concat([p_[0] for p_ in ivals]).merged(
+                    np.concatenate([p_[1] for p_ in ivals], axis=0))
+                sg_idx, _ = stats.enrich_ltr(fout, cl.d_sg, rcounts,
                                              colnames=cl.sg_names, rownames=rows, max_pval=self.max_pval, as_arrays=True)
                 enriched = {i: cl.sg_names[j] for i, j in enumerate(sg_idx.tolist()) if j >= 0}
             else:

@@ -492,7 +492,7 @@ def map_kmer3(chromfiles, d_kmers, fout=sys.stdout, k=None, window_size=10e6, bi
             if log:
                 logger.info("Mapped {} kmers to chromsome {}".format(c, rid))
     else:
-        from .textio import write_chunks
+        from ._native import write_chunks
         for featfile in chromfiles:
             ids, cat, off = read_fasta_bulk(featfile)
             lens = np.diff(off)
@@ -581,9 +581,11 @@ def read_bed(path):
         junk = df["c"].str.startswith(("track", "browser"))
         if junk.any():
             df = df[~junk]
-        if len(df) and not (df["s"].str.isdigit().all() and df["e"].str.isdigit().all()):
-            bad = df[~(df["s"].str.isdigit() & df["e"].str.isdigit())].iloc[0]
-            raise ValueError("{}: not a BED line: {!r}".format(path, "\t".join(map(str, bad.tolist()))))
+        # (a line with fewer than three fields gives NaN, which is truthy in an object Series: count it as not a digit)
+        good = (df["s"].str.isdigit() == True) & (df["e"].str.isdigit() == True)      # noqa: E712 (NaN == True is False)
+        if len(df) and not good.all():
+            bad = df[~good].iloc[0]
+            raise ValueError("{}: not a BED line: {!r}".format(path, "\t".join(str(x) for x in bad.tolist() if x == x)))
         code, names = pd.factorize(df["c"], sort=False)
         return list(names), code.astype(np.int64), df["s"].to_numpy().astype(np.int64), df["e"].to_numpy().astype(np.int64)
     except ImportError:
@@ -627,6 +629,23 @@ class IntervalRows:
         """the id column for _native.text_table"""
         return ("ival", np.stack([self.code, self.start, self.end], axis=1), self.names)
 
+    def merged(self, counts):
+        """(rows, counts) with the records that name the same interval added up, in order of first appearance -- what
+        Circos.stack_matrix (Circos.py:709-742) makes of FASTA lines that carry the same id: a BED file that lists an
+        interval twice must give the same `.custom.enrich` row as the FASTA of the same sub-sequences."""
+        if len(self) < 2:
+            return self, counts
+        key = np.stack([self.code, self.start, self.end], axis=1)
+        _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+        if first.size == len(self):
+            return self, counts
+        order = np.argsort(first, kind="stable")            # groups in order of first appearance
+        rank = np.empty(order.size, np.int64)
+        rank[order] = np.arange(order.size)
+        out = np.zeros((order.size, counts.shape[1]), counts.dtype)
+        np.add.at(out, rank[inv.reshape(-1)], counts)
+        return self.take(np.sort(first)), out
+
     @staticmethod
     def concat(parts):
         names, where, codes = [], {}, []
@@ -656,11 +675,14 @@ def map_intervals(bedfiles, d_kmers, chrom_index, fout=sys.stdout, k=None, bin_s
     labels = _as_labels(d_kmers, sg_names, k)
     if k is None:
         k = labels.k
+    if ctx.k != k:
+        raise ValueError("map_intervals: context was counted with k={} but k={} requested".format(ctx.k, k))
     sg_names = list(sg_names) if sg_names else labels.sg_names
     bin_size = int(bin_size)
     ctx.labels_set(labels.keys, labels.sg_idx, len(sg_names))
     fout.write("\t".join(["#chrom", "start", "end"] + sg_names) + "\n")
     aliases = aliases or {}
+    chrom_len = [int(ctx.genome_len(i)) for i in range(ctx.n_chrom)]
     n_seq = mapped_seqs = mapped_num = skipped = 0
     for bed in bedfiles:
         names, code, st, en = read_bed(bed)
@@ -670,6 +692,13 @@ def map_intervals(bedfiles, d_kmers, chrom_index, fout=sys.stdout, k=None, bin_s
         keep = np.flatnonzero(idx >= 0)
         skipped += int(code.size - keep.size)
         code, idx, st, en = code[keep], idx[keep], st[keep], en[keep]
+        # the library rejects the whole batch for one bad interval and can only name its index after splitting: name
+        # the BED record here (an annotation of another assembly version is the usual cause)
+        wrong = np.flatnonzero((st > en) | (en > np.asarray(chrom_len, np.int64)[idx])) if code.size else keep[:0]
+        if wrong.size:
+            w = int(wrong[0])
+            raise ValueError("{}: record {} ({}:{}-{}) does not lie on its chromosome (length {}); {} such record(s)".format(
+                bed, int(keep[w]) + 1, names[int(code[w])], int(st[w]), int(en[w]), chrom_len[int(idx[w])], wrong.size))
         lens = en - st
         n = int(code.size)
         if n and bool((lens > bin_size).any()):

@@ -171,7 +171,7 @@ def enrich_ltr(fout, d_sg, matrix, colnames=None, rownames=None, ncpu=4, min_rat
     intervals): the ids are then written straight from its arrays.  as_arrays: return (subgenome index or -1, exchange
     code) arrays instead of the two {id: ...} dicts."""
     from . import _native
-    from .textio import write_chunks
+    from ._native import write_chunks
     arr = np.ascontiguousarray(matrix, np.int64)
     if arr.ndim != 2:
         arr = arr.reshape(len(matrix), -1)

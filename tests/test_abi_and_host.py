@@ -481,3 +481,34 @@ elif a[0] == "dump":
     assert r["dumps_equal_oracle_and_hip"] is True and r["dump_kmers"] == sum(len(d[0]) for d in dumps) > 0
     bad = [(d[0], d[1] + 1) for d in dumps]
     assert bench.jellyfish_leg(seqs, ["c0", "c1"], k, L, 2, bad)["dumps_equal_oracle_and_hip"] is False
+
+
+def test_read_bed_errors_and_interval_merge(tmp_path, monkeypatch):
+    """advisor r03: a short BED line must raise the 'not a BED line' error with or without pandas; identical
+    intervals are one row (summed), in order of first appearance, like same-id FASTA lines in stack_matrix"""
+    import builtins
+    from subphaser_amd import seqs
+    good = tmp_path / "g.bed"
+    good.write_text("#c\nchr1\t5\t10\tx\nchr2 0 3\nchr1\t5\t10\n")
+    bad = tmp_path / "b.bed"
+    bad.write_text("chr1\t5\t10\nchr2\t5\n")
+    names, code, st, en = seqs.read_bed(str(good))
+    assert names == ["chr1", "chr2"] and code.tolist() == [0, 1, 0] and st.tolist() == [5, 0, 5] and en.tolist() == [10, 3, 10]
+    with pytest.raises(ValueError, match="not a BED line"):
+        seqs.read_bed(str(bad))
+    real_import = builtins.__import__
+
+    def no_pandas(name, *a, **kw):
+        if name == "pandas":
+            raise ImportError(name)
+        return real_import(name, *a, **kw)
+    monkeypatch.setattr(builtins, "__import__", no_pandas)
+    assert seqs.read_bed(str(good))[1].tolist() == [0, 1, 0]
+    with pytest.raises(ValueError, match="b.bed:2: not a BED line"):
+        seqs.read_bed(str(bad))
+    monkeypatch.undo()
+    rows = seqs.IntervalRows(names, code, st, en)
+    m, c = rows.merged(np.array([[1, 2], [3, 4], [10, 20]], np.int64))
+    assert m.ids() == ["chr1:5-10", "chr2:0-3"] and c.tolist() == [[11, 22], [3, 4]]
+    same, c2 = m.merged(c)
+    assert same is m and c2 is c
