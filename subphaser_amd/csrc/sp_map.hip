@@ -227,11 +227,20 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             fw[q] = xf <= xr;
             const map_bloom_probe p = map_bloom((uint64_t)canon[q], nbits);
             want[q] = p.bits;
+#ifdef MAP_EXP_NOPROBE      // bound experiments (tools/build_variant.sh): the scan alone, wrong answers
+            wd[q] = canon[q];
+#else
             wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
+#endif
         }
 #pragma unroll
         for (int q = 0; q < BATCH; q++) {
+#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)   // bound experiment: scan + filter probes, no exact look-up
+            // (wrong answers; canon is below 2^28 and never equals the value it is compared with, which the compiler cannot know)
+            const bool cand = (wd[q] & want[q]) == want[q] && canon[q] == ((uint32_t)nbits | 0x20000000u);
+#else
             const bool cand = (wd[q] & want[q]) == want[q];
+#endif
             if (COMPACT) {
                 const map_ct_hit r = map_ct_lookup(T, canon[q], cand);
                 e[q] = r.fields;

@@ -369,7 +369,36 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
                 mapped++;
                 return true;
             };
-            if (pairs)
+            if (pairs && P.S <= 8) {
+                // like k5_map (sp_map.hip): a lane's 64 starts lie in one or two output slots, so its hits are tallied
+                // in a register, one byte per subgenome, and reach the histogram once per slot -- not one LDS atomic
+                // and one 64-bit slot computation per hit (PMC round 3: 82 % of this kernel's LDS cycles were conflicts)
+                int64_t cur_end = -1, cur_os = 0;
+                unsigned long long acc = 0;
+                auto flush = [&]() {
+                    if (!acc) return;
+                    for (int sg = 0; sg < P.S; sg++) {
+                        const int v = (int)((acc >> (8 * sg)) & 255ULL);
+                        if (!v) continue;
+                        if (P.use_lds)
+                            atomicAdd(&hist[(int)(cur_os - slot_lo) * P.S + sg], v);
+                        else if (cur_os < P.nslots)
+                            atomicAdd(&slot_counts[cur_os * P.S + sg], v);
+                        mapped += v;
+                    }
+                    acc = 0;
+                };
+                map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
+                    if (start >= cur_end) {
+                        flush();
+                        cur_os = map_slot(start, P, kp.k);
+                        cur_end = map_slot_end(start, P, kp.k);
+                    }
+                    acc += 1ULL << (8 * sg);
+                    return true;
+                });
+                flush();
+            } else if (pairs)
                 map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, count);
             else
                 map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {

@@ -823,16 +823,23 @@ template <typename KR2>
 __device__ __forceinline__ void s3h_insert(s3h_lds<KR2> &L, KR2 key) {
     const KR2 EMPTY = (KR2)~(KR2)0;
     uint32_t h = s3h_hash2((unsigned long long)key) & (S3H_SLOTS - 1);
-    for (;;) {
+    // (bounded: with batched loads more keys than the table has free slots can be between two abort tests, and an
+    // unbounded probe loop over a full table never ends -- r03_notes.md; a closed table is nearly full: do not walk it)
+    for (int probe = 0; probe < S3H_SLOTS; probe++) {
+        if ((probe & 15) == 15 && L.abort_) return;
         const KR2 prev = atomicCAS(&L.u.t.key[h], EMPTY, key);
-        if (prev == key) break;
+        if (prev == key) {
+            atomicAdd(&L.u.t.cnt[h], 1u);
+            return;
+        }
         if (prev == EMPTY) {
             if (atomicAdd(&L.n_distinct, 1u) >= S3H_CAP) L.abort_ = 1;
-            break;
+            atomicAdd(&L.u.t.cnt[h], 1u);
+            return;
         }
         h = (h + 1) & (S3H_SLOTS - 1);
     }
-    atomicAdd(&L.u.t.cnt[h], 1u);
+    L.abort_ = 1;       // the table is full
 }
 // the kept entries of the table: a short list, ranked by residual, written at out_*[0 ..); returns their number
 template <typename KR2>
@@ -943,9 +950,17 @@ s3_final_hash(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span,
             s3h_clear_table_words(reinterpret_cast<uint4 *>(L.u.t.key), (int)(S3H_SLOTS * sizeof(KR2) / 16),
                                   reinterpret_cast<uint4 *>(L.u.t.cnt), S3H_SLOTS / 4);
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += S3_SORT_THREADS) {
+            // eight loads in flight per thread (2.55 -> 2.24 ms per 670-Mb chromosome for these buckets: most of their
+            // time is not the loads but same-address LDS atomics -- half of their keys are copies of a few dozen residuals)
+            for (uint32_t i0 = tid; i0 < n; i0 += 8 * S3_SORT_THREADS) {
+                KR2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n) v[q] = seg[i0 + q * S3_SORT_THREADS];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (i0 + q * S3_SORT_THREADS < n && !L.abort_) s3h_insert(L, v[q]);
                 if (L.abort_) break;
-                s3h_insert(L, seg[i]);
             }
             __syncthreads();
             m = L.abort_ ? ~0u : s3h_emit(L, lower, tmp_keys + o, tmp_cnts + o, lsum);
@@ -1422,6 +1437,18 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
               (const unsigned long long *)d_of, d_c2, buf2);
     SP_LAUNCH(ctx, "s3_spans", s3_spans, dim3((unsigned)((n_fine + 255) / 256)), dim3(256), 0, (const unsigned long long *)d_of,
               (const unsigned long long *)d_c2, n_fine, d_span, d_small + 6);
+    if (const char *dump = getenv("SP_S3_DUMP")) {      // dev hook (tools/s3_bucket_stats.py): spans and residuals of this chromosome -> files
+        std::vector<ulonglong2> hs((size_t)n_fine);
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SP_HIP(ctx, hipMemcpy(hs.data(), d_span, (size_t)n_fine * 16, hipMemcpyDeviceToHost));
+        unsigned long long hi = 0;
+        for (auto &e : hs) if (e.x + e.y > hi) hi = e.x + e.y;
+        std::vector<KR2> hk((size_t)hi);
+        SP_HIP(ctx, hipMemcpy(hk.data(), buf2, (size_t)hi * sizeof(KR2), hipMemcpyDeviceToHost));
+        const std::string base(dump);
+        if (FILE *f = fopen((base + ".spans").c_str(), "wb")) { fwrite(hs.data(), 16, hs.size(), f); fclose(f); }
+        if (FILE *f = fopen((base + ".keys").c_str(), "wb")) { fwrite(hk.data(), sizeof(KR2), hk.size(), f); fclose(f); }
+    }
     int64_t g4 = n_fine < (int64_t)ctx->n_cu * 64 ? n_fine : (int64_t)ctx->n_cu * 64;
     const bool bitmap = P.R2 <= S3_BM_MAXBITS && sizeof(KR2) == 4;      // k = 16, 17
     // k >= 18: hashed pre-count + exact table of the survivors (SP_S3_FINAL=sort: the block radix sort of round 2)
