@@ -142,6 +142,10 @@ struct sp_ctx {
         void *d_ws2 = nullptr;
         int64_t ws2_bytes = 0;
         sp_buf b_ovfw;
+        // k > 15 (sp_sparse2.hip, round 4): this lane's partition buffers, small arrays and the two events its split-phase
+        // chain is waited at
+        sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_s3_small;
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
     };
 #define SP_MAX_LANES 7
     lane_t lanes[SP_MAX_LANES];  // lanes 1..7 (lane 0 = the context's own stream and buffers above)
@@ -153,6 +157,8 @@ struct sp_ctx {
                                 // the map stage stays the dense pair-table one
     std::vector<sp_sparse_chrom> sparse;
     sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_sf_keys, b_sf_counts, b_sf_tot, b_sf_hist, b_s3_small, b_slots;
+    unsigned long long *h_s3 = nullptr;   // page-locked: 8 words per k > 15 counting lane (flags and totals of a chromosome's chain)
+    hipEvent_t s3_ev[2] = {nullptr, nullptr};   // the split-phase events of a chain issued on the context's own stream
     int64_t sf_n = 0;
     uint64_t *d_hkeys = nullptr;   // open-addressing hash table of the labelled k-mers: 16-B entries {key, label}
     int64_t hcap = 0;

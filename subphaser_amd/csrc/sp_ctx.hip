@@ -143,10 +143,20 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     for (auto &ln : ctx->lanes) {
         if (ln.d_ws2) hipFree(ln.d_ws2);
         sp_buf_free(ln.b_ovfw);
+        sp_buf_free(ln.b_sp_a);
+        sp_buf_free(ln.b_sp_b);
+        sp_buf_free(ln.b_sp_c);
+        sp_buf_free(ln.b_sp_tmp);
+        sp_buf_free(ln.b_s3_small);
+        if (ln.ev_a) hipEventDestroy(ln.ev_a);
+        if (ln.ev_b) hipEventDestroy(ln.ev_b);
         if (ln.done) hipEventDestroy(ln.done);
         if (ln.stream) hipStreamDestroy(ln.stream);
     }
     if (ctx->lane_go) hipEventDestroy(ctx->lane_go);
+    if (ctx->h_s3) hipHostFree(ctx->h_s3);
+    for (auto &e : ctx->s3_ev)
+        if (e) hipEventDestroy(e);
     sp_buf_free(ctx->b_map);
     sp_buf_free(ctx->b_mapdesc);
     sp_buf_free(ctx->b_ival);

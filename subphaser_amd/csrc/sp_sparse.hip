@@ -477,6 +477,13 @@ void sp_sparse_release(sp_ctx *ctx) {
     sp_buf_free(ctx->b_sp_c);
     sp_buf_free(ctx->b_sp_tmp);
     sp_buf_free(ctx->b_s3_small);
+    for (auto &ln : ctx->lanes) {       // the k > 15 counting lanes' workspaces (sp_sparse2.hip)
+        sp_buf_free(ln.b_sp_a);
+        sp_buf_free(ln.b_sp_b);
+        sp_buf_free(ln.b_sp_c);
+        sp_buf_free(ln.b_sp_tmp);
+        sp_buf_free(ln.b_s3_small);
+    }
     sp_buf_free(ctx->b_sf_keys);
     sp_buf_free(ctx->b_sf_counts);
     sp_buf_free(ctx->b_sf_tot);

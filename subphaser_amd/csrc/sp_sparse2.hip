@@ -1320,9 +1320,33 @@ static int s3_scan(sp_ctx *ctx, unsigned long long *a, int64_t n, unsigned long 
 #ifndef S3_P1T32
 #define S3_P1T32 512
 #endif
+// One chromosome's chain in three phases, so that several chains can be in flight on several streams (round 4: a chain
+// is ~20 launches, several of them one workgroup or latency-bound finish kernels, and used to end in three host
+// synchronisations during which the chip idled):
+//   A  everything up to s3_final; the overrun flag and the number of oversized buckets travel to page-locked memory
+//   B  (after A's event) the oversized buckets' device sort if there are any; scan of the kept counts; totals -> host
+//   C  (after B's event) the output list is sized, s3_gather writes it
+// The caller issues A for the next chromosomes on other lanes before it waits for B of this one.
+struct s3_job {
+    int phase = 0;                  // 0 idle, 1 A issued, 2 B issued
+    size_t ci = 0;
+    bool exact = false, overran = false, empty = false;
+    int64_t n_fine = 0;
+    unsigned long long cap_tot = 0;
+    size_t big_cap = 0;
+    unsigned long long *d_small = nullptr, *d_kp = nullptr, *d_big = nullptr, *d_bsum = nullptr;
+    ulonglong2 *d_span = nullptr;
+    void *buf1 = nullptr, *buf2 = nullptr, *tmp_keys = nullptr;
+    uint32_t *tmp_cnts = nullptr;
+    unsigned long long *h = nullptr;    // page-locked: [0] oversized buckets, [1] overrun flag, [2] length sum, [3] kept pairs
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+};
+#define S3_LANE_BUF(ctx, name) ((ctx)->lane ? (ctx)->lane->name : (ctx)->name)
+
 template <typename KR1, typename KR2>
-static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_plan &P, const sp_kparams &kp,
-                          int lower, bool exact, bool *overran) {
+static int s3_chain_a(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_plan &P, const sp_kparams &kp,
+                      int lower, s3_job &J) {
+    bool exact = J.exact;
     const int64_t len = c.len;
     const int64_t n_fine = (int64_t)P.F1 * P.F2;
     // small arrays: hist1 / off1 [F1+1], cursor1 [F1], tile_start [F1+1], hist2 -> off_fine [n_fine+1],
@@ -1333,9 +1357,9 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
                  o_kp = o_c2 + (size_t)n_fine * 8, o_span = o_kp + (size_t)(n_fine + 1) * 8,
                  o_pl = o_span + (size_t)n_fine * 16, o_big = o_pl + (((size_t)n_fine * 4 + 15) & ~(size_t)15),
                  o_small = o_big + big_cap * 8, o_bsum = o_small + 256, small_bytes = o_bsum + 1024 * 8;
-    int rc = sp_buf_ensure(ctx, ctx->b_s3_small, (int64_t)small_bytes);
+    int rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_s3_small), (int64_t)small_bytes);
     if (rc) return rc;
-    char *S = (char *)ctx->b_s3_small.p;
+    char *S = (char *)S3_LANE_BUF(ctx, b_s3_small).p;
     unsigned long long *d_h1 = (unsigned long long *)(S + o_h1), *d_c1 = (unsigned long long *)(S + o_c1),
                        *d_e1 = (unsigned long long *)(S + o_e1), *d_ts = (unsigned long long *)(S + o_ts), *d_of = (unsigned long long *)(S + o_of),
                        *d_c2 = (unsigned long long *)(S + o_c2), *d_kp = (unsigned long long *)(S + o_kp),
@@ -1377,7 +1401,9 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     }
     out.n = 0;
     out.length_sum = 0;
-    *overran = false;
+    J.overran = false;
+    J.empty = nv == 0;
+    J.phase = 1;
     if (nv == 0) return SP_OK;
     if (nv >= (1ULL << 32) - (1ULL << 20) || cap1 >= (1ULL << 32) - (1ULL << 20))
         return sp_fail(ctx, SP_EUNSUP, "k > 15: chromosomes of 2^32 or more k-mers are not supported");
@@ -1397,17 +1423,17 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     constexpr int P1T_ = sizeof(KR1) == 4 ? S3_P1T32 : 256;
     const size_t l1_entries = (size_t)cap1 + (size_t)P1T_ * S3_P1_UNIT + 64;      // regions + the trash area of one tile
     const size_t a_bytes = l1_entries * sizeof(KR1) > (size_t)cap_tot * sizeof(KR2) ? l1_entries * sizeof(KR1) : (size_t)cap_tot * sizeof(KR2);
-    rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes + 64);      // level-1 records, later the finish kernels' scratch (region-indexed)
+    rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_sp_a), (int64_t)a_bytes + 64);      // level-1 records, later the finish kernels' scratch (region-indexed)
     if (rc) return rc;
-    rc = sp_buf_ensure(ctx, ctx->b_sp_b, (int64_t)cap_tot * (int64_t)sizeof(KR2) + 64);
+    rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_sp_b), (int64_t)cap_tot * (int64_t)sizeof(KR2) + 64);
     if (rc) return rc;
     const size_t tk_bytes = ((size_t)cap_tot * sizeof(KR2) + 63) & ~(size_t)63;
-    rc = sp_buf_ensure(ctx, ctx->b_sp_c, (int64_t)(tk_bytes + (size_t)cap_tot * 4 + 64));
+    rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_sp_c), (int64_t)(tk_bytes + (size_t)cap_tot * 4 + 64));
     if (rc) return rc;
-    KR1 *buf1 = (KR1 *)ctx->b_sp_a.p;
-    KR2 *buf2 = (KR2 *)ctx->b_sp_b.p;
-    KR2 *tmp_keys = (KR2 *)ctx->b_sp_c.p;
-    uint32_t *tmp_cnts = (uint32_t *)((char *)ctx->b_sp_c.p + tk_bytes);
+    KR1 *buf1 = (KR1 *)S3_LANE_BUF(ctx, b_sp_a).p;
+    KR2 *buf2 = (KR2 *)S3_LANE_BUF(ctx, b_sp_b).p;
+    KR2 *tmp_keys = (KR2 *)S3_LANE_BUF(ctx, b_sp_c).p;
+    uint32_t *tmp_cnts = (uint32_t *)((char *)S3_LANE_BUF(ctx, b_sp_c).p + tk_bytes);
 
     constexpr int P1T = sizeof(KR1) == 4 ? S3_P1T32 : 256;
     const int64_t n_units32 = (len + S3_P1_UNIT - 1) / S3_P1_UNIT;
@@ -1473,12 +1499,42 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
               d_small + 1, (unsigned long long)big_cap, d_small + 2,
               (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP, use_hash ? 1 : 0, (const uint32_t *)d_pl,
               (const unsigned long long *)(d_small + 8));
-    unsigned long long n_big = 0, h_flag = 0;
-    SP_HIP(ctx, hipMemcpyAsync(&n_big, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(ctx, hipMemcpyAsync(&h_flag, d_small + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(J.h, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(J.h + 1, d_small + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipEventRecord(J.ev_a, ctx->stream));
+    J.exact = exact;
+    J.n_fine = n_fine;
+    J.cap_tot = cap_tot;
+    J.big_cap = big_cap;
+    J.d_small = d_small;
+    J.d_kp = d_kp;
+    J.d_big = d_big;
+    J.d_bsum = d_bsum;
+    J.d_span = d_span;
+    J.buf1 = buf1;
+    J.buf2 = buf2;
+    J.tmp_keys = tmp_keys;
+    J.tmp_cnts = tmp_cnts;
+    return SP_OK;
+}
+
+template <typename KR1, typename KR2>
+static int s3_chain_b(sp_ctx *ctx, sp_sparse_chrom &out, const s3_plan &P, int lower, s3_job &J) {
+    J.phase = 2;
+    if (J.empty) return SP_OK;
+    SP_HIP(ctx, hipEventSynchronize(J.ev_a));
+    const unsigned long long n_big = J.h[0], h_flag = J.h[1];
+    const int64_t n_fine = J.n_fine;
+    const size_t big_cap = J.big_cap;
+    const unsigned long long cap_tot = J.cap_tot;
+    unsigned long long *d_small = J.d_small, *d_kp = J.d_kp, *d_big = J.d_big, *d_bsum = J.d_bsum;
+    ulonglong2 *d_span = J.d_span;
+    KR1 *buf1 = (KR1 *)J.buf1;
+    KR2 *buf2 = (KR2 *)J.buf2, *tmp_keys = (KR2 *)J.tmp_keys;
+    uint32_t *tmp_cnts = J.tmp_cnts;
+    int rc = SP_OK;
     if (h_flag) {      // a region overran (keys were dropped): the caller counts the chromosome again with exact sizes
-        *overran = true;
+        J.overran = true;
         out.n = 0;
         out.length_sum = 0;
         return SP_OK;
@@ -1499,11 +1555,11 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
         SP_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, (const KR2 *)buf2, srt, (unsigned int)cap_tot, (unsigned int)n_big,
                                                        nul, nul, 0u, (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
         const size_t seg_bytes = 2 * (size_t)n_big * 8;
-        rc = sp_buf_ensure(ctx, ctx->b_sp_tmp, (int64_t)(tb + seg_bytes + 512));
+        rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_sp_tmp), (int64_t)(tb + seg_bytes + 512));
         if (rc) return rc;
-        unsigned long long *d_seg = (unsigned long long *)((char *)ctx->b_sp_tmp.p + ((tb + 255) & ~(size_t)255));
+        unsigned long long *d_seg = (unsigned long long *)((char *)S3_LANE_BUF(ctx, b_sp_tmp).p + ((tb + 255) & ~(size_t)255));
         SP_HIP(ctx, hipMemcpyAsync(d_seg, seg.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream));
-        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(ctx->b_sp_tmp.p, tb, (const KR2 *)buf2, srt, (unsigned int)cap_tot,
+        SP_HIP(ctx, rocprim::segmented_radix_sort_keys(S3_LANE_BUF(ctx, b_sp_tmp).p, tb, (const KR2 *)buf2, srt, (unsigned int)cap_tot,
                                                        (unsigned int)n_big, (const unsigned long long *)d_seg,
                                                        (const unsigned long long *)(d_seg + n_big), 0u,
                                                        (unsigned)(P.R2 > 0 ? P.R2 : 1), ctx->stream));
@@ -1514,9 +1570,22 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     }
     rc = s3_scan(ctx, d_kp, n_fine, d_small + 3, d_bsum);
     if (rc) return rc;
-    unsigned long long h[2] = {0, 0};
-    SP_HIP(ctx, hipMemcpyAsync(h, d_small + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SP_HIP(ctx, hipMemcpyAsync(J.h + 2, d_small + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(ctx, hipEventRecord(J.ev_b, ctx->stream));
+    return SP_OK;
+}
+
+template <typename KR1, typename KR2>
+static int s3_chain_c(sp_ctx *ctx, sp_sparse_chrom &out, const s3_plan &P, s3_job &J) {
+    J.phase = 0;
+    if (J.empty || J.overran) return SP_OK;
+    SP_HIP(ctx, hipEventSynchronize(J.ev_b));
+    const int64_t n_fine = J.n_fine;
+    unsigned long long *d_small = J.d_small, *d_kp = J.d_kp;
+    ulonglong2 *d_span = J.d_span;
+    KR2 *tmp_keys = (KR2 *)J.tmp_keys;
+    uint32_t *tmp_cnts = J.tmp_cnts;
+    const unsigned long long *h = J.h + 2;
     const int64_t keep = (int64_t)h[1];
     if (keep > out.cap) {
         if (out.d_keys) hipFree(out.d_keys);
@@ -1540,6 +1609,18 @@ static int s3_count_chrom(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const 
     return SP_OK;
 }
 
+// phase dispatch on the residual widths of the plan
+static int s3_chain(sp_ctx *ctx, int phase, sp_chrom &c, sp_sparse_chrom &o, const s3_plan &P, const sp_kparams &kp, int lower, s3_job &J) {
+#define S3_PHASES(KR1, KR2)                                                                 \
+    (phase == 0   ? s3_chain_a<KR1, KR2>(ctx, c, o, P, kp, lower, J)                        \
+     : phase == 1 ? s3_chain_b<KR1, KR2>(ctx, o, P, lower, J)                               \
+                  : s3_chain_c<KR1, KR2>(ctx, o, P, J))
+    if (!P.wide1) return S3_PHASES(uint32_t, uint32_t);
+    if (!P.wide2) return S3_PHASES(unsigned long long, uint32_t);
+    return S3_PHASES(unsigned long long, unsigned long long);
+#undef S3_PHASES
+}
+
 int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
     const size_t C = ctx->chroms.size();
     if (ctx->sparse.size() != C) {
@@ -1549,30 +1630,118 @@ int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
     const sp_kparams kp = sp_make_kparams(k);
     const s3_plan P = s3_make_plan(k);
     const char *env_exact = getenv("SP_S3_EXACT");      // "1": level-2 regions from the full histogram (the round-2 path)
-    for (size_t ci = 0; ci < C; ci++) {
-        sp_chrom &c = ctx->chroms[ci];
-        sp_sparse_chrom &o = ctx->sparse[ci];
-        o.n = 0;
-        o.length_sum = 0;
-        c.length_sum = 0;
-        c.n_dump = 0;
-        if (c.len <= 0) continue;
-        int rc = SP_OK;
-        bool exact = env_exact && env_exact[0] == '1';
-        for (int attempt = 0; attempt < 2; attempt++) {      // sampled region sizes first, exact ones if a region overran
-            bool overran = false;
-            if (!P.wide1) rc = s3_count_chrom<uint32_t, uint32_t>(ctx, c, o, P, kp, lower, exact, &overran);
-            else if (!P.wide2) rc = s3_count_chrom<unsigned long long, uint32_t>(ctx, c, o, P, kp, lower, exact, &overran);
-            else rc = s3_count_chrom<unsigned long long, unsigned long long>(ctx, c, o, P, kp, lower, exact, &overran);
-            if (rc || !overran) break;
-            if (exact) return sp_fail(ctx, SP_ESTATE, "k > 15: a bucket overran a region of its exact size");
-            exact = true;
-            ctx->c2_recounts++;
-            if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] k > 15: chromosome %zu recounted with exact bucket sizes\n", ci);
+    const bool exact0 = env_exact && env_exact[0] == '1';
+    // Lanes (round 4): the chains of SP_LANES_SPARSE chromosomes (default 3; 0 = the context's stream alone) are in
+    // flight at once, each on its own stream with its own buffers; a lane starts a chromosome when that chromosome's
+    // pack kernel is done (sp_chrom::ev_packed).
+    const char *el = getenv("SP_LANES_SPARSE");
+    int n_lanes = el ? atoi(el) : 3;
+    if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
+    if (n_lanes < 0 || C < 2) n_lanes = 0;
+    if (!ctx->h_s3) SP_HIP(ctx, hipHostMalloc((void **)&ctx->h_s3, (size_t)(SP_MAX_LANES + 1) * 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    for (auto &e : ctx->s3_ev)
+        if (!e) SP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int l = 0; l < n_lanes; l++) {
+        sp_ctx::lane_t &ln = ctx->lanes[l];
+        if (!ln.stream) {
+            SP_HIP(ctx, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            SP_HIP(ctx, hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         }
+        if (!ln.ev_a) SP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_a, hipEventDisableTiming));
+        if (!ln.ev_b) SP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_b, hipEventDisableTiming));
+    }
+    if (n_lanes) {      // chromosomes without an event of their own: the lanes start behind what the main stream holds now
+        if (!ctx->lane_go) SP_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_go, hipEventDisableTiming));
+        SP_HIP(ctx, hipEventRecord(ctx->lane_go, ctx->stream));
+    }
+    const int n_jobs = n_lanes ? n_lanes : 1;
+    std::vector<s3_job> jobs((size_t)n_jobs);
+    for (int l = 0; l < n_jobs; l++) {
+        jobs[(size_t)l].h = ctx->h_s3 + 8 * (size_t)l;
+        jobs[(size_t)l].ev_a = n_lanes ? ctx->lanes[l].ev_a : ctx->s3_ev[0];
+        jobs[(size_t)l].ev_b = n_lanes ? ctx->lanes[l].ev_b : ctx->s3_ev[1];
+    }
+    std::vector<size_t> redo;      // chromosomes whose sampled regions overran: counted again below, exact sizes, one by one
+    hipStream_t main_stream = ctx->stream;
+    // (a lambda: an error return inside must restore the context's stream and let the lanes drain)
+    auto on_lane = [&](int l, int phase, s3_job &J) -> int {
+        if (n_lanes) {
+            ctx->lane = &ctx->lanes[l];
+            ctx->stream = ctx->lanes[l].stream;
+        }
+        const int rc = s3_chain(ctx, phase, ctx->chroms[J.ci], ctx->sparse[J.ci], P, kp, lower, J);
+        ctx->lane = nullptr;
+        ctx->stream = main_stream;
+        return rc;
+    };
+    auto finish = [&](int l) -> int {
+        s3_job &J = jobs[(size_t)l];
+        if (!J.phase) return SP_OK;
+        int rc = on_lane(l, 1, J);
+        if (!rc) rc = on_lane(l, 2, J);
         if (rc) return rc;
-        c.length_sum = o.length_sum;
-        c.n_dump = o.n;
+        if (J.overran) redo.push_back(J.ci);
+        ctx->chroms[J.ci].length_sum = ctx->sparse[J.ci].length_sum;
+        ctx->chroms[J.ci].n_dump = ctx->sparse[J.ci].n;
+        return SP_OK;
+    };
+    auto run_all = [&]() -> int {
+        size_t issued = 0;
+        for (size_t ci = 0; ci < C; ci++) {
+            sp_chrom &c = ctx->chroms[ci];
+            sp_sparse_chrom &o = ctx->sparse[ci];
+            o.n = 0;
+            o.length_sum = 0;
+            c.length_sum = 0;
+            c.n_dump = 0;
+            if (c.len <= 0) continue;
+            const int l = (int)(issued++ % (size_t)n_jobs);
+            int rc = finish(l);      // the chain this lane issued before: its buffers are free once its gather is queued
+            if (rc) return rc;
+            s3_job &J = jobs[(size_t)l];
+            J.ci = ci;
+            J.exact = exact0;
+            if (n_lanes) SP_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, c.ev_packed ? c.ev_packed : ctx->lane_go, 0));
+            rc = on_lane(l, 0, J);
+            if (rc) return rc;
+        }
+        for (size_t q = 0; q < (size_t)n_jobs; q++) {      // the chains still in flight, oldest first
+            const int rc = finish((int)((issued + q) % (size_t)n_jobs));
+            if (rc) return rc;
+        }
+        return SP_OK;
+    };
+    int rc = run_all();
+    ctx->lane = nullptr;
+    ctx->stream = main_stream;
+    if (rc) {
+        const std::string msg = ctx->err;
+        for (int l = 0; l < n_lanes; l++) hipStreamSynchronize(ctx->lanes[l].stream);
+        hipStreamSynchronize(ctx->stream);
+        ctx->err = msg;
+        return rc;
+    }
+    for (int l = 0; l < n_lanes; l++) {      // the main stream goes on when every lane is done
+        SP_HIP(ctx, hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].stream));
+        SP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[l].done, 0));
+    }
+    for (size_t ci : redo) {
+        if (exact0) return sp_fail(ctx, SP_ESTATE, "k > 15: a bucket overran a region of its exact size");
+        ctx->c2_recounts++;
+        if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] k > 15: chromosome %zu recounted with exact bucket sizes\n", ci);
+        s3_job J;
+        J.ci = ci;
+        J.exact = true;
+        J.h = ctx->h_s3 + 8 * (size_t)SP_MAX_LANES;
+        J.ev_a = ctx->s3_ev[0];
+        J.ev_b = ctx->s3_ev[1];
+        for (int phase = 0; phase < 3; phase++) {
+            rc = s3_chain(ctx, phase, ctx->chroms[ci], ctx->sparse[ci], P, kp, lower, J);
+            if (rc) return rc;
+        }
+        if (J.overran) return sp_fail(ctx, SP_ESTATE, "k > 15: a bucket overran a region of its exact size");
+        ctx->chroms[ci].length_sum = ctx->sparse[ci].length_sum;
+        ctx->chroms[ci].n_dump = ctx->sparse[ci].n;
     }
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SP_OK;
