@@ -1233,6 +1233,126 @@ s3_big_rle(const KR2 *__restrict__ sorted, const unsigned long long *__restrict_
     }
 }
 
+// ---------------------------------------------------------------- oversized buckets without a device-wide sort (round 4)
+// The handful of buckets per chromosome that s3_final gives up on (a piece with more distinct residuals than its hash
+// table takes) used to go through ONE segmented library sort + s3_big_rle, with an 8-MB copy of the span table to the
+// host in front of it.  They are an aggregation problem like every other bucket, only larger, so they are cut by HASH
+// CLASS instead of by sorting: a bucket of n keys has P = n / 768 + 1 classes, class(key) = mix(key) mod P, and one
+// workgroup streams the whole bucket once per class it owns (the bucket sits in L2 / the Infinity Cache after the first
+// reader), counts the keys of that class exactly in the LDS table of s3_final_hash and appends the entries that reach
+// lower_count to the bucket's kept list.  S3B_SPREAD workgroups share the classes of one bucket.  s3_big_sort then
+// orders a bucket's kept list (a bitonic sort in LDS) and writes it where every finish kernel writes.  A class that
+// overflows the table or a kept list beyond S3B_KCAP raises a flag and the library path below takes the chromosome's
+// oversized buckets as before (wheat-like: never).
+#define S3B_SPREAD 32
+#define S3B_KCAP 4096
+#define S3B_MAXBIG 1024         // more oversized buckets than this per chromosome: the library path
+__device__ __forceinline__ uint32_t s3b_class(unsigned long long key, uint32_t P) {
+    key ^= key >> 33;
+    key *= 0xFF51AFD7ED558CCDULL;
+    key ^= key >> 29;
+    return (uint32_t)((key & 0xFFFFFFFFULL) % P);
+}
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_big_class(const KR2 *__restrict__ buf2, const unsigned long long *__restrict__ big, const ulonglong2 *__restrict__ span,
+             uint32_t lower, KR2 *__restrict__ list_keys, uint32_t *__restrict__ list_cnts,
+             unsigned long long *__restrict__ kcur /* per oversized bucket: kept entries so far */,
+             unsigned long long *__restrict__ fail) {
+    __shared__ s3h_lds<KR2> L;
+    const int tid = threadIdx.x;
+    const uint32_t bi = blockIdx.x / S3B_SPREAD, q = blockIdx.x % S3B_SPREAD;
+    const unsigned long long b = big[bi];
+    const unsigned long long o = span[b].x, n = span[b].y;
+    const uint32_t P = (uint32_t)(n / 768ULL) + 1u;
+    const KR2 *seg = buf2 + o;
+    for (uint32_t p = q; p < P; p += S3B_SPREAD) {
+        __syncthreads();
+        if (tid == 0) L.n_distinct = L.n_kept = L.abort_ = 0;
+        s3h_clear_table_words(reinterpret_cast<uint4 *>(L.u.t.key), (int)(S3H_SLOTS * sizeof(KR2) / 16),
+                              reinterpret_cast<uint4 *>(L.u.t.cnt), S3H_SLOTS / 4);
+        __syncthreads();
+        for (unsigned long long i0 = tid; i0 < n; i0 += 8 * S3_SORT_THREADS) {
+            KR2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (i0 + j * S3_SORT_THREADS < n) v[j] = seg[i0 + j * S3_SORT_THREADS];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (i0 + j * S3_SORT_THREADS < n && s3b_class((unsigned long long)v[j], P) == p && !L.abort_) s3h_insert(L, v[j]);
+            if (L.abort_) break;
+        }
+        __syncthreads();
+        if (L.abort_) {                 // block-uniform after the barrier
+            if (tid == 0) atomicAdd(fail, 1ULL);
+            return;
+        }
+        for (int s = tid; s < S3H_SLOTS; s += S3_SORT_THREADS) {
+            const uint32_t c = L.u.t.cnt[s];
+            if (c >= lower) {
+                const unsigned long long at = atomicAdd(&kcur[bi], 1ULL);
+                if (at < S3B_KCAP) {
+                    list_keys[(size_t)bi * S3B_KCAP + at] = L.u.t.key[s];
+                    list_cnts[(size_t)bi * S3B_KCAP + at] = c;
+                }
+            }
+        }
+    }
+}
+template <typename KR2>
+__global__ void __launch_bounds__(S3_SORT_THREADS)
+s3_big_sort(const unsigned long long *__restrict__ big, const ulonglong2 *__restrict__ span, const KR2 *__restrict__ list_keys,
+            const uint32_t *__restrict__ list_cnts, const unsigned long long *__restrict__ kcur,
+            unsigned long long *__restrict__ fail, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
+            unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum) {
+    __shared__ KR2 sk[S3B_KCAP];
+    __shared__ uint32_t sc[S3B_KCAP];
+    __shared__ unsigned long long red[16];
+    const int tid = threadIdx.x;
+    const uint32_t bi = blockIdx.x;
+    const unsigned long long b = big[bi], o = span[b].x, w64 = kcur[bi];
+    if (w64 > S3B_KCAP) {               // block-uniform
+        if (tid == 0) atomicAdd(fail, 1ULL);
+        return;
+    }
+    const uint32_t w = (uint32_t)w64;
+    uint32_t m = 1;
+    while (m < w) m <<= 1;
+    const KR2 PAD = (KR2)~(KR2)0;       // never a residual; sorts last
+    for (uint32_t i = tid; i < m; i += S3_SORT_THREADS) {
+        sk[i] = i < w ? list_keys[(size_t)bi * S3B_KCAP + i] : PAD;
+        sc[i] = i < w ? list_cnts[(size_t)bi * S3B_KCAP + i] : 0u;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (m >> 1); t += S3_SORT_THREADS) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const KR2 a = sk[lo], c = sk[hi];
+                if ((a > c) == up) {
+                    sk[lo] = c;
+                    sk[hi] = a;
+                    const uint32_t x = sc[lo];
+                    sc[lo] = sc[hi];
+                    sc[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    unsigned long long lsum = 0;
+    for (uint32_t i = tid; i < w; i += S3_SORT_THREADS) {
+        tmp_keys[o + i] = sk[i];
+        tmp_cnts[o + i] = sc[i];
+        lsum += sc[i];
+    }
+    const unsigned long long t = sp_block_sum_u64(lsum, red);
+    if (tid == 0) {
+        kept[b] = w;
+        if (t) atomicAdd(len_sum, t);
+    }
+}
+
 // ---------------------------------------------------------------- s3_gather
 template <typename KR2>
 __global__ void __launch_bounds__(256)
@@ -1540,7 +1660,34 @@ static int s3_chain_b(sp_ctx *ctx, sp_sparse_chrom &out, const s3_plan &P, int l
         return SP_OK;
     }
     if (n_big > big_cap) return sp_fail(ctx, SP_EUNSUP, "k > 15: %llu oversized k-mer buckets", n_big);
-    if (n_big) {   // hot keys: buckets beyond one workgroup -- ONE segmented device sort, then one block per bucket
+    bool big_done = false;
+    const char *env_big = getenv("SP_S3_BIG");      // "sort": the library path always (cross-check)
+    if (n_big && n_big <= S3B_MAXBIG && !(env_big && !strcmp(env_big, "sort"))) {      // round 4: by hash class, no device-wide sort
+        const size_t lk_bytes = ((size_t)n_big * S3B_KCAP * sizeof(KR2) + 255) & ~(size_t)255;
+        const size_t lc_bytes = ((size_t)n_big * S3B_KCAP * 4 + 255) & ~(size_t)255;
+        const size_t cur_bytes = (((size_t)n_big + 1) * 8 + 255) & ~(size_t)255;
+        rc = sp_buf_ensure(ctx, S3_LANE_BUF(ctx, b_sp_tmp), (int64_t)(lk_bytes + lc_bytes + cur_bytes + 256));
+        if (rc) return rc;
+        char *T = (char *)S3_LANE_BUF(ctx, b_sp_tmp).p;
+        KR2 *lk = (KR2 *)T;
+        uint32_t *lc = (uint32_t *)(T + lk_bytes);
+        unsigned long long *kcur = (unsigned long long *)(T + lk_bytes + lc_bytes), *d_fail = kcur + n_big;
+        SP_HIP(ctx, hipMemsetAsync(kcur, 0, ((size_t)n_big + 1) * 8, ctx->stream));
+        SP_LAUNCH(ctx, "s3_big_class", s3_big_class<KR2>, dim3((unsigned)(n_big * S3B_SPREAD)), dim3(S3_SORT_THREADS), 0,
+                  (const KR2 *)buf2, (const unsigned long long *)d_big, (const ulonglong2 *)d_span, (uint32_t)lower, lk, lc, kcur, d_fail);
+        // (the length sum is added by s3_big_sort; a failed bucket leaves the sum short, and the library path below then
+        // redoes EVERY oversized bucket -- so the sums of the buckets already written have to come out again)
+        SP_HIP(ctx, hipMemcpyAsync(J.h + 4, d_small + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_LAUNCH(ctx, "s3_big_sort", s3_big_sort<KR2>, dim3((unsigned)n_big), dim3(S3_SORT_THREADS), 0,
+                  (const unsigned long long *)d_big, (const ulonglong2 *)d_span, (const KR2 *)lk, (const uint32_t *)lc,
+                  (const unsigned long long *)kcur, d_fail, tmp_keys, tmp_cnts, d_kp, d_small + 2);
+        SP_HIP(ctx, hipMemcpyAsync(J.h + 5, d_fail, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        big_done = J.h[5] == 0;
+        if (!big_done)      // back to the length sum before s3_big_sort
+            SP_HIP(ctx, hipMemcpyAsync(d_small + 2, J.h + 4, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_big && !big_done) {   // the library path: ONE segmented device sort, then one block per bucket
         std::vector<unsigned long long> big((size_t)n_big), seg(2 * (size_t)n_big);
         std::vector<ulonglong2> spans((size_t)n_fine);
         SP_HIP(ctx, hipMemcpy(big.data(), d_big, (size_t)n_big * 8, hipMemcpyDeviceToHost));
