@@ -229,6 +229,8 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             want[q] = p.bits;
 #ifdef MAP_EXP_NOPROBE      // bound experiments (tools/build_variant.sh): the scan alone, wrong answers
             wd[q] = canon[q];
+#elif defined(MAP_EXP_SKIP3)  // two probes (and look-ups) in three: what one probe per THREE starts would leave of them
+            wd[q] = (((ok_x >> j) & 1u) && (g + q) % 3 != 2) ? bloom[p.word] : 0u;
 #else
             wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
 #endif
