@@ -309,10 +309,11 @@ def main():
     # byte-table filter, or the list filter (k > 15, and engine 3 on small genomes at k <= 15)
     FILTER_CHAIN = ["k3_eval", "k3_slow"] if "k3_eval" in prof else \
         sorted((n for n in prof if n.startswith("sps_") and "hash" not in n and "pair" not in n), key=lambda n: n != "sps_join")
-    # k <= 15, one process: pack + count chains overlap on up to four streams (sp_count's lanes)
+    # one process: the pack kernels and the count chains overlap on up to four streams (sp_count's lanes; round 4: also
+    # the k > 15 chains, three chromosomes in flight)
     LANE_KERNELS, lane_scale = set(), 1.0
     wall_pc = (hp.wall.get("pack+count", 0.0) / args.steps * 1e3) if runner is None else 0.0
-    if args.k <= 15 and wall_pc > 0:
+    if wall_pc > 0:
         lk = [n for n in COUNT_CHAIN + ["k0_pack"] if n in prof]
         ev = sum(prof[n]["ms"] for n in lk) / args.steps
         if ev > 0 and wall_pc / ev < 0.9:

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-tools/ab_round.sh "l2||SP_LANES_DENSE=2|" "l3||SP_LANES_DENSE=3|" "l4||SP_LANES_DENSE=4|" "l5||SP_LANES_DENSE=5|" "l6||SP_LANES_DENSE=6|" 2>&1 | grep Gbases
+python bench.py -k 17 2>/dev/null | tail -1 > gpurun_out/r04_bench_wheat_k17.json
+python bench.py -k 21 2>/dev/null | tail -1 > gpurun_out/r04_bench_wheat_k21.json
+python tools/stage_ms.py gpurun_out/r04_bench_wheat_k17.json gpurun_out/r04_bench_wheat_k21.json
