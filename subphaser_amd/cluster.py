@@ -198,9 +198,55 @@ TEST_METHODS = ("ttest_ind", "kruskal", "wilcoxon", "mannwhitneyu")
 TTEST_MAX_GROUP = 64     # SP_TT_MAXG in csrc/sp_enrich.hip
 
 
+def _kruskal_rows(a, b):
+    """scipy.stats.kruskal(a[i], b[i]).pvalue for every row, in array form (same operations in the same order as
+    scipy's: average ranks, tie correction 1 - sum(t^3 - t) / (N^3 - N), H = 12 / (N (N + 1)) * sum(R_j^2 / n_j)
+    - 3 (N + 1), chi-square survival function with one degree of freedom); rows whose values are all identical --
+    where scipy raises "All numbers are identical" -- get p = 1 like the row-wise wrapper below gives them."""
+    from scipy import special, stats as st
+    n1, n2 = a.shape[1], b.shape[1]
+    N = float(n1 + n2)
+    x = np.concatenate([a, b], axis=1)
+    ranked = st.rankdata(x, axis=1)
+    srt = np.sort(ranked, axis=1)
+    first = np.concatenate([np.ones((x.shape[0], 1), bool), srt[:, 1:] != srt[:, :-1]], axis=1)
+    # size of the tie group every element belongs to: distance between consecutive group starts
+    idx = np.where(first, np.arange(x.shape[1])[None, :], 0)
+    start = np.maximum.accumulate(idx, axis=1)
+    nxt = np.where(first, np.arange(x.shape[1])[None, :], x.shape[1])
+    end = np.minimum.accumulate(nxt[:, ::-1], axis=1)[:, ::-1]       # start of the NEXT group at or after this element
+    end = np.concatenate([end[:, 1:], np.full((x.shape[0], 1), x.shape[1])], axis=1)
+    end = np.where(first, end, 0)        # count every group once, at its first element
+    cnt = np.where(first, (end - start).astype(np.float64), 0.0)
+    ties = 1.0 - (cnt ** 3 - cnt).sum(axis=1) / (N ** 3 - N) if N >= 2 else np.ones(x.shape[0])
+    ssbn = ranked[:, :n1].sum(axis=1) ** 2 / n1 + ranked[:, n1:].sum(axis=1) ** 2 / n2
+    with np.errstate(all="ignore"):
+        h = (12.0 / (N * (N + 1)) * ssbn - 3 * (N + 1)) / ties
+        p = special.chdtrc(1, h)
+    return np.where(ties == 0, 1.0, p)
+
+
 def _scipy_rows(name, a, b):
-    """p-value of scipy.stats.<name>(a[i], b[i]) for every row (the reference calls the test per k-mer)."""
+    """p-value of scipy.stats.<name>(a[i], b[i]) for every row (the reference calls the test per k-mer).
+    mannwhitneyu: scipy's own axis argument, the rows split by the method a row-wise call picks (millions of rows in seconds); kruskal: the array form
+    above (equal to the row-wise call, tests/test_abi_and_host.py); wilcoxon stays row by row: with ties or zeros and
+    fewer than 14 pairs scipy >= 1.13 runs an exact permutation test per row (3 ms each)."""
     from scipy import stats as st
+    if a.shape[0] and name == "mannwhitneyu":
+        # method="auto" decides per CALL: exact unless both samples exceed 8 values or ANY value is tied -- so the rows
+        # are split by what a row-wise call would have chosen for each of them
+        n1, n2 = a.shape[1], b.shape[1]
+        xs = np.sort(np.concatenate([a, b], axis=1), axis=1)
+        tied = (xs[:, 1:] == xs[:, :-1]).any(axis=1)
+        exact = ~tied if not (n1 > 8 and n2 > 8) else np.zeros(a.shape[0], bool)
+        out = np.empty(a.shape[0])
+        if exact.any():
+            out[exact] = st.mannwhitneyu(a[exact], b[exact], axis=1, method="exact")[1]
+        if (~exact).any():
+            out[~exact] = st.mannwhitneyu(a[~exact], b[~exact], axis=1, method="asymptotic")[1]
+        return out
+    if a.shape[0] and name == "kruskal":
+        return _kruskal_rows(np.asarray(a, np.float64), np.asarray(b, np.float64))
     test = getattr(st, name)
     out = np.empty(a.shape[0])
     for i in range(a.shape[0]):

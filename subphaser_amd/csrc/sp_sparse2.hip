@@ -984,7 +984,8 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
          unsigned long long light_cap /* buckets up to this size were the light kernel's; S3_BM_PUNT: the ones
                                          the bitmap kernel marked in kept[] */,
          int hash_pieces /* k >= 18: count the pieces of a split bucket like s3_final_hash does, sort only on abort */,
-         const uint32_t *__restrict__ punt_list, const unsigned long long *__restrict__ n_punt) {
+         const uint32_t *__restrict__ punt_list, const unsigned long long *__restrict__ n_punt,
+         int force_big /* test hook: every bucket of more than one sort's worth of keys goes to the oversized path */) {
     __shared__ s3_final_lds<KR2> L;
     unsigned long long lsum = 0;
     // punt mode: the listed buckets; else (the round-2 sort kernels, SP_S3_FINAL=sort) every bucket above light_cap
@@ -1000,7 +1001,7 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
             if (threadIdx.x == 0) kept[bucket] = nk;
             continue;
         }
-        bool give_up = n64 >= (1ULL << 31);
+        bool give_up = n64 >= (1ULL << 31) || force_big;
         uint32_t w = 0;                      // kept pairs written so far (block-uniform)
         unsigned long long bsum = 0;         // their counts; dropped if the bucket goes to the fallback
         if (!give_up) {
@@ -1618,7 +1619,7 @@ static int s3_chain_a(sp_ctx *ctx, sp_chrom &c, sp_sparse_chrom &out, const s3_p
               (KR2 *)buf1, (const ulonglong2 *)d_span, n_fine, P.R2, (uint32_t)lower, tmp_keys, tmp_cnts, d_kp, d_big,
               d_small + 1, (unsigned long long)big_cap, d_small + 2,
               (bitmap || use_hash) ? S3_BM_PUNT : (unsigned long long)S3_SMALL_CAP, use_hash ? 1 : 0, (const uint32_t *)d_pl,
-              (const unsigned long long *)(d_small + 8));
+              (const unsigned long long *)(d_small + 8), getenv("SP_S3_FORCE_BIG") ? 1 : 0);
     SP_HIP(ctx, hipMemcpyAsync(J.h, d_small + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(J.h + 1, d_small + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(ctx, hipEventRecord(J.ev_a, ctx->stream));

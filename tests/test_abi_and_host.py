@@ -512,3 +512,30 @@ def test_read_bed_errors_and_interval_merge(tmp_path, monkeypatch):
     assert m.ids() == ["chr1:5-10", "chr2:0-3"] and c.tolist() == [[11, 22], [3, 4]]
     same, c2 = m.merged(c)
     assert same is m and c2 is c
+
+
+def test_rank_tests_in_array_form_equal_scipy_row_by_row():
+    """-test_method kruskal / mannwhitneyu (Cluster.py:178-194): the array forms in cluster._scipy_rows must give what
+    the reference's per-k-mer scipy call gives, bit for bit -- ties, zeros, all-identical rows, unequal group sizes"""
+    from scipy import stats
+    from subphaser_amd.cluster import _scipy_rows
+    rng = np.random.default_rng(3)
+    for n1, n2 in ((7, 7), (3, 9), (1, 5), (10, 2), (9, 12)):
+        M = 400
+        a = np.round(rng.random((M, n1)) * 4) / 4 * (rng.random((M, n1)) < 0.7)
+        b = np.round(rng.random((M, n2)) * 6) / 6 * (rng.random((M, n2)) < 0.5)
+        a[::7] = 0.25
+        b[::7] = 0.25
+        a[1::7] = rng.random(a[1::7].shape)
+        b[1::7] = rng.random(b[1::7].shape)
+        for name in ("kruskal", "mannwhitneyu"):
+            got = _scipy_rows(name, a, b)
+            f = getattr(stats, name)
+            exp = np.empty(M)
+            for i in range(M):
+                try:
+                    exp[i] = f(a[i], b[i])[1]
+                except ValueError as e:
+                    assert "identical" in str(e) or "zero" in str(e)
+                    exp[i] = 1.0
+            assert np.array_equal(got, exp, equal_nan=True), (name, n1, n2, np.nanmax(np.abs(got - exp)))

@@ -230,6 +230,41 @@ def test_count_sparse_engine_sampled_sizing_and_recount(gpu_ctx, monkeypatch):
     assert gpu_ctx.count_recounts() == n
 
 
+def test_count_sparse_engine_lanes_and_oversized_paths(gpu_ctx, monkeypatch):
+    """round 4: (a) several chromosome chains in flight (three phases on SP_LANES_SPARSE streams) against one chain at a
+    time; (b) every bucket above one sort's worth of keys forced through the oversized path (test hook): cut by hash
+    class (s3_big_class + s3_big_sort) and, as the cross-check, through the library sort (SP_S3_BIG=sort); (c) a kept
+    list beyond the class path's capacity must fall back to the library path.  All against the oracle."""
+    rng = np.random.RandomState(404)
+    unit = _rand_seq(rng, 29, 0, 0)
+    seqs = [np.concatenate([_rand_seq(rng, 250_000), np.tile(unit, 4000), _rand_seq(rng, 40_000)]),
+            _rand_seq(rng, 120_000), np.empty(0, np.uint8), _rand_seq(rng, 90_000),
+            np.concatenate([np.tile(_rand_seq(rng, 3000, 0, 0), 40), _rand_seq(rng, 60_000)]), _rand_seq(rng, 30)]
+    for lanes in ("0", "2", "3", "7"):
+        monkeypatch.setenv("SP_LANES_SPARSE", lanes)
+        for k in (16, 21, 27):
+            _count_both(gpu_ctx, seqs, k, 2, 0)
+    monkeypatch.delenv("SP_LANES_SPARSE")
+    monkeypatch.setenv("SP_S3_FORCE_BIG", "1")
+    for k in (17, 21, 26, 32):
+        _count_both(gpu_ctx, seqs, k, 1, 0)
+        _count_both(gpu_ctx, seqs, k, 3, 0)
+    monkeypatch.setenv("SP_S3_BIG", "sort")
+    for k in (17, 21, 32):
+        _count_both(gpu_ctx, seqs, k, 2, 0)
+    monkeypatch.delenv("SP_S3_BIG")
+    monkeypatch.delenv("SP_S3_FORCE_BIG")
+    # (c) ONE fine bucket with thousands of distinct residuals of count 2: blocks `AAAAAAAAAA + k - 10 random bases + N`
+    # hold one valid k-mer each, all with the same leading 20 bits.  3000 distinct: more than the finish kernels' tables
+    # take -> the hash classes; 6000: more kept pairs than the class path's list holds -> the library path
+    for k in (21, 31):
+        for distinct in (3000, 6000):
+            body = np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, size=(distinct, k - 10))]
+            blocks = np.concatenate([np.full((distinct, 10), ord("A"), np.uint8), body, np.full((distinct, 1), ord("N"), np.uint8)], axis=1)
+            seq = np.concatenate([blocks.reshape(-1), blocks.reshape(-1), _rand_seq(rng, 50_000)])
+            _count_both(gpu_ctx, [seq, _rand_seq(rng, 20_000)], k, 2, 0)
+
+
 def test_count_sparse_engine_hot_buckets(gpu_ctx):
     """Buckets beyond one workgroup's sort capacity (a k-mer repeated > 4096 times, and many distinct keys
     sharing the 18-19 partition bits) take the device-wide fallback of the MSD engine."""
