@@ -1784,6 +1784,9 @@ int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
     // pack kernel is done (sp_chrom::ev_packed).
     const char *el = getenv("SP_LANES_SPARSE");
     int n_lanes = el ? atoi(el) : 3;
+    int64_t total_len = 0;
+    for (const auto &c : ctx->chroms) total_len += c.len;
+    if (!el && total_len < (1LL << 24)) n_lanes = 0;      // (toy inputs: see sp_count)
     if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
     if (n_lanes < 0 || C < 2) n_lanes = 0;
     if (!ctx->h_s3) SP_HIP(ctx, hipHostMalloc((void **)&ctx->h_s3, (size_t)(SP_MAX_LANES + 1) * 8 * sizeof(unsigned long long), hipHostMallocDefault));

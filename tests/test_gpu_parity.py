@@ -265,6 +265,22 @@ def test_count_sparse_engine_lanes_and_oversized_paths(gpu_ctx, monkeypatch):
             _count_both(gpu_ctx, [seq, _rand_seq(rng, 20_000)], k, 2, 0)
 
 
+def test_count_chains_side_by_side_at_k15(gpu_ctx, monkeypatch):
+    """k <= 15: the byte-table chains (engine 2) and the list chains (engine 3) on several streams -- forced here, the
+    default takes one stream below 2^24 bases -- against the oracle, with chromosomes that are empty, shorter than k,
+    repeat-rich and N-rich in the same call"""
+    rng = np.random.RandomState(1515)
+    unit = _rand_seq(rng, 23, 0, 0)
+    seqs = [np.concatenate([_rand_seq(rng, 150_000), np.tile(unit, 5000)]), _rand_seq(rng, 90_000, 0.05), np.empty(0, np.uint8),
+            _rand_seq(rng, 9), _rand_seq(rng, 200_000), np.tile(_rand_seq(rng, 1, 0, 0), 70_000), _rand_seq(rng, 40_000)]
+    for var, engine in (("SP_LANES_DENSE", 2), ("SP_LANES", 3)):
+        for lanes in ("0", "1", "3", "7"):
+            monkeypatch.setenv(var, lanes)
+            for k in (11, 14, 15):
+                _count_both(gpu_ctx, seqs, k, 2, engine)
+        monkeypatch.delenv(var)
+
+
 def test_count_sparse_engine_hot_buckets(gpu_ctx):
     """Buckets beyond one workgroup's sort capacity (a k-mer repeated > 4096 times, and many distinct keys
     sharing the 18-19 partition bits) take the device-wide fallback of the MSD engine."""
