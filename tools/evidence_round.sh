@@ -1,7 +1,7 @@
 set -u
 # Round evidence on the GPU box (through gpurun, from the repo root): GPU suite, rocprofv3 kernel traces + stamped PMC
 # passes of the five bench workloads, their bench lines (in-run verification against the oracle), fuzz.
-export SP_COMMIT=ee46912
+export SP_COMMIT=1fc1a04
 R=r04
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -19,4 +19,3 @@ python bench.py --config peanut 2>/dev/null | tail -1 > gpurun_out/${R}_bench_pe
 python bench.py --config ara 2>/dev/null | tail -1 > gpurun_out/${R}_bench_ara_k15.json
 python tools/stage_ms.py gpurun_out/${R}_bench_*.json
 cat gpurun_out/${R}_final_pytest_gpu.txt
-tools/ab_round.sh "skip3|subphaser_amd/lib/variants/lib_map_skip3.so||" | tail -2
