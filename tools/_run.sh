@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 )
-t0=$SECONDS; ( timeout 600 python tools/fuzz_parity.py 2000 60606 2>&1 | tail -1 ); echo "  ($((SECONDS - t0)) s for 2000 default iterations)"
+for g in ara peanut wheat; do
+  timeout 900 python tools/e2e_cli.py $g /tmp/sp_e2e_$g > gpurun_out/r04_e2e_cli_$g.log 2>&1
+  tail -3 gpurun_out/r04_e2e_cli_$g.log | cut -c1-200
+done
+timeout 900 python tools/feat_bench.py wheat 2000000 > gpurun_out/r04_feature_mode_2M.log 2>&1
+tail -3 gpurun_out/r04_feature_mode_2M.log | cut -c1-300
