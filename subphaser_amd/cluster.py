@@ -226,11 +226,55 @@ def _kruskal_rows(a, b):
     return np.where(ties == 0, 1.0, p)
 
 
+def _wilcoxon_rows(a, b):
+    """scipy.stats.wilcoxon(a[i], b[i]).pvalue for every row.  scipy (>= 1.13) picks the method per call: exact when the
+    differences hold no ties and no zeros; with ties or zeros and at most 13 pairs an EXACT PERMUTATION TEST over all
+    2^n sign assignments (3 ms per call: two hours for the 2.2 M rows of a wheat-like run); the normal approximation
+    otherwise.  Here the rows are split the same way: scipy's own `axis` form for the exact and the asymptotic rows,
+    and for the permutation rows the null distribution of r_plus = all subset sums of the ranks of |d| (zeros rank 0:
+    they only duplicate subsets), one matrix product per block of rows; p = 2 min(#(null <= obs), #(null >= obs)) / 2^n
+    with scipy's tolerance, clipped at 1.  Sums of half-integers are exact in floating point, so the p-values are
+    scipy's bit for bit (tests/test_abi_and_host.py)."""
+    from scipy import stats as st
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    M, n = a.shape
+    out = np.ones(M)
+    if M == 0 or n == 0:
+        return out
+    d = a - b
+    nz = d != 0
+    ad = np.where(nz, np.abs(d), np.inf)              # zeros are dropped ("wilcox"): rank them last, out of the way
+    srt = np.sort(ad, axis=1)
+    tied = ((srt[:, 1:] == srt[:, :-1]) & np.isfinite(srt[:, 1:])).any(axis=1)
+    exact = ~tied & nz.all(axis=1) & (n <= 50)
+    perm = ~exact & (n <= 13)
+    asym = ~exact & ~perm
+    if exact.any():
+        out[exact] = st.wilcoxon(a[exact], b[exact], axis=1, method="exact")[1]
+    if asym.any():
+        out[asym] = st.wilcoxon(a[asym], b[asym], axis=1, method="asymptotic")[1]
+    if perm.any():
+        rows = np.flatnonzero(perm)
+        ranks = np.where(nz[rows], st.rankdata(ad[rows], axis=1), 0.0)
+        obs = np.where(d[rows] > 0, ranks, 0.0).sum(axis=1)
+        pat = ((np.arange(1 << n)[:, None] >> np.arange(n)[None, :]) & 1).astype(np.float64)      # [2^n, n]
+        gamma = np.abs(np.finfo(np.float64).eps * 100 * obs)
+        step = max(1, (1 << 22) >> n)                 # ~32 MB of null values per block
+        for lo in range(0, rows.size, step):
+            sl = slice(lo, lo + step)
+            null = ranks[sl] @ pat.T
+            le = (null <= (obs[sl] + gamma[sl])[:, None]).sum(axis=1)
+            ge = (null >= (obs[sl] - gamma[sl])[:, None]).sum(axis=1)
+            out[rows[sl]] = np.clip(np.minimum(le, ge) / float(1 << n) * 2, 0, 1)
+    return out
+
+
 def _scipy_rows(name, a, b):
     """p-value of scipy.stats.<name>(a[i], b[i]) for every row (the reference calls the test per k-mer).
     mannwhitneyu: scipy's own axis argument, the rows split by the method a row-wise call picks (millions of rows in seconds); kruskal: the array form
-    above (equal to the row-wise call, tests/test_abi_and_host.py); wilcoxon stays row by row: with ties or zeros and
-    fewer than 14 pairs scipy >= 1.13 runs an exact permutation test per row (3 ms each)."""
+    above (equal to the row-wise call, tests/test_abi_and_host.py); wilcoxon: _wilcoxon_rows; groups of unequal size
+    (scipy raises for every row) fall through to the row-wise loop, which reports scipy's error."""
     from scipy import stats as st
     if a.shape[0] and name == "mannwhitneyu":
         # method="auto" decides per CALL: exact unless both samples exceed 8 values or ANY value is tied -- so the rows
@@ -247,6 +291,8 @@ def _scipy_rows(name, a, b):
         return out
     if a.shape[0] and name == "kruskal":
         return _kruskal_rows(np.asarray(a, np.float64), np.asarray(b, np.float64))
+    if a.shape[0] and name == "wilcoxon" and a.shape[1] == b.shape[1] and a.shape[1] >= 2:      # (one pair: scipy's permutation branch raises)
+        return _wilcoxon_rows(a, b)
     test = getattr(st, name)
     out = np.empty(a.shape[0])
     for i in range(a.shape[0]):

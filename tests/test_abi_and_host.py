@@ -539,3 +539,17 @@ def test_rank_tests_in_array_form_equal_scipy_row_by_row():
                     assert "identical" in str(e) or "zero" in str(e)
                     exp[i] = 1.0
             assert np.array_equal(got, exp, equal_nan=True), (name, n1, n2, np.nanmax(np.abs(got - exp)))
+    # wilcoxon (paired): scipy picks exact / permutation (ties or zeros, <= 13 pairs: all 2^n sign assignments, 3 ms to
+    # 0.6 s per call) / asymptotic per call; the array form splits the rows the same way and enumerates the subset sums
+    import warnings
+    for n, M in ((2, 60), (5, 60), (7, 60), (10, 24), (13, 4), (14, 40), (60, 20)):
+        a = np.round(rng.random((M, n)) * 5) / 5 * (rng.random((M, n)) < 0.8)
+        b = np.round(rng.random((M, n)) * 5) / 5 * (rng.random((M, n)) < 0.6)
+        a[::6] = rng.random(a[::6].shape)
+        b[::6] = rng.random(b[::6].shape)
+        a[1::6] = b[1::6]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = _scipy_rows("wilcoxon", a, b)
+            exp = np.array([stats.wilcoxon(a[i], b[i])[1] for i in range(M)])
+        assert np.array_equal(got, exp, equal_nan=True), ("wilcoxon", n, np.nanmax(np.abs(got - exp)))

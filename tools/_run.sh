@@ -1,8 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for g in ara peanut wheat; do
-  timeout 900 python tools/e2e_cli.py $g /tmp/sp_e2e_$g > gpurun_out/r04_e2e_cli_$g.log 2>&1
-  tail -3 gpurun_out/r04_e2e_cli_$g.log | cut -c1-200
+: > gpurun_out/r04_fuzz_long.txt
+for seed in 70001 70002 70003 70004 70005 70006 70007 70008; do
+  t0=$SECONDS
+  ( timeout 900 python tools/fuzz_parity.py 15000 $seed 2>&1 | tail -2 ) >> gpurun_out/r04_fuzz_long.txt
+  echo "  (seed $seed: $((SECONDS - t0)) s)" >> gpurun_out/r04_fuzz_long.txt
 done
-timeout 900 python tools/feat_bench.py wheat 2000000 > gpurun_out/r04_feature_mode_2M.log 2>&1
-tail -3 gpurun_out/r04_feature_mode_2M.log | cut -c1-300
+cat gpurun_out/r04_fuzz_long.txt
