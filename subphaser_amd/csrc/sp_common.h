@@ -26,6 +26,8 @@ struct sp_chrom {
                                // 255 = the count is >= 255 and lives in the overflow list (valid after sp_count)
     uint2 *d_ovf = nullptr;    // overflow list: (slot, raw count >= 255), ascending slot
     int64_t n_ovf = 0, cap_ovf = 0;
+    uint32_t *d_ovf_idx = nullptr;   // per-bucket starts of d_ovf (what ovf_scan computed), kept for the filter's look-ups
+    int64_t ovf_idx_n = 0, ovf_idx_cap = 0;   // entries it holds (n_buckets + 1; 0: none) and its capacity
     int64_t length_sum = 0;    // sum of counts >= lower_count
     int64_t n_dump = 0;        // number of k-mers with count >= lower_count
     hipEvent_t ev_packed = nullptr;   // recorded behind this chromosome's pack kernel: a counting lane waits for it, not for
@@ -67,6 +69,9 @@ struct sp_tabref {
     const uint8_t *tab;
     const uint2 *ovf;
     int64_t n_ovf;
+    // where the pairs of every bucket of 2^SP_OVF_SHIFT slots start in `ovf` (n_buckets + 1 entries), or NULL:
+    // a look-up searches its bucket's handful of pairs instead of the whole list (merged / caller-owned lists have none)
+    const uint32_t *ovf_idx = nullptr;
 };
 
 struct sp_prof_entry {

@@ -329,7 +329,19 @@ static int ovf_finalize_to(sp_ctx *ctx, uint2 *out, const uint2 *tmp, const uint
 }
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
                     uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total) {
-    return ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets, d_total);
+    const int rc = ovf_finalize_to(ctx, c.d_ovf, tmp, seg_base, seg_cnt, seg_off, n_buckets, d_total);
+    if (rc) return rc;
+    // the bucket starts live in a workspace the next chromosome reuses: keep a copy for the filter (sp_tabref::ovf_idx)
+    if (c.ovf_idx_cap < n_buckets + 1) {
+        if (c.d_ovf_idx) hipFree(c.d_ovf_idx);
+        c.d_ovf_idx = nullptr;
+        c.ovf_idx_cap = c.ovf_idx_n = 0;
+        SP_HIP(ctx, hipMalloc(&c.d_ovf_idx, (size_t)(n_buckets + 1) * sizeof(uint32_t)));
+        c.ovf_idx_cap = n_buckets + 1;
+    }
+    c.ovf_idx_n = n_buckets + 1;
+    SP_HIP(ctx, hipMemcpyAsync(c.d_ovf_idx, seg_off, (size_t)(n_buckets + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return SP_OK;
 }
 int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
                           const uint32_t *seg_cnt, uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total) {

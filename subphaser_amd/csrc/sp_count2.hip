@@ -1025,6 +1025,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     if (n_units == 0) {
         if (!list) SP_HIP(ctx, hipMemsetAsync(c.d_tab, 0, (size_t)ctx->nslots, ctx->stream));
         c.n_ovf = 0;
+        c.ovf_idx_n = 0;
         return SP_OK;
     }
     const size_t nf = (size_t)P.n_fine;

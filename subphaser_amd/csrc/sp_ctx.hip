@@ -114,6 +114,9 @@ static void free_chrom(sp_chrom &c) {
     if (c.d_nm) hipFree(c.d_nm);
     if (c.d_tab && !c.tab_external) hipFree(c.d_tab);
     if (c.d_ovf) hipFree(c.d_ovf);
+    if (c.d_ovf_idx) hipFree(c.d_ovf_idx);
+    c.d_ovf_idx = nullptr;
+    c.ovf_idx_n = c.ovf_idx_cap = 0;
     if (c.ev_packed) hipEventDestroy(c.ev_packed);
     c = sp_chrom();
 }
@@ -207,6 +210,7 @@ int sp_genome_reset(sp_ctx *ctx, int n_chrom) {
             c.length_sum = 0;
             c.n_dump = 0;
             c.n_ovf = 0;
+            c.ovf_idx_n = 0;     // (the buffer stays; the next count's overflow pass fills it again)
         }
     } else {
         for (auto &c : ctx->chroms) free_chrom(c);

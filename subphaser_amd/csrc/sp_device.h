@@ -351,12 +351,27 @@ __device__ __forceinline__ uint32_t sp_ovf_lookup(const uint2 *__restrict__ ovf,
     }
     return (lo < n && ovf[lo].x == slot) ? ovf[lo].y : 255u;
 }
+// the same through the per-bucket index when the list has one: ~4 steps inside the bucket instead of ~17 over the list
+#define SP_OVF_SHIFT_ 15
+__device__ __forceinline__ uint32_t sp_ovf_lookup_t(const sp_tabref &t, uint32_t slot) {
+    if (!t.ovf_idx) return sp_ovf_lookup(t.ovf, t.n_ovf, slot);
+    const uint32_t b = slot >> SP_OVF_SHIFT_;
+    uint32_t lo = t.ovf_idx[b], hi = t.ovf_idx[b + 1];
+    const uint32_t end = hi;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (t.ovf[mid].x < slot) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < end && t.ovf[lo].x == slot) ? t.ovf[lo].y : 255u;
+}
 __device__ __forceinline__ uint32_t sp_tab_count(const sp_tabref &t, int64_t local, int64_t slot_base) {
     const uint32_t b = t.tab[local];
-    return b < 255u ? b : sp_ovf_lookup(t.ovf, t.n_ovf, (uint32_t)(slot_base + local));
+    return b < 255u ? b : sp_ovf_lookup_t(t, (uint32_t)(slot_base + local));
 }
 // overflow lists are produced bucket by bucket (2^15 consecutive slots), see sp_count2.hip / sp_count.hip
 #define SP_OVF_SHIFT 15
+static_assert(SP_OVF_SHIFT == SP_OVF_SHIFT_, "bucket width of the overflow index");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it
 // also drains every global load in flight, so a software pipeline that prefetches the next tile's keys across a

@@ -418,7 +418,7 @@ k3_slow(const sp_tabref *__restrict__ tabs, sp_filter_params P, unsigned long lo
             uint32_t y = (e[1 + r / 4] >> (8 * (r & 3))) & 255u;
             if (y == 255u) {
                 const sp_tabref t = tabs[P.rowdesc[r] & F3_CHROM_MASK];
-                y = sp_ovf_lookup(t.ovf, t.n_ovf, (uint32_t)(P.slot_base + sl));
+                y = sp_ovf_lookup_t(t, (uint32_t)(P.slot_base + sl));
             }
             mine[r] = y >= P.lower ? y : 0u;
         }
@@ -522,6 +522,7 @@ static sp_tabref filter_tab(sp_ctx *ctx, int i) {
     t.tab = c.d_tab;
     t.ovf = c.d_ovf;
     t.n_ovf = c.n_ovf;
+    t.ovf_idx = (c.ovf_idx_n > 0 && c.ovf_idx_n == ((ctx->nslots + (1LL << SP_OVF_SHIFT) - 1) >> SP_OVF_SHIFT) + 1) ? c.d_ovf_idx : nullptr;
     return t;
 }
 static int64_t filter_len(sp_ctx *ctx, int i) {

@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-: > gpurun_out/r04_fuzz_long.txt
-for seed in 70001 70002 70003 70004 70005 70006 70007 70008; do
-  t0=$SECONDS
-  ( timeout 900 python tools/fuzz_parity.py 15000 $seed 2>&1 | tail -2 ) >> gpurun_out/r04_fuzz_long.txt
-  echo "  (seed $seed: $((SECONDS - t0)) s)" >> gpurun_out/r04_fuzz_long.txt
-done
-cat gpurun_out/r04_fuzz_long.txt
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 )
+tools/ab_round.sh "ovfidx|||" "ovfidx_b|||" | grep -A1 Gbases
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/ab_ovfidx.json")); print({k:v["ms_per_step"] for k,v in d["stages"].items() if k.startswith("k3")}, d["host_wall_ms_per_step"])
+PY
+( timeout 300 python tools/fuzz_parity.py 2000 80808 2>&1 | tail -1 )
