@@ -1,7 +1,7 @@
 set -u
 # Round evidence on the GPU box (through gpurun, from the repo root): GPU suite, rocprofv3 kernel traces + stamped PMC
 # passes of the five bench workloads, their bench lines (in-run verification against the oracle), fuzz.
-export SP_COMMIT=00e6a4f
+export SP_COMMIT=82f03f1
 R=r04
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
