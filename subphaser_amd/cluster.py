@@ -270,13 +270,35 @@ def _wilcoxon_rows(a, b):
     return out
 
 
+# scipy releases whose per-call method rules the array forms below restate (wilcoxon: exact for n <= 50 without ties
+# or zeros, permutation for n <= 13, else asymptotic -- scipy 1.13; mannwhitneyu: exact unless both samples exceed 8
+# values or any value is tied) and whose `axis=` / `method=` keywords they rely on.  Checked against the row-wise
+# calls of 1.15 (tests/test_abi_and_host.py); any other release takes the row-wise loop (advisor r04).
+_SCIPY_ARRAY_RANGE = ((1, 13), (1, 17))
+
+
+def _scipy_array_ok(version=None):
+    if version is None:
+        import scipy
+        version = scipy.__version__
+    try:
+        v = tuple(int(x) for x in version.split(".")[:2])
+    except ValueError:
+        return False
+    return _SCIPY_ARRAY_RANGE[0] <= v < _SCIPY_ARRAY_RANGE[1]
+
+
 def _scipy_rows(name, a, b):
     """p-value of scipy.stats.<name>(a[i], b[i]) for every row (the reference calls the test per k-mer).
     mannwhitneyu: scipy's own axis argument, the rows split by the method a row-wise call picks (millions of rows in seconds); kruskal: the array form
     above (equal to the row-wise call, tests/test_abi_and_host.py); wilcoxon: _wilcoxon_rows; groups of unequal size
     (scipy raises for every row) fall through to the row-wise loop, which reports scipy's error."""
     from scipy import stats as st
-    if a.shape[0] and name == "mannwhitneyu":
+    if not _scipy_array_ok():
+        name_array = None        # an unvalidated scipy release: its own row-wise calls decide (slow, but its answers)
+    else:
+        name_array = name
+    if a.shape[0] and name_array == "mannwhitneyu":
         # method="auto" decides per CALL: exact unless both samples exceed 8 values or ANY value is tied -- so the rows
         # are split by what a row-wise call would have chosen for each of them
         n1, n2 = a.shape[1], b.shape[1]
@@ -289,9 +311,9 @@ def _scipy_rows(name, a, b):
         if (~exact).any():
             out[~exact] = st.mannwhitneyu(a[~exact], b[~exact], axis=1, method="asymptotic")[1]
         return out
-    if a.shape[0] and name == "kruskal":
+    if a.shape[0] and name_array == "kruskal":
         return _kruskal_rows(np.asarray(a, np.float64), np.asarray(b, np.float64))
-    if a.shape[0] and name == "wilcoxon" and a.shape[1] == b.shape[1] and a.shape[1] >= 2:      # (one pair: scipy's permutation branch raises)
+    if a.shape[0] and name_array == "wilcoxon" and a.shape[1] == b.shape[1] and a.shape[1] >= 2:      # (one pair: scipy's permutation branch raises)
         return _wilcoxon_rows(a, b)
     test = getattr(st, name)
     out = np.empty(a.shape[0])

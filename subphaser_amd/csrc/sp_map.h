@@ -82,29 +82,35 @@ __host__ __device__ __forceinline__ map_pair_loc map_pair_loc_suffix(uint64_t o,
     return r;
 }
 
-// ----------------------------------------------------------------- compact exact pair table (S <= 3, round 4)
+// ----------------------------------------------------------------- compact exact pair table (S <= 3; round 5: QUAD buckets)
 // The direct pair table is 4^(k-1) words (1 GiB at k = 15) for a few million used entries, and every gather from it
-// leaves the chip's caches (54 G/s).  With the gathers confined to <= 128 MB the same kernel ran 43-44 instead of
-// 50.8 ms per wheat-like pass (profiles/r03_notes.md): the 256-MB Infinity Cache serves them.  The tagged
-// open-addressing table of round 3 lost that again to its probe loops.  This one answers with ONE 8-byte load and no
-// loop: 2^bb buckets of two 32-bit entries; the canonical (k-1)-mer x goes through a BIJECTIVE mix of its 2(k-1) bits,
-// the top bb bits of the mix choose the bucket, the remaining tb <= 7 bits are the entry's tag -- bucket and tag
-// determine x, so a tag match is an exact match.  Entry: tag << 25 | overflow flag << 24 | eight 3-bit fields (label
-// 1..3 in the low two bits, "seen" in the third; the field order of the direct table).  0 = empty (an entry has at
-// least one label).  A key that finds both entries of its bucket taken goes to a small open-addressing overflow table
-// of {x + 1, fields} words and raises the flag in the bucket's first entry: only a look-up that matches neither
-// entry of a flagged bucket (about one in a thousand at the load chosen) probes further.
+// leaves the chip's caches (54 G/s).  Round 4 put the entries into 2^23 buckets of two tagged words behind a bijective
+// mix of the (k-1)-mer (64 MB, served by the Infinity Cache: one 8-byte load per candidate PAIR, 51 -> 46 ms per
+// wheat-like pass).  What is left of the map stage after the filter probes is exactly those look-ups (1.4 G per pass at
+// 12.8 ns per G), and labelled k-mers come in runs: the two pairs of a QUAD of starts 4g .. 4g+3 are almost always
+// candidates together.  Their (k-1)-mers x1 (at 4g+1) and x2 (at 4g+3) overlap in the (k-3)-mer s = suffix of x1 =
+// prefix of x2, so the table is now addressed by s: bucket = top bits of a bijective mix of the CANONICAL t = min(s,
+// rc(s)), FOUR tagged 32-bit entries per 16-byte bucket, and ONE 16-byte load answers all four starts of the quad.
+// An entry belongs to a (k-1)-mer y read in the orientation in which its (k-3)-mer at one end is canonical:
+//     side 0 ("L"):  y = e + t      side 1 ("R"):  y = t + e        e = the two bases beyond t (4 bits)
+// and holds the labels of the eight k-mers b + y and y + b in THAT orientation (field b / 4 + b, as in the direct
+// table).  Every (k-1)-mer of a labelled k-mer is entered twice -- under its prefix and under its suffix (k-3)-mer --
+// because which of the two a genome position shares with its neighbour pair depends on the position modulo 4.
+// Entry: tag << 25 | overflow flag << 24 | eight 3-bit fields (label 1..3, "seen" in the third bit); tag = the low tb
+// <= 2 bits of mix(t) << 5 | side << 4 | e; bucket + tag determine (t, side, e): a tag match is an exact match.
+// 0 = empty.  A key that finds its bucket full goes to a small open-addressing overflow table of {key id + 1, fields}
+// words and raises the flag in the bucket's first entry.
 #define MAP_CT_FIELD 3
 #define MAP_CT_ANY 0x6DB6DBu          // the label bits of all eight fields
 #define MAP_CT_PAYLOAD 0xFFFFFFu
 #define MAP_CT_OVF (1u << 24)
-#define MAP_CT_MAX_TAG_BITS 7
+#define MAP_CT_MAX_TAG_BITS 2         // bits of mix(t) in the tag (next to side and e)
 struct map_ptab {
     uint32_t *direct;                 // 4^(k-1) words, 4-bit fields (S <= 7), or NULL
-    uint2 *buckets;                   // compact table
-    unsigned long long *ovf;          // overflow table: (x + 1) << 32 | fields, 0 = empty
+    uint4 *buckets;                   // compact table: four entries per bucket
+    unsigned long long *ovf;          // overflow table: (key id + 1) << 32 | fields, 0 = empty
     uint32_t ovf_mask;                // its size - 1
-    int kb, tb;                       // key bits 2(k-1), tag bits
+    int sb, tb;                       // bits of the shared (k-3)-mer 2(k-3), bits of mix(t) kept in the tag
 };
 __host__ __device__ __forceinline__ uint32_t map_ct_mix(uint32_t x, int kb) {
     const uint32_t m = kb >= 32 ? 0xFFFFFFFFu : ((1u << kb) - 1u);
@@ -115,27 +121,41 @@ __host__ __device__ __forceinline__ uint32_t map_ct_mix(uint32_t x, int kb) {
     return h;
 }
 __host__ __device__ __forceinline__ uint32_t map_ct_ovf_home(uint32_t x) { return (x * 0xC2B2AE35u) >> 7; }
-// look x up: the eight fields (0: absent) and where they live (for the "seen" mark): bucket * 2 + entry, or
-// 0x80000000 | overflow slot
+struct map_ct_key {
+    uint32_t bucket, tag, kid;        // kid: (t, side, e) packed, the overflow table's key
+};
+__host__ __device__ __forceinline__ map_ct_key map_ct_key_of(const map_ptab &T, uint32_t t, uint32_t side, uint32_t e) {
+    const uint32_t h = map_ct_mix(t, T.sb);
+    map_ct_key r;
+    r.bucket = h >> T.tb;
+    r.tag = ((h & ((1u << T.tb) - 1u)) << 5) | (side << 4) | e;
+    r.kid = (t << 5) | (side << 4) | e;
+    return r;
+}
+// the eight fields of a key (0: absent) and where they live (for the "seen" mark): bucket * 4 + entry, or
+// 0x80000000 | overflow slot.  `B` = the key's bucket, already loaded.
 struct map_ct_hit {
     uint32_t fields, loc;
 };
-__device__ __forceinline__ map_ct_hit map_ct_lookup(const map_ptab &T, uint32_t x, bool want) {
+__device__ __forceinline__ map_ct_hit map_ct_find(const map_ptab &T, const uint4 &B, const map_ct_key &q) {
     map_ct_hit r;
+    const uint32_t w[4] = {B.x, B.y, B.z, B.w};
     r.fields = 0;
-    r.loc = 0;
-    const uint32_t h = map_ct_mix(x, T.kb), b = h >> T.tb, tag = h & ((1u << T.tb) - 1u);
-    uint2 e = make_uint2(0u, 0u);
-    if (want) e = T.buckets[b];
-    const bool m0 = (e.x >> 25) == tag && (e.x & MAP_CT_PAYLOAD), m1 = (e.y >> 25) == tag && (e.y & MAP_CT_PAYLOAD);
-    r.fields = m0 ? (e.x & MAP_CT_PAYLOAD) : (m1 ? (e.y & MAP_CT_PAYLOAD) : 0u);
-    r.loc = 2u * b + (m1 ? 1u : 0u);
-    if (!m0 && !m1 && (e.x & MAP_CT_OVF)) {        // rare: the bucket overflowed and x is in neither entry
-        uint32_t i = map_ct_ovf_home(x) & T.ovf_mask;
-        for (;;) {
+    r.loc = 4u * q.bucket;
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+        if ((w[i] >> 25) == q.tag && (w[i] & MAP_CT_PAYLOAD)) {
+            r.fields = w[i] & MAP_CT_PAYLOAD;
+            r.loc = 4u * q.bucket + (uint32_t)i;
+        }
+    if (!r.fields && (B.x & MAP_CT_OVF)) {         // rare: the bucket overflowed and the key is in none of its entries
+        uint32_t i = map_ct_ovf_home(q.kid) & T.ovf_mask;
+        // bounded like map_ct_insert's loop: a table that ended exactly full has no empty slot to stop an absent key
+        // (advisor r04; sp_labels_set also keeps the table at most half full)
+        for (uint32_t probes = 0; probes <= T.ovf_mask; probes++) {
             const unsigned long long o = T.ovf[i];
             if (o == 0ULL) break;
-            if ((uint32_t)(o >> 32) == x + 1u) {
+            if ((uint32_t)(o >> 32) == q.kid + 1u) {
                 r.fields = (uint32_t)o & MAP_CT_PAYLOAD;
                 r.loc = 0x80000000u | i;
                 break;
@@ -148,6 +168,33 @@ __device__ __forceinline__ map_ct_hit map_ct_lookup(const map_ptab &T, uint32_t 
 __device__ __forceinline__ void map_ct_mark(const map_ptab &T, uint32_t loc, uint32_t bits) {
     if (loc & 0x80000000u) atomicOr(&T.ovf[loc & 0x7fffffffu], (unsigned long long)bits);
     else atomicOr(reinterpret_cast<uint32_t *>(T.buckets) + loc, bits);
+}
+// The (up to four) table keys under which the k-mer `o` (ONE orientation, as given) is entered / found: its prefix and
+// its suffix (k-1)-mer, each under its prefix and its suffix (k-3)-mer -- but only where that (k-3)-mer is canonical AS
+// READ in this orientation (u <= rc(u)); the other orientation of the k-mer supplies the rest, and a palindromic
+// (k-3)-mer is entered from both (the scan meets it with either flank on either side).  k >= 4.
+struct map_ct_site {
+    uint32_t t, side, e;
+    int field;
+};
+__host__ __device__ __forceinline__ int map_ct_sites(uint64_t o, int k, map_ct_site out[4]) {
+    const int sb = 2 * (k - 3);
+    const uint64_t m1mask = (1ULL << (2 * (k - 1))) - 1ULL, smask = (1ULL << sb) - 1ULL;
+    const uint64_t x[2] = {o >> 2, o & m1mask};                                  // prefix / suffix (k-1)-mer
+    const int field[2] = {4 + (int)(o & 3ULL), (int)((o >> (2 * (k - 1))) & 3ULL)};      // o = x + b  /  o = b + x
+    int n = 0;
+    for (int i = 0; i < 2; i++) {
+        const uint64_t u1 = x[i] >> 4, u2 = x[i] & smask;
+        if (u1 <= sp_revcomp(u1, k - 3)) {       // x = u1 + e: side R
+            out[n].t = (uint32_t)u1; out[n].side = 1u; out[n].e = (uint32_t)(x[i] & 15ULL); out[n].field = field[i];
+            n++;
+        }
+        if (u2 <= sp_revcomp(u2, k - 3)) {       // x = e + u2: side L
+            out[n].t = (uint32_t)u2; out[n].side = 0u; out[n].e = (uint32_t)(x[i] >> sb); out[n].field = field[i];
+            n++;
+        }
+    }
+    return n;
 }
 
 // ----------------------------------------------------------------- K5

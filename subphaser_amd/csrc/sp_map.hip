@@ -123,33 +123,35 @@ k4_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, cons
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
+#ifdef MAP_EXP_COUNT
+__device__ unsigned long long g_map_dbg[4];
+#endif
 // ----------------------------------------------------------------- K4c: compact pair table (sp_map.h), S <= 3
-// insert-or-find x, then OR the field in.  Both entries of a bucket are tried in order and never freed, so two threads
-// that insert the same x meet in the same entry; a bucket with two foreign entries raises its overflow flag and the
-// key goes to the overflow table (linear probing; *fail is set when that table is full -- the host then falls back
-// to the direct table).
-__device__ __forceinline__ void map_ct_insert(const map_ptab &T, uint32_t x, uint32_t bits, unsigned long long *fail) {
-    const uint32_t h = map_ct_mix(x, T.kb), b = h >> T.tb, tag = h & ((1u << T.tb) - 1u);
-    uint32_t *e = reinterpret_cast<uint32_t *>(T.buckets + b);
-    const uint32_t fresh = (tag << 25) | bits;
-    for (int i = 0; i < 2; i++) {
+// insert-or-find a key, then OR the field in.  The four entries of a bucket are tried in order and never freed, so two
+// threads that insert the same key meet in the same entry; a bucket with four foreign entries raises its overflow flag
+// and the key goes to the overflow table (linear probing; *fail is set when that table is full -- the host then falls
+// back to the direct table).
+__device__ __forceinline__ void map_ct_insert(const map_ptab &T, const map_ct_key &q, uint32_t bits, unsigned long long *fail) {
+    uint32_t *e = reinterpret_cast<uint32_t *>(T.buckets + q.bucket);
+    const uint32_t fresh = (q.tag << 25) | bits;
+    for (int i = 0; i < 4; i++) {
         const uint32_t old = atomicCAS(&e[i], 0u, fresh);
         if (old == 0u) return;
-        if ((old >> 25) == tag && (old & MAP_CT_PAYLOAD)) {
+        if ((old >> 25) == q.tag && (old & MAP_CT_PAYLOAD)) {
             atomicOr(&e[i], bits);
             return;
         }
     }
     atomicOr(&e[0], MAP_CT_OVF);
-    const unsigned long long mine = ((unsigned long long)(x + 1u) << 32) | bits;
-    uint32_t i = map_ct_ovf_home(x) & T.ovf_mask;
+    const unsigned long long mine = ((unsigned long long)(q.kid + 1u) << 32) | bits;
+    uint32_t i = map_ct_ovf_home(q.kid) & T.ovf_mask;
     for (uint32_t probes = 0; probes <= T.ovf_mask; probes++) {
         const unsigned long long old = atomicCAS(&T.ovf[i], 0ULL, mine);
         if (old == 0ULL) {
             atomicAdd(fail + 1, 1ULL);      // (statistics: keys in the overflow table)
             return;
         }
-        if ((uint32_t)(old >> 32) == x + 1u) {
+        if ((uint32_t)(old >> 32) == q.kid + 1u) {
             atomicOr(&T.ovf[i], (unsigned long long)bits);
             return;
         }
@@ -162,45 +164,185 @@ k4_ctab_build(const unsigned long long *__restrict__ keys, const uint8_t *__rest
               unsigned long long *__restrict__ fail) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t key = keys[i], r = sp_revcomp(key, k);
+    const uint64_t o2[2] = {keys[i], sp_revcomp(keys[i], k)};
     const uint32_t l = 1u + sg[i];
-    const map_pair_loc a = map_pair_loc_prefix(key, k), b = map_pair_loc_suffix(key, k);
-    const map_pair_loc c = map_pair_loc_prefix(r, k), d = map_pair_loc_suffix(r, k);
-    map_ct_insert(T, a.idx, l << (MAP_CT_FIELD * a.field), fail);
-    map_ct_insert(T, b.idx, l << (MAP_CT_FIELD * b.field), fail);
-    // (the reverse complement leads to the same two fields unless a (k-1)-mer is its own reverse complement)
-    if (c.idx != b.idx || c.field != b.field) map_ct_insert(T, c.idx, l << (MAP_CT_FIELD * c.field), fail);
-    if (d.idx != a.idx || d.field != a.field) map_ct_insert(T, d.idx, l << (MAP_CT_FIELD * d.field), fail);
+    // each (k-1)-mer / (k-3)-mer combination is canonical-as-read in exactly one of the two orientations (in both for a
+    // palindromic (k-3)-mer; a palindromic k-mer, even k, enters the same fields twice: idempotent)
+    for (int r = 0; r < 2; r++) {
+        map_ct_site st[4];
+        const int ns = map_ct_sites(o2[r], k, st);
+        for (int j = 0; j < ns; j++)
+            map_ct_insert(T, map_ct_key_of(T, st[j].t, st[j].side, st[j].e), l << (MAP_CT_FIELD * st[j].field), fail);
+    }
 }
 __global__ void __launch_bounds__(256)
 k4_ctab_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, map_ptab T, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long red[16];
     unsigned long long c = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = keys[i], r = sp_revcomp(key, k);
-        const map_pair_loc L[4] = {map_pair_loc_prefix(key, k), map_pair_loc_suffix(key, k), map_pair_loc_prefix(r, k),
-                                   map_pair_loc_suffix(r, k)};
+        const uint64_t o2[2] = {keys[i], sp_revcomp(keys[i], k)};
         uint32_t seen = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) seen |= (map_ct_lookup(T, L[j].idx, true).fields >> (MAP_CT_FIELD * L[j].field)) & 4u;
+        for (int r = 0; r < 2; r++) {
+            map_ct_site st[4];
+            const int ns = map_ct_sites(o2[r], k, st);
+            for (int j = 0; j < ns; j++) {
+                const map_ct_key q = map_ct_key_of(T, st[j].t, st[j].side, st[j].e);
+                const uint4 B = T.buckets[q.bucket];
+                seen |= (map_ct_find(T, B, q).fields >> (MAP_CT_FIELD * st[j].field)) & 4u;
+            }
+        }
         c += seen ? 1 : 0;
     }
     unsigned long long t = sp_block_sum_u64(c, red);
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
+// The compact-table form of the same walk, batched for memory-level parallelism (round 5).  Measured on the wheat-like
+// pass: 1.55 G candidate pairs but only 0.96 G candidate QUADS, and yet the quad-bucket table did not move the kernel
+// (45.9 ms) -- the look-ups are not bound by their number but by how many are in flight: one load instruction per wave
+// and quad with ~16 of 64 lanes active, 24 waves per CU, ~2 us per miss = 49 G look-ups/s.  So a lane now issues the
+// filter probes of MAP_QB quads (2 MAP_QB pairs) together, then the bucket loads of all candidate quads among them,
+// then takes the hits in position order: 2 memory round trips per MAP_QB quads instead of 2 per quad.
+#ifndef MAP_QB
+#define MAP_QB 4
+#endif
+template <typename F>
+__device__ __forceinline__ void map_quad_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
+                                                const uint32_t *__restrict__ bloom, int nbits,
+                                                const map_ptab &T, F &&hit) {
+    constexpr int FW = MAP_CT_FIELD;
+    constexpr uint32_t LBL = 3u, SEEN = 4u, FMASK = 7u;
+    constexpr int QB = MAP_QB, PB = 2 * MAP_QB;
+    static_assert(8 % QB == 0, "a 32-start unit holds 8 quads");
+    const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
+    const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+    const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
+    const uint32_t ok_x = ~(uint32_t)(bad_k1 >> 1);                    // (k-1)-mer starting at s0+j+1
+    if (__all((ok_x & 0x55555555u) == 0)) return;
+    const sp_words32 x = sp_load_words32(pk, pm, s0);
+    const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
+    const uint32_t m1mask = kp.kmask >> 2;
+    const int sb = T.sb;
+    const uint32_t smask = (1u << sb) - 1u;
+    auto xf_of = [&](uint32_t V) { return (V >> sh) & m1mask; };      // the pair's shared (k-1)-mer, forward, key order
+    auto xr_of = [&](uint32_t W) { return (~W >> 2) & m1mask; };      // its reverse complement
+#pragma unroll
+    for (int g0 = 0; g0 < 8; g0 += QB) {
+        // A: the filter probes of the batch (the windows are cheap to extract again later: nothing but wd[] is kept)
+        uint32_t wd[PB];
+#pragma unroll
+        for (int q = 0; q < PB; q++) {
+            const int j = 2 * (2 * g0 + q);
+            const uint32_t xf = xf_of(sp_win_msb_at(x, j)), xr = xr_of(sp_win_lsb_at(x, j));
+            const map_bloom_probe p = map_bloom((uint64_t)(xf < xr ? xf : xr), nbits);
+#ifdef MAP_EXP_NOPROBE
+            wd[q] = xf;
+#else
+            wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
+#endif
+        }
+        // B: candidates, then one bucket load per candidate quad
+        uint32_t candm = 0;
+#pragma unroll
+        for (int q = 0; q < PB; q++) {
+            const int j = 2 * (2 * g0 + q);
+            const uint32_t xf = xf_of(sp_win_msb_at(x, j)), xr = xr_of(sp_win_lsb_at(x, j));
+            const uint32_t canon = xf < xr ? xf : xr;
+            const uint32_t want = map_bloom((uint64_t)canon, nbits).bits;
+#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)
+            const bool cand = (wd[q] & want) == want && canon == ((uint32_t)nbits | 0x20000000u);
+#else
+            const bool cand = (wd[q] & want) == want;
+#endif
+            candm |= (cand ? 1u : 0u) << q;
+        }
+        uint4 B[QB];
+#pragma unroll
+        for (int g = 0; g < QB; g++) {
+            B[g] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t cm = (candm >> (2 * g)) & 3u;
+            if (cm) {
+                // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
+                const int j1 = 2 * (2 * (g0 + g)), j2 = j1 + 2;
+                const uint32_t s_f = (cm & 1u) ? (xf_of(sp_win_msb_at(x, j1)) & smask) : (xf_of(sp_win_msb_at(x, j2)) >> 4);
+                const uint32_t s_r = (cm & 1u) ? (xr_of(sp_win_lsb_at(x, j1)) >> 4) : (xr_of(sp_win_lsb_at(x, j2)) & smask);
+                const uint32_t t = s_f <= s_r ? s_f : s_r;
+                B[g] = T.buckets[map_ct_mix(t, sb) >> T.tb];
+            }
+        }
+#ifdef MAP_EXP_COUNT
+        {
+            unsigned long long any = 0;
+            uint32_t np = __popc(candm), nq = 0;
+            for (int g = 0; g < QB; g++) nq += ((candm >> (2 * g)) & 3u) ? 1u : 0u;
+            for (int o = 32; o > 0; o >>= 1) { np += __shfl_down(np, o, 64); nq += __shfl_down(nq, o, 64); }
+            any = __ballot(candm != 0);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&g_map_dbg[0], (unsigned long long)np);
+                atomicAdd(&g_map_dbg[1], (unsigned long long)nq);
+                atomicAdd(&g_map_dbg[2], 1ULL);
+                atomicAdd(&g_map_dbg[3], any ? 1ULL : 0ULL);
+            }
+        }
+#endif
+        // C: the hits, in position order
+#pragma unroll
+        for (int g = 0; g < QB; g++) {
+            const uint32_t cm = (candm >> (2 * g)) & 3u;
+            if (!cm) continue;
+            const int j1 = 2 * (2 * (g0 + g)), j2 = j1 + 2;
+            const uint32_t V1 = sp_win_msb_at(x, j1), V2 = sp_win_msb_at(x, j2);
+            const uint32_t xf1 = xf_of(V1), xr1 = xr_of(sp_win_lsb_at(x, j1));
+            const uint32_t xf2 = xf_of(V2), xr2 = xr_of(sp_win_lsb_at(x, j2));
+            const uint32_t s_f = (cm & 1u) ? (xf1 & smask) : (xf2 >> 4), s_r = (cm & 1u) ? (xr1 >> 4) : (xr2 & smask);
+            const bool sfw = s_f <= s_r;
+            const uint32_t t = sfw ? s_f : s_r;
+            // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+            const map_ct_key k1 = map_ct_key_of(T, t, sfw ? 0u : 1u, sfw ? (xf1 >> sb) : (xr1 & 15u));
+            const map_ct_key k2 = map_ct_key_of(T, t, sfw ? 1u : 0u, sfw ? (xf2 & 15u) : (xr2 >> sb));
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (!((cm >> h) & 1u)) continue;
+                const map_ct_hit r = map_ct_find(T, B[g], h ? k2 : k1);
+                if (!(r.fields & MAP_CT_ANY)) continue;
+#ifdef MAP_EXP_NOHIT    // bound experiment: probes and look-ups as they are, no hit is ever taken (wrong answers)
+                if (r.fields != ((uint32_t)nbits | 0x200000u)) continue;
+#endif
+                const int j = h ? j2 : j1;
+                const uint32_t V = h ? V2 : V1;
+                const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
+                // the fields are laid out in the orientation in which t is canonical
+                const int f0 = sfw ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
+                const int f1 = sfw ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
+                const uint32_t v0 = ((ok_k >> j) & 1u) ? (r.fields >> (FW * f0)) & FMASK : 0u;
+                const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (r.fields >> (FW * f1)) & FMASK : 0u;
+                uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
+                if ((v0 & LBL) && hit(s0 + j, (int)(v0 & LBL) - 1) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+                if ((v1 & LBL) && hit(s0 + j + 1, (int)(v1 & LBL) - 1) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+                if (mark) map_ct_mark(T, r.loc, mark);           // "seen": first touch only
+            }
+        }
+    }
+}
+
 // Walk the 32 starts [s0, s0+32) pair by pair: ONE filter probe per pair, ONE pair-table gather per
 // candidate pair; hit(start, sg) for every valid start that carries a labelled k-mer.  k <= 15.
-// COMPACT: the exact table is the compact one (3-bit fields, one 8-byte bucket load), else the direct one (4-bit fields).
+// COMPACT: the exact table is the compact one (3-bit fields; the two pairs of a QUAD of starts share one 16-byte
+// bucket load, sp_map.h), else the direct one (4-bit fields, one 4-byte gather per candidate pair).
 template <bool COMPACT, typename F>
 __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                 const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
                                                 const uint32_t *__restrict__ bloom, int nbits,
                                                 const map_ptab &T, F &&hit) {
-    constexpr int FW = COMPACT ? MAP_CT_FIELD : 4;
-    constexpr uint32_t LBL = COMPACT ? 3u : 7u, SEEN = COMPACT ? 4u : 8u, FMASK = COMPACT ? 7u : 15u;
-    constexpr uint32_t ANY = COMPACT ? MAP_CT_ANY : 0x77777777u;
-    constexpr int BATCH = COMPACT ? MAP_BATCH_COMPACT : MAP_BATCH;
+    if (COMPACT) {
+        map_quad_scan32(pk, pm, nm, s0, kp, bloom, nbits, T, hit);
+        return;
+    }
+    constexpr int FW = 4;
+    constexpr uint32_t LBL = 7u, SEEN = 8u, FMASK = 15u;
+    constexpr uint32_t ANY = 0x77777777u;
+    constexpr int BATCH = MAP_BATCH;
     const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
     const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
     const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
@@ -235,20 +377,20 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
 #endif
         }
+        bool cand[BATCH];
 #pragma unroll
         for (int q = 0; q < BATCH; q++) {
 #if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)   // bound experiment: scan + filter probes, no exact look-up
             // (wrong answers; canon is below 2^28 and never equals the value it is compared with, which the compiler cannot know)
-            const bool cand = (wd[q] & want[q]) == want[q] && canon[q] == ((uint32_t)nbits | 0x20000000u);
+            cand[q] = (wd[q] & want[q]) == want[q] && canon[q] == ((uint32_t)nbits | 0x20000000u);
 #else
-            const bool cand = (wd[q] & want[q]) == want[q];
+            cand[q] = (wd[q] & want[q]) == want[q];
 #endif
-            if (COMPACT) {
-                const map_ct_hit r = map_ct_lookup(T, canon[q], cand);
-                e[q] = r.fields;
-                loc[q] = r.loc;
-            } else {
-                e[q] = cand ? T.direct[canon[q]] : 0u;
+        }
+        {
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) {
+                e[q] = cand[q] ? T.direct[canon[q]] : 0u;
                 loc[q] = canon[q];
             }
         }
@@ -264,10 +406,7 @@ __device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk,
             uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
             if ((v0 & LBL) && hit(s0 + j, (int)(v0 & LBL) - 1) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
             if ((v1 & LBL) && hit(s0 + j + 1, (int)(v1 & LBL) - 1) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
-            if (mark) {                                        // "seen": first touch only
-                if (COMPACT) map_ct_mark(T, loc[q], mark);
-                else atomicOr(&T.direct[loc[q]], mark);
-            }
+            if (mark) atomicOr(&T.direct[loc[q]], mark);       // "seen": first touch only
         }
     }
 }
@@ -285,8 +424,11 @@ struct map_chrom_desc {
     unsigned long long *n_mapped;
 };
 
+#ifndef MAP_MIN_WAVES
+#define MAP_MIN_WAVES 1     // waves per SIMD the register allocation must leave room for
+#endif
 template <bool COMPACT>
-__global__ void __launch_bounds__(MAP_BLOCK)
+__global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
 k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, sp_kparams32 kp, sp_map_params P,
        map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
     __shared__ int hist[MAP_LDS_ENTRIES];
@@ -366,15 +508,261 @@ k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, s
     flush_mapped();
 }
 
+#ifndef MAP_MIN_WAVES
+#define MAP_MIN_WAVES 1     // waves per SIMD the register allocation must leave room for
+#endif
+// ----------------------------------------------------------------- K5, round 5: the same walk in 1/30 of the code
+// k5_map above is 258 KB of machine code (k5_map_sparse: 532 KB): sixteen fully unrolled copies of the quad walk,
+// each with four inlined copies of the hit path (64-bit divisions for the output slot, an LDS flush loop, the overflow
+// probe loop).  The instruction cache holds 64 KB.  Every wave therefore streams the whole kernel from the L2 once
+// per 64 starts -- ~14 G instruction-line requests per wheat-like pass next to the 7 G filter probes the kernel was
+// believed to be bound by, and the reason why no change to its memory accesses ever moved it (quad buckets: 1.55 G ->
+// 0.96 G look-ups, same 45.9 ms; more loads in flight per lane: slower).  k5_map2 keeps the loop over the quads of a
+// unit ROLLED (windows by run-time shifts out of a rotating pair of registers per stream), records a hit as a bit in
+// three 64-bit label planes instead of calling into the slot arithmetic, and settles a unit's hits once: popcounts
+// into the range's LDS histogram when the whole range lies in one output slot run (the common case; the boundaries
+// are found once per range), the general walk otherwise.  TABLE: 1 = compact quad buckets (S <= 3), 0 = direct pair
+// table (S <= 7).
+#ifndef MAP2_QI
+#define MAP2_QI 1      // quads per inner iteration (their probes, then their bucket loads, travel together)
+#endif
+template <int TABLE>
+__device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
+                                                const uint32_t *__restrict__ bloom, int nbits, const map_ptab &T,
+                                                unsigned long long lab[3]) {
+    constexpr int FW = TABLE ? MAP_CT_FIELD : 4;
+    constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
+    constexpr uint32_t ANY = TABLE ? MAP_CT_ANY : 0x77777777u;
+    // validity of the 64 starts: k-mer at s0+j, shared (k-1)-mer at s0+j+1
+    unsigned long long ok_k, ok_x;
+    {
+        const uint64_t badA = sp_bad_starts64(nm, s0, kp.k - 1), badB = sp_bad_starts64(nm, s0 + 32, kp.k - 1);
+        const uint64_t invA = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+        const uint64_t invB = (uint64_t)nm[(s0 >> 5) + 1] | ((uint64_t)nm[(s0 >> 5) + 2] << 32);
+        const uint32_t kA = ~(uint32_t)(badA | (invA >> (kp.k - 1))), kB = ~(uint32_t)(badB | (invB >> (kp.k - 1)));
+        const uint32_t xA = ~(uint32_t)(badA >> 1), xB = ~(uint32_t)(badB >> 1);
+        ok_k = (unsigned long long)kA | ((unsigned long long)kB << 32);
+        ok_x = (unsigned long long)xA | ((unsigned long long)xB << 32);
+    }
+    if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
+    const int64_t w0 = s0 >> 4;   // a multiple of 4: 16-byte aligned
+    const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0), ma = *reinterpret_cast<const uint4 *>(pm + w0);
+    uint32_t l0 = la.x, l1 = la.y, l2 = la.z, l3 = la.w, l4 = pk[w0 + 4];
+    uint32_t m0 = ma.x, m1 = ma.y, m2 = ma.z, m3 = ma.w, m4 = pm[w0 + 4];
+    const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
+    const uint32_t m1mask = kp.kmask >> 2;
+    const int sb = T.sb;
+    const uint32_t smask = TABLE ? ((1u << sb) - 1u) : 0u;
+    constexpr int QI = MAP2_QI;
+    static_assert(QI == 1 || QI == 2 || QI == 4, "quads per inner iteration");
+#pragma unroll 1
+    for (int w = 0; w < 4; w++) {
+#pragma unroll 1
+        for (int r0 = 0; r0 < 16; r0 += 4 * QI) {
+            // QI quads per iteration: their filter probes travel together, then the bucket loads of the candidate quads
+            uint32_t V1[QI], V2[QI], xf1[QI], xr1[QI], xf2[QI], xr2[QI], c1[QI], c2[QI], wd1[QI], wd2[QI], okk[QI];
+            map_bloom_probe p1[QI], p2[QI];
+#pragma unroll
+            for (int q = 0; q < QI; q++) {
+                const int r = r0 + 4 * q, j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
+                // 16-base windows at j and j + 2: LSB-first out of {l1, l0}, MSB-first out of {m0, m1}
+                const uint32_t W1 = __builtin_amdgcn_alignbit(l1, l0, 2 * r), W2 = __builtin_amdgcn_alignbit(l1, l0, 2 * r + 4);
+                const unsigned long long mm = ((unsigned long long)m0 << 32) | m1;
+                V1[q] = (uint32_t)((mm << (2 * r)) >> 32);
+                V2[q] = (uint32_t)((mm << (2 * r + 4)) >> 32);
+                xf1[q] = (V1[q] >> sh) & m1mask;       // x1 forward / reverse complement, key order
+                xr1[q] = (~W1 >> 2) & m1mask;
+                xf2[q] = (V2[q] >> sh) & m1mask;
+                xr2[q] = (~W2 >> 2) & m1mask;
+                c1[q] = xf1[q] < xr1[q] ? xf1[q] : xr1[q];
+                c2[q] = xf2[q] < xr2[q] ? xf2[q] : xr2[q];
+                p1[q] = map_bloom((uint64_t)c1[q], nbits);
+                p2[q] = map_bloom((uint64_t)c2[q], nbits);
+                const uint32_t okx = (uint32_t)(ok_x >> j);
+                okk[q] = (uint32_t)(ok_k >> j);
+                wd1[q] = wd2[q] = 0;
+#ifdef MAP_EXP_NOPROBE      // bound experiments (tools/build_variant.sh): wrong answers, conditions the compiler cannot resolve
+                wd1[q] = c1[q];
+                wd2[q] = c2[q];
+#else
+                if (okx & 1u) wd1[q] = bloom[p1[q].word];
+                if (okx & 4u) wd2[q] = bloom[p2[q].word];
+#endif
+            }
+            bool cand1[QI], cand2[QI], sfw[QI];
+            uint4 B[QI];
+            map_ct_key k1[QI], k2[QI];
+            uint32_t e1[QI], e2[QI];
+#pragma unroll
+            for (int q = 0; q < QI; q++) {
+#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)
+                cand1[q] = (wd1[q] & p1[q].bits) == p1[q].bits && c1[q] == ((uint32_t)nbits | 0x200000u);
+                cand2[q] = (wd2[q] & p2[q].bits) == p2[q].bits && c2[q] == ((uint32_t)nbits | 0x200000u);
+#else
+                cand1[q] = (wd1[q] & p1[q].bits) == p1[q].bits;
+                cand2[q] = (wd2[q] & p2[q].bits) == p2[q].bits;
+#endif
+                e1[q] = e2[q] = 0;
+                B[q] = make_uint4(0u, 0u, 0u, 0u);
+                if (TABLE) {
+                    // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
+                    const uint32_t s_f = cand1[q] ? (xf1[q] & smask) : (xf2[q] >> 4), s_r = cand1[q] ? (xr1[q] >> 4) : (xr2[q] & smask);
+                    sfw[q] = s_f <= s_r;
+                    const uint32_t t = sfw[q] ? s_f : s_r;
+                    // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+                    k1[q] = map_ct_key_of(T, t, sfw[q] ? 0u : 1u, sfw[q] ? (xf1[q] >> sb) : (xr1[q] & 15u));
+                    k2[q] = map_ct_key_of(T, t, sfw[q] ? 1u : 0u, sfw[q] ? (xf2[q] & 15u) : (xr2[q] >> sb));
+                    if (cand1[q] || cand2[q]) B[q] = T.buckets[k1[q].bucket];
+                } else {
+                    if (cand1[q]) e1[q] = T.direct[c1[q]];
+                    if (cand2[q]) e2[q] = T.direct[c2[q]];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QI; q++) {
+                if (!(cand1[q] || cand2[q])) continue;
+                const int j = 16 * w + r0 + 4 * q;
+                uint32_t loc1 = c1[q], loc2 = c2[q];
+                bool fw1 = xf1[q] <= xr1[q], fw2 = xf2[q] <= xr2[q];
+                if (TABLE) {
+                    if (cand1[q]) {
+                        const map_ct_hit h = map_ct_find(T, B[q], k1[q]);
+                        e1[q] = h.fields;
+                        loc1 = h.loc;
+                    }
+                    if (cand2[q]) {
+                        const map_ct_hit h = map_ct_find(T, B[q], k2[q]);
+                        e2[q] = h.fields;
+                        loc2 = h.loc;
+                    }
+                    fw1 = fw2 = sfw[q];       // the fields are laid out in the orientation in which t is canonical
+                }
+                // the (up to four) labelled starts of the quad: start j + 2h = b0 + x, start j + 2h + 1 = x + b1
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t e = h ? e2[q] : e1[q];
+                    if (!(e & ANY)) continue;
+#ifdef MAP_EXP_NOHIT
+                    if (e != ((uint32_t)nbits | 0x200000u)) continue;
+#endif
+                    const uint32_t V = h ? V2[q] : V1[q];
+                    const bool fw = h ? fw2 : fw1;
+                    const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
+                    const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
+                    const uint32_t v0 = ((okk[q] >> (2 * h)) & 1u) ? (e >> (FW * f0)) & FMASK : 0u;
+                    const uint32_t v1 = ((okk[q] >> (2 * h + 1)) & 1u) ? (e >> (FW * f1)) & FMASK : 0u;
+                    const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
+                    if (!two) continue;
+#pragma unroll
+                    for (int bit = 0; bit < (TABLE ? 2 : 3); bit++)
+                        lab[bit] |= (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1)) << (j + 2 * h);
+                    uint32_t mark = 0;       // "seen": first touch only
+                    if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+                    if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+                    if (mark) {
+                        if (TABLE) map_ct_mark(T, h ? loc2 : loc1, mark);
+                        else atomicOr(&T.direct[h ? loc2 : loc1], mark);
+                    }
+                }
+            }
+        }
+        l0 = l1; l1 = l2; l2 = l3; l3 = l4;
+        m0 = m1; m1 = m2; m2 = m3; m3 = m4;
+    }
+}
+
+template <int TABLE>
+__global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
+k5_map2(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, sp_kparams32 kp, sp_map_params P,
+        map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
+    __shared__ int hist[MAP_LDS_ENTRIES];
+    __shared__ unsigned long long red[16];
+    unsigned long long mapped = 0;
+    int cur = -1;          // chromosome the block is accumulating `mapped` for
+    auto flush_mapped = [&]() {     // block-uniform control flow
+        if (cur < 0) return;
+        const unsigned long long t = sp_block_sum_u64(mapped, red);
+        if (threadIdx.x == 0 && t) atomicAdd(desc[cur].n_mapped, t);
+        mapped = 0;
+    };
+    for (int64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        int lo = 0, hi = n_chrom;              // last chromosome with range0 <= rg (uniform: scalar loads)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (desc[mid].range0 <= rg) lo = mid;
+            else hi = mid;
+        }
+        if (lo != cur) {
+            flush_mapped();
+            cur = lo;
+        }
+        const map_chrom_desc D = desc[lo];
+        const int64_t r = rg - D.range0;
+        const int64_t u = r * MAP_BLOCK + threadIdx.x;
+        // the range's first output slot and where it ends (uniform; once per range, not per hit)
+        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k), end_lo = map_slot_end(r * MAP_RANGE, P, kp.k);
+        const bool one_slot = end_lo >= (r + 1) * MAP_RANGE;
+        if (P.use_lds) {
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        if (u < D.n_units) {
+            unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+            map_unit_scan64<TABLE>(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab);
+            if (lab[0] | lab[1] | lab[2]) {
+                auto add = [&](int64_t os, unsigned long long within) {       // the unit's hits among the starts `within` -> slot os
+                    for (int sg = 0; sg < P.S; sg++) {
+                        const int l = sg + 1;
+                        const unsigned long long m = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) &
+                                                     ((l & 4) ? lab[2] : ~lab[2]) & within;
+                        const int v = __popcll(m);
+                        if (!v) continue;
+                        if (P.use_lds) atomicAdd(&hist[(int)(os - slot_lo) * P.S + sg], v);
+                        else if (os < D.nslots) atomicAdd(&D.counts[os * P.S + sg], v);
+                        mapped += v;
+                    }
+                };
+                const int64_t s0 = u * SP_UNIT;
+                if (one_slot) {
+                    add(slot_lo, ~0ULL);
+                } else {
+                    int64_t p = s0;
+                    while (p < s0 + SP_UNIT) {
+                        int64_t e = map_slot_end(p, P, kp.k);
+                        if (e > s0 + SP_UNIT) e = s0 + SP_UNIT;
+                        const int a = (int)(p - s0), b = (int)(e - s0);      // starts [a, b) of the unit
+                        const unsigned long long within = (b >= 64 ? ~0ULL : ((1ULL << b) - 1ULL)) & ~((1ULL << a) - 1ULL);
+                        if ((lab[0] | lab[1] | lab[2]) & within) add(map_slot(p, P, kp.k), within);
+                        p = e;
+                    }
+                }
+            }
+        }
+        if (P.use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
+                int v = hist[i];
+                if (v) {
+                    int64_t os = slot_lo + i / P.S;
+                    if (os < D.nslots) atomicAdd(&D.counts[os * P.S + (i % P.S)], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    flush_mapped();
+}
+
 // the exact pair table the current label set lives in (compact when ctx->ct_bb != 0)
 static map_ptab map_ptab_of(const sp_ctx *ctx) {
     map_ptab T;
     T.direct = ctx->ct_bb ? nullptr : (uint32_t *)ctx->b_ptab.p;
-    T.buckets = ctx->ct_bb ? (uint2 *)ctx->b_ctab.p : nullptr;
+    T.buckets = ctx->ct_bb ? (uint4 *)ctx->b_ctab.p : nullptr;
     T.ovf = (unsigned long long *)ctx->b_covf.p;
     T.ovf_mask = ctx->ct_ovf_mask;
-    T.kb = 2 * (ctx->k - 1);
-    T.tb = T.kb - ctx->ct_bb;
+    T.sb = 2 * (ctx->k - 3);
+    T.tb = ctx->ct_bb ? T.sb - ctx->ct_bb : 0;
     return T;
 }
 
@@ -390,9 +778,27 @@ static int map_launch_dense(sp_ctx *ctx, const std::vector<map_chrom_desc> &hd, 
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
     const map_ptab T = map_ptab_of(ctx);
+    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the fully unrolled kernels of rounds 2-4 (cross-check)
+    if (!(env_mk && env_mk[0] == '1')) {
+        if (T.buckets)
+            SP_LAUNCH(ctx, "k5_map", k5_map2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+                      (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+        else
+            SP_LAUNCH(ctx, "k5_map", k5_map2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+                      (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+        return SP_OK;
+    }
     if (T.buckets)
+    {
         SP_LAUNCH(ctx, "k5_map", k5_map<true>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
                   (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
+#ifdef MAP_EXP_COUNT
+        unsigned long long h[4];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_map_dbg), 32);
+        fprintf(stderr, "[sp] k5_map (cumulative): %llu candidate pairs, %llu candidate quads, %llu quad wave-steps, %llu of them load\n", h[0], h[1], h[2], h[3]);
+#endif
+    }
     else
         SP_LAUNCH(ctx, "k5_map", k5_map<false>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
                   (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
@@ -735,6 +1141,15 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
     }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (!ctx->h_lflags) SP_HIP(ctx, hipHostMalloc((void **)&ctx->h_lflags, 64, hipHostMallocDefault));
+    if (on_device && n > 0) {
+        // the labels are checked BEFORE any table is touched (one more round trip of a 64-byte flag block, ~20 us): a
+        // bad hand-over must leave the previous label set intact -- and must not leave labels >= n_sg in the hashed
+        // table of the k > 15 engine (advisor r04)
+        SP_LAUNCH(ctx, "k4_flags_out", k4_flags_out, dim3(1), dim3(64), 0, (const unsigned long long *)d_flags, ctx->h_lflags);
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((int)(unsigned int)ctx->h_lflags[0] >= n_sg)
+            return sp_fail(ctx, SP_EINVAL, "sp_labels_set: label %d >= n_sg %d", (int)(unsigned int)ctx->h_lflags[0], n_sg);
+    }
     auto label_check = [&]() -> int {      // after k4_flags_out and a synchronisation of the stream
         if (!(on_device && n > 0)) return SP_OK;
         const unsigned long long hf = ctx->h_lflags[0];
@@ -759,21 +1174,23 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
     ctx->labels_ready = false;
     const int64_t entries = 1LL << (2 * (ctx->k - 1));
     // Compact table (sp_map.h) when the labels fit 2-bit fields, the direct table is beyond every cache and the
-    // compact one is at least four times smaller: 2^bb buckets >= SP_CTAB_FACTOR (default 3) x n, tag bits <= 7.
+    // compact one is at least four times smaller: 2^bb buckets of four entries, bb >= log2(SP_CTAB_FACTOR (default 2) x n)
+    // -- a labelled k-mer brings ~3.6 keys (two (k-1)-mers, each under two (k-3)-mers, shared with its neighbours in
+    // a run) -- and at most 2 bits of the mixed (k-3)-mer in the tag.
     ctx->ct_bb = 0;
     bool compact = false;
-    int bb = 10;
+    int bb = 8;
     {
         const char *env_ct = getenv("SP_CTAB");           // "0": never (cross-check), "1": whenever the tag fits
         const char *env_f = getenv("SP_CTAB_FACTOR");
-        const int64_t factor = env_f && atoll(env_f) > 0 ? atoll(env_f) : 3;
-        const int kb = 2 * (ctx->k - 1);
+        const int64_t factor = env_f && atoll(env_f) > 0 ? atoll(env_f) : 2;
+        const int sb = 2 * (ctx->k - 3);
         while (bb < 30 && ((int64_t)1 << bb) < factor * (n > 0 ? n : 1)) bb++;
-        if (bb < kb - MAP_CT_MAX_TAG_BITS) bb = kb - MAP_CT_MAX_TAG_BITS;
-        const bool fits = ctx->map_engine == 0 && n_sg <= 3 && kb >= 2 && bb <= kb && bb <= 28;
+        if (bb < sb - MAP_CT_MAX_TAG_BITS) bb = sb - MAP_CT_MAX_TAG_BITS;
+        const bool fits = ctx->map_engine == 0 && n_sg <= 3 && ctx->k >= 5 && bb >= 1 && bb <= sb && bb <= 27;
         const bool forced = env_ct && env_ct[0] == '1';
         compact = fits && !(env_ct && env_ct[0] == '0') &&
-                  (forced || (entries * 4 > (64LL << 20) && ((int64_t)8 << bb) * 4 <= entries * 4));
+                  (forced || (entries * 4 > (64LL << 20) && ((int64_t)16 << bb) * 4 <= entries * 4));
     }
     // direct table: the previous label set (same k, same buffer) is un-built key by key instead of memset -- while its
     // keys are still in b_labkeys
@@ -799,11 +1216,11 @@ static int labels_set_impl(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg,
         const int64_t nb = (int64_t)1 << bb;
         int64_t ovf_n = 4096;
         while (ovf_n < n / 2) ovf_n <<= 1;
-        rcb = sp_buf_ensure(ctx, ctx->b_ctab, nb * 8);
+        rcb = sp_buf_ensure(ctx, ctx->b_ctab, nb * 16);
         if (rcb) return rcb;
         rcb = sp_buf_ensure(ctx, ctx->b_covf, ovf_n * 8);
         if (rcb) return rcb;
-        SP_HIP(ctx, hipMemsetAsync(ctx->b_ctab.p, 0, (size_t)nb * 8, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_ctab.p, 0, (size_t)nb * 16, ctx->stream));
         SP_HIP(ctx, hipMemsetAsync(ctx->b_covf.p, 0, (size_t)ovf_n * 8, ctx->stream));
         ctx->ct_bb = bb;
         ctx->ct_ovf_mask = (uint32_t)(ovf_n - 1);

@@ -439,6 +439,20 @@ class Pipeline:
                 for rows, cc in ivals:
                     ids = list(ids) + [(x, 0, 100000000) for x in rows.ids()]
                     counts = list(counts) + cc.tolist()
+                if ivals:
+                    # lines that share an id are ONE row whatever file they came from (Circos.stack_matrix,
+                    # Circos.py:709-742, sums them): a BED interval listed twice, or listed next to a FASTA record of
+                    # the same id, must give the row the intervals-only branch above gives (advisor r04)
+                    where, m_ids, m_counts = {}, [], []
+                    for rid, row in zip(ids, counts):
+                        j = where.get(rid)
+                        if j is None:
+                            where[rid] = len(m_ids)
+                            m_ids.append(rid)
+                            m_counts.append(list(row))
+                        else:
+                            m_counts[j] = [x + y for x, y in zip(m_counts[j], row)]
+                    ids, counts = m_ids, m_counts
                 enriched, _ = stats.enrich_ltr(fout, cl.d_sg, np.asarray(counts, np.int64).reshape(len(ids), S),
                                                colnames=cl.sg_names, rownames=ids, max_pval=self.max_pval)
         logger.info("wrote {}".format(feat_enrich))
