@@ -246,6 +246,8 @@ c2_tiles(const unsigned long long *__restrict__ cursor1, int V1, unsigned long l
 }
 
 // block-wide exclusive scan of hist[0..F) (F <= 256 <= blockDim) -> start[]; returns total
+// LDSB: the two barriers order LDS traffic only (sp_barrier_lds): global stores of the previous tile stay in flight
+template <bool LDSB = false>
 __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *start, int F,
                                               uint32_t *wsum /*>=4*/) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -257,7 +259,8 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
         if (lane >= o) incl += n;
     }
     if (lane == 63 && wave < 4) wsum[wave] = incl;
-    __syncthreads();
+    if (LDSB) sp_barrier_lds();
+    else __syncthreads();
     uint32_t base = 0, total = 0;
     const int nwv = (int)(blockDim.x >> 6) < 4 ? (int)(blockDim.x >> 6) : 4;
     for (int w = 0; w < nwv; w++) {
@@ -266,7 +269,8 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
         total += s;
     }
     if (t < F) start[t] = base + incl - v;
-    __syncthreads();
+    if (LDSB) sp_barrier_lds();
+    else __syncthreads();
     return total;
 }
 
@@ -296,32 +300,87 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     sp_words32 p_x;
     uint32_t p_nm0 = 0, p_nm1 = 0;
     auto fetch = [&](int64_t t) {
-        const int64_t u = t * C2_P1_THREADS + threadIdx.x;
-        if (t < n_tiles && u < n_units) {
-            p_nm0 = nm[u];              // (u * 32) >> 5
-            p_nm1 = nm[u + 1];
-            p_x = sp_load_words32(pk, pm, u * C2_P1_UNIT);
-        }
+        // (unconditional, from a clamped unit: a load under a condition is merged with the old value through moves
+        // that wait for it on the spot, which made the "prefetch" a plain load)
+        int64_t u = (t < n_tiles ? t : n_tiles - 1) * C2_P1_THREADS + threadIdx.x;
+        u = u < n_units ? u : n_units - 1;
+        p_nm0 = nm[u];              // (u * 32) >> 5
+        p_nm1 = nm[u + 1];
+        p_x = sp_load_words32(pk, pm, u * C2_P1_UNIT);
+    };
+    // STORES THAT DRAIN BEHIND THE NEXT SCAN (round 5).  On this ISA loads and stores share one counter (vmcnt) and a
+    // wait cannot leave the stores out, so wherever a prefetched register is first used the wave also waits for every
+    // store it has in flight -- and __syncthreads() waits for them too.  With the prefetch consumed at the top of the
+    // next tile, each wave sat out the round trip of its own copy-out stores once per tile, and since the blocks of a
+    // CU start together and take equal steps, both were in that wait at the same time: the kernel was the SUM of its
+    // scan (0.23 ms of VALU per 667-Mb chain, + 0.13 of rank atomics) and its 2.1 GB of stores, not their maximum
+    // (bound variants C2_P1_EXP).  Now the words of the next tile are taken over (`take`: an empty asm that uses them,
+    // which is where the compiler puts the wait) BEFORE the copy-out is issued -- the loads are a scan old by then --
+    // and every barrier of the loop orders LDS traffic only: the stores drain while the next tile is scanned.
+#ifndef C2_P1_ASYNC
+#define C2_P1_ASYNC 1
+#endif
+    sp_words32 n_x;
+    uint32_t n_nm0 = 0, n_nm1 = 0;
+    auto take = [&]() {
+#if C2_P1_ASYNC
+        asm volatile("" : "+v"(p_x.l[0]), "+v"(p_x.l[1]), "+v"(p_x.l[2]), "+v"(p_x.m[0]), "+v"(p_x.m[1]), "+v"(p_x.m[2]),
+                     "+v"(p_nm0), "+v"(p_nm1));
+#endif
+        n_x = p_x;
+        n_nm0 = p_nm0;
+        n_nm1 = p_nm1;
+    };
+    auto bar = [&]() {
+#if C2_P1_ASYNC
+        sp_barrier_lds();
+#else
+        __syncthreads();
+#endif
     };
     fetch(blockIdx.x);
+#if C2_P1_ASYNC
+    take();
+#endif
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (threadIdx.x < F1) hist[threadIdx.x] = 0;
         const int64_t u = tile * C2_P1_THREADS + threadIdx.x;
-        const sp_words32 x = p_x;
-        const uint32_t c_nm0 = p_nm0, c_nm1 = p_nm1;
+#if !C2_P1_ASYNC
+        take();
+#endif
+        const sp_words32 x = n_x;
+        const uint32_t c_nm0 = n_nm0, c_nm1 = n_nm1;
         fetch(tile + gridDim.x);
-        __syncthreads();
+        bar();
         uint32_t slot[32], rank[32], ok = 0;
         if (u < n_units) {
             ok = ~(uint32_t)sp_bad_from_words64((uint64_t)c_nm0 | ((uint64_t)c_nm1 << 32), kp.k);
             auto f = [&](int j, uint32_t V, uint32_t W) {
                 slot[j] = kp.odd ? sp_slot_of32_t<true>(V >> sh, ~W & kp.kmask, kp)
                                  : sp_slot_of32_t<false>(V >> sh, ~W & kp.kmask, kp);
+#if !defined(C2_P1_EXP) || C2_P1_EXP == 1 || C2_P1_EXP > 3
                 if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[slot[j] >> shift1], 1u);
+#else
+                rank[j] = 0;
+#endif
             };
             sp_win_loop<0, 1, decltype(f)>::run(x, f);
         }
-        __syncthreads();
+#if defined(C2_P1_EXP) && C2_P1_EXP <= 3     // bound experiments (tools/build_variant.sh; wrong answers): 1 = the scan and its rank atomics only,
+                     // 2 = the scan without the atomics, 3 = as 2 without the tile barriers
+        {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) acc ^= slot[j] + rank[j];
+            if (acc == 0x12345678u && ok == 77u) lo1[tile] = (uint16_t)acc;
+#if C2_P1_EXP != 3
+            __syncthreads();
+            __syncthreads();
+#endif
+            continue;
+        }
+#endif
+        bar();
         unsigned long long g = 0;
         bool fits = true;
         uint32_t c = 0;
@@ -330,13 +389,17 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
             const uint32_t cpad = (c + 3u) & ~3u;
             hist[threadIdx.x] = cpad;     // (own entry: the scan below reads it from this thread)
             const int vb = (int)threadIdx.x * C2_SPLIT + (split > 1 ? (int)(tile & (C2_SPLIT - 1)) : 0);
+#if defined(C2_P1_EXP) && C2_P1_EXP == 5     // no cursor atomic: a position made up from the tile number (overlapping runs: wrong answers)
+            const unsigned long long at = (unsigned long long)(tile / C2_SPLIT) * 160ULL;
+#else
             const unsigned long long at = c ? atomicAdd(&cursor1[C2_CUR1(vb)], (unsigned long long)cpad) : 0ULL;
+#endif
             g = off1[vb] + at;
             // estimate mode: a run that does not fit its bucket's region is dropped (c2_tiles sees the cursor and
             // raises the flag; the chromosome is then counted again from the exact histogram)
             fits = at + cpad <= off1[vb + 1] - off1[vb];
         }
-        const uint32_t total = c2_scan_F(hist, start, F1, wsum);
+        const uint32_t total = c2_scan_F<C2_P1_ASYNC != 0>(hist, start, F1, wsum);
         if (threadIdx.x < F1) {
             delta[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;
             for (uint32_t i = c; i < ((c + 3u) & ~3u); i++) keys[start[threadIdx.x] + i] = ((uint32_t)threadIdx.x << 24) | C2_INVALID1;
@@ -347,18 +410,24 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
                 const uint32_t b = slot[j] >> shift1;
                 keys[start[b] + rank[j]] = (b << 24) | (slot[j] & mask1);
             }
-        __syncthreads();
+        bar();
+#if C2_P1_ASYNC
+        take();      // (the next tile's words: loaded a scan ago; no store of this wave is in flight here)
+#endif
         const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
         for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P1_THREADS) {
             const uint4 v = k4[q];
             const unsigned long long d = delta[v.x >> 24];
             if (d == C2_DROP) continue;
             const unsigned long long o = d + 4ULL * q;      // a multiple of 4: region starts, reservations and LDS starts are
+#if defined(C2_P1_EXP) && C2_P1_EXP == 4     // no stores
+            if (v.x != 0x12345678u) continue;
+#endif
             *reinterpret_cast<uint2 *>(lo1 + o) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
             *reinterpret_cast<uint32_t *>(hi1 + o) = c2_pack_lo(__builtin_amdgcn_perm(v.y, v.x, 0x0c0c0602u),
                                                                 __builtin_amdgcn_perm(v.w, v.z, 0x0c0c0602u));
         }
-        __syncthreads();
+        bar();
     }
 }
 

@@ -422,6 +422,155 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
     if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
 }
 
+// ------------------------------------------------------------------ k5_map_sparse2 (round 5)
+// k5_map_sparse is 532 KB of machine code -- the rolling scan unrolled over 95 bases with the hit path inlined at every
+// start -- against 64 KB of instruction cache, and it keeps ONE probe in flight per lane.  This is the k5_map2 walk
+// (sp_map.hip) for 64-bit keys: the loop over the pairs of a unit stays rolled (32-base windows by run-time shifts out
+// of three rotating registers per stream), two pairs travel together (their filter probes, then their table look-ups),
+// a hit is a bit in three label planes and a unit's hits are settled once, by popcounts.  Pair-keyed table only
+// (S <= 7); the per-k-mer table keeps the old kernel.
+__device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
+                                                  const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
+                                                  const uint32_t *__restrict__ bloom, int nbits,
+                                                  unsigned long long *__restrict__ htab, uint64_t hmask,
+                                                  unsigned long long lab[3]) {
+    unsigned long long ok_k, ok_x;      // k-mer at s0+j valid; shared (k-1)-mer at s0+j+1 valid
+    {
+        const uint64_t badA = sp_bad_starts64(nm, s0, kp.k - 1), badB = sp_bad_starts64(nm, s0 + 32, kp.k - 1);
+        const uint64_t invA = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
+        const uint64_t invB = (uint64_t)nm[(s0 >> 5) + 1] | ((uint64_t)nm[(s0 >> 5) + 2] << 32);
+        const uint32_t kA = ~(uint32_t)(badA | (invA >> (kp.k - 1))), kB = ~(uint32_t)(badB | (invB >> (kp.k - 1)));
+        const uint32_t xA = ~(uint32_t)(badA >> 1), xB = ~(uint32_t)(badB >> 1);
+        ok_k = (unsigned long long)kA | ((unsigned long long)kB << 32);
+        ok_x = (unsigned long long)xA | ((unsigned long long)xB << 32);
+    }
+    if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
+    const int64_t w0 = s0 >> 4;   // a multiple of 4: 16-byte aligned
+    const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0), ma = *reinterpret_cast<const uint4 *>(pm + w0);
+    uint32_t l0 = la.x, l1 = la.y, l2 = la.z, l3 = la.w, l4 = pk[w0 + 4], l5 = pk[w0 + 5];
+    uint32_t m0 = ma.x, m1 = ma.y, m2 = ma.z, m3 = ma.w, m4 = pm[w0 + 4], m5 = pm[w0 + 5];
+    const int sh = 64 - 2 * kp.k;
+    const uint64_t m1mask = kp.kmask >> 2;
+#pragma unroll 1
+    for (int w = 0; w < 4; w++) {
+#pragma unroll 1
+        for (int r = 0; r < 16; r += 4) {
+            const int j = 16 * w + r;           // two pairs: x1 at j + 1 (starts j, j + 1), x2 at j + 3 (starts j + 2, j + 3)
+            uint64_t V[2], xf[2], xr[2], canon[2];
+            uint32_t wd[2], b1[2];
+            map_bloom_probe pr[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int rr = r + 2 * h;       // <= 14: the 32-base window at 16 w + rr lies in words w .. w + 2
+                const uint64_t W = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, 2 * rr) |
+                                   ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, 2 * rr) << 32);
+                const unsigned long long mA = ((unsigned long long)m0 << 32) | m1, mB = ((unsigned long long)m1 << 32) | m2;
+                V[h] = (((mA << (2 * rr)) >> 32) << 32) | ((mB << (2 * rr)) >> 32);
+                xf[h] = (V[h] >> sh) & m1mask;          // x forward (the k-mer at the pair's first start without its first base)
+                xr[h] = (~W >> 2) & m1mask;             // its reverse complement
+                canon[h] = xf[h] < xr[h] ? xf[h] : xr[h];
+                pr[h] = map_bloom(canon[h], nbits);
+                wd[h] = ((ok_x >> (j + 2 * h)) & 1ULL) ? bloom[pr[h].word] : 0u;
+                // the base behind x (last base of the pair's second k-mer): position rr + k of the current words, k >= 16
+                const int pb = rr + kp.k;
+                const uint32_t lw = (pb >> 4) == 1 ? l1 : ((pb >> 4) == 2 ? l2 : l3);
+                b1[h] = (lw >> (2 * (pb & 15))) & 3u;
+            }
+            uint32_t e[2] = {0u, 0u};
+            uint64_t slot[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if ((wd[h] & pr[h].bits) == pr[h].bits) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (!(e[h] & 0x77777777u)) continue;
+                const bool fw = xf[h] <= xr[h];
+                const uint32_t b0 = (uint32_t)(V[h] >> 62);
+                const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
+                const uint32_t okk = (uint32_t)(ok_k >> (j + 2 * h));
+                const uint32_t v0 = (okk & 1u) ? (e[h] >> (4 * f0)) & 15u : 0u;
+                const uint32_t v1 = (okk & 2u) ? (e[h] >> (4 * f1)) & 15u : 0u;
+                const uint32_t two = (v0 & 7u) | ((v1 & 7u) << 8);
+                if (!two) continue;
+#pragma unroll
+                for (int bit = 0; bit < 3; bit++)
+                    lab[bit] |= (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1)) << (j + 2 * h);
+                uint32_t mark = 0;       // "seen": first touch only
+                if ((v0 & 7u) && !(v0 & 8u)) mark |= 8u << (4 * f0);
+                if ((v1 & 7u) && !(v1 & 8u)) mark |= 8u << (4 * f1);
+                if (mark) atomicOr(&htab[2 * slot[h] + 1], (unsigned long long)mark);
+            }
+        }
+        l0 = l1; l1 = l2; l2 = l3; l3 = l4; l4 = l5;
+        m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5;
+    }
+}
+
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
+               sp_map_params P, unsigned long long *__restrict__ htab, uint64_t hmask, const uint32_t *__restrict__ bloom,
+               int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
+    __shared__ int hist[MAP_LDS_ENTRIES];
+    __shared__ unsigned long long red[16];
+    unsigned long long mapped = 0;
+    const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
+    for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const int64_t u = r * MAP_BLOCK + threadIdx.x;
+        // the range's first output slot and where it ends (uniform; once per range, not per hit)
+        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k), end_lo = map_slot_end(r * MAP_RANGE, P, kp.k);
+        const bool one_slot = end_lo >= (r + 1) * MAP_RANGE;
+        if (P.use_lds) {
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
+            __syncthreads();
+        }
+        if (u < P.n_units) {
+            unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+            map_unit_scan64_h(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, lab);
+            if (lab[0] | lab[1] | lab[2]) {
+                auto add = [&](int64_t os, unsigned long long within) {
+                    for (int sg = 0; sg < P.S; sg++) {
+                        const int l = sg + 1;
+                        const unsigned long long m = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) &
+                                                     ((l & 4) ? lab[2] : ~lab[2]) & within;
+                        const int v = __popcll(m);
+                        if (!v) continue;
+                        if (P.use_lds) atomicAdd(&hist[(int)(os - slot_lo) * P.S + sg], v);
+                        else if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + sg], v);
+                        mapped += v;
+                    }
+                };
+                const int64_t s0 = u * SP_UNIT;
+                if (one_slot) {
+                    add(slot_lo, ~0ULL);
+                } else {
+                    int64_t p = s0;
+                    while (p < s0 + SP_UNIT) {
+                        int64_t e = map_slot_end(p, P, kp.k);
+                        if (e > s0 + SP_UNIT) e = s0 + SP_UNIT;
+                        const int a = (int)(p - s0), b = (int)(e - s0);
+                        const unsigned long long within = (b >= 64 ? ~0ULL : ((1ULL << b) - 1ULL)) & ~((1ULL << a) - 1ULL);
+                        if ((lab[0] | lab[1] | lab[2]) & within) add(map_slot(p, P, kp.k), within);
+                        p = e;
+                    }
+                }
+            }
+        }
+        if (P.use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
+                int v = hist[i];
+                if (v) {
+                    int64_t os = slot_lo + i / P.S;
+                    if (os < P.nslots) atomicAdd(&slot_counts[os * P.S + (i % P.S)], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned long long t = sp_block_sum_u64(mapped, red);
+    if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
+}
+
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
                    const int64_t *__restrict__ foff, int64_t n_feat, int S,
@@ -1356,6 +1505,12 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
     int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernel of rounds 1-4 (cross-check)
+    if (ctx->map_engine == 0 && P.S <= 7 && !(env_mk && env_mk[0] == '1')) {
+        SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
+                  (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
+        return SP_OK;
+    }
     SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
               (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts,
               d_n, ctx->map_engine == 0 ? 1 : 0);

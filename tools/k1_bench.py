@@ -12,12 +12,17 @@ d = ctx.dev_alloc(n)
 ctx.synth_chrom(d, n, 3, 0, 0, 3, 0)
 ctx.genome_reset(1)
 ctx.genome_add_device(0, d, n)
-ctx.count(K, 3, engine)
+def _count():       # (bound-experiment variants produce wrong partitions: their kernel times are still what is asked for)
+    try:
+        ctx.count(K, 3, engine)
+    except ValueError as e:
+        print("count failed (%s): kernel times only" % str(e)[:60])
+_count()
 ctx.prof_enable(True)
 for _ in range(3):
-    ctx.count(K, 3, engine)
+    _count()
 ctx.prof_enable(False)
 rep = ctx.prof_report()
 tot = sum(v["ms"] / v["calls"] for v in rep.values())
 print(os.environ.get("SUBPHASER_HIP_LIB", "default"), {k: round(v["ms"] / v["calls"], 3) for k, v in rep.items()}, "total %.3f ms" % tot,
-      "-> %.1f Gbases/s" % (n / tot / 1e6), "lengths", int(ctx.lengths()[0]))
+      "-> %.1f Gbases/s" % (n / tot / 1e6), "lengths", int(ctx.lengths()[0]) if not os.environ.get("K1_NOLEN") else -1)
