@@ -381,51 +381,74 @@ c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         }
 #endif
         bar();
-        unsigned long long g = 0;
-        bool fits = true;
-        uint32_t c = 0;
+        unsigned long long at = 0, r_lo = 0, r_hi = 0;
+        uint32_t c = 0, cpad = 0;
         if (threadIdx.x < F1) {
             c = hist[threadIdx.x];
-            const uint32_t cpad = (c + 3u) & ~3u;
+            cpad = (c + 3u) & ~3u;
             hist[threadIdx.x] = cpad;     // (own entry: the scan below reads it from this thread)
             const int vb = (int)threadIdx.x * C2_SPLIT + (split > 1 ? (int)(tile & (C2_SPLIT - 1)) : 0);
 #if defined(C2_P1_EXP) && C2_P1_EXP == 5     // no cursor atomic: a position made up from the tile number (overlapping runs: wrong answers)
-            const unsigned long long at = (unsigned long long)(tile / C2_SPLIT) * 160ULL;
+            at = (unsigned long long)(tile / C2_SPLIT) * 160ULL;
 #else
-            const unsigned long long at = c ? atomicAdd(&cursor1[C2_CUR1(vb)], (unsigned long long)cpad) : 0ULL;
+            if (c) at = atomicAdd(&cursor1[C2_CUR1(vb)], (unsigned long long)cpad);
 #endif
-            g = off1[vb] + at;
-            // estimate mode: a run that does not fit its bucket's region is dropped (c2_tiles sees the cursor and
-            // raises the flag; the chromosome is then counted again from the exact histogram)
-            fits = at + cpad <= off1[vb + 1] - off1[vb];
+            r_lo = off1[vb];
+            r_hi = off1[vb + 1];
+            // (nothing that depends on the atomic's result before the scan below: the two waves that reserve would
+            // sit out its round trip in front of a barrier the whole block waits at)
         }
         const uint32_t total = c2_scan_F<C2_P1_ASYNC != 0>(hist, start, F1, wsum);
         if (threadIdx.x < F1) {
+            const unsigned long long g = r_lo + at;
+            // estimate mode: a run that does not fit its bucket's region is dropped (c2_tiles sees the cursor and
+            // raises the flag; the chromosome is then counted again from the exact histogram)
+            const bool fits = at + cpad <= r_hi - r_lo;
             delta[threadIdx.x] = fits ? g - start[threadIdx.x] : C2_DROP;
             for (uint32_t i = c; i < ((c + 3u) & ~3u); i++) keys[start[threadIdx.x] + i] = ((uint32_t)threadIdx.x << 24) | C2_INVALID1;
         }
+        // (the run starts of eight keys are read together: one LDS round trip per eight keys instead of one per key)
 #pragma unroll
-        for (int j = 0; j < 32; j++)
-            if ((ok >> j) & 1u) {
-                const uint32_t b = slot[j] >> shift1;
-                keys[start[b] + rank[j]] = (b << 24) | (slot[j] & mask1);
+        for (int j0 = 0; j0 < 32; j0 += 8) {
+            uint32_t st[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) st[jj] = start[slot[j0 + jj] >> shift1];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int j = j0 + jj;
+                if ((ok >> j) & 1u) keys[st[jj] + rank[j]] = ((slot[j] >> shift1) << 24) | (slot[j] & mask1);
             }
+        }
         bar();
 #if C2_P1_ASYNC
         take();      // (the next tile's words: loaded a scan ago; no store of this wave is in flight here)
 #endif
         const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
-        for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P1_THREADS) {
-            const uint4 v = k4[q];
-            const unsigned long long d = delta[v.x >> 24];
-            if (d == C2_DROP) continue;
-            const unsigned long long o = d + 4ULL * q;      // a multiple of 4: region starts, reservations and LDS starts are
+        // (four quads per round: their LDS reads, then their run bases, then their stores -- two LDS round trips per
+        // four quads instead of two per quad)
+        const uint32_t nq = total >> 2;
+        for (uint32_t q0 = threadIdx.x; q0 < nq; q0 += 4u * C2_P1_THREADS) {
+            uint4 v[4];
+            unsigned long long d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t q = q0 + (uint32_t)i * C2_P1_THREADS;
+                v[i] = k4[q < nq ? q : nq - 1u];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i] = delta[v[i].x >> 24];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t q = q0 + (uint32_t)i * C2_P1_THREADS;
+                if (q >= nq || d[i] == C2_DROP) continue;
+                const unsigned long long o = d[i] + 4ULL * q;      // a multiple of 4: region starts, reservations and LDS starts are
 #if defined(C2_P1_EXP) && C2_P1_EXP == 4     // no stores
-            if (v.x != 0x12345678u) continue;
+                if (v[i].x != 0x12345678u) continue;
 #endif
-            *reinterpret_cast<uint2 *>(lo1 + o) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
-            *reinterpret_cast<uint32_t *>(hi1 + o) = c2_pack_lo(__builtin_amdgcn_perm(v.y, v.x, 0x0c0c0602u),
-                                                                __builtin_amdgcn_perm(v.w, v.z, 0x0c0c0602u));
+                *reinterpret_cast<uint2 *>(lo1 + o) = make_uint2(c2_pack_lo(v[i].x, v[i].y), c2_pack_lo(v[i].z, v[i].w));
+                *reinterpret_cast<uint32_t *>(hi1 + o) = c2_pack_lo(__builtin_amdgcn_perm(v[i].y, v[i].x, 0x0c0c0602u),
+                                                                    __builtin_amdgcn_perm(v[i].w, v[i].z, 0x0c0c0602u));
+            }
         }
         bar();
     }
@@ -764,6 +787,10 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
         for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_nov = 0;
     }
+#ifdef C2_DESYNC     // experiment: the second block of every CU starts half a bucket late (blocks of a CU otherwise move in step)
+    if (blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < C2_DESYNC; i++) __builtin_amdgcn_s_sleep(127);
+#endif
     prefetch(blockIdx.x);
     __syncthreads();
     // a record adds 1 to its half of the word; a pad record (0xFFFF) adds 0 to the last word
@@ -786,12 +813,27 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
                 add(pf[q].y >> 16);
             }
         }
-        for (unsigned long long i = threadIdx.x + (unsigned long long)C2_C16_PF * C2_C16_THREADS; i < n4; i += C2_C16_THREADS) {
-            const uint2 v = p2[i];
-            add(v.x & 0xffffu);
-            add(v.x >> 16);
-            add(v.y & 0xffffu);
-            add(v.y >> 16);
+        // the rest of the bucket (an average bucket holds 2.5 x what the prefetch covers) in rounds of C2_C16_PF loads
+        // per lane: one load per round trip -- what this loop was -- kept 8 KB in flight per CU, i.e. ~1.4 TB/s for the
+        // whole chip at 1.5 us per trip, and that, not the LDS, was the kernel's rate (round 5)
+        for (unsigned long long base = (unsigned long long)C2_C16_PF * C2_C16_THREADS; base < n4;
+             base += (unsigned long long)C2_C16_PF * C2_C16_THREADS) {
+            uint2 v[C2_C16_PF];
+#pragma unroll
+            for (int q = 0; q < C2_C16_PF; q++) {
+                // (unconditional, from a clamped index: a load under a condition is followed by a wait of its own)
+                const unsigned long long i = base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS;
+                v[q] = p2[i < n4 ? i : n4 - 1ULL];
+            }
+#pragma unroll
+            for (int q = 0; q < C2_C16_PF; q++) {
+                if (base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
+                    add(v[q].x & 0xffffu);
+                    add(v[q].x >> 16);
+                    add(v[q].y & 0xffffu);
+                    add(v[q].y >> 16);
+                }
+            }
         }
         prefetch(fb + gridDim.x);   // in flight across the write-out below
         __syncthreads();
