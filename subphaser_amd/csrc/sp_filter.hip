@@ -64,6 +64,9 @@ __device__ __forceinline__ uint32_t k3_ge_mask(uint32_t x, uint32_t addL /* (0x8
 // NCH > 0: the column has at most 8 * NCH rows and every loop over rows is unrolled, so that the row
 // descriptors (set / unit boundaries, reciprocal lengths) are uniform values held in scalar registers.
 // NCH = 0: any number of rows; every qualifying slot takes the generic decision.
+#ifndef K3_STAGE
+#define K3_STAGE 8      // 16-byte loads a thread keeps in flight while a tile is staged
+#endif
 template <bool SWAR, int NCH>
 __global__ void __launch_bounds__(F_BLOCK)
 k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
@@ -131,6 +134,33 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         const int n16 = TS / 16, total16 = R * n16;
         if (threadIdx.x == 0) s_qn = s_q2n = 0;
         for (int i = threadIdx.x; i < TS / 16; i += F_BLOCK) reinterpret_cast<uint32_t *>(bmr)[i] = 0;   // both bitmaps: 2*TS/32 words
+        // Round 5: the "eight loads in flight" below were eight loads ONE AFTER THE OTHER -- every one sat behind two
+        // dependent loads of its own (rowdesc[r], then tabs[c].tab) and a branch, and the compiler waits for everything
+        // in flight (vmcnt(0)) before it uses a loaded pointer: three serial round trips per 16 bytes, in a kernel that
+        // streams 11 GB per pass.  A tile that lies inside the table -- every tile but the last of a tiny table -- is now
+        // loaded without a condition, from a clamped index: eight independent 16-byte loads per thread and one wait.
+        // A wave's 64 consecutive 16-byte pieces lie in ONE row when a row is a multiple of 64 pieces (TS = 1024: exactly
+        // one): the row, its table and the piece offset are wave-uniform -- scalar loads and a scalar base for the load.
+        const bool whole = base + TS <= P.nslots && (n16 & 63) == 0;     // block-uniform
+        if (whole)
+        for (int i0 = threadIdx.x; i0 < total16; i0 += K3_STAGE * F_BLOCK) {
+            uint32_t vx[K3_STAGE], vy[K3_STAGE], vz[K3_STAGE], vw[K3_STAGE];
+#pragma unroll
+            for (int q = 0; q < K3_STAGE; q++) {
+                int iw = __builtin_amdgcn_readfirstlane(i0 - lane + q * F_BLOCK);     // the wave's first piece
+                iw = iw < total16 ? iw : total16 - 64;
+                const int r = iw / n16, j0 = iw - r * n16;
+                const uint8_t *__restrict__ tab = tabs[rowdesc[r] & F3_CHROM_MASK].tab;
+                const uint4 t = *reinterpret_cast<const uint4 *>(tab + base + (int64_t)(j0 + lane) * 16);
+                vx[q] = t.x; vy[q] = t.y; vz[q] = t.z; vw[q] = t.w;
+            }
+#pragma unroll
+            for (int q = 0; q < K3_STAGE; q++) {
+                const int i = i0 + q * F_BLOCK;
+                if (i < total16) reinterpret_cast<uint4 *>(tile)[i] = make_uint4(vx[q], vy[q], vz[q], vw[q]);
+            }
+        }
+        if (!whole)
         for (int i0 = threadIdx.x; i0 < total16; i0 += 8 * F_BLOCK) {
             uint4 v[8];
 #pragma unroll
