@@ -939,6 +939,8 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
         p_base[d] = (uint32_t)(sp.y >> 32);
         const uint32_t nq = (p_off[d] + p_n[d] + 3u) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + p_a0[d]);
+        // (kept under their condition: unconditional clamped loads -- what helped c2_count16 -- cost the list counter
+        // 12 % on 20-Mb chromosomes, where most lanes have nothing to load; round 5)
 #pragma unroll
         for (int q = 0; q < C2L_PF; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
@@ -975,9 +977,20 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nq) quad(cur[d][q], i, off, end, add);
         }
-        if (!in_regs)
-            for (uint32_t i = threadIdx.x + (uint32_t)C2L_PF * C2_COUNT_THREADS; i < nq; i += C2_COUNT_THREADS)
-                quad(p2[i], i, off, end, add);
+        if (!in_regs)      // (four clamped loads per round: one load per round trip held this loop at a quarter of its rate)
+            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L_PF * C2_COUNT_THREADS; i0 < nq; i0 += 4u * C2_COUNT_THREADS) {
+                uint2 vv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t i = i0 + (uint32_t)t * C2_COUNT_THREADS;
+                    vv[t] = p2[i < nq ? i : nq - 1u];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t i = i0 + (uint32_t)t * C2_COUNT_THREADS;
+                    if (i < nq) quad(vv[t], i, off, end, add);
+                }
+            }
         sp_barrier_lds();   // (A) counts complete
         auto emit = [&](uint32_t r, uint32_t c) {
             if (c >= lower) {
