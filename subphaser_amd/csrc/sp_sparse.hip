@@ -1078,6 +1078,254 @@ sps_join(sps_join_args A) {
     if (lane == 0 && uni) atomicAdd(A.n_union, uni);
 }
 
+// ------------------------------------------------------------------ sps_join_blk (round 5): the same join, one WORKGROUP per range
+// The wave-per-range join reads ~90 bytes per list entry for 12 useful ones (PMC, round 4): a range of ~100 entries is
+// 21 list segments of ~5 entries -- one or two 64-byte lines of keys and one of counts per segment, used to a tenth --
+// plus two strided range-edge words per list and range.  With ranges of ~BJ_T / 1.5 entries (a segment is ~35 entries:
+// four lines of keys, used in full) the fixed costs -- edges, cursors, hash clear, the tallies -- are paid once per ~700
+// entries instead of once per ~100.  A workgroup of BJ_THREADS takes a range: wave 0 runs the cursor logic of the
+// wave kernel (lane c owns list c: pivot, share, offsets by shuffles) and publishes it through LDS, every thread loads
+// and hash-inserts BJ_T / BJ_THREADS entries, the owners screen, and the survivors rebuild their rows wave by wave
+// exactly as before.  Same outputs, same staging protocol (hist totals at the range's closed-form position, rows in
+// chunks with their rank inside the range), so sps_tally_* / sps_place_* are unchanged.
+#ifndef BJ_T
+#define BJ_T 1024         // entries per round
+#endif
+#define BJ_H (2 * BJ_T)   // hash slots
+#ifndef BJ_THREADS
+#define BJ_THREADS 256
+#endif
+#define BJ_WAVES (BJ_THREADS / 64)
+#define BJ_Q (BJ_T / BJ_THREADS)
+template <typename RT>
+struct bj_lds {
+    RT Kk[BJ_T], Hk[BJ_H];
+    uint32_t Vv[BJ_T], Hhead[BJ_H], Hmin[BJ_H];
+    uint16_t Nx[BJ_T], Sl[BJ_T], RL[BJ_T];
+    uint8_t Ch[BJ_T];
+    uint32_t seg_off[SPS_MAXC + 2], cur[SPS_MAXC];
+    const unsigned long long *keys[SPS_MAXC];
+    const uint32_t *cnts[SPS_MAXC];
+    uint32_t T, more, n_hist, n_row;
+    unsigned long long hist_pos, chunk_pos;
+};
+
+template <typename RT>
+__global__ void __launch_bounds__(BJ_THREADS)
+sps_join_blk(sps_join_args A) {
+    __shared__ bj_lds<RT> L;
+    extern __shared__ uint32_t jw_rows[];      // [BJ_WAVES][JW_ROWS][C]: rows being decided
+    __shared__ int32_t s_set_off[JW_FS + 1], s_unit_off[JW_FU + 1], s_unit_chrom[JW_FC];
+    __shared__ double s_unit_den[2 * JW_FU];
+    __shared__ unsigned long long s_csets[SPS_MAXC];
+    const int C = A.C, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    sp_fsets F = A.F;
+    {
+        const int n_units = A.F.set_off[A.F.n_sets], n_uc = A.F.unit_off[n_units];
+        if (A.F.n_sets <= JW_FS && n_units <= JW_FU && n_uc <= JW_FC) {
+            for (int i = threadIdx.x; i <= A.F.n_sets; i += blockDim.x) s_set_off[i] = A.F.set_off[i];
+            for (int i = threadIdx.x; i <= n_units; i += blockDim.x) s_unit_off[i] = A.F.unit_off[i];
+            for (int i = threadIdx.x; i < n_uc; i += blockDim.x) s_unit_chrom[i] = A.F.unit_chrom[i];
+            for (int i = threadIdx.x; i < n_units; i += blockDim.x) {
+                s_unit_den[i] = A.F.unit_den[i];
+                s_unit_den[n_units + i] = A.F.unit_inv[i];
+            }
+            F.set_off = s_set_off;
+            F.unit_off = s_unit_off;
+            F.unit_chrom = s_unit_chrom;
+            F.unit_den = s_unit_den;
+            F.unit_inv = s_unit_den + n_units;
+        }
+        for (int i = threadIdx.x; i < C; i += blockDim.x) {
+            s_csets[i] = A.chrom_sets[i];
+            L.keys[i] = A.lists[i].keys;
+            L.cnts[i] = A.lists[i].cnts;
+        }
+        __syncthreads();
+    }
+    const RT EMPTY = (RT)~(RT)0;
+    const unsigned long long rmask = A.shift >= 64 ? ~0ULL : ((1ULL << A.shift) - 1ULL);
+    const unsigned long long *my_keys = nullptr;      // wave 0, lane c: list c
+    if (w == 0 && lane < C) my_keys = A.lists[lane].keys;
+    unsigned long long uni = 0;
+    unsigned long long chunk_pos = 0, chunk_end = 0;   // block-uniform (every thread keeps the same copy)
+    const uint32_t per = BJ_T / (uint32_t)C;
+    for (long long r = blockIdx.x; r < A.R; r += gridDim.x) {
+        uint32_t cur = 0, endp = 0;                    // wave 0 only
+        if (w == 0 && lane < C) {
+            cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r];
+            endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r + 1];
+        }
+        if (w == 0) {
+            const unsigned long long hp = jw_sum((unsigned long long)cur);   // the range's place in the virtual concatenation
+            if (lane == 0) L.hist_pos = hp;
+        }
+        const unsigned long long hi_bits = A.shift >= 64 ? 0ULL : ((unsigned long long)r << A.shift);
+        uint32_t rows_before = 0, hist_before = 0;     // block-uniform
+        for (;;) {
+            uint32_t take = 0;
+            if (w == 0) {
+                // ---- the round's share of every list: everything, or everything below the pivot key
+                const uint32_t left = endp - cur;
+                unsigned long long pivot = SPS_SENTINEL;
+                if (jw_sum(left) > BJ_T) pivot = jw_min((lane < C && left > per) ? my_keys[cur + per] : SPS_SENTINEL);
+                take = left;
+                if (pivot != SPS_SENTINEL && lane < C) {     // entries below the pivot: at most `per` (the per-th is >= pivot)
+                    const unsigned long long *kk = my_keys + cur;
+                    uint32_t lo = 0, hi = left < per ? left : per;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (kk[mid] < pivot) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    take = lo;
+                }
+                uint32_t incl = take;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t x = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += x;
+                }
+                const uint32_t T0 = __shfl(incl, 63, 64);                 // <= BJ_T by construction
+                const bool more0 = __any(cur + take < endp);
+                if (lane <= C) L.seg_off[lane] = lane < C ? incl - take : T0;
+                if (lane < C) L.cur[lane] = cur;
+                if (lane == 0) {
+                    L.T = T0;
+                    L.more = more0 ? 1u : 0u;
+                    L.n_hist = 0;
+                    L.n_row = 0;
+                }
+            }
+            for (uint32_t i = threadIdx.x; i < BJ_H; i += BJ_THREADS) {
+                L.Hk[i] = EMPTY;
+                L.Hhead[i] = 0xFFFFu;
+                L.Hmin[i] = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            const uint32_t T = L.T;
+            const bool more = L.more != 0;
+            uint32_t Hn = 64;
+            while (Hn < 2 * T) Hn <<= 1;
+            // ---- load + hash-insert (chain per key; owner = the entry of the lowest chromosome)
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                if (e < T) {
+                    int lo = 0, hi = C;       // list of entry e: last c with seg_off[c] <= e
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (L.seg_off[mid] <= e) lo = mid;
+                        else hi = mid;
+                    }
+                    const int c = lo;
+                    const size_t i = (size_t)L.cur[c] + (e - L.seg_off[c]);
+                    const RT res = (RT)(L.keys[c][i] & rmask);
+                    L.Kk[e] = res;
+                    L.Vv[e] = L.cnts[c][i];
+                    L.Ch[e] = (uint8_t)c;
+                    uint32_t h = (uint32_t)sps_mix((uint64_t)res) & (Hn - 1);
+                    for (;;) {
+                        const RT prev = atomicCAS(&L.Hk[h], EMPTY, res);
+                        if (prev == EMPTY || prev == res) break;
+                        h = (h + 1) & (Hn - 1);
+                    }
+                    L.Sl[e] = (uint16_t)h;
+                    L.Nx[e] = (uint16_t)atomicExch(&L.Hhead[h], e);
+                    atomicMin(&L.Hmin[h], ((uint32_t)c << 16) | e);
+                }
+            }
+            __syncthreads();
+            // ---- owners rebuild their row and decide
+            bool is_row[BJ_Q], is_hist[BJ_Q];
+            unsigned long long tots[BJ_Q];
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                is_row[q] = is_hist[q] = false;
+                tots[q] = 0;
+                bool pending = false;      // an owner that passed the screen and still needs the full decision
+                if (e < T && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) {
+                    uni++;
+                    unsigned long long sets = 0, tot = 0;
+                    for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) {
+                        sets |= s_csets[L.Ch[x]];
+                        tot += L.Vv[x];
+                    }
+                    tots[q] = tot;
+                    pending = !A.screen || !((double)__popcll(sets) / (double)F.n_multi < F.ratio);
+                }
+                for (unsigned long long pb = __ballot(pending); pb; pb = __ballot(pending)) {
+                    const int slot = __popcll(pb & ((1ULL << lane) - 1ULL));
+                    if (pending && slot < JW_ROWS) {
+                        uint32_t *row = jw_rows + ((size_t)w * JW_ROWS + slot) * (size_t)C;
+                        for (int c = 0; c < C; c++) row[c] = 0;
+                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) row[L.Ch[x]] = L.Vv[x];
+                        sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tots[q], F, is_row[q], is_hist[q]);
+                        pending = false;
+                    }
+                }
+                // fold-passing totals: range start + tally so far + a place of the wave's in this round (any order)
+                const unsigned long long bh = __ballot(is_hist[q]);
+                if (bh) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&L.n_hist, (uint32_t)__popcll(bh));
+                    base = __shfl(base, 0, 64);
+                    if (is_hist[q])
+                        A.hist_stage[L.hist_pos + hist_before + base + __popcll(bh & ((1ULL << lane) - 1ULL))] = tots[q];
+                }
+                const unsigned long long br = __ballot(is_row[q]);
+                if (br) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&L.n_row, (uint32_t)__popcll(br));
+                    base = __shfl(base, 0, 64);
+                    if (is_row[q]) L.RL[base + __popcll(br & ((1ULL << lane) - 1ULL))] = (uint16_t)e;
+                }
+            }
+            __syncthreads();
+            const uint32_t nrow = L.n_row, nh = L.n_hist;
+            if (nrow) {       // rare: rows to the staging area, ranked by key inside the round
+                if (chunk_pos + nrow > chunk_end) {      // block-uniform
+                    const unsigned long long grab = nrow > JOIN_CHUNK ? nrow : JOIN_CHUNK;
+                    if (threadIdx.x == 0) L.chunk_pos = atomicAdd(A.row_cursor, grab);
+                    __syncthreads();
+                    chunk_pos = L.chunk_pos;
+                    chunk_end = chunk_pos + grab;
+                }
+#pragma unroll
+                for (int q = 0; q < BJ_Q; q++) {
+                    if (!is_row[q]) continue;
+                    const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                    const RT res = L.Kk[e];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.RL[j]] < res;
+                    const unsigned long long pos = chunk_pos + rank;
+                    if (pos < A.row_cap) {
+                        A.row_keys[pos] = hi_bits | (unsigned long long)res;
+                        A.row_tot[pos] = tots[q];
+                        A.row_rank[pos] = rows_before + rank;
+                        uint32_t *out = A.row_counts + pos * (size_t)C;
+                        for (int c = 0; c < C; c++) out[c] = 0;
+                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) out[L.Ch[x]] = L.Vv[x];
+                    }
+                }
+                chunk_pos += nrow;
+                rows_before += nrow;
+            }
+            hist_before += nh;
+            __syncthreads();      // the round's LDS state is rewritten by the next round / range
+            if (!more) break;
+            cur += take;
+        }
+        if (threadIdx.x == 0) {
+            A.n_rows[r] = rows_before;
+            A.n_hist[r] = hist_before;
+        }
+    }
+    uni = jw_sum(uni);
+    if (lane == 0 && uni) atomicAdd(A.n_union, uni);
+}
+
 // per-range tallies -> offsets: block sums, one-block scan of the sums, offsets inside every block
 #define TALLY_CHUNK 4096
 __global__ void __launch_bounds__(256)
@@ -1271,8 +1519,13 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
         while ((1LL << bits) < ctx->nslots) bits++;
     }
     if (bits > 64) bits = 64;
+    // SP_LIST_FILTER=wave: the one-wave-per-range kernel of round 3 on ~100-entry ranges (cross-check); default: one
+    // workgroup per range of ~2/3 of a round
+    const char *env_lf = getenv("SP_LIST_FILTER");
+    const bool wave_join = env_lf && !strcmp(env_lf, "wave");
+    const int64_t per_range = wave_join ? 96 : (int64_t)BJ_T * 2 / 3;
     int rb = 0;
-    while (rb < bits && rb < 23 && ((int64_t)1 << rb) * 96 < total) rb++;
+    while (rb < bits && rb < 23 && ((int64_t)1 << rb) * per_range < total) rb++;
     if (bits - rb > 63) rb = bits - 63;      // k = 32 and a handful of k-mers: `key >> 64` is not a shift (fuzz case k32_join)
     const long long R = 1LL << rb;
     const int shift = bits - rb;
@@ -1363,13 +1616,23 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
         A.row_counts = (uint32_t *)(S0 + 2 * al(row_cap * 8) + al(row_cap * 4));
         SP_HIP(ctx, hipMemsetAsync(A.row_keys, 0xff, row_cap * 8, ctx->stream));
         SP_HIP(ctx, hipMemsetAsync(small, 0, 64, ctx->stream));
-        int64_t grid = (R + JW_WAVES - 1) / JW_WAVES;
-        if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-        const size_t row_lds = (size_t)JW_WAVES * JW_ROWS * (size_t)C * 4;     // <= 16 KiB
-        if (shift <= 31)
-            SP_LAUNCH(ctx, "sps_join", sps_join<uint32_t>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
-        else
-            SP_LAUNCH(ctx, "sps_join", sps_join<unsigned long long>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
+        if (wave_join) {
+            int64_t grid = (R + JW_WAVES - 1) / JW_WAVES;
+            if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+            const size_t row_lds = (size_t)JW_WAVES * JW_ROWS * (size_t)C * 4;     // <= 16 KiB
+            if (shift <= 31)
+                SP_LAUNCH(ctx, "sps_join", sps_join<uint32_t>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
+            else
+                SP_LAUNCH(ctx, "sps_join", sps_join<unsigned long long>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
+        } else {
+            int64_t grid = R;
+            if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+            const size_t row_lds = (size_t)BJ_WAVES * JW_ROWS * (size_t)C * 4;
+            if (shift <= 31)
+                SP_LAUNCH(ctx, "sps_join", sps_join_blk<uint32_t>, dim3((unsigned)grid), dim3(BJ_THREADS), row_lds, A);
+            else
+                SP_LAUNCH(ctx, "sps_join", sps_join_blk<unsigned long long>, dim3((unsigned)grid), dim3(BJ_THREADS), row_lds, A);
+        }
         const long long nb = (R + TALLY_CHUNK - 1) / TALLY_CHUNK;
         unsigned long long *bs_r = (unsigned long long *)(A0 + o_bs), *bs_h = bs_r + (R / TALLY_CHUNK + 2);
         SP_LAUNCH(ctx, "sps_tally_sums", sps_tally_sums, dim3((unsigned)nb), dim3(256), 0, (const uint32_t *)n_rows, R, bs_r);
