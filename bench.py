@@ -209,6 +209,7 @@ def main():
     # the same steps once more WITHOUT the two HIP events per launch that the roofline figures are made of (they cost
     # ~1 % of a wheat-like pass and ~10 % of an Arabidopsis-like one): reported next to the contract's figure, never as it
     n_plain = min(args.steps, 3)
+    wall_timed = dict((hp if runner is None else runner).wall)      # (the stage walls of the timed steps only)
     barrier()
     t1 = time.perf_counter()
     for _ in range(n_plain):
@@ -225,7 +226,7 @@ def main():
     # what every rank spent waiting for / issuing the table (or key-range) exchange and the other collectives
     rank_wall = None
     if runner is not None:
-        mine = torch.tensor([runner.wall.get(k_, 0.0) / args.steps * 1e3 for k_ in EXCHANGE_KEYS], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([wall_timed.get(k_, 0.0) / args.steps * 1e3 for k_ in EXCHANGE_KEYS], dtype=torch.float64, device="cuda")
         allw = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allw, mine)
         rank_wall = [{"rank": r_, **{k_: round(float(v_), 3) for k_, v_ in zip(EXCHANGE_KEYS, w_.tolist()) if v_}}
@@ -322,7 +323,7 @@ def main():
     # one process: the pack kernels and the count chains overlap on up to four streams (sp_count's lanes; round 4: also
     # the k > 15 chains, three chromosomes in flight)
     LANE_KERNELS, lane_scale = set(), 1.0
-    wall_pc = (hp.wall.get("pack+count", 0.0) / args.steps * 1e3) if runner is None else 0.0
+    wall_pc = (wall_timed.get("pack+count", 0.0) / args.steps * 1e3) if runner is None else 0.0
     if wall_pc > 0:
         lk = [n for n in COUNT_CHAIN + ["k0_pack"] if n in prof]
         ev = sum(prof[n]["ms"] for n in lk) / args.steps
@@ -378,7 +379,7 @@ def main():
                              for r_, p_ in enumerate(runner.pieces)] if runner is not None else None),
         "traffic_commit": traffic_commit, "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),
         "host_wall_ms_per_step": {k_: round(v / args.steps * 1e3, 2)
-                                  for k_, v in (hp if runner is None else runner).wall.items()},
+                                  for k_, v in wall_timed.items()},
     }
     if runner is not None:
         a = b = None

@@ -186,14 +186,17 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     sp_words64 p_x;
     uint32_t p_nm0 = 0, p_nm1 = 0;
     auto fetch = [&](int64_t t) {
-        const int64_t u = t * THREADS + threadIdx.x;
-        if (t < n_tiles && u < n_units) {
-            p_nm0 = nm[u];              // (u * 32) >> 5
-            p_nm1 = nm[u + 1];
-            p_x = sp_load_words64(pk, pm, u * S3_P1_UNIT);
-        }
+        // (round 5: unconditional, from a clamped unit -- a load under a condition is merged with the old value through
+        // moves that wait for it on the spot, which made this "prefetch" a plain load; as in c2_part1)
+        int64_t u = (t < n_tiles ? t : n_tiles - 1) * THREADS + threadIdx.x;
+        u = u < n_units ? u : n_units - 1;
+        p_nm0 = nm[u];              // (u * 32) >> 5
+        p_nm1 = nm[u + 1];
+        p_x = sp_load_words64(pk, pm, u * S3_P1_UNIT);
     };
     fetch(blockIdx.x);
+    static_assert(S3_MAXF <= 2 * THREADS || THREADS == 256, "two cursor atomics per thread (four at 256 threads)");
+    constexpr int BPT = (S3_MAXF + THREADS - 1) / THREADS;      // level-1 buckets per thread
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
         const sp_words64 x = p_x;
@@ -215,9 +218,17 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
             }
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < F1; b += THREADS) {
-            const uint32_t c = hist[b];
-            gbase[b] = c ? (uint32_t)atomicAdd(&cursor1[b], (unsigned long long)c) : 0u;
+        // (the cursors' answers are looked at only after the scan and the placement: stored to LDS here, the threads
+        // sat out the atomics' round trip in front of the barriers the whole workgroup waits at)
+        unsigned long long at_[BPT];
+#pragma unroll
+        for (int t = 0; t < BPT; t++) {
+            const int b = threadIdx.x + t * THREADS;
+            at_[t] = 0;
+            if (b < F1) {
+                const uint32_t c = hist[b];
+                if (c) at_[t] = atomicAdd(&cursor1[b], (unsigned long long)c);
+            }
         }
         const uint32_t total = s3_block_scan<THREADS>(hist, start, F1, wsum);
         if (threadIdx.x == 0) start[F1] = total;
@@ -225,9 +236,21 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         __syncthreads();
         for (int b = threadIdx.x; b < F1; b += THREADS)
             if (hist[b]) atomicOr(&head[start[b] >> 5], 1u << (start[b] & 31));
+        // (the run starts of eight keys are read together: one LDS round trip per eight keys instead of one per key)
 #pragma unroll
-        for (int j = 0; j < 32; j++)
-            if ((ok >> j) & 1u) keys[start[(uint32_t)(key[j] >> R1)] + rank[j]] = (KR1)(key[j] & rmask);
+        for (int j0 = 0; j0 < 32; j0 += 8) {
+            uint32_t st[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) st[jj] = (ok >> (j0 + jj)) & 1u ? start[(uint32_t)(key[j0 + jj] >> R1)] : 0u;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++)
+                if ((ok >> (j0 + jj)) & 1u) keys[st[jj] + rank[j0 + jj]] = (KR1)(key[j0 + jj] & rmask);
+        }
+#pragma unroll
+        for (int t = 0; t < BPT; t++) {
+            const int b = threadIdx.x + t * THREADS;
+            if (b < F1) gbase[b] = (uint32_t)at_[t];
+        }
         // Which run does sorted position i belong to?  A binary search over start[] (10 dependent LDS reads and ~60
         // VALU instructions per key) was most of this kernel; instead: rank of the last run head at or before i,
         // from a prefix popcount over the head bitmap, indexes the runs' (global base - tile start) table.
@@ -244,9 +267,28 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
                 delta[r] = ((unsigned long long)at + hist[b] <= (unsigned long long)lim[b] ? at : trash) - p0;
             }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += THREADS) {
-            const uint32_t r = (uint32_t)hpre[i >> 5] + (uint32_t)__popc(head[i >> 5] & (0xFFFFFFFFu >> (31 - (i & 31)))) - 1u;
-            buf1[(size_t)(delta[r] + i)] = keys[i];
+        // (four positions per round: their LDS reads, then the run look-ups, then the stores)
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 4u * THREADS) {
+            uint32_t hp[4], hd[4];
+            KR1 kv[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t i = i0 + (uint32_t)t * THREADS, ic = i < total ? i : total - 1u;
+                hp[t] = hpre[ic >> 5];
+                hd[t] = head[ic >> 5];
+                kv[t] = keys[ic];
+            }
+            uint32_t dl[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t i = i0 + (uint32_t)t * THREADS, ic = i < total ? i : total - 1u;
+                dl[t] = delta[hp[t] + (uint32_t)__popc(hd[t] & (0xFFFFFFFFu >> (31 - (ic & 31)))) - 1u];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t i = i0 + (uint32_t)t * THREADS;
+                if (i < total) buf1[(size_t)(dl[t] + i)] = kv[t];
+            }
         }
         __syncthreads();
     }
