@@ -577,6 +577,12 @@ class Context:
         self._ck(self.L.sp_filter_fetch_async(self.h, _p(keys), _p(counts), _p(tot), n_rows))
         return keys, counts, tot
 
+    def filter_fetch_async_ptr(self, h_keys, h_counts, n_rows):
+        """The same copy into page-locked host memory given by ADDRESS (a registered shared-memory segment: the
+        multi-GPU matrix hand-over); the row totals go to a scratch buffer of the context."""
+        tot = self.pinned_empty("ff_tot", (max(int(n_rows), 1),), np.uint64)
+        self._ck(self.L.sp_filter_fetch_async(self.h, C.c_void_p(int(h_keys)), C.c_void_p(int(h_counts)), _p(tot), int(n_rows)))
+
     def filter_fetch_wait(self):
         self._ck(self.L.sp_filter_fetch_wait(self.h))
 

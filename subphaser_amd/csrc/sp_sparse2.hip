@@ -732,8 +732,11 @@ __device__ __forceinline__ uint32_t s3_scan_reg(uint32_t v, uint32_t *wsum /* >=
     return base + incl - v;
 }
 
+#ifndef S3_BM_MINW
+#define S3_BM_MINW 1      // waves per SIMD the register allocation of s3_final_bitmap must leave room for
+#endif
 template <typename KR2>
-__global__ void __launch_bounds__(S3_SORT_THREADS)
+__global__ void __launch_bounds__(S3_SORT_THREADS, S3_BM_MINW)
 s3_final_bitmap(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, int R2,
                 uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
                 unsigned long long *__restrict__ kept, unsigned long long *__restrict__ len_sum,

@@ -292,6 +292,14 @@ class DistHotPath:
             ctx.filter_view(ptrs, base, self.nview, lengths, self.k, self.lower_count, optrs, ons)
             n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                                  self.max_freq, self.ratio)
+        if self.shared_rows and not host_rows_on_all_ranks and self.nview and hasattr(ctx, "filter_fetch_async_ptr"):
+            # round 5: every rank's rows travel straight from the filter's buffers to ITS row range of the shared
+            # page-locked segment on the copy stream, behind the map stage; `result.wait()` = copy done + barrier
+            r = self._rows_shared_async(n_rows, n_union, n_hist, lengths)
+            ctx.filter_view(None, 0, 0, None, 0, 0)
+            self._merged = []
+            self._t("filter+fetch", tt)
+            return r
         # surviving rows stay on the device: gathered over xGMI, copied to the host once, where needed
         keys_t = t.empty((max(n_rows, 1),), dtype=t.int64, device=self.device)
         counts_t = t.empty((max(n_rows, 1), self.C), dtype=t.int32, device=self.device)
@@ -302,6 +310,40 @@ class DistHotPath:
         self._merged = []
         tt = self._t("filter+fetch", tt)
         return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
+
+    def _rows_shared_async(self, n_rows, n_union, n_hist, lengths):
+        t, dist = self.torch, self.dist
+        r = HotPathResult()
+        r.kmer_lengths = lengths
+        stats = t.tensor([n_union, n_rows, n_hist], dtype=t.int64, device=self.device)
+        per_rank = [t.zeros(3, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(per_rank, stats)
+        else:
+            per_rank = [stats]
+        per_rank = np.stack([x.cpu().numpy() for x in per_rank])
+        r.n_union, r.n_rows, r.n_hist = (int(x) for x in per_rank.sum(axis=0))
+        r.freqs = r.tot = None
+        ms = per_rank[:, 1]
+        M, first = int(ms.sum()), int(ms[:self.rank].sum())
+        kbytes, cbytes = 8 * max(M, 1), 4 * self.C * max(M, 1)
+        koff = (kbytes + 4095) & ~4095
+        self._shm_ensure(koff + cbytes)
+        base = self._shm_addr
+        self.ctx.filter_fetch_async_ptr(base + 8 * first, base + koff + 4 * self.C * first, n_rows)
+        buf = self._shm.buf
+        r.keys = np.frombuffer(buf, np.uint64, M, 0)
+        r.counts = np.frombuffer(buf, np.uint32, M * self.C, koff).reshape(M, self.C)
+        ctx, world = self.ctx, self.world
+
+        def wait():
+            ctx.filter_fetch_wait()
+            if world > 1:
+                dist.barrier()      # every rank's rows are in place
+
+        r.wait = wait
+        self.rows_handover = "shared, asynchronous"
+        return r
 
     def _gather_rows(self, keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt):
         """Surviving rows of every rank's slot / key range -> one matrix (rank order = ascending range).
@@ -335,6 +377,7 @@ class DistHotPath:
             r.keys = np.frombuffer(buf, np.uint64, M, 0)
             r.counts = np.frombuffer(buf, np.uint32, M * self.C, (kbytes + 4095) & ~4095).reshape(M, self.C)
             tt = self._t("rows to shared host memory", tt)
+            self.rows_handover = "shared"
             return r
         to_host = host_rows_on_all_ranks or self.rank == 0
         gk = self._all_gather_dev(keys_t[:n_rows].reshape(-1, 1), n_rows)
@@ -343,6 +386,7 @@ class DistHotPath:
             r.keys = self._to_host(gk).ravel().view(np.uint64)
             r.counts = self._to_host(gc).view(np.uint32)
         tt = self._t("gather rows", tt)
+        self.rows_handover = "gather"
         return r
 
     # shared, page-locked host segment for the matrix (growth-only; rank 0 creates, the others attach)
