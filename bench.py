@@ -375,7 +375,9 @@ def main():
                    "sig_kmers": int(len(kmer_labels.keys)), "windows": int(len(b.window_counts)),
                    "mapped_positions": int(b.n_mapped), "parallelism": ("single GPU" if world == 1 else "genome-position-sharded count/map + slot-range-sharded filter x%d" % world)},
         "rccl_ranks": rccl_ranks, "dist_selfcheck": selfcheck,
-        "rows": (getattr(runner, "rows_handover", None) if runner is not None else "device->host copy stream"),   # how the M x C matrix reached rank 0 "exchange_ms_per_rank": rank_wall,
+        # how the M x C matrix reached rank 0
+        "rows": (getattr(runner, "rows_handover", None) if runner is not None else "device->host copy stream"),
+        "exchange_ms_per_rank": rank_wall,
         "pieces_per_rank": ([{"rank": r_, "pieces": len(p_), "bases": int(sum(e_ - a_ for _, a_, e_ in p_))}
                              for r_, p_ in enumerate(runner.pieces)] if runner is not None else None),
         "traffic_commit": traffic_commit, "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),

@@ -206,14 +206,19 @@ class DistHotPath:
         for li, pc in enumerate(mine):
             ctx.tables_bind(li, self._ptr(self.tabs[li]))
             ctx.genome_add_device(li, d_pieces[li], pc["stop"] - pc["start"])
-        ctx.sync()
-        tt = self._t("pack", tt)
+        if self.world > 1:
+            ctx.sync()
+            tt = self._t("pack", tt)
         # count piece i and put its byte table on the wire (slot-range slice r -> rank r) while piece i+1 is
-        # being counted: the exchange hides behind the counting kernels
+        # being counted: the exchange hides behind the counting kernels.  One rank: nothing goes on the wire, so the
+        # pieces are counted in one call (packing and the chains of several pieces side by side, as sp_count does)
         works, n_ovf = [], np.zeros(self.max_local, np.int64)
+        if self.world == 1 and mine:
+            ctx.count_range(self.k, self.lower_count, self.engine, 0, len(mine))
         for i in range(self.max_local):
             if i < len(mine):
-                ctx.count_range(self.k, self.lower_count, self.engine, i, i + 1)   # synchronises
+                if self.world > 1:
+                    ctx.count_range(self.k, self.lower_count, self.engine, i, i + 1)   # synchronises
                 n_ovf[i] = ctx.table_overflow(i)
                 send = self.tabs[i]
             else:
