@@ -4,6 +4,7 @@
 // Replaces the external `jellyfish count --canonical | dump -c -L` step
 // (reference: subphaser/Jellyfish.py:671-704).
 #include "sp_device.h"
+#include "sp_c2batch.h"
 
 // ----------------------------------------------------------------- K1 / engine 1
 // Baseline engine: one global atomic per k-mer occurrence into the dense
@@ -88,8 +89,7 @@ k1_narrow(const uint32_t *__restrict__ tab32, int64_t nslots, uint32_t lower, ui
 
 // ----------------------------------------------------------------- overflow list: segments -> sorted list
 // exclusive scan of the per-bucket overflow counts (n <= 2^16 buckets; single block)
-__global__ void __launch_bounds__(1024)
-ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/,
+__device__ __forceinline__ void ovf_scan_body(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off /*n+1*/,
          unsigned long long *__restrict__ total_out /* number of pairs, or NULL */) {
     __shared__ uint32_t wsum[16];
     const int64_t per = (n + 1023) / 1024;
@@ -115,8 +115,7 @@ ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__
 // SPLIT: the pairs go to separate (u64 slot, u32 count) arrays, the form the list engines work on.
 #define OVF_BRUTE 96
 template <bool SPLIT>
-__global__ void __launch_bounds__(256)
-ovf_place(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+__device__ __forceinline__ void ovf_place_body(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
           const uint32_t *__restrict__ seg_off, int64_t n_buckets, uint2 *__restrict__ out,
           unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_cnts) {
     __shared__ uint32_t bits[4][1 << (SP_OVF_SHIFT - 5)], pre[4][1 << (SP_OVF_SHIFT - 5)];
@@ -244,6 +243,7 @@ static int grid_for(sp_ctx *ctx, int64_t work_items, int per_block, int max_per_
 
 int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower,
                      unsigned long long *d_len4, bool exact, sp_sparse_chrom *list);  // sp_count2.hip
+int sp_count_engine3_batch(sp_ctx *ctx, const int *chrom_idx, int n, const sp_kparams &kp, int lower, unsigned long long *d_len);   // sp_count2.hip
 void sp_sparse_release(sp_ctx *ctx);                                                  // sp_sparse.hip
 bool sp_engine2_supported(int64_t nslots);
 int sp_sparse_count(sp_ctx *ctx, int k, int lower);                                   // sp_sparse.hip
@@ -297,6 +297,35 @@ kx_merge(uint8_t *dst /* may alias A.tab */, sp_tabref A, sp_tabref B, int64_t s
         }
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(1024)
+ovf_scan(const uint32_t *__restrict__ seg_cnt, int64_t n, uint32_t *__restrict__ seg_off, unsigned long long *__restrict__ total_out) {
+    ovf_scan_body(seg_cnt, n, seg_off, total_out);
+}
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+ovf_place(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+          const uint32_t *__restrict__ seg_off, int64_t n_buckets, uint2 *__restrict__ out,
+          unsigned long long *__restrict__ out_keys, uint32_t *__restrict__ out_cnts) {
+    ovf_place_body<SPLIT>(tmp, seg_base, seg_cnt, seg_off, n_buckets, out, out_keys, out_cnts);
+}
+// one chromosome per blockIdx.y (sp_c2batch.h)
+__global__ void __launch_bounds__(1024)
+ovf_scan_b(const c2_bdesc *__restrict__ desc, int64_t n) {
+    const c2_bdesc D = desc[blockIdx.y];
+    ovf_scan_body(D.seg_cnt, n, D.seg_off, D.d_len4 + 2);
+}
+__global__ void __launch_bounds__(256)
+ovf_place_list_b(const c2_bdesc *__restrict__ desc, int64_t n_buckets) {
+    const c2_bdesc D = desc[blockIdx.y];
+    ovf_place_body<true>(D.stage, D.seg_base, D.seg_cnt, D.seg_off, n_buckets, (uint2 *)nullptr, D.out_keys, D.out_cnts);
+}
+int sp_ovf_finalize_split_batch(sp_ctx *ctx, const c2_bdesc *d_desc, int n_chrom, int64_t n_buckets) {
+    SP_LAUNCH(ctx, "ovf_scan", ovf_scan_b, dim3(1, (unsigned)n_chrom), dim3(1024), 0, d_desc, n_buckets);
+    SP_LAUNCH(ctx, "ovf_place_list", ovf_place_list_b, dim3((unsigned)((n_buckets + 3) / 4), (unsigned)n_chrom), dim3(256), 0, d_desc,
+              n_buckets);
+    return SP_OK;
 }
 
 // sum and number of the counts >= lower of a byte slice (+ the overflow pairs that fall into it)
@@ -454,6 +483,15 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     // while the context's stream is still packing the chromosomes behind it.
     int n_lanes = 0;
     const bool dense_lanes = !list_mode && C > 1 && first == 0 && last == (int)C && engine != 1;
+    // round 5: list mode counts all its chromosomes with ONE launch per kernel type (sp_c2batch.h) instead of a chain
+    // of ten launches per chromosome on four streams; SP_C2_BATCH=0 keeps the lanes (cross-check)
+    const char *env_batch = getenv("SP_C2_BATCH");
+    // (chromosomes below 2^26 bases: at 128 Mb -- peanut-like -- the per-chromosome chains on four streams are 3 % ahead;
+    // SP_C2_BATCH=1 batches whatever the lengths)
+    int64_t longest = 0;
+    for (size_t ci = (size_t)first; ci < (size_t)last; ci++) longest = ctx->chroms[ci].len > longest ? ctx->chroms[ci].len : longest;
+    const bool batch = list_mode && last - first > 1 && sized_by_sample && !(env_batch && env_batch[0] == '0') &&
+                       (longest < (1LL << 26) || (env_batch && env_batch[0] == '1'));
     if ((list_mode && C > 1) || dense_lanes) {
         const char *el = getenv(list_mode ? "SP_LANES" : "SP_LANES_DENSE");
         n_lanes = el ? atoi(el) : 3;
@@ -479,6 +517,54 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
     }
     // (a lambda: an error return inside must not leave the other lanes' kernels running on the shared scratch)
     auto count_all = [&]() -> int {
+        if (batch) {
+            for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
+                sp_chrom &c = ctx->chroms[ci];
+                if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);
+                sp_sparse_chrom &o = ctx->sparse[ci];
+                o.n = 0;
+                o.length_sum = 0;
+                int64_t need = c.len / lower_count + 16;     // (as below: every kept slot accounts for >= lower occurrences)
+                if (need > nslots) need = nslots;
+                if (need > o.cap) {
+                    SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (o.d_keys) hipFree(o.d_keys);
+                    if (o.d_cnts) hipFree(o.d_cnts);
+                    o.d_keys = nullptr;
+                    o.d_cnts = nullptr;
+                    o.cap = 0;
+                    SP_HIP(ctx, hipMalloc(&o.d_keys, (size_t)(need + 1) * 8));
+                    SP_HIP(ctx, hipMalloc(&o.d_cnts, (size_t)(need + 1) * 4));
+                    o.cap = need;
+                }
+                by_engine2[ci] = 1;
+            }
+            SP_HIP(ctx, hipMemsetAsync(d_len + 4 * (size_t)first, 0, 4 * (size_t)(last - first) * sizeof(unsigned long long), ctx->stream));
+            // groups of chromosomes (g, g + G, g + 2 G, ...) on the context's stream and the lanes: one launch per kernel
+            // type and GROUP -- the kernels of a chain are bound by different things and fill each other's gaps side by
+            // side (one group: 15.4 ms per peanut-like pass against 13.9 for per-chromosome chains on four streams)
+            const int G = n_lanes + 1;
+            if (n_lanes) {       // (the lanes were told to wait for lane_go above; it must follow the memset)
+                SP_HIP(ctx, hipEventRecord(ctx->lane_go, ctx->stream));
+                for (int l = 0; l < n_lanes; l++) SP_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lane_go, 0));
+            }
+            hipStream_t main_stream = ctx->stream;
+            int rcb = SP_OK;
+            for (int g = 0; g < G && !rcb; g++) {
+                std::vector<int> idx;
+                for (int ci = first + g; ci < last; ci += G) idx.push_back(ci);
+                if (idx.empty()) continue;
+                sp_ctx::lane_t *ln = g ? &ctx->lanes[g - 1] : nullptr;
+                if (ln) {
+                    ctx->lane = ln;
+                    ctx->stream = ln->stream;
+                }
+                rcb = sp_count_engine3_batch(ctx, idx.data(), (int)idx.size(), kp, lower_count, d_len);
+                ctx->lane = nullptr;
+                ctx->stream = main_stream;
+            }
+            return rcb;
+        }
         for (size_t ci = (size_t)first; ci < (size_t)last; ci++) {
             sp_chrom &c = ctx->chroms[ci];
             if (!c.d_pk && c.len > 0) return sp_fail(ctx, SP_EINVAL, "chromosome %zu not loaded", ci);

@@ -23,6 +23,7 @@
 // accesses left are LDS atomics.  Physical HBM bytes per base (k = 15):
 //   0.625 x2 (scans) + 3 w + 3 r + 2 w + 2 r + 1 x slots/base (table write).
 #include "sp_device.h"
+#include "sp_c2batch.h"
 
 #define C2_B3 15                      // slot bits resolved inside LDS
 #define C2_FINE (1 << C2_B3)          // slots per fine bucket
@@ -117,8 +118,7 @@ __device__ __forceinline__ int64_t c2_sample_unit(int64_t j, int sample_shift) {
     const int64_t phase = (g * 7 + (g >> 4)) & ((1 << sample_shift) - 1);
     return ((g << sample_shift) + phase) * C2_STRIPE + (j % C2_STRIPE);
 }
-__global__ void __launch_bounds__(C2_P1_THREADS)
-c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+__device__ __forceinline__ void c2_hist_fine_body(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
              int64_t n_units /* of 32 starts */, int64_t n_visit, int sample_shift, sp_kparams32 kp, int shift_fine,
              int n_fine, unsigned long long *__restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // n_fine
@@ -147,8 +147,7 @@ c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
 // where every fine bucket's residuals start in buf2; off1[b] = where level-1 bucket b starts in the level-1 planes
 // (its own bound + three pad records per part1 tile, a multiple of 4).  Sizes and tile starts come later, from
 // part1's cursors (c2_tiles).
-__global__ void __launch_bounds__(1024)
-c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2, unsigned long long mult8,
+__device__ __forceinline__ void c2_offsets_body(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2, unsigned long long mult8,
            unsigned long long mult8_1, unsigned long long slack, unsigned long long slack1, unsigned long long pad1,
            int split /* C2_SPLIT, or 1: everything into sub-region 0 (exact mode) */, unsigned long long sslack,
            unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1 /* F1 * C2_SPLIT + 1 starts */) {
@@ -223,8 +222,7 @@ c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int
 // After part1: the exact sizes of the level-1 sub-regions are its cursors.  off1[V1 + 1 + b] = end of the keys of
 // sub-region b, tile_start[] = first part2 tile of every sub-region.  A bucket that outgrew its region (estimate mode only) had its
 // surplus runs dropped by part1: the flag makes the host count the chromosome again with exact sizes.
-__global__ void __launch_bounds__(C2_MAXV)
-c2_tiles(const unsigned long long *__restrict__ cursor1, int V1, unsigned long long *__restrict__ off1,
+__device__ __forceinline__ void c2_tiles_body(const unsigned long long *__restrict__ cursor1, int V1, unsigned long long *__restrict__ off1,
          unsigned long long *__restrict__ tile_start /* V1 + 1 */, unsigned long long *__restrict__ flag) {
     const int b = threadIdx.x;
     unsigned long long tc = 0;
@@ -285,14 +283,14 @@ __device__ __forceinline__ uint32_t c2_scan_F(const uint32_t *hist, uint32_t *st
 __device__ __forceinline__ uint32_t c2_pack_lo(uint32_t a, uint32_t b) {   // low halves of a and b
     return __builtin_amdgcn_perm(b, a, 0x05040100u);
 }
-__global__ void __launch_bounds__(C2_P1_THREADS)
-c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+__device__ __forceinline__ void c2_part1_body(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
           int64_t n_units /* of 32 starts */, sp_kparams32 kp, int shift1 /* T-B1 */, int F1, int split,
           const unsigned long long *__restrict__ off1, unsigned long long *__restrict__ cursor1, int64_t n_tiles,
           uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
     __shared__ uint32_t hist[C2_MAXF], start[C2_MAXF], wsum[4];
     __shared__ unsigned long long delta[C2_MAXF];
     __shared__ __attribute__((aligned(16))) uint32_t keys[C2_P1_KEYS + C2_PADS];
+    if (n_tiles <= 0 || n_units <= 0) return;      // (an empty chromosome of a batched launch: the prefetch below is unconditional)
     const int sh = 32 - 2 * kp.k;
     const uint32_t mask1 = (1u << shift1) - 1u;
     // the words of the NEXT tile's unit travel while this tile is sorted and written (copy to working registers, issue
@@ -469,8 +467,7 @@ __device__ __forceinline__ int c2_bucket_of(const unsigned long long *__restrict
     return lo;
 }
 
-__global__ void __launch_bounds__(C2_P2_THREADS)
-c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
+__device__ __forceinline__ void c2_part2_body(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1 /* sub-regions of level 1 */, int F2, int shift2 /* B3 */,
          const unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ cursor2 /*n_fine*/,
          uint16_t *__restrict__ buf2) {
@@ -578,8 +575,7 @@ c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, cons
 // written with plain stores so that c2_count's per-bucket look-up is one L2-resident 16-byte load (the cursors
 // themselves were updated by atomics and live beyond L2: reading them inside c2_count's per-bucket prefetch
 // cost 3.8 ms per wheat-like pass).  A bucket that outgrew its region (estimate mode) raises the flag.
-__global__ void __launch_bounds__(256)
-c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
+__device__ __forceinline__ void c2_spans_body(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
          ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag, uint32_t list_div) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_fine) return;
@@ -903,8 +899,7 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
 #define C2L_PF 2         // 8-byte loads per thread and bucket held in registers (8 K keys per bucket)
 #endif
 #define C2L_MAXB 256      // fine buckets per block at most (the launch sizes the grid accordingly)
-__global__ void __launch_bounds__(C2_COUNT_THREADS)
-c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
+__device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
               unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n*/,
               uint2 *__restrict__ stage, unsigned long long stage_cap, uint32_t *__restrict__ seg_base,
               uint32_t *__restrict__ seg_cnt) {
@@ -1126,6 +1121,83 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- kernels: one chromosome, or one per blockIdx.y
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+             int64_t n_units, int64_t n_visit, int sample_shift, sp_kparams32 kp, int shift_fine, int n_fine,
+             unsigned long long *__restrict__ ghist) {
+    c2_hist_fine_body(pk, pm, nm, n_units, n_visit, sample_shift, kp, shift_fine, n_fine, ghist);
+}
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_hist_fine_b(const c2_bdesc *__restrict__ desc, sp_kparams32 kp, int shift_fine, int n_fine) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_hist_fine_body(D.pk, D.pm, D.nm, D.n_units32, D.n_visit, D.sample_shift, kp, shift_fine, n_fine, D.ghist);
+}
+__global__ void __launch_bounds__(1024)
+c2_offsets(const unsigned long long *__restrict__ ghist, int n_fine, int F1, int F2, unsigned long long mult8,
+           unsigned long long mult8_1, unsigned long long slack, unsigned long long slack1, unsigned long long pad1,
+           int split, unsigned long long sslack, unsigned long long *__restrict__ off_fine, unsigned long long *__restrict__ off1) {
+    c2_offsets_body(ghist, n_fine, F1, F2, mult8, mult8_1, slack, slack1, pad1, split, sslack, off_fine, off1);
+}
+__global__ void __launch_bounds__(1024)
+c2_offsets_b(const c2_bdesc *__restrict__ desc, int n_fine, int F1, int F2) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_offsets_body(D.ghist, n_fine, F1, F2, D.mult8, D.mult8_1, D.slack, D.slack1, D.pad1, D.split, D.sslack, D.off_fine, D.off1);
+}
+__global__ void __launch_bounds__(C2_MAXV)
+c2_tiles(const unsigned long long *__restrict__ cursor1, int V1, unsigned long long *__restrict__ off1,
+         unsigned long long *__restrict__ tile_start, unsigned long long *__restrict__ flag) {
+    c2_tiles_body(cursor1, V1, off1, tile_start, flag);
+}
+__global__ void __launch_bounds__(C2_MAXV)
+c2_tiles_b(const c2_bdesc *__restrict__ desc, int V1) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_tiles_body(D.cur1, V1, D.off1, D.tile_start, D.d_len4 + 3);
+}
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+         int64_t n_units, sp_kparams32 kp, int shift1, int F1, int split, const unsigned long long *__restrict__ off1,
+         unsigned long long *__restrict__ cursor1, int64_t n_tiles, uint16_t *__restrict__ lo1, uint8_t *__restrict__ hi1) {
+    c2_part1_body(pk, pm, nm, n_units, kp, shift1, F1, split, off1, cursor1, n_tiles, lo1, hi1);
+}
+__global__ void __launch_bounds__(C2_P1_THREADS)
+c2_part1_b(const c2_bdesc *__restrict__ desc, sp_kparams32 kp, int shift1, int F1) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_part1_body(D.pk, D.pm, D.nm, D.n_units32, kp, shift1, F1, D.split, D.off1, D.cur1, D.n_tiles, D.lo1, D.hi1);
+}
+__global__ void __launch_bounds__(C2_P2_THREADS)
+c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
+         const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2, const unsigned long long *__restrict__ off_fine,
+         unsigned long long *__restrict__ cursor2, uint16_t *__restrict__ buf2) {
+    c2_part2_body(lo1, hi1, off1, tile_start, F1, F2, shift2, off_fine, cursor2, buf2);
+}
+__global__ void __launch_bounds__(C2_P2_THREADS)
+c2_part2_b(const c2_bdesc *__restrict__ desc, int V1, int F2, int shift2) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_part2_body(D.lo1, D.hi1, D.off1, D.tile_start, V1, F2, shift2, D.off_fine, D.cur2, D.buf2);
+}
+__global__ void __launch_bounds__(256)
+c2_spans(const unsigned long long *__restrict__ off_fine, const unsigned long long *__restrict__ cursor2, int64_t n_fine,
+         ulonglong2 *__restrict__ span, unsigned long long *__restrict__ flag, uint32_t list_div) {
+    c2_spans_body(off_fine, cursor2, n_fine, span, flag, list_div);
+}
+__global__ void __launch_bounds__(256)
+c2_spans_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t list_div) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_spans_body(D.off_fine, D.cur2, n_fine, D.span, D.d_len4 + 3, list_div);
+}
+__global__ void __launch_bounds__(C2_COUNT_THREADS)
+c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
+              unsigned long long *__restrict__ out3, uint2 *__restrict__ stage, unsigned long long stage_cap,
+              uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
+    c2_count_list_body(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
+}
+__global__ void __launch_bounds__(C2_COUNT_THREADS)
+c2_count_list_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_count_list_body(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
+}
+
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
                     uint32_t *seg_off, int64_t n_buckets, unsigned long long *d_total);   // sp_count.hip
 int sp_ovf_finalize_split(sp_ctx *ctx, unsigned long long *keys, uint32_t *cnts, const uint2 *tmp, const uint32_t *seg_base,
@@ -1300,4 +1372,141 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
                   ovf_tmp, ovf_cap, seg_base, seg_cnt);
     }
     return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf, d_len4 + 2);
+}
+
+// ---------------------------------------------------------------- engine 3, batched: one launch per kernel type (sp_c2batch.h)
+// Same chain, same layout arithmetic as sp_count_engine2 (estimate mode only: a chromosome whose flag comes back up is
+// counted again, alone, from the exact histogram by the caller).  Workspace: the zeroed heads (histogram .. cursors) of all
+// chromosomes back to back -- one memset -- then their bodies.
+int sp_ovf_finalize_split_batch(sp_ctx *ctx, const c2_bdesc *d_desc, int n_chrom, int64_t n_buckets);   // sp_count.hip
+int sp_count_engine3_batch(sp_ctx *ctx, const int *chrom_idx, int n, const sp_kparams &kp, int lower, unsigned long long *d_len /* 4 per chromosome */) {
+    c2_plan P;
+    if (!c2_make_plan(ctx->nslots, P))
+        return sp_fail(ctx, SP_EUNSUP, "count engine 3 needs a dense slot space of 2^17..2^31 slots (k=%d)", kp.k);
+    const size_t nf = (size_t)P.n_fine;
+    const int V1 = P.F1 * C2_SPLIT;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // head (zeroed): ghist | off_fine | off1 | tile_start | cursor1 | cursor2
+    const size_t h_ghist = 0, h_offf = h_ghist + al(nf * 8), h_off1 = h_offf + al((nf + 1) * 8),
+                 h_tile = h_off1 + al((size_t)(V1 + 1) * 16), h_cur1 = h_tile + al((size_t)(V1 + 1) * 8),
+                 h_cur2 = h_cur1 + al((size_t)C2_MAXV * 8 * C2_CSTRIDE), head_bytes = h_cur2 + al(nf * 8 * C2_CSTRIDE2);
+    const char *env_mult = getenv("SP_C2_MULT8"), *env_slack = getenv("SP_C2_SLACK");   // test hooks (force overruns)
+    std::vector<c2_bdesc> hd((size_t)n);
+    std::vector<size_t> body_off((size_t)n), lo1_bytes_v((size_t)n), k1((size_t)n), k2((size_t)n), stage_n((size_t)n);
+    size_t body_total = 0;
+    int64_t max_tiles = 0, max_hist_tiles = 0, max_tiles2 = 0;
+    for (int i = 0; i < n; i++) {
+        const sp_chrom &c = ctx->chroms[(size_t)chrom_idx[i]];
+        c2_bdesc &D = hd[(size_t)i];
+        D.pk = c.d_pk;
+        D.pm = c.d_pm;
+        D.nm = c.d_nm;
+        D.n_units32 = (c.len + C2_P1_UNIT - 1) / C2_P1_UNIT;
+        D.n_tiles = (D.n_units32 + C2_P1_THREADS - 1) / C2_P1_THREADS;
+        D.sample_shift = C2_SAMPLE_SHIFT;
+        D.mult8 = (unsigned long long)(env_mult ? atoll(env_mult) : (9 << C2_SAMPLE_SHIFT));
+        int64_t sl = c.len / 64;
+        sl = sl < 4096 ? 4096 : (sl > 32768 ? 32768 : sl);
+        D.slack = (unsigned long long)(env_slack ? atoll(env_slack) : sl);
+        D.slack1 = env_slack ? D.slack : 4ULL * D.slack + 65536ULL;
+        D.mult8_1 = env_mult ? D.mult8 : (unsigned long long)(33 << (C2_SAMPLE_SHIFT - 2));
+        const int64_t n_stripes = (D.n_units32 + C2_STRIPE - 1) / C2_STRIPE;
+        D.n_visit = ((n_stripes + (1 << C2_SAMPLE_SHIFT) - 1) >> C2_SAMPLE_SHIFT) * C2_STRIPE;
+        D.pad1 = 3ULL * (unsigned long long)D.n_tiles + 3ULL * C2_SPLIT;
+        D.split = C2_SPLIT;
+        D.sslack = D.slack1 / 4;
+        const size_t cap_keys1 = (size_t)(((unsigned long long)D.n_visit * C2_P1_UNIT * D.mult8_1 + 7) / 8) + (size_t)P.F1 * (size_t)D.slack1 +
+                                 (size_t)P.F1 * (size_t)(D.pad1 + 4) + (size_t)V1 * (size_t)(D.sslack + 8);
+        const size_t tiles2_max = cap_keys1 / C2_TILE_KEYS + 2 * (size_t)V1;
+        const size_t cap_keys2 = (size_t)(((unsigned long long)D.n_visit * C2_P1_UNIT * D.mult8 + 7) / 8) + nf * (size_t)(D.slack + 4) +
+                                 3 * (size_t)P.F2 * tiles2_max;
+        const size_t cap_keys = cap_keys1 > cap_keys2 ? cap_keys1 : cap_keys2;
+        if (c.len >= (1LL << 32) - 16 || cap_keys / (size_t)lower + C2_FINE >= ((size_t)1 << 32))
+            return sp_fail(ctx, SP_EUNSUP, "count engine 3: a chromosome of %lld bases", (long long)c.len);
+        k1[(size_t)i] = cap_keys1;
+        k2[(size_t)i] = cap_keys2;
+        stage_n[(size_t)i] = cap_keys / (size_t)lower + C2_FINE + 16;
+        lo1_bytes_v[(size_t)i] = al(cap_keys1 * 2 + 64 + (size_t)V1 * 8);
+        // body: span | level-1 planes | buf2 | seg_base | seg_cnt | seg_off | stage
+        body_off[(size_t)i] = body_total;
+        body_total += al(nf * 16) + lo1_bytes_v[(size_t)i] + al(cap_keys1 + 64 + (size_t)V1 * 4) + al(cap_keys2 * 2 + 64) + 2 * al(nf * 4) +
+                      al((nf + 1) * 4) + al(stage_n[(size_t)i] * 8);
+        if (D.n_tiles > max_tiles) max_tiles = D.n_tiles;
+        const int64_t ht = (D.n_visit + C2_P1_THREADS - 1) / C2_P1_THREADS;
+        if (ht > max_hist_tiles) max_hist_tiles = ht;
+        if ((int64_t)tiles2_max > max_tiles2) max_tiles2 = (int64_t)tiles2_max;
+    }
+    const size_t total = al((size_t)n * sizeof(c2_bdesc)) + (size_t)n * head_bytes + body_total;
+    void *&d_ws2 = ctx->lane ? ctx->lane->d_ws2 : ctx->d_ws2;           // this lane's workspace (sp_common.h)
+    int64_t &ws2_bytes = ctx->lane ? ctx->lane->ws2_bytes : ctx->ws2_bytes;
+    if ((int64_t)total > ws2_bytes) {
+        if (d_ws2) {
+            SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SP_HIP(ctx, hipFree(d_ws2));
+            d_ws2 = nullptr;
+            ws2_bytes = 0;
+        }
+        SP_HIP(ctx, hipMalloc(&d_ws2, total));
+        ws2_bytes = (int64_t)total;
+    }
+    char *ws = (char *)d_ws2;
+    c2_bdesc *d_desc = (c2_bdesc *)ws;
+    char *heads = ws + al((size_t)n * sizeof(c2_bdesc)), *bodies = heads + (size_t)n * head_bytes;
+    for (int i = 0; i < n; i++) {
+        c2_bdesc &D = hd[(size_t)i];
+        char *h = heads + (size_t)i * head_bytes, *b = bodies + body_off[(size_t)i];
+        D.ghist = (unsigned long long *)(h + h_ghist);
+        D.off_fine = (unsigned long long *)(h + h_offf);
+        D.off1 = (unsigned long long *)(h + h_off1);
+        D.tile_start = (unsigned long long *)(h + h_tile);
+        D.cur1 = (unsigned long long *)(h + h_cur1);
+        D.cur2 = (unsigned long long *)(h + h_cur2);
+        D.span = (ulonglong2 *)b;
+        b += al(nf * 16);
+        D.lo1 = (uint16_t *)b;
+        D.hi1 = (uint8_t *)b + lo1_bytes_v[(size_t)i];
+        b += lo1_bytes_v[(size_t)i] + al(k1[(size_t)i] + 64 + (size_t)V1 * 4);
+        D.buf2 = (uint16_t *)b;
+        b += al(k2[(size_t)i] * 2 + 64);
+        D.seg_base = (uint32_t *)b;
+        b += al(nf * 4);
+        D.seg_cnt = (uint32_t *)b;
+        b += al(nf * 4);
+        D.seg_off = (uint32_t *)b;
+        b += al((nf + 1) * 4);
+        D.stage = (uint2 *)b;
+        D.stage_cap = (unsigned long long)stage_n[(size_t)i];
+        D.d_len4 = d_len + 4 * (size_t)chrom_idx[i];
+        D.out_keys = (unsigned long long *)ctx->sparse[(size_t)chrom_idx[i]].d_keys;
+        D.out_cnts = ctx->sparse[(size_t)chrom_idx[i]].d_cnts;
+    }
+    // (pageable source: hipMemcpyAsync returns once the runtime has staged it)
+    SP_HIP(ctx, hipMemcpyAsync(d_desc, hd.data(), (size_t)n * sizeof(c2_bdesc), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(ctx, hipMemsetAsync(heads, 0, (size_t)n * head_bytes, ctx->stream));
+    const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
+    const unsigned un = (unsigned)n;
+    // grids: what the largest chromosome needs, capped so that all chromosomes together fill the chip a few times over
+    auto cap_grid = [&](int64_t need, int64_t per_cu) {
+        int64_t g = ((int64_t)ctx->n_cu * per_cu + n - 1) / n;
+        if (g > need) g = need;
+        return (unsigned)(g < 1 ? 1 : g);
+    };
+    const size_t sh_hist = nf * 4;
+    if (sh_hist > 48 * 1024)
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_hist_fine_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_hist));
+    SP_LAUNCH(ctx, "c2_hist_sample", c2_hist_fine_b, dim3(cap_grid(max_hist_tiles, 2), un), dim3(C2_P1_THREADS), sh_hist, (const c2_bdesc *)d_desc,
+              kp32, C2_B3, (int)nf);
+    SP_LAUNCH(ctx, "c2_offsets", c2_offsets_b, dim3(1, un), dim3(1024), 0, (const c2_bdesc *)d_desc, (int)nf, P.F1, P.F2);
+    SP_LAUNCH(ctx, "c2_part1", c2_part1_b, dim3(cap_grid(max_tiles, 8), un), dim3(C2_P1_THREADS), 0, (const c2_bdesc *)d_desc, kp32, P.T - P.B1,
+              P.F1);
+    SP_LAUNCH(ctx, "c2_tiles", c2_tiles_b, dim3(1, un), dim3(C2_MAXV), 0, (const c2_bdesc *)d_desc, V1);
+    SP_LAUNCH(ctx, "c2_part2", c2_part2_b, dim3(cap_grid(max_tiles2, 8), un), dim3(C2_P2_THREADS), 0, (const c2_bdesc *)d_desc, V1, P.F2, C2_B3);
+    SP_LAUNCH(ctx, "c2_spans", c2_spans_b, dim3((unsigned)((nf + 255) / 256), un), dim3(256), 0, (const c2_bdesc *)d_desc, (int64_t)nf,
+              (uint32_t)lower);
+    unsigned gridc = cap_grid((int64_t)nf, 1);
+    if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (unsigned)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
+    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list_b, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+    SP_LAUNCH(ctx, "c2_count_list", c2_count_list_b, dim3(gridc, un), dim3(C2_COUNT_THREADS), C2_FINE * 4, (const c2_bdesc *)d_desc, (int64_t)nf,
+              (uint32_t)lower);
+    return sp_ovf_finalize_split_batch(ctx, d_desc, n, (int64_t)nf);
 }

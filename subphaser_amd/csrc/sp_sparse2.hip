@@ -177,6 +177,7 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], delta[S3_MAXF], wsum[THREADS / 64];
     __shared__ uint32_t head[THREADS];      // tile positions / 32 = THREADS words
     __shared__ uint32_t lim[S3_MAXF];       // end of every bucket's region (read once per workgroup)
+    if (n_tiles <= 0 || n_units <= 0) return;      // (the prefetch below is unconditional)
     for (int b = threadIdx.x; b < F1; b += THREADS) lim[b] = (uint32_t)off1[b + 1];
     __syncthreads();
     __shared__ uint16_t hpre[THREADS];
