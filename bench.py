@@ -298,12 +298,18 @@ def main():
         avg_s = avg_ev * (lane_scale if names[0] in LANE_KERNELS else 1.0)
         traffic = None
         # the profiler's labels -> the kernel symbols rocprofv3 reports (one kernel launched under two labels)
-        sym = {"c2_hist_sample": "c2_hist_fine", "ovf_place_list": "ovf_place", "k5_map_mask_lab": "k5_map_mask",
+        sym = {"k5_map": "k5_map2", "k5_map_sparse": "k5_map_sparse2", "sps_join": "sps_join_blk",
+               "c2_hist_sample": "c2_hist_fine", "ovf_place_list": "ovf_place", "k5_map_mask_lab": "k5_map_mask",
                "sps_emit_hist": "sps_emit", "k3_emit_hist": "k3_emit", "s3_hist1_sample": "s3_hist1",
                "s3_hist2_sample": "s3_hist2"}
-        if tj and all(sym.get(n, n) in tj for n in names if n in prof):
+        def _sym(n):       # the symbol a label's kernel has in the PMC table (batched wrappers carry a _b suffix)
+            for cand in (sym.get(n, n), n, sym.get(n, n) + "_b", n + "_b"):
+                if cand in tj:
+                    return cand
+            return None
+        if tj and all(_sym(n) for n in names if n in prof):
             # PMC bytes are per launch; launches per pass of the chain come from THIS run's launch counts
-            traffic = int(sum((tj[sym.get(n, n)].get("read_bytes", 0) + tj[sym.get(n, n)].get("write_bytes", 0))
+            traffic = int(sum((tj[_sym(n)].get("read_bytes", 0) + tj[_sym(n)].get("write_bytes", 0))
                               * (prof[n]["calls"] / args.steps / units) for n in names if n in prof))
         ach = alg / avg_s
         return {"bound": "hbm", "kernel": label, "achieved": round(ach / 1e9, 3), "peak": HBM_PEAK / 1e9,

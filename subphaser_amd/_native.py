@@ -341,6 +341,10 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for d_keys, d_sg in getattr(self, "_label_copies", {}).values():     # device copies of label sets (seqs.KmerLabels)
+                self.L.sp_dev_free(self.h, C.c_void_p(d_keys))
+                self.L.sp_dev_free(self.h, C.c_void_p(d_sg))
+            self._label_copies = {}
             for ptr, _ in self._pinned.values():
                 self.L.sp_host_free(self.h, C.c_void_p(ptr))
             self._pinned = {}

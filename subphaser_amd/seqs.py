@@ -372,6 +372,13 @@ class KmerLabels:
         self.sg_idx = np.ascontiguousarray(sg_idx, np.uint8)
         self.sg_names = list(sg_names)
         self.k = int(k)
+        # the device copy below is keyed on the identity of these two arrays: they are frozen so that nobody edits them
+        # in place behind it (assigning new arrays to .keys / .sg_idx is seen and makes a new copy) -- advisor r04
+        for a in (self.keys, self.sg_idx):
+            try:
+                a.setflags(write=False)
+            except ValueError:
+                pass
 
     def __len__(self):           # the reference's dict holds both orientations
         return 2 * len(self.keys)
@@ -383,7 +390,8 @@ class KmerLabels:
     _dev = None
 
     def on_device(self, ctx):
-        if self._dev is None or self._dev[0] is not ctx or not ctx.h:
+        stamp = (id(self.keys), id(self.sg_idx), len(self.keys))
+        if self._dev is None or self._dev[0] is not ctx or not ctx.h or self._dev[3] != stamp:
             self.release_device()
             n = len(self.keys)
             d_keys = ctx.dev_alloc(max(n, 1) * 8)
@@ -391,14 +399,20 @@ class KmerLabels:
             if n:
                 ctx.host_to_dev(d_keys, self.keys)
                 ctx.host_to_dev(d_sg, self.sg_idx)
-            self._dev = (ctx, d_keys, d_sg)
+            self._dev = (ctx, d_keys, d_sg, stamp)
+            # the context frees the copy if it is closed first (a closed context has no handle to free with)
+            reg = getattr(ctx, "_label_copies", None)
+            if reg is None:
+                reg = ctx._label_copies = {}
+            reg[id(self)] = (d_keys, d_sg)
         return self._dev[1], self._dev[2]
 
     def release_device(self):
         if self._dev is not None:
-            ctx, d_keys, d_sg = self._dev
+            ctx, d_keys, d_sg = self._dev[:3]
             self._dev = None
-            if ctx.h:
+            reg = getattr(ctx, "_label_copies", None)
+            if reg is not None and reg.pop(id(self), None) is not None and ctx.h:
                 ctx.dev_free(d_keys)
                 ctx.dev_free(d_sg)
 

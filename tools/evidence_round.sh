@@ -1,8 +1,8 @@
 set -u
 # Round evidence on the GPU box (through gpurun, from the repo root): GPU suite, rocprofv3 kernel traces + stamped PMC
 # passes of the five bench workloads, their bench lines (in-run verification against the oracle), fuzz.
-export SP_COMMIT=82f03f1
-R=r04
+export SP_COMMIT=${SP_COMMIT:-unknown}
+R=${SP_ROUND:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${R}_final_pytest_gpu.txt

@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-GATHER = ("k5_map", "k5_map_lab", "k5_map_sparse", "k5_map_feat", "k5_map_feat_sparse")
+GATHER = ("k5_map", "k5_map2", "k5_map_lab", "k5_map_sparse", "k5_map_sparse2", "k5_map_feat", "k5_map_feat_sparse")
 
 
 def main(paths):
