@@ -529,6 +529,21 @@ __device__ __forceinline__ void c2_part2_body(const uint16_t *__restrict__ lo1, 
         for (int j = 0; j < C2_P2_PER; j++)
             if (j < nmine && my[j] != C2_INVALID1) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
         __syncthreads();  // (B)
+#if defined(C2_P2_EXP) && C2_P2_EXP == 2      // bound experiment: loads and rank atomics only
+        {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < C2_P2_PER; j++) acc ^= my[j] + rank[j];
+            if (acc == 0x12345678u && nmine == 77) buf2[tile] = (uint16_t)acc;
+            nnext = 0;
+            if (ntile < n_tiles) {
+                const int nb = s_bucket[p ^ 1];
+                fetch(nb, ntile - tile_start[nb]);
+            }
+            p ^= 1;
+            continue;
+        }
+#endif
         unsigned long long g = 0;
         bool fits = true;
         uint32_t c = 0;
@@ -564,6 +579,9 @@ __device__ __forceinline__ void c2_part2_body(const uint16_t *__restrict__ lo1, 
         for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P2_THREADS) {
             const uint4 v = k4[q];
             const unsigned long long gb = gbase[v.x >> 16];
+#if defined(C2_P2_EXP) && C2_P2_EXP == 1      // bound experiment: no stores (wrong answers)
+            if (v.x != 0x12345678u) continue;
+#endif
             if (gb != C2_DROP)
                 *reinterpret_cast<uint2 *>(buf2 + gb + 4ULL * q) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
         }

@@ -533,7 +533,7 @@ template <int TABLE>
 __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                 const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
                                                 const uint32_t *__restrict__ bloom, int nbits, const map_ptab &T,
-                                                unsigned long long lab[3]) {
+                                                unsigned long long lab[3], unsigned long long cm = ~0ULL /* starts that count */) {
     constexpr int FW = TABLE ? MAP_CT_FIELD : 4;
     constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
     constexpr uint32_t ANY = TABLE ? MAP_CT_ANY : 0x77777777u;
@@ -653,8 +653,10 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                     const bool fw = h ? fw2 : fw1;
                     const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
                     const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
-                    const uint32_t v0 = ((okk[q] >> (2 * h)) & 1u) ? (e >> (FW * f0)) & FMASK : 0u;
-                    const uint32_t v1 = ((okk[q] >> (2 * h + 1)) & 1u) ? (e >> (FW * f1)) & FMASK : 0u;
+                    // (a start outside `cm` -- interval mode: not covered by a feature -- is neither counted nor marked seen)
+                    const uint32_t cnt2 = (uint32_t)(cm >> (j + 2 * h)) & okk[q] >> (2 * h);
+                    const uint32_t v0 = (cnt2 & 1u) ? (e >> (FW * f0)) & FMASK : 0u;
+                    const uint32_t v1 = (cnt2 & 2u) ? (e >> (FW * f1)) & FMASK : 0u;
                     const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
                     if (!two) continue;
 #pragma unroll
@@ -755,6 +757,26 @@ k5_map2(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, 
         }
     }
     flush_mapped();
+}
+
+// interval (BED) mode on the rolled walk: the label planes of a unit, restricted to the covered starts, ARE its masks
+template <int TABLE>
+__global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
+k5_map_mask2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams32 kp,
+             int64_t n_units, int S, map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
+             const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks /* n_units x S */) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        const unsigned long long cv = cov[u];
+        if (__all(cv == 0ULL)) continue;         // nothing of this wave's 4096 starts lies in a feature
+        unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+        map_unit_scan64<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab, cv);
+        for (int sg = 0; sg < S; sg++) {
+            const int l = sg + 1;
+            masks[u * S + sg] = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) & ((l & 4) ? lab[2] : ~lab[2]) & cv;
+        }
+    }
 }
 
 // the exact pair table the current label set lives in (compact when ctx->ct_bb != 0)
@@ -1634,7 +1656,17 @@ int sp_map_intervals(sp_ctx *ctx, const int32_t *chrom, const int64_t *start, co
         const sp_kparams32 kp = sp_make_kparams32(k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        if (ctx->map_engine == 0 && ctx->ct_bb)
+        const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernels of rounds 2-4 (cross-check)
+        const bool rolled = !(env_mk && env_mk[0] == '1');
+        if (ctx->map_engine == 0 && rolled && ctx->ct_bb)
+            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
+                      n_units, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
+        else if (ctx->map_engine == 0 && rolled)
+            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
+                      n_units, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
+        else if (ctx->map_engine == 0 && ctx->ct_bb)
             SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<2>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
                       n_units, S, map_ptab_of(ctx), (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);

@@ -433,7 +433,7 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                                                   const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
                                                   const uint32_t *__restrict__ bloom, int nbits,
                                                   unsigned long long *__restrict__ htab, uint64_t hmask,
-                                                  unsigned long long lab[3]) {
+                                                  unsigned long long lab[3], unsigned long long cm = ~0ULL /* starts that count */) {
     unsigned long long ok_k, ok_x;      // k-mer at s0+j valid; shared (k-1)-mer at s0+j+1 valid
     {
         const uint64_t badA = sp_bad_starts64(nm, s0, kp.k - 1), badB = sp_bad_starts64(nm, s0 + 32, kp.k - 1);
@@ -487,7 +487,7 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                 const bool fw = xf[h] <= xr[h];
                 const uint32_t b0 = (uint32_t)(V[h] >> 62);
                 const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
-                const uint32_t okk = (uint32_t)(ok_k >> (j + 2 * h));
+                const uint32_t okk = (uint32_t)((ok_k & cm) >> (j + 2 * h));     // (not covered: neither counted nor marked seen)
                 const uint32_t v0 = (okk & 1u) ? (e[h] >> (4 * f0)) & 15u : 0u;
                 const uint32_t v1 = (okk & 2u) ? (e[h] >> (4 * f1)) & 15u : 0u;
                 const uint32_t two = (v0 & 7u) | ((v1 & 7u) << 8);
@@ -1824,11 +1824,36 @@ k5_map_mask_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_mask_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
+                    int64_t n_units, int S, unsigned long long *__restrict__ htab, uint64_t hmask, const uint32_t *__restrict__ bloom,
+                    int bloom_bits, const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; u < n_units; u += stride) {
+        const unsigned long long cv = cov[u];
+        if (__all(cv == 0ULL)) continue;
+        unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+        map_unit_scan64_h(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, lab, cv);
+        for (int sg = 0; sg < S; sg++) {
+            const int l = sg + 1;
+            masks[u * S + sg] = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) & ((l & 4) ? lab[2] : ~lab[2]) & cv;
+        }
+    }
+}
+
 int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, const unsigned long long *d_cov,
                           unsigned long long *d_masks) {
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
+    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernel (cross-check)
+    if (ctx->map_engine == 0 && S <= 7 && !(env_mk && env_mk[0] == '1')) {
+        SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
+                  (const uint32_t *)c.d_pm, (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys,
+                  (uint64_t)(ctx->hcap - 1), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
+        return SP_OK;
+    }
     SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
               (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1),
               (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks, ctx->map_engine == 0 ? 1 : 0);
