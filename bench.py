@@ -320,7 +320,7 @@ def main():
 
     COUNT_CHAIN = [n for n in ("c2_hist_sample", "c2_hist_fine", "c2_offsets", "c2_part1", "c2_tiles", "c2_part2", "c2_spans",
                                "c2_count16", "c2_count", "c2_count_list", "ovf_scan", "ovf_place", "ovf_place_list", "k1_count_atomic",
-                               "k1_narrow") if n in prof and prof[n]["calls"] >= args.steps * max(1, n_local)]
+                               "k1_narrow") if n in prof and prof[n]["calls"] >= args.steps]      # (batched small genomes: one launch per group of chromosomes)
     if args.k > 15:     # the MSD-partition engine for 64-bit keys: one chain of s3_* kernels per chromosome
         COUNT_CHAIN = sorted(n for n in prof if n.startswith("s3_"))
     # byte-table filter, or the list filter (k > 15, and engine 3 on small genomes at k <= 15)
