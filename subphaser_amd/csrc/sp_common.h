@@ -34,6 +34,9 @@ struct sp_chrom {
                                       // the packing of the chromosomes after it
 };
 #define SP_PAD_WORDS 8
+#ifndef SP_DERIVE_PM
+#define SP_DERIVE_PM 1      // the MSB-first packed stream is derived in registers instead of stored (sp_device.h)
+#endif
 
 // growth-only device buffer: hipMalloc/hipFree are slow (a hipMalloc that follows the release of
 // tens of GiB was measured at 1.4-2.3 s on MI355X), so hot-path buffers are kept and reused.

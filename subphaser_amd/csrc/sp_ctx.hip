@@ -287,7 +287,11 @@ k0_pack(const uint8_t *__restrict__ ascii, int64_t len, uint32_t *__restrict__ p
             }
         }
         *reinterpret_cast<uint2 *>(pk + 2 * t) = make_uint2(w0, w1);
+#if !SP_DERIVE_PM      // (round 5: the scans derive the MSB-first words from the LSB-first ones, sp_device.h)
         *reinterpret_cast<uint2 *>(pm + 2 * t) = make_uint2(r0, r1);
+#else
+        (void)r0; (void)r1; (void)pm;
+#endif
         nm[t] = m;
     }
 }
@@ -316,8 +320,13 @@ static int genome_add_impl(sp_ctx *ctx, int chrom, const uint8_t *d_ascii, int64
         if (c.d_nm) hipFree(c.d_nm);
         c.d_pk = c.d_pm = c.d_nm = nullptr;
         c.cap_mw = 0;
+#if SP_DERIVE_PM      // one stream: 0.375 B/base resident instead of 0.625 (3.5 GB less for the wheat-like genome)
+        SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(2 * nmw) * sizeof(uint32_t)));
+        c.d_pm = c.d_pk;
+#else
         SP_HIP(ctx, hipMalloc(&c.d_pk, (size_t)(4 * nmw) * sizeof(uint32_t)));   // LSB-first | MSB-first
         c.d_pm = c.d_pk + 2 * nmw;
+#endif
         SP_HIP(ctx, hipMalloc(&c.d_nm, (size_t)nmw * sizeof(uint32_t)));
         c.cap_mw = nmw;
     }

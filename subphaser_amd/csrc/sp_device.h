@@ -201,6 +201,14 @@ __device__ __forceinline__ uint64_t sp_bad_starts64(const uint32_t *__restrict__
     return e;   // bit j: an invalid base in [s0+j, s0+j+w)
 }
 
+// Round 5: the MSB-first stream is no longer read (nor written): the MSB-first twin of a 16-base word is its bit
+// reversal with the two bits of every code swapped back -- four VALU operations per word, i.e. 12 per 32 k-mers in the
+// kernels that scan, against a second 0.25-B/base stream written by k0_pack and read by every scan (SP_DERIVE_PM=0
+// restores the loads; the kernels keep their `pm` argument)
+__device__ __forceinline__ uint32_t sp_msb_of_lsb(uint32_t w) {
+    const uint32_t r = __builtin_bitreverse32(w);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
 struct sp_words32 {
     uint32_t l[3], m[3];
 };
@@ -209,9 +217,14 @@ __device__ __forceinline__ sp_words32 sp_load_words32(const uint32_t *__restrict
     const int64_t w0 = s0 >> 4;   // even: 8-byte aligned
     sp_words32 r;
     const uint2 a = *reinterpret_cast<const uint2 *>(pk + w0);
-    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0);
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = pk[w0 + 2];
+#if SP_DERIVE_PM
+    (void)pm;
+    r.m[0] = sp_msb_of_lsb(r.l[0]); r.m[1] = sp_msb_of_lsb(r.l[1]); r.m[2] = sp_msb_of_lsb(r.l[2]);
+#else
+    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0);
     r.m[0] = b.x; r.m[1] = b.y; r.m[2] = pm[w0 + 2];
+#endif
     return r;
 }
 // 16-base windows starting at base s0 + J (J a compile-time constant after unrolling)
@@ -282,9 +295,15 @@ __device__ __forceinline__ sp_words64 sp_load_words64(const uint32_t *__restrict
     const int64_t w0 = s0 >> 4;   // even: 8-byte aligned
     sp_words64 r;
     const uint2 a = *reinterpret_cast<const uint2 *>(pk + w0), a2 = *reinterpret_cast<const uint2 *>(pk + w0 + 2);
-    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0), b2 = *reinterpret_cast<const uint2 *>(pm + w0 + 2);
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a2.x; r.l[3] = a2.y;
+#if SP_DERIVE_PM
+    (void)pm;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.m[i] = sp_msb_of_lsb(r.l[i]);
+#else
+    const uint2 b = *reinterpret_cast<const uint2 *>(pm + w0), b2 = *reinterpret_cast<const uint2 *>(pm + w0 + 2);
     r.m[0] = b.x; r.m[1] = b.y; r.m[2] = b2.x; r.m[3] = b2.y;
+#endif
     return r;
 }
 template <int J>

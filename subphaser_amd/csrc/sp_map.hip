@@ -550,9 +550,15 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     }
     if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
     const int64_t w0 = s0 >> 4;   // a multiple of 4: 16-byte aligned
-    const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0), ma = *reinterpret_cast<const uint4 *>(pm + w0);
+    const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0);
     uint32_t l0 = la.x, l1 = la.y, l2 = la.z, l3 = la.w, l4 = pk[w0 + 4];
+#if SP_DERIVE_PM
+    (void)pm;
+    uint32_t m0 = sp_msb_of_lsb(l0), m1 = sp_msb_of_lsb(l1), m2 = sp_msb_of_lsb(l2), m3 = sp_msb_of_lsb(l3), m4 = sp_msb_of_lsb(l4);
+#else
+    const uint4 ma = *reinterpret_cast<const uint4 *>(pm + w0);
     uint32_t m0 = ma.x, m1 = ma.y, m2 = ma.z, m3 = ma.w, m4 = pm[w0 + 4];
+#endif
     const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
     const uint32_t m1mask = kp.kmask >> 2;
     const int sb = T.sb;
