@@ -503,6 +503,27 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
         if (dense_lanes && n_lanes > 0) n_lanes++;       // (the context's stream takes no chain)
         if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
         if (n_lanes < 0) n_lanes = 0;
+        {   // every lane owns a workspace of ~6 bytes per base of the longest chromosome (sp_count2.hip / sp_sparse2.hip):
+            // lanes whose workspace is not allocated yet must fit what the device has free, with a margin (advisor r04)
+            int64_t longest_c = 0;
+            for (size_t ci = (size_t)first; ci < (size_t)last; ci++) longest_c = ctx->chroms[ci].len > longest_c ? ctx->chroms[ci].len : longest_c;
+            const int64_t per_lane = 6 * longest_c + (256LL << 20);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                int64_t budget = (int64_t)free_b - (int64_t)(total_b / 16);      // keep a sixteenth of the device free
+                int fit = 0;
+                for (int l = 0; l < n_lanes; l++) {
+                    const int64_t need = ctx->lanes[l].ws2_bytes >= per_lane ? 0 : per_lane;
+                    if (need > budget) break;
+                    budget -= need;
+                    fit++;
+                }
+                if (fit < n_lanes) {
+                    if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] count: %d of %d lanes fit the free device memory\n", fit, n_lanes);
+                    n_lanes = (dense_lanes && fit == 1) ? 0 : fit;      // (one dense lane = the plain single-stream path)
+                }
+            }
+        }
         for (int l = 0; l < n_lanes; l++) {
             if (!ctx->lanes[l].stream) {
                 SP_HIP(ctx, hipStreamCreateWithFlags(&ctx->lanes[l].stream, hipStreamNonBlocking));
