@@ -279,6 +279,16 @@ def test_count_chains_side_by_side_at_k15(gpu_ctx, monkeypatch):
             for k in (11, 14, 15):
                 _count_both(gpu_ctx, seqs, k, 2, engine)
         monkeypatch.delenv(var)
+    # engine 3, round 5: one launch per kernel type and GROUP of chromosomes (sp_c2batch.h; the default below 2^26
+    # bases) against the per-chromosome chains (SP_C2_BATCH=0), one to four groups, incl. the empty chromosome
+    for batch in ("1", "0"):
+        monkeypatch.setenv("SP_C2_BATCH", batch)
+        for lanes in ("0", "3"):
+            monkeypatch.setenv("SP_LANES", lanes)
+            _count_both(gpu_ctx, seqs, 15, 3, 3)
+            _count_both(gpu_ctx, seqs, 13, 1, 3)
+    monkeypatch.delenv("SP_C2_BATCH")
+    monkeypatch.delenv("SP_LANES")
 
 
 def test_count_sparse_engine_hot_buckets(gpu_ctx):
@@ -343,13 +353,18 @@ def test_list_filter_handful_of_kmers(gpu_ctx, oracle_ctx):
             assert a.shape == b.shape and (a == b).all(), (k, lower)
 
 
-@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer"])
+@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer", "pairs-unrolled+wave-join"])
 @pytest.mark.parametrize("k", [17, 21, 32])
 def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkeypatch):
     """k = 17 / 21 (BASELINE config 5) and 32: matrix rows and bin counts bit-exact vs the oracle, with the
-    pair-keyed label table (one look-up per pair of starts, <= 7 subgenomes) and with the per-k-mer table."""
+    pair-keyed label table (one look-up per pair of starts, <= 7 subgenomes) and with the per-k-mer table; the third
+    variant keeps the round-3/4 kernels behind their switches covered (the unrolled map walk, the wave-per-range join) --
+    the defaults since round 5 are the rolled walk (k5_map_sparse2) and the workgroup-per-range join (sps_join_blk)."""
     if map_engine == "per-kmer":
         monkeypatch.setenv("SP_MAP_ENGINE", "1")
+    if map_engine == "pairs-unrolled+wave-join":
+        monkeypatch.setenv("SP_MAP_KERNEL", "1")
+        monkeypatch.setenv("SP_LIST_FILTER", "wave")
     rng = np.random.RandomState(400 + k)
     reps = [_rand_seq(rng, 350, 0, 0) for _ in range(6)]
     seqs = []
@@ -840,13 +855,15 @@ def test_labels_set_device(gpu_ctx, k):
 
 
 @pytest.mark.parametrize("k", [2, 5, 9, 13, 14, 15])
-@pytest.mark.parametrize("mode", ["compact", "compact-crowded", "direct"])
+@pytest.mark.parametrize("mode", ["compact", "compact-crowded", "direct", "compact-unrolled", "direct-unrolled"])
 def test_map_compact_pair_table(gpu_ctx, monkeypatch, k, mode):
     """The compact exact pair table (S <= 3: buckets of two tagged entries + overflow table, sp_map.h) against the
     oracle and against the direct table: forced on at every k (tag bits 0..7), with a load that sends many keys to the
     overflow table, with palindromic (k-1)-mers, N runs, both strands; bins, n_mapped, labels_hit, features and BED
     intervals go through the same look-up."""
-    monkeypatch.setenv("SP_CTAB", "0" if mode == "direct" else "1")
+    monkeypatch.setenv("SP_CTAB", "0" if mode.startswith("direct") else "1")
+    if mode.endswith("unrolled"):       # the kernels of rounds 2-4 (258 KB of code), kept as a cross-check of k5_map2
+        monkeypatch.setenv("SP_MAP_KERNEL", "1")
     if mode == "compact-crowded":
         monkeypatch.setenv("SP_CTAB_FACTOR", "1")      # ~2 keys per bucket of two: a fifth of the keys overflow
     rng = np.random.RandomState(4100 + k)
