@@ -1183,7 +1183,10 @@ c2_part1_b(const c2_bdesc *__restrict__ desc, sp_kparams32 kp, int shift1, int F
     const c2_bdesc D = desc[blockIdx.y];
     c2_part1_body(D.pk, D.pm, D.nm, D.n_units32, kp, shift1, F1, D.split, D.off1, D.cur1, D.n_tiles, D.lo1, D.hi1);
 }
-__global__ void __launch_bounds__(C2_P2_THREADS)
+#ifndef C2_P2_MINW
+#define C2_P2_MINW 1      // waves per SIMD the register allocation of c2_part2 must leave room for
+#endif
+__global__ void __launch_bounds__(C2_P2_THREADS, C2_P2_MINW)
 c2_part2(const uint16_t *__restrict__ lo1, const uint8_t *__restrict__ hi1, const unsigned long long *__restrict__ off1,
          const unsigned long long *__restrict__ tile_start, int F1, int F2, int shift2, const unsigned long long *__restrict__ off_fine,
          unsigned long long *__restrict__ cursor2, uint16_t *__restrict__ buf2) {

@@ -1157,12 +1157,19 @@ sps_join_blk(sps_join_args A) {
     unsigned long long uni = 0;
     unsigned long long chunk_pos = 0, chunk_end = 0;   // block-uniform (every thread keeps the same copy)
     const uint32_t per = BJ_T / (uint32_t)C;
-    for (long long r = blockIdx.x; r < A.R; r += gridDim.x) {
-        uint32_t cur = 0, endp = 0;                    // wave 0 only
+    // the edges of the NEXT range of this workgroup travel while the current one is joined (unconditional, clamped)
+    uint32_t n_cur = 0, n_endp = 0;
+    auto edges = [&](long long r) {
         if (w == 0 && lane < C) {
-            cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r];
-            endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r + 1];
+            const long long rc = r < A.R ? r : A.R - 1;
+            n_cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)rc];
+            n_endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)rc + 1];
         }
+    };
+    edges(blockIdx.x);
+    for (long long r = blockIdx.x; r < A.R; r += gridDim.x) {
+        uint32_t cur = n_cur, endp = n_endp;           // wave 0 only
+        edges(r + gridDim.x);
         if (w == 0) {
             const unsigned long long hp = jw_sum((unsigned long long)cur);   // the range's place in the virtual concatenation
             if (lane == 0) L.hist_pos = hp;
