@@ -526,10 +526,6 @@ s3_part2(const KR1 *__restrict__ buf1, const unsigned long long *__restrict__ of
 
 template <typename KR2, int PER>
 struct s3_sort_lds {
-    union {
-        typename rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER>::storage_type sort;
-        typename rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER, uint32_t>::storage_type pair_sort;
-    };
     KR2 s[S3_SORT_THREADS * PER];
     uint32_t heads[S3_SORT_THREADS * PER + 1];
     uint32_t wsum[S3_SORT_THREADS / 64], cnt1[S3_SORT_THREADS], cnt2[S3_SORT_THREADS];
@@ -589,13 +585,234 @@ __device__ __forceinline__ uint32_t s3_hash(unsigned long long v) {
     return (uint32_t)(v >> 40);
 }
 
+// ---- the workgroup's sort: a bitonic network over S3_SORT_THREADS x PER keys, thread t owning the PER consecutive
+// positions t * PER ...  Compare-exchange steps whose partner sits in the same thread run in registers (distance < PER),
+// steps whose partner sits in the same wave run as lane exchanges (distance < 64 PER), and only the steps across waves
+// go through LDS and a barrier: 3 of the 66 steps of a 2048-key sort, 1 of 36 at 256 keys.  Keys come back in the
+// blocked arrangement they went in with, ascending.  With PAIRS a 32-bit value travels with each key and equal keys
+// are ordered by DESCENDING value (a network is not stable: this is what keeps a real (all-ones, count) entry ahead of
+// the (all-ones, 0) padding).  xk / xv: S3_SORT_THREADS * PER words each of exchange space, free on entry (the caller
+// put a barrier behind its last use), free again on return.
+template <typename K, bool PAIRS>
+__device__ __forceinline__ bool s3_kv_less(K ka, uint32_t va, K kb, uint32_t vb) {
+    if (PAIRS) return ka < kb || (ka == kb && va > vb);
+    return ka < kb;
+}
+template <typename K, bool PAIRS>
+__device__ __forceinline__ void s3_cmpx(K &ka, uint32_t &va, K &kb, uint32_t &vb, bool up) {
+    // up: the smaller one ends in a
+    const bool sw = up ? s3_kv_less<K, PAIRS>(kb, vb, ka, va) : s3_kv_less<K, PAIRS>(ka, va, kb, vb);
+    const K ta = sw ? kb : ka, tb = sw ? ka : kb;
+    ka = ta;
+    kb = tb;
+    if (PAIRS) {
+        const uint32_t ua = sw ? vb : va, ub = sw ? va : vb;
+        va = ua;
+        vb = ub;
+    }
+}
+__device__ __forceinline__ uint32_t s3_lane_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ unsigned long long s3_lane_xor(unsigned long long v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <typename K, int PER, bool PAIRS>
+__device__ __forceinline__ void s3_block_sort(K (&k)[PER], uint32_t (&v)[PER], K *__restrict__ xk, uint32_t *__restrict__ xv) {
+    constexpr int N = S3_SORT_THREADS * PER;
+    const int t = threadIdx.x;
+    // phases 2 .. PER: all inside the thread
+#pragma unroll
+    for (int kk = 2; kk <= PER; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < PER; a++) {
+                if (a & j) continue;
+                const bool up = (kk < PER) ? ((a & kk) == 0) : ((t & 1) == 0);
+                s3_cmpx<K, PAIRS>(k[a], v[a], k[a | j], v[a | j], up);
+            }
+        }
+    }
+    // phases 2 PER .. N: distances >= PER first (other threads), then the tail inside the thread
+#pragma unroll 1
+    for (int kt = 2; kt <= S3_SORT_THREADS; kt <<= 1) {
+        const bool up = (t & kt) == 0;
+#pragma unroll 1
+        for (int pt = kt >> 1; pt >= 1; pt >>= 1) {
+            const bool keep_min = ((t & pt) == 0) == up;
+            if (pt >= 64) {          // (workgroup-uniform)
+#pragma unroll
+                for (int a = 0; a < PER; a++) {
+                    xk[a * S3_SORT_THREADS + t] = k[a];
+                    if (PAIRS) xv[a * S3_SORT_THREADS + t] = v[a];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < PER; a++) {
+                    const K ok = xk[a * S3_SORT_THREADS + (t ^ pt)];
+                    const uint32_t ov = PAIRS ? xv[a * S3_SORT_THREADS + (t ^ pt)] : 0u;
+                    const bool take = keep_min ? s3_kv_less<K, PAIRS>(ok, ov, k[a], v[a]) : s3_kv_less<K, PAIRS>(k[a], v[a], ok, ov);
+                    k[a] = take ? ok : k[a];
+                    if (PAIRS) v[a] = take ? ov : v[a];
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int a = 0; a < PER; a++) {
+                    const K ok = s3_lane_xor(k[a], pt);
+                    const uint32_t ov = PAIRS ? s3_lane_xor(v[a], pt) : 0u;
+                    const bool take = keep_min ? s3_kv_less<K, PAIRS>(ok, ov, k[a], v[a]) : s3_kv_less<K, PAIRS>(k[a], v[a], ok, ov);
+                    k[a] = take ? ok : k[a];
+                    if (PAIRS) v[a] = take ? ov : v[a];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = PER >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < PER; a++) {
+                if (a & j) continue;
+                s3_cmpx<K, PAIRS>(k[a], v[a], k[a | j], v[a | j], up);
+            }
+        }
+    }
+    (void)N;
+}
+
+// the value lane ^ PT holds, without the LDS crossbar: DPP row operations for distances 1, 2, 4, 8 (4 = a shift by four
+// lanes in each direction, each written to the banks it is right for), the gfx950 row / half swaps for 16 and 32
+template <int PT>
+__device__ __forceinline__ uint32_t s3_partner32(uint32_t v) {
+    if constexpr (PT == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+    else if constexpr (PT == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    else if constexpr (PT == 4) {
+        const int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xA, false);                               // row_shr:4 -> banks 1, 3
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x104, 0xF, 0x5, false);                           // row_shl:4 -> banks 0, 2
+    } else {
+        static_assert(PT == 8, "DPP lane distance");
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);                            // row_ror:8
+    }
+}
+template <int PT> __device__ __forceinline__ uint32_t s3_partner(uint32_t v) { return s3_partner32<PT>(v); }
+template <int PT> __device__ __forceinline__ unsigned long long s3_partner(unsigned long long v) {
+    return ((unsigned long long)s3_partner32<PT>((uint32_t)(v >> 32)) << 32) | s3_partner32<PT>((uint32_t)v);
+}
+// distances 16 and 32: both ends of every pair side by side after one swap (r0: the low-side lane's key, r1: the
+// high-side lane's, on both lanes)
+template <int PT>
+__device__ __forceinline__ void s3_pair_sides(uint32_t v, uint32_t &r0, uint32_t &r1) {
+    if constexpr (PT == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);    // rows 0,0,2,2 | rows 1,1,3,3
+        r0 = r[0];
+        r1 = r[1];
+    } else {
+        static_assert(PT == 32, "swap lane distance");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // low half twice | high half twice
+        r0 = r[0];
+        r1 = r[1];
+    }
+}
+template <int PT>
+__device__ __forceinline__ void s3_pair_sides(unsigned long long v, unsigned long long &r0, unsigned long long &r1) {
+    uint32_t a0, a1, b0, b1;
+    s3_pair_sides<PT>((uint32_t)v, a0, a1);
+    s3_pair_sides<PT>((uint32_t)(v >> 32), b0, b1);
+    r0 = ((unsigned long long)b0 << 32) | a0;
+    r1 = ((unsigned long long)b1 << 32) | a1;
+}
+// one compare-exchange step at lane distance PT: the low-side lane keeps the smaller key (ties: either)
+template <typename K, int PER, int PT>
+__device__ __forceinline__ void s3_lane_step(K (&k)[PER]) {
+    const bool low = (threadIdx.x & PT) == 0;
+#pragma unroll
+    for (int a = 0; a < PER; a++) {
+        if constexpr (PT >= 16) {
+            K r0, r1;
+            s3_pair_sides<PT>(k[a], r0, r1);
+            const K lo = r0 < r1 ? r0 : r1, hi = r0 < r1 ? r1 : r0;
+            k[a] = low ? lo : hi;
+        } else {
+            // (min, max, select: measured faster than compare, flip the mask by the lane's side, select)
+            const K o = s3_partner<PT>(k[a]);
+            const K lo = k[a] < o ? k[a] : o, hi = k[a] < o ? o : k[a];
+            k[a] = low ? lo : hi;
+        }
+    }
+}
+template <typename K, int PER>
+__device__ __forceinline__ void s3_wave_step(K (&k)[PER], K *__restrict__ xk, int pt) {
+    const int t = threadIdx.x;
+    const bool low = (t & pt) == 0;
+#pragma unroll
+    for (int a = 0; a < PER; a++) xk[a * S3_SORT_THREADS + t] = k[a];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < PER; a++) {
+        const K o = xk[a * S3_SORT_THREADS + (t ^ pt)];
+        const K lo = k[a] < o ? k[a] : o, hi = k[a] < o ? o : k[a];
+        k[a] = low ? lo : hi;
+    }
+    __syncthreads();
+}
+
+// keys only: a thread's direction in a phase is one bit of t, the same for both ends of every compare-exchange of
+// that phase, so keys of a descending thread are kept COMPLEMENTED for the phase and every step is an ascending one:
+// min / max in registers, min-or-max by the lane's side of the exchange across lanes.
+template <typename K, int PER>
+__device__ __forceinline__ void s3_block_sort_keys(K (&k)[PER], K *__restrict__ xk) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int kk = 2; kk < PER; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < PER; a++) {
+                if (a & j) continue;
+                const K lo = k[a] < k[a | j] ? k[a] : k[a | j], hi = k[a] < k[a | j] ? k[a | j] : k[a];
+                k[a] = (a & kk) ? hi : lo;
+                k[a | j] = (a & kk) ? lo : hi;
+            }
+        }
+    }
+    K flip = 0;
+#pragma unroll 1
+    for (int kt = (PER > 1 ? 1 : 2); kt <= S3_SORT_THREADS; kt <<= 1) {
+        {
+            const K m = (t & kt) ? (K)~(K)0 : (K)0, d = m ^ flip;
+#pragma unroll
+            for (int a = 0; a < PER; a++) k[a] ^= d;
+            flip = m;
+        }
+        // (kt is workgroup-uniform: one copy of each step's code, the phase picks where it enters the sequence)
+#pragma unroll 1
+        for (int pt = kt >> 1; pt >= 64; pt >>= 1) s3_wave_step<K, PER>(k, xk, pt);
+        if (kt > 32) s3_lane_step<K, PER, 32>(k);
+        if (kt > 16) s3_lane_step<K, PER, 16>(k);
+        if (kt > 8) s3_lane_step<K, PER, 8>(k);
+        if (kt > 4) s3_lane_step<K, PER, 4>(k);
+        if (kt > 2) s3_lane_step<K, PER, 2>(k);
+        if (kt > 1) s3_lane_step<K, PER, 1>(k);
+#pragma unroll
+        for (int j = PER >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < PER; a++) {
+                if (a & j) continue;
+                const K lo = k[a] < k[a | j] ? k[a] : k[a | j], hi = k[a] < k[a | j] ? k[a | j] : k[a];
+                k[a] = lo;
+                k[a | j] = hi;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < PER; a++) k[a] ^= flip;      // (the last phase is ascending everywhere: flip is 0 already)
+}
+
 // sort + run-length encode + keep of one segment of <= S3_SORT_THREADS * PER residuals (all threads of the
 // block); appends at out[0...], returns the number kept; lsum accumulates the kept counts (per thread)
 template <typename KR2, int PER>
 __device__ __forceinline__ uint32_t s3_sort_segment(const KR2 *__restrict__ seg, uint32_t n, int bits, uint32_t lower,
                                                     s3_sort_lds<KR2, PER> &L, KR2 *__restrict__ out_keys,
                                                     uint32_t *__restrict__ out_cnts, unsigned long long &lsum) {
-    using sort_t = rocprim::block_radix_sort<KR2, S3_SORT_THREADS, PER>;
     KR2 items[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
@@ -603,7 +820,8 @@ __device__ __forceinline__ uint32_t s3_sort_segment(const KR2 *__restrict__ seg,
         items[j] = (i < n) ? seg[i] : (KR2)~(KR2)0;   // padding sorts last (stable: after equal valid keys)
     }
     __syncthreads();
-    sort_t().sort(items, L.sort, 0, (unsigned)(bits > 0 ? bits : 1));
+    s3_block_sort_keys<KR2, PER>(items, L.s);     // (full-width compares: the bits above `bits` are equal inside a segment)
+    (void)bits;
 #pragma unroll
     for (int j = 0; j < PER; j++) L.s[threadIdx.x * PER + j] = items[j];
     __syncthreads();
@@ -1021,8 +1239,14 @@ s3_final_hash(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span,
     if (tid == 0 && tot) atomicAdd(len_sum, tot);
 }
 
+#ifndef S3_FINAL_MINW
+#define S3_FINAL_MINW 3     // 32-bit residuals: <= 168 VGPRs, three workgroups per CU as the 49 KB of LDS allow (it took
+                            // 181 and ran two: 1.11 -> 0.97 ms at k = 21, 8.7 -> 6.4 ms with SP_S3_FINAL=sort at k = 19);
+                            // 64-bit residuals: 73 KB of LDS, two either way
+#endif
+#define S3_FINAL_BOUNDS __launch_bounds__(S3_SORT_THREADS, (sizeof(KR2) == 4 ? S3_FINAL_MINW : 2))
 template <typename KR2>
-__global__ void __launch_bounds__(S3_SORT_THREADS)
+__global__ void S3_FINAL_BOUNDS
 s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglong2 *__restrict__ span,
          int64_t n_fine, int R2, uint32_t lower, KR2 *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_cnts,
          unsigned long long *__restrict__ kept, unsigned long long *__restrict__ big_list,
@@ -1043,7 +1267,14 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
         const unsigned long long o = sp_.x, n64 = sp_.y;
         if (!listed && n64 <= light_cap) continue;   // the light kernel's
         if (n64 <= S3_SORT_CAP) {
-            const uint32_t nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
+            // (a sorting network's work grows with the padded size: size classes as in the light kernel)
+            uint32_t nk;
+            if (n64 <= 2 * S3_SORT_THREADS)
+                nk = s3_sort_segment<KR2, 2>(buf2 + o, (uint32_t)n64, R2, lower, L.q2, tmp_keys + o, tmp_cnts + o, lsum);
+            else if (n64 <= 4 * S3_SORT_THREADS)
+                nk = s3_sort_segment<KR2, 4>(buf2 + o, (uint32_t)n64, R2, lower, L.q4, tmp_keys + o, tmp_cnts + o, lsum);
+            else
+                nk = s3_sort_segment<KR2, S3_SORT_PER>(buf2 + o, (uint32_t)n64, R2, lower, L.q, tmp_keys + o, tmp_cnts + o, lsum);
             if (threadIdx.x == 0) kept[bucket] = nk;
             continue;
         }
@@ -1191,7 +1422,6 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
                             L.q.heads[ww] = L.ones;
                         }
                         __syncthreads();
-                        using psort_t = rocprim::block_radix_sort<KR2, S3_SORT_THREADS, S3_SORT_PER, uint32_t>;
                         KR2 pk_[S3_SORT_PER];
                         uint32_t pv_[S3_SORT_PER];
 #pragma unroll
@@ -1201,11 +1431,11 @@ s3_final(const KR2 *__restrict__ buf2, KR2 *__restrict__ scratch, const ulonglon
                             pv_[j] = (i < n_kept) ? L.q.heads[i] : 0u;
                         }
                         __syncthreads();
-                        psort_t().sort(pk_, pv_, L.q.pair_sort, 0, (unsigned)(R2 > 0 ? R2 : 1));
+                        s3_block_sort<KR2, S3_SORT_PER, true>(pk_, pv_, L.q.s, L.q.heads);
 #pragma unroll
                         for (int j = 0; j < S3_SORT_PER; j++) {
                             const uint32_t i = threadIdx.x * S3_SORT_PER + j;
-                            if (i < n_kept) {          // stable: real entries precede the padding
+                            if (i < n_kept) {          // real entries precede the padding (ties: larger count first)
                                 tmp_keys[o + w + i] = pk_[j];
                                 tmp_cnts[o + w + i] = pv_[j];
                                 bsum += pv_[j];
