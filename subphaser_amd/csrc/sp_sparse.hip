@@ -846,6 +846,11 @@ struct sps_join_args {
     unsigned long long *n_union;
     const unsigned long long *chrom_sets;     // per chromosome: bit s set if it belongs to non-singleton set number s
     int screen;                               // the bit masks are usable (<= 64 non-singleton sets)
+    int fast;                                 // every non-singleton set uses baseline 1 or -1 and has no empty unit: the
+                                              // uniform fp32 walk of sps_join_blk applies (k3_eval's P.fast)
+    const int32_t *rd;                        // its row descriptors: chromosome | JD_UNIT_END | JD_SET_END | JD_BI1, the
+    const float *rinv;                        // non-singleton sets in config order; 1 / (unit length) at unit ends, fp32
+    int n_rd;
 };
 
 // ONE WAVE per key range: a range holds ~100 entries, and a 256-thread workgroup per range spent its time in
@@ -1092,9 +1097,17 @@ sps_join(sps_join_args A) {
 // four lines of keys, used in full) the fixed costs -- edges, cursors, hash clear, the tallies -- are paid once per ~700
 // entries instead of once per ~100.  A workgroup of BJ_THREADS takes a range: wave 0 runs the cursor logic of the
 // wave kernel (lane c owns list c: pivot, share, offsets by shuffles) and publishes it through LDS, every thread loads
-// and hash-inserts BJ_T / BJ_THREADS entries, the owners screen, and the survivors rebuild their rows wave by wave
-// exactly as before.  Same outputs, same staging protocol (hist totals at the range's closed-form position, rows in
-// chunks with their rank inside the range), so sps_tally_* / sps_place_* are unchanged.
+// and hash-inserts BJ_T / BJ_THREADS entries.  Same outputs, same staging protocol (hist totals at the range's
+// closed-form position, rows in chunks with their rank inside the range), so sps_tally_* / sps_place_* are unchanged.
+//
+// Nothing after the hash build walks a chain (second half of round 5).  The first version kept the wave kernel's
+// per-key chains: the owner of a key walked them for the screen (set mask, total), again to rebuild its row for the
+// decision, again to write a kept row -- dependent LDS reads, ~20 deep for exactly the k-mers that pass the screen, one
+// lane busy while 63 wait.  Bound experiments on the peanut-like genome (5.2 ms): no decisions 2.3 ms, nothing after the
+// hash build 1.2 ms.  Now every ENTRY works for its owner, all in parallel: it adds its set bit and count to the owner's
+// tallies (two LDS atomics), writes its count into the owner's row when the owner is up for a decision or kept, and the
+// decision itself is k3_eval's uniform row walk over a descriptor list (chromosome | unit end | set end, reciprocal
+// lengths) -- the same instructions in every lane, independent LDS reads.
 #ifndef BJ_T
 #define BJ_T 1024         // entries per round
 #endif
@@ -1104,16 +1117,26 @@ sps_join(sps_join_args A) {
 #endif
 #define BJ_WAVES (BJ_THREADS / 64)
 #define BJ_Q (BJ_T / BJ_THREADS)
+#define BJ_ROWS 16        // rows a wave decides at a time
+#define BJ_NR (BJ_WAVES * BJ_ROWS)
+#define JD_CHROM_MASK 0xfffff
+#define JD_UNIT_END (1 << 20)
+#define JD_SET_END (1 << 21)
+#define JD_BI1 (1 << 22)      // the set's baseline is the second largest frequency (else the smallest)
 template <typename RT>
 struct bj_lds {
     RT Kk[BJ_T], Hk[BJ_H];
-    uint32_t Vv[BJ_T], Hhead[BJ_H], Hmin[BJ_H];
-    uint16_t Nx[BJ_T], Sl[BJ_T], RL[BJ_T];
-    uint8_t Ch[BJ_T];
+    unsigned long long Et[BJ_T];          // per owner entry: sum of the key's counts
+    uint32_t Vv[BJ_T], Hmin[BJ_H];
+    uint32_t Es[BJ_T];                    // per owner entry: set mask -> place in the decision queue -> rank among the kept rows
+    uint16_t Sl[BJ_T], PQ[BJ_T];          // PQ: decision queue, then the list of kept rows
+    uint8_t Ch[BJ_T], Flag[BJ_T];
+    int32_t rd[JW_FC];
+    float rinv[JW_FC];
     uint32_t seg_off[SPS_MAXC + 2], cur[SPS_MAXC];
     const unsigned long long *keys[SPS_MAXC];
     const uint32_t *cnts[SPS_MAXC];
-    uint32_t T, more, n_hist, n_row;
+    uint32_t T, more, n_hist, n_row, n_pend;
     unsigned long long hist_pos, chunk_pos;
 };
 
@@ -1121,30 +1144,18 @@ template <typename RT>
 __global__ void __launch_bounds__(BJ_THREADS)
 sps_join_blk(sps_join_args A) {
     __shared__ bj_lds<RT> L;
-    extern __shared__ uint32_t jw_rows[];      // [BJ_WAVES][JW_ROWS][C]: rows being decided
-    __shared__ int32_t s_set_off[JW_FS + 1], s_unit_off[JW_FU + 1], s_unit_chrom[JW_FC];
-    __shared__ double s_unit_den[2 * JW_FU];
-    __shared__ unsigned long long s_csets[SPS_MAXC];
+    extern __shared__ uint32_t jw_rows[];      // [BJ_NR][C | 1]: rows being decided / written
+    __shared__ uint32_t s_csets[SPS_MAXC];
     const int C = A.C, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    sp_fsets F = A.F;
+    const int Cs = C | 1;                      // row stride in words (odd: consecutive rows start in different banks)
+    const sp_fsets F = A.F;                    // (global memory: only the generic decision reads it)
     {
-        const int n_units = A.F.set_off[A.F.n_sets], n_uc = A.F.unit_off[n_units];
-        if (A.F.n_sets <= JW_FS && n_units <= JW_FU && n_uc <= JW_FC) {
-            for (int i = threadIdx.x; i <= A.F.n_sets; i += blockDim.x) s_set_off[i] = A.F.set_off[i];
-            for (int i = threadIdx.x; i <= n_units; i += blockDim.x) s_unit_off[i] = A.F.unit_off[i];
-            for (int i = threadIdx.x; i < n_uc; i += blockDim.x) s_unit_chrom[i] = A.F.unit_chrom[i];
-            for (int i = threadIdx.x; i < n_units; i += blockDim.x) {
-                s_unit_den[i] = A.F.unit_den[i];
-                s_unit_den[n_units + i] = A.F.unit_inv[i];
-            }
-            F.set_off = s_set_off;
-            F.unit_off = s_unit_off;
-            F.unit_chrom = s_unit_chrom;
-            F.unit_den = s_unit_den;
-            F.unit_inv = s_unit_den + n_units;
+        for (int i = threadIdx.x; i < A.n_rd; i += blockDim.x) {
+            L.rd[i] = A.rd[i];
+            L.rinv[i] = A.rinv[i];
         }
         for (int i = threadIdx.x; i < C; i += blockDim.x) {
-            s_csets[i] = A.chrom_sets[i];
+            s_csets[i] = (uint32_t)A.chrom_sets[i];
             L.keys[i] = A.lists[i].keys;
             L.cnts[i] = A.lists[i].cnts;
         }
@@ -1157,6 +1168,7 @@ sps_join_blk(sps_join_args A) {
     unsigned long long uni = 0;
     unsigned long long chunk_pos = 0, chunk_end = 0;   // block-uniform (every thread keeps the same copy)
     const uint32_t per = BJ_T / (uint32_t)C;
+    const float fold32 = (float)F.min_fold;
     // the edges of the NEXT range of this workgroup travel while the current one is joined (unconditional, clamped)
     uint32_t n_cur = 0, n_endp = 0;
     auto edges = [&](long long r) {
@@ -1165,6 +1177,21 @@ sps_join_blk(sps_join_args A) {
             n_cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)rc];
             n_endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)rc + 1];
         }
+    };
+    // rows [0, n) of jw_rows <- the counts of the entries whose owner's Es lies in [first, first + n)
+    auto build_rows = [&](uint32_t T, uint32_t first, uint32_t n) {
+        for (uint32_t i = threadIdx.x; i < n * (uint32_t)Cs; i += BJ_THREADS) jw_rows[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BJ_Q; q++) {
+            const uint32_t e = threadIdx.x + BJ_THREADS * q;
+            if (e < T) {
+                const uint32_t o = L.Hmin[L.Sl[e]] & 0xFFFFu;
+                const uint32_t ri = L.Es[o] - first;
+                if (ri < n) jw_rows[ri * (uint32_t)Cs + L.Ch[e]] = L.Vv[e];
+            }
+        }
+        __syncthreads();
     };
     edges(blockIdx.x);
     for (long long r = blockIdx.x; r < A.R; r += gridDim.x) {
@@ -1209,19 +1236,23 @@ sps_join_blk(sps_join_args A) {
                     L.more = more0 ? 1u : 0u;
                     L.n_hist = 0;
                     L.n_row = 0;
+                    L.n_pend = 0;
                 }
             }
             for (uint32_t i = threadIdx.x; i < BJ_H; i += BJ_THREADS) {
                 L.Hk[i] = EMPTY;
-                L.Hhead[i] = 0xFFFFu;
                 L.Hmin[i] = 0xFFFFFFFFu;
+            }
+            for (uint32_t i = threadIdx.x; i < BJ_T; i += BJ_THREADS) {
+                L.Es[i] = 0;
+                L.Et[i] = 0;
             }
             __syncthreads();
             const uint32_t T = L.T;
             const bool more = L.more != 0;
             uint32_t Hn = 64;
             while (Hn < 2 * T) Hn <<= 1;
-            // ---- load + hash-insert (chain per key; owner = the entry of the lowest chromosome)
+            // ---- load + hash-insert (owner of a key = its entry of the lowest chromosome)
 #pragma unroll
             for (int q = 0; q < BJ_Q; q++) {
                 const uint32_t e = threadIdx.x + BJ_THREADS * q;
@@ -1238,6 +1269,7 @@ sps_join_blk(sps_join_args A) {
                     L.Kk[e] = res;
                     L.Vv[e] = L.cnts[c][i];
                     L.Ch[e] = (uint8_t)c;
+                    L.Flag[e] = 0;
                     uint32_t h = (uint32_t)sps_mix((uint64_t)res) & (Hn - 1);
                     for (;;) {
                         const RT prev = atomicCAS(&L.Hk[h], EMPTY, res);
@@ -1245,55 +1277,119 @@ sps_join_blk(sps_join_args A) {
                         h = (h + 1) & (Hn - 1);
                     }
                     L.Sl[e] = (uint16_t)h;
-                    L.Nx[e] = (uint16_t)atomicExch(&L.Hhead[h], e);
                     atomicMin(&L.Hmin[h], ((uint32_t)c << 16) | e);
                 }
             }
             __syncthreads();
-            // ---- owners rebuild their row and decide
-            bool is_row[BJ_Q], is_hist[BJ_Q];
-            unsigned long long tots[BJ_Q];
+            // ---- every entry adds itself to its owner's tallies
 #pragma unroll
             for (int q = 0; q < BJ_Q; q++) {
                 const uint32_t e = threadIdx.x + BJ_THREADS * q;
-                is_row[q] = is_hist[q] = false;
-                tots[q] = 0;
-                bool pending = false;      // an owner that passed the screen and still needs the full decision
+                if (e < T) {
+                    const uint32_t o = L.Hmin[L.Sl[e]] & 0xFFFFu;
+                    if (A.screen) atomicOr(&L.Es[o], s_csets[L.Ch[e]]);
+                    atomicAdd(&L.Et[o], (unsigned long long)L.Vv[e]);
+                }
+            }
+            __syncthreads();
+            // ---- owners: the union tally, the screen; the ones that pass queue up for the full decision
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                bool pending = false;
                 if (e < T && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) {
                     uni++;
-                    unsigned long long sets = 0, tot = 0;
-                    for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) {
-                        sets |= s_csets[L.Ch[x]];
-                        tot += L.Vv[x];
-                    }
-                    tots[q] = tot;
-                    pending = !A.screen || !((double)__popcll(sets) / (double)F.n_multi < F.ratio);
+                    pending = !A.screen || !((double)__popc(L.Es[e]) / (double)F.n_multi < F.ratio);
+                    L.Es[e] = 0xFFFFFFFFu;     // (no row)
                 }
-                for (unsigned long long pb = __ballot(pending); pb; pb = __ballot(pending)) {
-                    const int slot = __popcll(pb & ((1ULL << lane) - 1ULL));
-                    if (pending && slot < JW_ROWS) {
-                        uint32_t *row = jw_rows + ((size_t)w * JW_ROWS + slot) * (size_t)C;
-                        for (int c = 0; c < C; c++) row[c] = 0;
-                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) row[L.Ch[x]] = L.Vv[x];
-                        sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tots[q], F, is_row[q], is_hist[q]);
-                        pending = false;
+                const unsigned long long pb = __ballot(pending);
+                if (pb) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&L.n_pend, (uint32_t)__popcll(pb));
+                    base = __shfl(base, 0, 64);
+                    if (pending) {
+                        const uint32_t p = base + __popcll(pb & ((1ULL << lane) - 1ULL));
+                        L.PQ[p] = (uint16_t)e;
+                        L.Es[e] = p;
                     }
                 }
+            }
+            __syncthreads();
+            // ---- decisions, BJ_NR rows at a time
+            const uint32_t n_p = L.n_pend;
+            for (uint32_t p0 = 0; p0 < n_p; p0 += BJ_NR) {
+                const uint32_t n = n_p - p0 < BJ_NR ? n_p - p0 : BJ_NR;
+                build_rows(T, p0, n);
+                const uint32_t ri = (uint32_t)lane * BJ_WAVES + (uint32_t)w;     // the rows spread evenly over the waves
+                if (lane < BJ_ROWS && ri < n) {
+                    const uint32_t e = L.PQ[p0 + ri];
+                    const uint32_t *row = jw_rows + ri * (uint32_t)Cs;
+                    const unsigned long long tot = L.Et[e];
+                    bool r_ = false, h_ = false, generic = !A.fast;
+                    if (A.fast) {
+                        // _filter_kmer (Jellyfish.py:611-648) for baseline 1 / -1, as in k3_eval: running max, second max
+                        // and min of the unit frequencies in fp32 on reciprocal products; a k-mer with a set inside the
+                        // 1e-5 band around the threshold takes the generic code (fp64 quotients, the reference's order)
+                        int include = 0;
+                        unsigned long long num = 0;
+                        float m1 = -1.0f, m2 = -1.0f, mn = 3e38f;
+                        for (int j = 0; j < A.n_rd; j++) {
+                            const int d = L.rd[j];                   // (uniform)
+                            num += row[d & JD_CHROM_MASK];
+                            if (d & JD_UNIT_END) {
+                                const float x = (float)num * L.rinv[j];
+                                m2 = fmaxf(m2, fminf(m1, x));
+                                m1 = fmaxf(m1, x);
+                                mn = fminf(mn, x);
+                                num = 0;
+                            }
+                            if (d & JD_SET_END) {
+                                const float thr = fold32 * (((d & JD_BI1) ? m2 : mn) + 1e-20f);
+                                const bool pass = m1 > thr * (1.0f + 1e-5f);
+                                include += pass ? 1 : 0;
+                                generic = generic || (!pass && !(m1 < thr * (1.0f - 1e-5f)));
+                                m1 = -1.0f; m2 = -1.0f; mn = 3e38f;
+                            }
+                        }
+                        if (!generic && !((double)include / (double)F.n_multi < F.ratio)) {   // :642-644
+                            h_ = true;
+                            const double t = (double)tot;
+                            r_ = !(t < F.min_freq || t > F.max_freq);                          // :645-646
+                        }
+                    }
+                    if (generic) sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tot, F, r_, h_);
+                    L.Flag[e] = (uint8_t)((r_ ? 1 : 0) | (h_ ? 2 : 0));
+                }
+                __syncthreads();
+            }
+            // ---- fold-passing totals out; kept rows listed
+            bool is_row[BJ_Q];
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                const uint32_t fl = e < T ? (uint32_t)L.Flag[e] : 0u;
+                is_row[q] = (fl & 1u) != 0;
+                const bool is_hist = (fl & 2u) != 0;
                 // fold-passing totals: range start + tally so far + a place of the wave's in this round (any order)
-                const unsigned long long bh = __ballot(is_hist[q]);
+                const unsigned long long bh = __ballot(is_hist);
                 if (bh) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&L.n_hist, (uint32_t)__popcll(bh));
                     base = __shfl(base, 0, 64);
-                    if (is_hist[q])
-                        A.hist_stage[L.hist_pos + hist_before + base + __popcll(bh & ((1ULL << lane) - 1ULL))] = tots[q];
+                    if (is_hist)
+                        A.hist_stage[L.hist_pos + hist_before + base + __popcll(bh & ((1ULL << lane) - 1ULL))] = L.Et[e];
                 }
+            }
+            __syncthreads();       // (PQ is the decision queue no longer)
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
                 const unsigned long long br = __ballot(is_row[q]);
                 if (br) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&L.n_row, (uint32_t)__popcll(br));
                     base = __shfl(base, 0, 64);
-                    if (is_row[q]) L.RL[base + __popcll(br & ((1ULL << lane) - 1ULL))] = (uint16_t)e;
+                    if (is_row[q]) L.PQ[base + __popcll(br & ((1ULL << lane) - 1ULL))] = (uint16_t)e;
                 }
             }
             __syncthreads();
@@ -1306,22 +1402,38 @@ sps_join_blk(sps_join_args A) {
                     chunk_pos = L.chunk_pos;
                     chunk_end = chunk_pos + grab;
                 }
+                // Es: rank among the round's kept rows; every other owner out of the way (the ones that were decided still
+                // hold their queue place)
+#pragma unroll
+                for (int q = 0; q < BJ_Q; q++) {
+                    const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                    if (e < T && !is_row[q] && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) L.Es[e] = 0xFFFFFFFFu;
+                }
 #pragma unroll
                 for (int q = 0; q < BJ_Q; q++) {
                     if (!is_row[q]) continue;
                     const uint32_t e = threadIdx.x + BJ_THREADS * q;
                     const RT res = L.Kk[e];
                     uint32_t rank = 0;
-                    for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.RL[j]] < res;
+                    for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.PQ[j]] < res;
+                    L.Es[e] = rank;
                     const unsigned long long pos = chunk_pos + rank;
                     if (pos < A.row_cap) {
                         A.row_keys[pos] = hi_bits | (unsigned long long)res;
-                        A.row_tot[pos] = tots[q];
+                        A.row_tot[pos] = L.Et[e];
                         A.row_rank[pos] = rows_before + rank;
-                        uint32_t *out = A.row_counts + pos * (size_t)C;
-                        for (int c = 0; c < C; c++) out[c] = 0;
-                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) out[L.Ch[x]] = L.Vv[x];
                     }
+                }
+                __syncthreads();
+                for (uint32_t r0 = 0; r0 < nrow; r0 += BJ_NR) {
+                    const uint32_t n = nrow - r0 < BJ_NR ? nrow - r0 : BJ_NR;
+                    build_rows(T, r0, n);
+                    for (uint32_t i = threadIdx.x; i < n * (uint32_t)C; i += BJ_THREADS) {
+                        const uint32_t rr = i / (uint32_t)C, c = i - rr * (uint32_t)C;
+                        const unsigned long long pos = chunk_pos + r0 + rr;
+                        if (pos < A.row_cap) A.row_counts[pos * (size_t)C + c] = jw_rows[rr * (uint32_t)Cs + c];
+                    }
+                    __syncthreads();
                 }
                 chunk_pos += nrow;
                 rows_before += nrow;
@@ -1551,7 +1663,8 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
                  o_set = o_hoff + al((size_t)(R + 1) * 8), o_uo = o_set + al((size_t)(n_sets + 1) * 4),
                  o_uc = o_uo + al((size_t)(n_units + 1) * 4), o_den = o_uc + al((size_t)(n_uc + 1) * 4),
                  o_small = o_den + al((size_t)n_units * 16), o_cs = o_small + 256, o_bs = o_cs + al((size_t)C * 8),
-                 a_bytes = o_bs + 2 * al((size_t)(R / TALLY_CHUNK + 2) * 8);
+                 o_rd = o_bs + 2 * al((size_t)(R / TALLY_CHUNK + 2) * 8), o_rinv = o_rd + al((size_t)JW_FC * 4),
+                 a_bytes = o_rinv + al((size_t)JW_FC * 4);
     int rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes);
     if (rc) return rc;
     rc = sp_buf_ensure(ctx, ctx->b_sp_b, total * 8 + 64);
@@ -1589,17 +1702,58 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
     A.F.min_freq = min_freq;
     A.F.max_freq = max_freq;
     A.F.ratio = ratio;
+    A.fast = A.F.n_multi > 0 ? 1 : 0;
+    for (int st = 0; st < n_sets; st++) {
+        const int nu = set_off[st + 1] - set_off[st];
+        if (nu == 1) continue;
+        const int bi = baseline < 0 ? nu + baseline : baseline;
+        if (!(bi == 1 || bi == nu - 1)) A.fast = 0;
+        for (int u = set_off[st]; u < set_off[st + 1]; u++)
+            if (unit_off[u + 1] == unit_off[u]) A.fast = 0;
+    }
+    if (getenv("SP_JOIN_GENERIC") && atoi(getenv("SP_JOIN_GENERIC"))) A.fast = 0;     // cross-check switch
+    std::vector<int32_t> h_rd;
+    std::vector<float> h_rinv;
+    if (A.fast) {
+        for (int st = 0; st < n_sets; st++) {
+            const int nu = set_off[st + 1] - set_off[st];
+            if (nu == 1) continue;
+            const int bi = baseline < 0 ? nu + baseline : baseline;
+            for (int u = set_off[st]; u < set_off[st + 1]; u++)
+                for (int j = unit_off[u]; j < unit_off[u + 1]; j++) {
+                    int d = unit_chrom[j];
+                    if (j == unit_off[u + 1] - 1) {
+                        d |= JD_UNIT_END;
+                        if (u == set_off[st + 1] - 1) d |= JD_SET_END | (bi == 1 ? JD_BI1 : 0);
+                    }
+                    h_rd.push_back(d);
+                    h_rinv.push_back(j == unit_off[u + 1] - 1 ? (float)den[(size_t)n_units + (size_t)u] : 0.0f);
+                }
+        }
+        if (h_rd.size() > JW_FC) A.fast = 0;
+    }
+    if (!A.fast) {
+        h_rd.clear();
+        h_rinv.clear();
+    }
+    A.n_rd = (int)h_rd.size();
+    A.rd = (const int32_t *)(A0 + o_rd);
+    A.rinv = (const float *)(A0 + o_rinv);
+    if (A.n_rd) {      // (the stream is synchronized below, before the vectors go out of scope)
+        SP_HIP(ctx, hipMemcpyAsync(A0 + o_rd, h_rd.data(), (size_t)A.n_rd * 4, hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP(ctx, hipMemcpyAsync(A0 + o_rinv, h_rinv.data(), (size_t)A.n_rd * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     {   // per chromosome: which non-singleton sets it belongs to (screen of sps_join)
         std::vector<unsigned long long> cs((size_t)C, 0ULL);
         int ms = 0;
         for (int st = 0; st < n_sets; st++) {
             if (set_off[st + 1] - set_off[st] <= 1) continue;
-            if (ms < 64)
+            if (ms < 32)
                 for (int u = set_off[st]; u < set_off[st + 1]; u++)
                     for (int j = unit_off[u]; j < unit_off[u + 1]; j++) cs[(size_t)unit_chrom[j]] |= 1ULL << ms;
             ms++;
         }
-        A.screen = ms <= 64 ? 1 : 0;
+        A.screen = ms <= 32 ? 1 : 0;      // (sps_join_blk keeps 32-bit masks)
         SP_HIP(ctx, hipMemcpyAsync(A0 + o_cs, cs.data(), (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
         SP_HIP(ctx, hipStreamSynchronize(ctx->stream));     // cs goes out of scope
         A.chrom_sets = (const unsigned long long *)(A0 + o_cs);
@@ -1641,7 +1795,12 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
         } else {
             int64_t grid = R;
             if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-            const size_t row_lds = (size_t)BJ_WAVES * JW_ROWS * (size_t)C * 4;
+            const size_t row_lds = (size_t)BJ_NR * (size_t)(C | 1) * 4;     // <= 16.3 KiB
+            // (static + dynamic LDS passes 64 KiB with many chromosomes and 64-bit residuals)
+            if (shift <= 31)
+                SP_HIP(ctx, hipFuncSetAttribute((const void *)sps_join_blk<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
+            else
+                SP_HIP(ctx, hipFuncSetAttribute((const void *)sps_join_blk<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
             if (shift <= 31)
                 SP_LAUNCH(ctx, "sps_join", sps_join_blk<uint32_t>, dim3((unsigned)grid), dim3(BJ_THREADS), row_lds, A);
             else

@@ -1,36 +1,27 @@
 #!/usr/bin/env python3
-"""experiment helper: time the filter stage alone on a synthetic genome (kernel times from the library's profiler)
-    python tools/join_bench.py --config peanut [-k 15] [--engine 3] [--reps 3]"""
-import argparse
-import os
-import sys
-
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from subphaser_amd import _native                     # noqa: E402
-from subphaser_amd.hotpath import HotPath             # noqa: E402
-from subphaser_amd.synth import SynthGenome           # noqa: E402
-
-ap = argparse.ArgumentParser()
-ap.add_argument("--config", default="peanut")
-ap.add_argument("-k", type=int, default=15)
-ap.add_argument("--engine", type=int, default=0)
-ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--scale", type=float, default=1.0)
-a = ap.parse_args()
-gen = SynthGenome(a.config, a.scale)
+"""Timing of the list-join filter (sps_bounds / sps_join / tallies / placement) on a synthetic genome (dev tool).
+usage: join_bench.py [config] [k] [engine];  SUBPHASER_HIP_LIB selects a library variant."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from subphaser_amd import _native
+from subphaser_amd.config import sets_to_csr
+from subphaser_amd.synth import SynthGenome
+gen = SynthGenome(sys.argv[1] if len(sys.argv) > 1 else "peanut")
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+engine = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = _native.Context(0)
-ptrs = []
-for c in gen.chroms:
+ctx.genome_reset(len(gen.chroms))
+for i, c in enumerate(gen.chroms):
     p = ctx.dev_alloc(c["length"])
     ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], gen.S, c["chrom_id"], c["exchange"])
-    ptrs.append(p)
-hp = HotPath(ctx, gen.labels, [c["length"] for c in gen.chroms], gen.sgs, k=a.k, engine=a.engine)
-r = hp.count_and_filter(ptrs)
-print("union %d rows %d hist %d" % (r.n_union, r.n_rows, r.n_hist))
-ctx.prof_reset()
+    ctx.genome_add_device(i, p, c["length"])
+    ctx.dev_free(p)
+ctx.count(K, 3, engine)
+csr = sets_to_csr(gen.sgs, gen.labels)
+ctx.filter(*csr, 2.0, 1, 200, 1e9, 1.0)
 ctx.prof_enable(True)
-for _ in range(a.reps):
-    ctx.filter(*hp.csr, hp.min_fold, hp.baseline, hp.min_freq, hp.max_freq, hp.ratio)
+for _ in range(3):
+    res = ctx.filter(*csr, 2.0, 1, 200, 1e9, 1.0)
 ctx.prof_enable(False)
-for name, st in sorted(ctx.prof_report().items(), key=lambda kv: -kv[1]["ms"]):
-    print("%-20s %8.3f ms/call  x%d" % (name, st["ms"] / st["calls"], st["calls"] // a.reps))
+print(res)
+print(os.environ.get("SUBPHASER_HIP_LIB", "default"), {k: round(v["ms"] / v["calls"], 3) for k, v in ctx.prof_report().items()})
