@@ -416,6 +416,52 @@ def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkey
     assert int(gpu_ctx.lengths()[0]) == int(po.count(seqs[0], 15, 3)[1].astype(np.int64).sum())
 
 
+@pytest.mark.parametrize("variant", ["walk", "generic", "baseline2", "wave"])
+def test_list_join_decision_paths(gpu_ctx, oracle_ctx, variant, monkeypatch):
+    """The workgroup-per-range join (sps_join_blk) decides a k-mer with a uniform fp32 walk over row descriptors
+    (baselines 1 / -1), with the generic fp64 code (SP_JOIN_GENERIC=1, or a baseline the walk does not cover), and the
+    wave-per-range kernel stays as a cross-check: all bit-exact vs the oracle, on a set structure with units of several
+    chromosomes, a singleton set, thresholds that keep hundreds of rows per round (several row chunks per round) and a
+    ratio below one (k-mers missing from a set are decided, not screened out)."""
+    if variant == "generic":
+        monkeypatch.setenv("SP_JOIN_GENERIC", "1")
+    if variant == "wave":
+        monkeypatch.setenv("SP_LIST_FILTER", "wave")
+    rng = np.random.RandomState(977)
+    C = 11
+    reps = [_rand_seq(rng, 4000, 0, 0) for _ in range(8)]
+    seqs = []
+    for c in range(C):
+        s = _rand_seq(rng, 60000 + 700 * c)
+        for _ in range(20 + 3 * (c % 3)):
+            r = reps[rng.randint(0, 8)] if c % 2 else reps[rng.randint(0, 4)]
+            p = rng.randint(0, s.size - r.size)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    from subphaser_amd.config import sets_to_csr
+    sgs = [[[0, 1], [2], [3]], [[4], [5, 6]], [[7], [8], [9]], [[10]]]
+    if variant == "baseline2":      # four units per set: baseline 2 is neither the second largest nor the smallest
+        sgs = [[[0, 1], [2], [3], [4]], [[5], [6], [7, 8], [9]], [[10]]]
+    csr = sets_to_csr(sgs, list(range(C)))
+    for k in (17, 24):
+        for ctx in (gpu_ctx, oracle_ctx):
+            ctx.genome_reset(C)
+            for i, s in enumerate(seqs):
+                ctx.genome_add(i, s)
+            ctx.count(k, 2)
+        for fold, baseline, q, ratio in ((1.2, 1, 3, 1.0), (2.0, -1, 10, 0.5), (1.0, 2 if variant == "baseline2" else 1, 1, 0.6)):
+            res = []
+            for ctx in (gpu_ctx, oracle_ctx):
+                nu, nr, nh = ctx.filter(*csr, fold, baseline, q, 1e9, ratio)
+                keys, counts, freqs, tot = ctx.filter_fetch(nr)
+                res.append((nu, nr, nh, keys, counts, freqs, tot, np.sort(ctx.filter_hist(nh))))
+            g, o = res
+            assert g[:3] == o[:3], (variant, k, fold, baseline, g[:3], o[:3])
+            for a, b in zip(g[3:], o[3:]):
+                assert a.shape == b.shape and (a == b).all(), (variant, k, fold, baseline)
+        assert g[1] > 15000     # (the last configuration keeps ~50 rows per range on average: rounds of one and of two row chunks)
+
+
 def test_count_edges(gpu_ctx):
     k = 15
     seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",
