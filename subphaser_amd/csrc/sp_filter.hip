@@ -585,7 +585,7 @@ static int upload_tabs(sp_ctx *ctx, const sp_tabref **d_tabs, double **d_len) {
 int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *unit_off,
                      const int32_t *unit_chrom, const std::vector<double> &den, double min_fold, int baseline,
                      double min_freq, double max_freq, double ratio);                      // sp_sparse.hip
-int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot);
+int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot, bool async);
 
 extern "C" {
 
@@ -635,6 +635,9 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
         return sp_fail(ctx, SP_EINVAL, "sp_filter: bad arguments");
     if (!ctx->counted && !ctx->fv_on && !ctx->sv_on) return sp_fail(ctx, SP_EINVAL, "sp_filter: call sp_count first");
     SP_HIP(ctx, hipSetDevice(ctx->device));
+    // rows of the previous filter call still on their way to the host (sp_filter_fetch_async without its wait): this
+    // call rewrites the buffers they are read from
+    if (ctx->copy_stream) SP_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     const int C = filter_C(ctx);
     // the reference's precondition checks, same messages (Jellyfish.py:474-489)
     if (min_freq > max_freq)
@@ -873,7 +876,7 @@ static int emit_common(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts,
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (cap < M) return sp_fail(ctx, SP_EINVAL, "capacity %lld < %lld rows", (long long)cap, (long long)M);
     if (M == 0) return SP_OK;
-    if (ctx->sparse_mode || ctx->list_mode) return sp_sparse_fetch(ctx, hist, keys, counts, freqs, tot);
+    if (ctx->sparse_mode || ctx->list_mode) return sp_sparse_fetch(ctx, hist, keys, counts, freqs, tot, async);
     const int C = filter_C(ctx);
     const sp_tabref *d_tabs = nullptr;
     double *d_len = nullptr;
@@ -932,7 +935,6 @@ int sp_filter_fetch(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, double *freqs
 
 int sp_filter_fetch_async(sp_ctx *ctx, uint64_t *keys, uint32_t *counts, uint64_t *tot, int64_t cap_rows) {
     if (!ctx) return SP_EINVAL;
-    if (ctx->sparse_mode || ctx->list_mode) return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows);   // synchronous
     return emit_common(ctx, false, keys, counts, nullptr, tot, cap_rows, true);
 }
 

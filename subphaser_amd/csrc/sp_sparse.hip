@@ -1861,7 +1861,7 @@ int sp_sparse_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int3
     return sps_filter_join(ctx, n_sets, set_off, unit_off, unit_chrom, den, min_fold, baseline, min_freq, max_freq, ratio);
 }
 
-int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot) {
+int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, double *freqs, uint64_t *tot, bool async) {
     const int C = sps_C(ctx);
     const int64_t M = hist ? ctx->n_hist : ctx->n_rows;
     if (M == 0) return SP_OK;
@@ -1876,9 +1876,24 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
         tmp.resize((size_t)M * C);
         cdst = tmp.data();
     }
-    if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, ctx->b_sf_keys.p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, ctx->b_sf_tot.p, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (cdst) SP_HIP(ctx, hipMemcpyAsync(cdst, ctx->b_sf_counts.p, (size_t)M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // async (sp_filter_fetch_async: no frequencies): the join left the rows in device buffers that nothing writes before the
+    // next filter call -- a copy stream takes them to the (page-locked) host buffers while the compute stream goes on with the
+    // map stage; sp_filter_fetch_wait joins the two (as the table engines do since round 4)
+    hipStream_t cs = ctx->stream;
+    async = async && !freqs;
+    if (async) {
+        if (!ctx->copy_stream) {
+            SP_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            SP_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
+        }
+        SP_HIP(ctx, hipEventRecord(ctx->copy_event, ctx->stream));
+        SP_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0));
+        cs = ctx->copy_stream;
+    }
+    if (keys) SP_HIP(ctx, hipMemcpyAsync(keys, ctx->b_sf_keys.p, (size_t)M * 8, hipMemcpyDeviceToHost, cs));
+    if (tot) SP_HIP(ctx, hipMemcpyAsync(tot, ctx->b_sf_tot.p, (size_t)M * 8, hipMemcpyDeviceToHost, cs));
+    if (cdst) SP_HIP(ctx, hipMemcpyAsync(cdst, ctx->b_sf_counts.p, (size_t)M * C * 4, hipMemcpyDeviceToHost, cs));
+    if (async) return SP_OK;
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (freqs)
         for (int64_t r = 0; r < M; r++)

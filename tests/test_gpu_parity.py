@@ -394,6 +394,11 @@ def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkey
     for a, b in zip(g[3:], o[3:]):
         assert a.shape == b.shape and (a == b).all()
     keys, counts = g[3], g[4]
+    # the same rows through the copy stream (the list engines' rows travel while the map stage runs since round 5)
+    ak, ac, at = gpu_ctx.filter_fetch_async(g[1])
+    gpu_ctx.filter_fetch_wait()
+    oa, og = np.argsort(ak, kind="stable"), np.argsort(keys, kind="stable")
+    assert (ak[oa] == keys[og]).all() and (ac[oa] == counts[og]).all() and (at[oa] == g[6][og]).all()
     sg = (counts[:, 1::2].sum(axis=1) > counts[:, 0::2].sum(axis=1)).astype(np.uint8)
     gpu_ctx.labels_set(keys, sg, 2)
     for i, s in enumerate(seqs):
