@@ -1123,27 +1123,38 @@ sps_join(sps_join_args A) {
 #define JD_UNIT_END (1 << 20)
 #define JD_SET_END (1 << 21)
 #define JD_BI1 (1 << 22)      // the set's baseline is the second largest frequency (else the smallest)
+// LDS of a workgroup: 31.6 KB + the rows (32-bit residuals) -- FOUR workgroups per CU.  The kernel's time follows its occupancy
+// (two / three workgroups per CU: 3.61 / 2.70 ms on the peanut-like genome, 15.3 / 10.9 at wheat-like k = 21), so two tables share
+// their space with the two that are dead by the time they are needed: the per-owner totals live where the hash keys were (no key
+// is compared after the last insert), the per-owner set masks / queue places / ranks where the slot owners were (every entry
+// copies its owner's index into Sl[] first).
+#define BJ_FC 128         // row descriptors of the uniform walk held in LDS (more: generic decisions)
 template <typename RT>
 struct bj_lds {
-    RT Kk[BJ_T], Hk[BJ_H];
-    unsigned long long Et[BJ_T];          // per owner entry: sum of the key's counts
-    uint32_t Vv[BJ_T], Hmin[BJ_H];
-    uint32_t Es[BJ_T];                    // per owner entry: set mask -> place in the decision queue -> rank among the kept rows
-    uint16_t Sl[BJ_T], PQ[BJ_T];          // PQ: decision queue, then the list of kept rows
-    uint8_t Ch[BJ_T], Flag[BJ_T];
-    int32_t rd[JW_FC];
-    float rinv[JW_FC];
+    alignas(8) RT Hk[BJ_H];               // hash keys; after the inserts: Et[BJ_T], per owner entry the sum of the key's counts
+    uint32_t Hmin[BJ_H];                  // per slot: (chromosome << 16 | entry) of the owner; after the owner pass: Es[BJ_T], per
+                                          // owner entry the set mask -> place in the decision queue -> rank among the kept rows
+    RT Kk[BJ_T];
+    uint32_t Vv[BJ_T];
+    uint16_t Sl[BJ_T], PQ[BJ_T];          // Sl: hash slot, then the owner's entry; PQ: decision queue, then the list of kept rows
+    uint8_t Ch[BJ_T];                     // chromosome (6 bits) | kept row << 6 | fold-passing << 7 (owners, after the decision)
+    int32_t rd[BJ_FC];
+    float rinv[BJ_FC];
     uint32_t seg_off[SPS_MAXC + 2], cur[SPS_MAXC];
     const unsigned long long *keys[SPS_MAXC];
     const uint32_t *cnts[SPS_MAXC];
     uint32_t T, more, n_hist, n_row, n_pend;
     unsigned long long hist_pos, chunk_pos;
 };
+static_assert(sizeof(unsigned long long) * BJ_T <= sizeof(uint32_t) * BJ_H, "Et fits where the 32-bit hash keys were");
+static_assert(SPS_MAXC <= 64, "six bits of Ch[] hold the chromosome");
 
 template <typename RT>
 __global__ void __launch_bounds__(BJ_THREADS)
 sps_join_blk(sps_join_args A) {
     __shared__ bj_lds<RT> L;
+    unsigned long long *const Et = reinterpret_cast<unsigned long long *>(L.Hk);
+    uint32_t *const Es = L.Hmin;
     extern __shared__ uint32_t jw_rows[];      // [BJ_NR][C | 1]: rows being decided / written
     __shared__ uint32_t s_csets[SPS_MAXC];
     const int C = A.C, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1186,9 +1197,8 @@ sps_join_blk(sps_join_args A) {
         for (int q = 0; q < BJ_Q; q++) {
             const uint32_t e = threadIdx.x + BJ_THREADS * q;
             if (e < T) {
-                const uint32_t o = L.Hmin[L.Sl[e]] & 0xFFFFu;
-                const uint32_t ri = L.Es[o] - first;
-                if (ri < n) jw_rows[ri * (uint32_t)Cs + L.Ch[e]] = L.Vv[e];
+                const uint32_t ri = Es[L.Sl[e]] - first;
+                if (ri < n) jw_rows[ri * (uint32_t)Cs + (L.Ch[e] & 63u)] = L.Vv[e];
             }
         }
         __syncthreads();
@@ -1243,10 +1253,6 @@ sps_join_blk(sps_join_args A) {
                 L.Hk[i] = EMPTY;
                 L.Hmin[i] = 0xFFFFFFFFu;
             }
-            for (uint32_t i = threadIdx.x; i < BJ_T; i += BJ_THREADS) {
-                L.Es[i] = 0;
-                L.Et[i] = 0;
-            }
             __syncthreads();
             const uint32_t T = L.T;
             const bool more = L.more != 0;
@@ -1269,7 +1275,6 @@ sps_join_blk(sps_join_args A) {
                     L.Kk[e] = res;
                     L.Vv[e] = L.cnts[c][i];
                     L.Ch[e] = (uint8_t)c;
-                    L.Flag[e] = 0;
                     uint32_t h = (uint32_t)sps_mix((uint64_t)res) & (Hn - 1);
                     for (;;) {
                         const RT prev = atomicCAS(&L.Hk[h], EMPTY, res);
@@ -1281,14 +1286,25 @@ sps_join_blk(sps_join_args A) {
                 }
             }
             __syncthreads();
+            // ---- every entry learns its owner (Sl: slot -> owner's entry); the totals' space is dead hash keys by now
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) {
+                const uint32_t e = threadIdx.x + BJ_THREADS * q;
+                if (e < T) L.Sl[e] = (uint16_t)(L.Hmin[L.Sl[e]] & 0xFFFFu);
+                Et[e] = 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BJ_Q; q++) Es[threadIdx.x + BJ_THREADS * q] = 0;      // (where the slot owners were)
+            __syncthreads();
             // ---- every entry adds itself to its owner's tallies
 #pragma unroll
             for (int q = 0; q < BJ_Q; q++) {
                 const uint32_t e = threadIdx.x + BJ_THREADS * q;
                 if (e < T) {
-                    const uint32_t o = L.Hmin[L.Sl[e]] & 0xFFFFu;
-                    if (A.screen) atomicOr(&L.Es[o], s_csets[L.Ch[e]]);
-                    atomicAdd(&L.Et[o], (unsigned long long)L.Vv[e]);
+                    const uint32_t o = L.Sl[e];
+                    if (A.screen) atomicOr(&Es[o], s_csets[L.Ch[e]]);
+                    atomicAdd(&Et[o], (unsigned long long)L.Vv[e]);
                 }
             }
             __syncthreads();
@@ -1297,10 +1313,10 @@ sps_join_blk(sps_join_args A) {
             for (int q = 0; q < BJ_Q; q++) {
                 const uint32_t e = threadIdx.x + BJ_THREADS * q;
                 bool pending = false;
-                if (e < T && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) {
+                if (e < T && L.Sl[e] == e) {
                     uni++;
-                    pending = !A.screen || !((double)__popc(L.Es[e]) / (double)F.n_multi < F.ratio);
-                    L.Es[e] = 0xFFFFFFFFu;     // (no row)
+                    pending = !A.screen || !((double)__popc(Es[e]) / (double)F.n_multi < F.ratio);
+                    Es[e] = 0xFFFFFFFFu;     // (no row)
                 }
                 const unsigned long long pb = __ballot(pending);
                 if (pb) {
@@ -1310,7 +1326,7 @@ sps_join_blk(sps_join_args A) {
                     if (pending) {
                         const uint32_t p = base + __popcll(pb & ((1ULL << lane) - 1ULL));
                         L.PQ[p] = (uint16_t)e;
-                        L.Es[e] = p;
+                        Es[e] = p;
                     }
                 }
             }
@@ -1324,7 +1340,7 @@ sps_join_blk(sps_join_args A) {
                 if (lane < BJ_ROWS && ri < n) {
                     const uint32_t e = L.PQ[p0 + ri];
                     const uint32_t *row = jw_rows + ri * (uint32_t)Cs;
-                    const unsigned long long tot = L.Et[e];
+                    const unsigned long long tot = Et[e];
                     bool r_ = false, h_ = false, generic = !A.fast;
                     if (A.fast) {
                         // _filter_kmer (Jellyfish.py:611-648) for baseline 1 / -1, as in k3_eval: running max, second max
@@ -1333,7 +1349,7 @@ sps_join_blk(sps_join_args A) {
                         int include = 0;
                         unsigned long long num = 0;
                         float m1 = -1.0f, m2 = -1.0f, mn = 3e38f;
-                        for (int j = 0; j < A.n_rd; j++) {
+                        for (int j = 0; j < A.n_rd; j++) {     // (A.n_rd <= BJ_FC: host)
                             const int d = L.rd[j];                   // (uniform)
                             num += row[d & JD_CHROM_MASK];
                             if (d & JD_UNIT_END) {
@@ -1358,7 +1374,7 @@ sps_join_blk(sps_join_args A) {
                         }
                     }
                     if (generic) sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tot, F, r_, h_);
-                    L.Flag[e] = (uint8_t)((r_ ? 1 : 0) | (h_ ? 2 : 0));
+                    L.Ch[e] = (uint8_t)(L.Ch[e] | (r_ ? 0x40 : 0) | (h_ ? 0x80 : 0));
                 }
                 __syncthreads();
             }
@@ -1367,7 +1383,7 @@ sps_join_blk(sps_join_args A) {
 #pragma unroll
             for (int q = 0; q < BJ_Q; q++) {
                 const uint32_t e = threadIdx.x + BJ_THREADS * q;
-                const uint32_t fl = e < T ? (uint32_t)L.Flag[e] : 0u;
+                const uint32_t fl = e < T ? (uint32_t)L.Ch[e] >> 6 : 0u;      // (set for owners only)
                 is_row[q] = (fl & 1u) != 0;
                 const bool is_hist = (fl & 2u) != 0;
                 // fold-passing totals: range start + tally so far + a place of the wave's in this round (any order)
@@ -1377,7 +1393,7 @@ sps_join_blk(sps_join_args A) {
                     if (lane == 0) base = atomicAdd(&L.n_hist, (uint32_t)__popcll(bh));
                     base = __shfl(base, 0, 64);
                     if (is_hist)
-                        A.hist_stage[L.hist_pos + hist_before + base + __popcll(bh & ((1ULL << lane) - 1ULL))] = L.Et[e];
+                        A.hist_stage[L.hist_pos + hist_before + base + __popcll(bh & ((1ULL << lane) - 1ULL))] = Et[e];
                 }
             }
             __syncthreads();       // (PQ is the decision queue no longer)
@@ -1407,7 +1423,7 @@ sps_join_blk(sps_join_args A) {
 #pragma unroll
                 for (int q = 0; q < BJ_Q; q++) {
                     const uint32_t e = threadIdx.x + BJ_THREADS * q;
-                    if (e < T && !is_row[q] && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) L.Es[e] = 0xFFFFFFFFu;
+                    if (e < T && !is_row[q] && L.Sl[e] == e) Es[e] = 0xFFFFFFFFu;
                 }
 #pragma unroll
                 for (int q = 0; q < BJ_Q; q++) {
@@ -1416,11 +1432,11 @@ sps_join_blk(sps_join_args A) {
                     const RT res = L.Kk[e];
                     uint32_t rank = 0;
                     for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.PQ[j]] < res;
-                    L.Es[e] = rank;
+                    Es[e] = rank;
                     const unsigned long long pos = chunk_pos + rank;
                     if (pos < A.row_cap) {
                         A.row_keys[pos] = hi_bits | (unsigned long long)res;
-                        A.row_tot[pos] = L.Et[e];
+                        A.row_tot[pos] = Et[e];
                         A.row_rank[pos] = rows_before + rank;
                     }
                 }
@@ -1730,7 +1746,7 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
                     h_rinv.push_back(j == unit_off[u + 1] - 1 ? (float)den[(size_t)n_units + (size_t)u] : 0.0f);
                 }
         }
-        if (h_rd.size() > JW_FC) A.fast = 0;
+        if (h_rd.size() > BJ_FC) A.fast = 0;
     }
     if (!A.fast) {
         h_rd.clear();
