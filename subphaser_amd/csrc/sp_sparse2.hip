@@ -548,8 +548,11 @@ struct __attribute__((aligned(16))) s3h_lds {
             uint32_t cnt[S3H_SLOTS];
         } t;
     } u;
-    KR2 lk[S3H_CAP + S3_SORT_THREADS];
-    uint32_t lc[S3H_CAP + S3_SORT_THREADS];
+    KR2 lk[S3H_CAP + 64];                       // the kept residuals: the list is written only when the table did not close, so
+                                                // it holds <= S3H_CAP of them (their counts are looked up in the table again when they
+                                                // are written: a list of counts next to this one was 7 KB more -- 30.2 KB,
+                                                // five workgroups per CU; 22.9 KB: seven.  s3_final_hash follows its occupancy:
+                                                // four workgroups 4.53 ms, five 3.96 at k = 21)
     uint32_t n_distinct, n_kept, abort_;
     unsigned long long red[16];
 };
@@ -1119,7 +1122,6 @@ __device__ __forceinline__ uint32_t s3h_emit(s3h_lds<KR2> &L, uint32_t lower, KR
             if (c >= lower) {
                 const uint32_t at = atomicAdd(&L.n_kept, 1u);
                 L.lk[at] = L.u.t.key[4 * i4 + q];
-                L.lc[at] = c;
                 lsum += c;
             }
         }
@@ -1131,7 +1133,9 @@ __device__ __forceinline__ uint32_t s3h_emit(s3h_lds<KR2> &L, uint32_t lower, KR
         uint32_t rank = 0;
         for (uint32_t j = 0; j < m; j++) rank += L.lk[j] < key;
         out_keys[rank] = key;
-        out_cnts[rank] = L.lc[i];
+        uint32_t h = s3h_hash2((unsigned long long)key) & (S3H_SLOTS - 1);
+        while (L.u.t.key[h] != key) h = (h + 1) & (S3H_SLOTS - 1);      // (it is there)
+        out_cnts[rank] = L.u.t.cnt[h];
     }
     return m;
 }
