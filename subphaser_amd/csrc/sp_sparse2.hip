@@ -167,19 +167,32 @@ s3_hist1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
 // ---------------------------------------------------------------- s3_part1
 // Output runs are reserved with one
 // global atomic per (tile, non-empty bucket); the order inside a bucket does not matter downstream.
+// Round 5, last third: TWO workgroups per CU for 32-bit residuals (k <= 21).  The kernel ran one (89 KB of LDS, 160 VGPRs at 512
+// threads), and its twin of the dense engine, c2_part1, loses half of its speed when it is held to one (0.78 -> 1.16 ms).  LDS:
+// the runs' global bases and the region ends are values a thread writes and reads back itself (the same buckets every tile):
+// registers, 8 KB less -- 80 944 B.  VGPRs: a key of <= 42 bits carries its 14-bit rank inside the run in its bits 48..61
+// instead of in a second array of 32 registers (S3_P1_PACK) -- 128 without a spill.
+#ifndef S3_P1_MINW
+#define S3_P1_MINW 4      // waves per SIMD the register allocation leaves room for (512 threads: two workgroups per CU)
+#endif
 template <typename KR1, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, (sizeof(KR1) == 4 ? S3_P1_MINW : 1))
 s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
          int64_t n_units /* of 32 starts */, sp_kparams kp, int R1, int F1, unsigned long long *__restrict__ cursor1, KR1 *__restrict__ buf1,
          int64_t n_tiles, const unsigned long long *__restrict__ off1 /* F1+1: where the regions start */, uint32_t trash) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     KR1 *keys = reinterpret_cast<KR1 *>(s3_lds);                        // [THREADS * 32]
-    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], gbase[S3_MAXF], delta[S3_MAXF], wsum[THREADS / 64];
+    __shared__ uint32_t hist[S3_MAXF], start[S3_MAXF + 1], delta[S3_MAXF], wsum[THREADS / 64];
     __shared__ uint32_t head[THREADS];      // tile positions / 32 = THREADS words
-    __shared__ uint32_t lim[S3_MAXF];       // end of every bucket's region (read once per workgroup)
     if (n_tiles <= 0 || n_units <= 0) return;      // (the prefetch below is unconditional)
-    for (int b = threadIdx.x; b < F1; b += THREADS) lim[b] = (uint32_t)off1[b + 1];
-    __syncthreads();
+    constexpr int BPT = (S3_MAXF + THREADS - 1) / THREADS;      // level-1 buckets per thread: b = threadIdx.x + t * THREADS
+    constexpr bool PACK = sizeof(KR1) == 4;                     // keys of <= 42 bits: the rank rides in bits 48..61
+    uint32_t lim_[BPT];                                         // end of the thread's buckets' regions (read once)
+#pragma unroll
+    for (int t = 0; t < BPT; t++) {
+        const int b = threadIdx.x + t * THREADS;
+        lim_[t] = b < F1 ? (uint32_t)off1[b + 1] : 0u;
+    }
     __shared__ uint16_t hpre[THREADS];
     const uint64_t rmask = (R1 >= 64) ? ~0ULL : ((1ULL << R1) - 1ULL);
     // the NEXT tile's unit (validity words + both packed streams) travels while this tile is sorted and written: copy
@@ -197,7 +210,8 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
     };
     fetch(blockIdx.x);
     static_assert(S3_MAXF <= 2 * THREADS || THREADS == 256, "two cursor atomics per thread (four at 256 threads)");
-    constexpr int BPT = (S3_MAXF + THREADS - 1) / THREADS;      // level-1 buckets per thread
+    static_assert(THREADS * S3_P1_UNIT <= (1 << 14), "a rank inside a tile fits 14 bits");
+    const uint64_t kmask = PACK ? ((1ULL << 48) - 1ULL) : ~0ULL;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < F1; i += THREADS) hist[i] = 0;
         const sp_words64 x = p_x;
@@ -208,13 +222,17 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         // registers are plentiful); the rank inside the bucket run is what the histogram atomic returns
         const int64_t u = tile * THREADS + threadIdx.x;
         uint64_t key[32];
-        uint32_t rank[32], ok = 0;
+        uint32_t rank[PACK ? 1 : 32], ok = 0;
         if (u < n_units) {
             ok = ~(uint32_t)sp_bad_from_words64((uint64_t)c_nm0 | ((uint64_t)c_nm1 << 32), kp.k);
             if (ok) {
                 sp_scan32_keys64(x, kp, [&](int j, uint64_t fwd, uint64_t rc) {
                     key[j] = fwd < rc ? fwd : rc;
-                    if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[key[j] >> R1], 1u);
+                    if ((ok >> j) & 1u) {
+                        const uint32_t rk = atomicAdd(&hist[key[j] >> R1], 1u);
+                        if (PACK) key[j] |= (uint64_t)rk << 48;
+                        else rank[j] = rk;
+                    }
                 });
             }
         }
@@ -242,15 +260,11 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         for (int j0 = 0; j0 < 32; j0 += 8) {
             uint32_t st[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) st[jj] = (ok >> (j0 + jj)) & 1u ? start[(uint32_t)(key[j0 + jj] >> R1)] : 0u;
+            for (int jj = 0; jj < 8; jj++) st[jj] = (ok >> (j0 + jj)) & 1u ? start[(uint32_t)((key[j0 + jj] & kmask) >> R1)] : 0u;
 #pragma unroll
             for (int jj = 0; jj < 8; jj++)
-                if ((ok >> (j0 + jj)) & 1u) keys[st[jj] + rank[j0 + jj]] = (KR1)(key[j0 + jj] & rmask);
-        }
-#pragma unroll
-        for (int t = 0; t < BPT; t++) {
-            const int b = threadIdx.x + t * THREADS;
-            if (b < F1) gbase[b] = (uint32_t)at_[t];
+                if ((ok >> (j0 + jj)) & 1u)
+                    keys[st[jj] + (PACK ? (uint32_t)(key[j0 + jj] >> 48) : rank[PACK ? 0 : j0 + jj])] = (KR1)(key[j0 + jj] & rmask);
         }
         // Which run does sorted position i belong to?  A binary search over start[] (10 dependent LDS reads and ~60
         // VALU instructions per key) was most of this kernel; instead: rank of the last run head at or before i,
@@ -259,14 +273,17 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         const uint32_t wpre = s3_scan_reg_t<THREADS>((uint32_t)__popc(head[threadIdx.x]), wsum, &tot_runs);
         hpre[threadIdx.x] = (uint16_t)wpre;      // ends with a barrier: placement is complete as well
         __syncthreads();
-        for (int b = threadIdx.x; b < F1; b += THREADS)
-            if (hist[b]) {       // (the placement cursor = the run's length)
+#pragma unroll
+        for (int t = 0; t < BPT; t++) {
+            const int b = threadIdx.x + t * THREADS;
+            if (b < F1 && hist[b]) {       // (the placement cursor = the run's length)
                 const uint32_t p0 = start[b];
                 const uint32_t r = (uint32_t)hpre[p0 >> 5] + (uint32_t)__popc(head[p0 >> 5] & ((1u << (p0 & 31)) - 1u));
                 // (sampled regions: a run that does not fit goes to the trash area behind them; s3_tiles sees the cursor)
-                const uint32_t at = gbase[b];
-                delta[r] = ((unsigned long long)at + hist[b] <= (unsigned long long)lim[b] ? at : trash) - p0;
+                const uint32_t at = (uint32_t)at_[t];
+                delta[r] = ((unsigned long long)at + hist[b] <= (unsigned long long)lim_[t] ? at : trash) - p0;
             }
+        }
         __syncthreads();
         // (four positions per round: their LDS reads, then the run look-ups, then the stores)
         for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 4u * THREADS) {
