@@ -467,6 +467,45 @@ def test_list_join_decision_paths(gpu_ctx, oracle_ctx, variant, monkeypatch):
         assert g[1] > 15000     # (the last configuration keeps ~50 rows per range on average: rounds of one and of two row chunks)
 
 
+@pytest.mark.parametrize("layout", ["32 sets", "33 sets"])
+def test_list_join_many_chromosomes(gpu_ctx, oracle_ctx, layout):
+    """64 chromosomes (the list filter's limit): 32 non-singleton sets fill the join's 32-bit screen mask to its last bit; 33
+    sets (chromosome 0 paired with each of 33 others) switch the screen off -- every owner is decided."""
+    rng = np.random.RandomState(4242)
+    C = 64
+    reps = [_rand_seq(rng, 1500, 0, 0) for _ in range(6)]
+    seqs = []
+    for c in range(C):
+        s = _rand_seq(rng, 6000 + 37 * c)
+        for _ in range(3):
+            r = reps[rng.randint(0, 6)] if c % 2 else reps[rng.randint(0, 3)]
+            p = rng.randint(0, s.size - r.size)
+            s[p:p + r.size] = r
+        seqs.append(s)
+    from subphaser_amd.config import sets_to_csr
+    if layout == "32 sets":
+        sgs = [[[2 * i], [2 * i + 1]] for i in range(32)]
+    else:
+        sgs = [[[0], [i]] for i in range(1, 34)] + [[[i]] for i in range(34, C)]
+    csr = sets_to_csr(sgs, list(range(C)))
+    for ctx in (gpu_ctx, oracle_ctx):
+        ctx.genome_reset(C)
+        for i, s in enumerate(seqs):
+            ctx.genome_add(i, s)
+        ctx.count(19, 1)
+    for fold, baseline, q, ratio in ((1.5, 1, 4, 0.5), (1.0, -1, 1, 0.1)):
+        res = []
+        for ctx in (gpu_ctx, oracle_ctx):
+            nu, nr, nh = ctx.filter(*csr, fold, baseline, q, 1e9, ratio)
+            keys, counts, freqs, tot = ctx.filter_fetch(nr)
+            res.append((nu, nr, nh, keys, counts, freqs, tot, np.sort(ctx.filter_hist(nh))))
+        g, o = res
+        assert g[:3] == o[:3], (layout, fold, g[:3], o[:3])
+        for a, b in zip(g[3:], o[3:]):
+            assert a.shape == b.shape and (a == b).all(), (layout, fold)
+    assert g[1] > 100
+
+
 def test_count_edges(gpu_ctx):
     k = 15
     seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",
