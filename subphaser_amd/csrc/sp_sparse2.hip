@@ -269,6 +269,13 @@ s3_part1(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const
         // Which run does sorted position i belong to?  A binary search over start[] (10 dependent LDS reads and ~60
         // VALU instructions per key) was most of this kernel; instead: rank of the last run head at or before i,
         // from a prefix popcount over the head bitmap, indexes the runs' (global base - tile start) table.
+        // (round 5: a BARRIER between the run-head bits and their first read.  Word w of head[] is read by thread w and
+        // set by whichever threads own the buckets that start in it; without the barrier a wave that got ahead counted a
+        // word before another wave had set its bits, the run ranks of the tile shifted, and a few dozen runs went to
+        // their neighbours' regions -- keys counted under another bucket's high bits, one pass in ~300 at wheat scale
+        // with three chains in flight, found by tools/stress_lanes.py.  Since round 3 the 32 dependent placements
+        // between the two had kept the window shut; batching them in round 5 opened it.)
+        __syncthreads();
         uint32_t tot_runs;
         const uint32_t wpre = s3_scan_reg_t<THREADS>((uint32_t)__popc(head[threadIdx.x]), wsum, &tot_runs);
         hpre[threadIdx.x] = (uint16_t)wpre;      // ends with a barrier: placement is complete as well
