@@ -506,6 +506,18 @@ def test_list_join_many_chromosomes(gpu_ctx, oracle_ctx, layout):
     assert g[1] > 100
 
 
+@pytest.mark.parametrize("k", [15, 19])
+def test_count_with_streams_equals_single_stream(k):
+    """Tripwire for timing-dependent miscounts (tools/stress_lanes.py): 300 counts of a 21-chromosome synthetic genome with
+    the default streams, each compared chromosome by chromosome with a single-stream count.  (Round 5: a missing barrier
+    in s3_part1 miscounted one k > 15 pass in a few hundred when three chains were in flight; no parity test saw it.)"""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_lanes.py")
+    out = subprocess.run([sys.executable, tool, "wheat", str(k), "300", "0.01"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "300 iterations, 0 bad" in out.stdout, out.stdout[-2000:]
+
+
 def test_count_edges(gpu_ctx):
     k = 15
     seqs = [b"", b"ACGT", b"N" * 100, b"A" * 50, b"T" * 50, b"ACGTACGTACGTACnACGTACGTACGTAC",

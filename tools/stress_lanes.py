@@ -17,15 +17,19 @@ for i, c in enumerate(gen.chroms):
     ctx.synth_chrom(p, c["length"], gen.seed, c["set_id"], c["sg_id"], gen.S, c["chrom_id"], c["exchange"])
     ctx.genome_add_device(i, p, c["length"])
     ctx.dev_free(p)
-lanes = os.environ.pop("SP_LANES_SPARSE", None)
-os.environ["SP_LANES_SPARSE"] = "0"
+# the reference count runs on ONE stream: SP_LANES_SPARSE (k > 15), SP_LANES_DENSE (byte tables), SP_LANES + SP_C2_BATCH (lists)
+names = ["SP_LANES_SPARSE"] if K > 15 else ["SP_LANES_DENSE", "SP_LANES", "SP_C2_BATCH"]
+saved = {n: os.environ.pop(n, None) for n in names}
+for n in names:
+    os.environ[n] = "0"
 ctx.count(K, 3, 0)
 ref = (ctx.lengths().tolist(), [ctx.dump_size(i) for i in range(len(gen.chroms))])
-ref_dumps = [ctx.dump(i) for i in range(len(gen.chroms))] if scale <= 0.05 else None
-if lanes is None:
-    del os.environ["SP_LANES_SPARSE"]
-else:
-    os.environ["SP_LANES_SPARSE"] = lanes
+ref_dumps = [ctx.dump(i) for i in range(len(gen.chroms))] if scale <= 0.05 and K > 15 else None
+for n in names:
+    if saved[n] is None:
+        del os.environ[n]
+    else:
+        os.environ[n] = saved[n]
 bad = 0
 for it in range(iters):
     ctx.count(K, 3, 0)
