@@ -150,6 +150,8 @@ struct sp_ctx {
         void *d_ws2 = nullptr;
         int64_t ws2_bytes = 0;
         sp_buf b_ovfw;
+        void *h_desc = nullptr;      // page-locked: the descriptor table of this lane's batched list count (sp_count2.hip)
+        int64_t h_desc_cap = 0;
         // k > 15 (sp_sparse2.hip, round 4): this lane's partition buffers, small arrays and the two events its split-phase
         // chain is waited at
         sp_buf b_sp_a, b_sp_b, b_sp_c, b_sp_tmp, b_s3_small;
@@ -158,6 +160,8 @@ struct sp_ctx {
 #define SP_MAX_LANES 7
     lane_t lanes[SP_MAX_LANES];  // lanes 1..7 (lane 0 = the context's own stream and buffers above)
     lane_t *lane = nullptr;      // the auxiliary lane the engine-2 chain is being issued on, or NULL
+    void *h_desc = nullptr;      // page-locked descriptor table of a batched list count issued on the context's own stream
+    int64_t h_desc_cap = 0;
     hipEvent_t lane_go = nullptr;
     // sparse engine (k = 16..32)
     bool sparse_mode = false;

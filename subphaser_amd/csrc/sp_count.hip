@@ -507,7 +507,9 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
             // lanes whose workspace is not allocated yet must fit what the device has free, with a margin (advisor r04)
             int64_t longest_c = 0;
             for (size_t ci = (size_t)first; ci < (size_t)last; ci++) longest_c = ctx->chroms[ci].len > longest_c ? ctx->chroms[ci].len : longest_c;
-            const int64_t per_lane = 6 * longest_c + (256LL << 20);
+            // (a batched list count puts a whole GROUP of chromosomes into one lane's workspace: about 1 / (lanes + 1) of the
+            // genome, at most one chromosome more -- advisor r05)
+            const int64_t per_lane = 6 * (batch ? total_len / (int64_t)(n_lanes + 1) + longest_c : longest_c) + (256LL << 20);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 int64_t budget = (int64_t)free_b - (int64_t)(total_b / 16);      // keep a sixteenth of the device free
@@ -641,6 +643,10 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                 sp_ctx::lane_t *ln = n_lanes > 0 ? &ctx->lanes[ci % (size_t)n_lanes] : nullptr;
                 hipStream_t main_stream = ctx->stream;
                 if (ln && c.ev_packed) SP_HIP(ctx, hipStreamWaitEvent(ln->stream, c.ev_packed, 0));
+                // (round 6 audit: the one reader of the byte tables that returns without a host synchronisation is k3_emit
+                // behind sp_filter_fetch_async; copy_event sits right behind it on the context's stream -- a count that
+                // follows without sp_filter_fetch_wait must not rewrite the tables under it)
+                if (ln && ctx->copy_event) SP_HIP(ctx, hipStreamWaitEvent(ln->stream, ctx->copy_event, 0));
                 SP_HIP(ctx, hipMemsetAsync(d_len + 4 * ci, 0, 4 * sizeof(unsigned long long), ln ? ln->stream : main_stream));
                 if (ln) {       // (no early return between here and the restore below)
                     ctx->lane = ln;

@@ -312,7 +312,7 @@ __device__ __forceinline__ void c2_part1_body(const uint32_t *__restrict__ pk, c
     // next tile, each wave sat out the round trip of its own copy-out stores once per tile, and since the blocks of a
     // CU start together and take equal steps, both were in that wait at the same time: the kernel was the SUM of its
     // scan (0.23 ms of VALU per 667-Mb chain, + 0.13 of rank atomics) and its 2.1 GB of stores, not their maximum
-    // (bound variants C2_P1_EXP).  Now the words of the next tile are taken over (`take`: an empty asm that uses them,
+    // (bound variants: tools/bound_experiments.patch).  Now the words of the next tile are taken over (`take`: an empty asm that uses them,
     // which is where the compiler puts the wait) BEFORE the copy-out is issued -- the loads are a scan old by then --
     // and every barrier of the loop orders LDS traffic only: the stores drain while the next tile is scanned.
 #ifndef C2_P1_ASYNC
@@ -351,33 +351,19 @@ __device__ __forceinline__ void c2_part1_body(const uint32_t *__restrict__ pk, c
         fetch(tile + gridDim.x);
         bar();
         uint32_t slot[32], rank[32], ok = 0;
+        if (u >= n_units) {      // (a thread without a unit: its slots index start[] below, unconditionally -- advisor r05)
+#pragma unroll
+            for (int j = 0; j < 32; j++) slot[j] = 0;
+        }
         if (u < n_units) {
             ok = ~(uint32_t)sp_bad_from_words64((uint64_t)c_nm0 | ((uint64_t)c_nm1 << 32), kp.k);
             auto f = [&](int j, uint32_t V, uint32_t W) {
                 slot[j] = kp.odd ? sp_slot_of32_t<true>(V >> sh, ~W & kp.kmask, kp)
                                  : sp_slot_of32_t<false>(V >> sh, ~W & kp.kmask, kp);
-#if !defined(C2_P1_EXP) || C2_P1_EXP == 1 || C2_P1_EXP > 3
                 if ((ok >> j) & 1u) rank[j] = atomicAdd(&hist[slot[j] >> shift1], 1u);
-#else
-                rank[j] = 0;
-#endif
             };
             sp_win_loop<0, 1, decltype(f)>::run(x, f);
         }
-#if defined(C2_P1_EXP) && C2_P1_EXP <= 3     // bound experiments (tools/build_variant.sh; wrong answers): 1 = the scan and its rank atomics only,
-                     // 2 = the scan without the atomics, 3 = as 2 without the tile barriers
-        {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < 32; j++) acc ^= slot[j] + rank[j];
-            if (acc == 0x12345678u && ok == 77u) lo1[tile] = (uint16_t)acc;
-#if C2_P1_EXP != 3
-            __syncthreads();
-            __syncthreads();
-#endif
-            continue;
-        }
-#endif
         bar();
         unsigned long long at = 0, r_lo = 0, r_hi = 0;
         uint32_t c = 0, cpad = 0;
@@ -386,11 +372,7 @@ __device__ __forceinline__ void c2_part1_body(const uint32_t *__restrict__ pk, c
             cpad = (c + 3u) & ~3u;
             hist[threadIdx.x] = cpad;     // (own entry: the scan below reads it from this thread)
             const int vb = (int)threadIdx.x * C2_SPLIT + (split > 1 ? (int)(tile & (C2_SPLIT - 1)) : 0);
-#if defined(C2_P1_EXP) && C2_P1_EXP == 5     // no cursor atomic: a position made up from the tile number (overlapping runs: wrong answers)
-            at = (unsigned long long)(tile / C2_SPLIT) * 160ULL;
-#else
             if (c) at = atomicAdd(&cursor1[C2_CUR1(vb)], (unsigned long long)cpad);
-#endif
             r_lo = off1[vb];
             r_hi = off1[vb + 1];
             // (nothing that depends on the atomic's result before the scan below: the two waves that reserve would
@@ -440,9 +422,6 @@ __device__ __forceinline__ void c2_part1_body(const uint32_t *__restrict__ pk, c
                 const uint32_t q = q0 + (uint32_t)i * C2_P1_THREADS;
                 if (q >= nq || d[i] == C2_DROP) continue;
                 const unsigned long long o = d[i] + 4ULL * q;      // a multiple of 4: region starts, reservations and LDS starts are
-#if defined(C2_P1_EXP) && C2_P1_EXP == 4     // no stores
-                if (v[i].x != 0x12345678u) continue;
-#endif
                 *reinterpret_cast<uint2 *>(lo1 + o) = make_uint2(c2_pack_lo(v[i].x, v[i].y), c2_pack_lo(v[i].z, v[i].w));
                 *reinterpret_cast<uint32_t *>(hi1 + o) = c2_pack_lo(__builtin_amdgcn_perm(v[i].y, v[i].x, 0x0c0c0602u),
                                                                     __builtin_amdgcn_perm(v[i].w, v[i].z, 0x0c0c0602u));
@@ -529,21 +508,6 @@ __device__ __forceinline__ void c2_part2_body(const uint16_t *__restrict__ lo1, 
         for (int j = 0; j < C2_P2_PER; j++)
             if (j < nmine && my[j] != C2_INVALID1) rank[j] = atomicAdd(&hist[(my[j] >> shift2) & mask2], 1u);
         __syncthreads();  // (B)
-#if defined(C2_P2_EXP) && C2_P2_EXP == 2      // bound experiment: loads and rank atomics only
-        {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < C2_P2_PER; j++) acc ^= my[j] + rank[j];
-            if (acc == 0x12345678u && nmine == 77) buf2[tile] = (uint16_t)acc;
-            nnext = 0;
-            if (ntile < n_tiles) {
-                const int nb = s_bucket[p ^ 1];
-                fetch(nb, ntile - tile_start[nb]);
-            }
-            p ^= 1;
-            continue;
-        }
-#endif
         unsigned long long g = 0;
         bool fits = true;
         uint32_t c = 0;
@@ -579,9 +543,6 @@ __device__ __forceinline__ void c2_part2_body(const uint16_t *__restrict__ lo1, 
         for (uint32_t q = threadIdx.x; q < (total >> 2); q += C2_P2_THREADS) {
             const uint4 v = k4[q];
             const unsigned long long gb = gbase[v.x >> 16];
-#if defined(C2_P2_EXP) && C2_P2_EXP == 1      // bound experiment: no stores (wrong answers)
-            if (v.x != 0x12345678u) continue;
-#endif
             if (gb != C2_DROP)
                 *reinterpret_cast<uint2 *>(buf2 + gb + 4ULL * q) = make_uint2(c2_pack_lo(v.x, v.y), c2_pack_lo(v.z, v.w));
         }
@@ -801,15 +762,15 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
         for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_nov = 0;
     }
-#ifdef C2_DESYNC     // experiment: the second block of every CU starts half a bucket late (blocks of a CU otherwise move in step)
-    if (blockIdx.x >= gridDim.x / 2)
-        for (int i = 0; i < C2_DESYNC; i++) __builtin_amdgcn_s_sleep(127);
-#endif
     prefetch(blockIdx.x);
     __syncthreads();
     // a record adds 1 to its half of the word; a pad record (0xFFFF) adds 0 to the last word
     auto add = [&](uint32_t r) { atomicAdd(&cnt[(r & (C2_FINE - 1)) >> 1], ((r >> C2_B3) ^ 1u) << (16u * (r & 1u))); };
     for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
+        // (round 6 audit: the tally is cleared HERE, behind the barrier that ends the previous bucket.  It used to be cleared
+        // by thread 0 right after it had read `nov` below -- with no barrier between that store and the other waves' read
+        // of s_nov, so a wave that left the barrier late could read 0 and skip its share of the staged overflow pairs.)
+        if (threadIdx.x == 0) s_nov = 0;
         const unsigned long long lo = pf_lo, hi = pf_hi;
         if (hi - lo >= 65536ULL) {               // block-uniform: c2_count takes this bucket
             if (threadIdx.x == 0) big_list[atomicAdd(n_big, 1ULL)] = (uint32_t)fb;
@@ -879,10 +840,7 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
                 if (base + p < ovf_cap) ovf_tmp[base + p] = stage[p];
             if (threadIdx.x == 0) seg_base[fb] = (uint32_t)base;
         }
-        if (threadIdx.x == 0) {
-            seg_cnt[fb] = nov;
-            s_nov = 0;
-        }
+        if (threadIdx.x == 0) seg_cnt[fb] = nov;
         __syncthreads();
     }
     unsigned long long ts = sp_block_sum_u64(s, red);
@@ -1501,8 +1459,24 @@ int sp_count_engine3_batch(sp_ctx *ctx, const int *chrom_idx, int n, const sp_kp
         D.out_keys = (unsigned long long *)ctx->sparse[(size_t)chrom_idx[i]].d_keys;
         D.out_cnts = ctx->sparse[(size_t)chrom_idx[i]].d_cnts;
     }
-    // (pageable source: hipMemcpyAsync returns once the runtime has staged it)
-    SP_HIP(ctx, hipMemcpyAsync(d_desc, hd.data(), (size_t)n * sizeof(c2_bdesc), hipMemcpyHostToDevice, ctx->stream));
+    // the table travels from a page-locked buffer of this lane's (advisor r05: a pageable source is only safe because the
+    // runtime stages it before hipMemcpyAsync returns -- and that staging made the host wait on the lane's stream).  The
+    // buffer is free: a lane issues one batched count per sp_count call, and sp_count ends with a host synchronisation.
+    void *&h_desc = ctx->lane ? ctx->lane->h_desc : ctx->h_desc;
+    int64_t &h_desc_cap = ctx->lane ? ctx->lane->h_desc_cap : ctx->h_desc_cap;
+    if ((int64_t)((size_t)n * sizeof(c2_bdesc)) > h_desc_cap) {
+        if (h_desc) {
+            SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SP_HIP(ctx, hipHostFree(h_desc));
+            h_desc = nullptr;
+            h_desc_cap = 0;
+        }
+        const size_t cap = (size_t)(n < 64 ? 64 : n) * sizeof(c2_bdesc);
+        SP_HIP(ctx, hipHostMalloc(&h_desc, cap, hipHostMallocDefault));
+        h_desc_cap = (int64_t)cap;
+    }
+    memcpy(h_desc, hd.data(), (size_t)n * sizeof(c2_bdesc));
+    SP_HIP(ctx, hipMemcpyAsync(d_desc, h_desc, (size_t)n * sizeof(c2_bdesc), hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(ctx, hipMemsetAsync(heads, 0, (size_t)n * head_bytes, ctx->stream));
     const sp_kparams32 kp32 = sp_make_kparams32(kp.k);
     const unsigned un = (unsigned)n;

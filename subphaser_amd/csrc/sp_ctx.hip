@@ -146,6 +146,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     for (auto &ln : ctx->lanes) {
         if (ln.d_ws2) hipFree(ln.d_ws2);
         sp_buf_free(ln.b_ovfw);
+        if (ln.h_desc) hipHostFree(ln.h_desc);
         sp_buf_free(ln.b_sp_a);
         sp_buf_free(ln.b_sp_b);
         sp_buf_free(ln.b_sp_c);
@@ -158,6 +159,7 @@ int sp_ctx_destroy(sp_ctx *ctx) {
     }
     if (ctx->lane_go) hipEventDestroy(ctx->lane_go);
     if (ctx->h_s3) hipHostFree(ctx->h_s3);
+    if (ctx->h_desc) hipHostFree(ctx->h_desc);
     for (auto &e : ctx->s3_ev)
         if (e) hipEventDestroy(e);
     sp_buf_free(ctx->b_map);

@@ -276,13 +276,7 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         // most: outside a 1e-5 band around the threshold this and the reference's fp64 quotient test
         // agree; a k-mer with any set inside the band goes to the exact fp64 code (slow queue).
         if (NCH > 0) {
-#if defined(K3_P1)
-            const uint32_t qn = 0;
-#elif defined(K3_P3)
-            const uint32_t qn = s_qn < F_BLOCK ? s_qn : F_BLOCK;
-#else
             const uint32_t qn = s_qn;
-#endif
             for (uint32_t q0 = 0; q0 < qn; q0 += F_BLOCK) {
                 const uint32_t q = q0 + threadIdx.x;
                 const bool live = q < qn;
@@ -302,7 +296,6 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
                         const uint32_t c = y[i] >= P.lower ? y[i] : 0u;
                         if ((mk_tot >> r) & 1u) tot += c;            // uniform branches on register bits
                         num += c;
-#ifndef K3_P2
                         if ((mk_unit >> r) & 1u) {
                             const float x = (float)num * inv[r];
                             m2 = fmaxf(m2, fminf(m1, x));            // running max / second max / min, branch-free
@@ -317,7 +310,6 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
                             exact = exact || (!pass && !(m1 < thr * (1.0f - 1e-5f)));
                             m1 = -1.0f; m2 = -1.0f; mn = 3e38f;
                         }
-#endif
                     }
                 }
                 if (live && tot) {

@@ -50,12 +50,6 @@ __device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, c
 }
 
 #define MAP_PAIR_MAX_SG 7
-#ifndef MAP_BATCH
-#define MAP_BATCH 4     // pairs whose probes / gathers are in flight together (16 pairs per 32-start unit)
-#endif
-#ifndef MAP_BATCH_COMPACT
-#define MAP_BATCH_COMPACT 2   // with the compact table (8-byte bucket loads, more live registers per pair): 2: 46.0, 4: 47.1, 8: 59.8 ms
-#endif
 
 struct map_pair_loc {
     uint32_t idx;   // canonical (k-1)-mer

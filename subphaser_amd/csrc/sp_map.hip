@@ -123,9 +123,6 @@ k4_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, cons
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
-#ifdef MAP_EXP_COUNT
-__device__ unsigned long long g_map_dbg[4];
-#endif
 // ----------------------------------------------------------------- K4c: compact pair table (sp_map.h), S <= 3
 // insert-or-find a key, then OR the field in.  The four entries of a bucket are tried in order and never freed, so two
 // threads that insert the same key meet in the same entry; a bucket with four foreign entries raises its overflow flag
@@ -200,220 +197,6 @@ k4_ctab_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, map_
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
-// The compact-table form of the same walk, batched for memory-level parallelism (round 5).  Measured on the wheat-like
-// pass: 1.55 G candidate pairs but only 0.96 G candidate QUADS, and yet the quad-bucket table did not move the kernel
-// (45.9 ms) -- the look-ups are not bound by their number but by how many are in flight: one load instruction per wave
-// and quad with ~16 of 64 lanes active, 24 waves per CU, ~2 us per miss = 49 G look-ups/s.  So a lane now issues the
-// filter probes of MAP_QB quads (2 MAP_QB pairs) together, then the bucket loads of all candidate quads among them,
-// then takes the hits in position order: 2 memory round trips per MAP_QB quads instead of 2 per quad.
-#ifndef MAP_QB
-#define MAP_QB 4
-#endif
-template <typename F>
-__device__ __forceinline__ void map_quad_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
-                                                const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
-                                                const uint32_t *__restrict__ bloom, int nbits,
-                                                const map_ptab &T, F &&hit) {
-    constexpr int FW = MAP_CT_FIELD;
-    constexpr uint32_t LBL = 3u, SEEN = 4u, FMASK = 7u;
-    constexpr int QB = MAP_QB, PB = 2 * MAP_QB;
-    static_assert(8 % QB == 0, "a 32-start unit holds 8 quads");
-    const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
-    const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
-    const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
-    const uint32_t ok_x = ~(uint32_t)(bad_k1 >> 1);                    // (k-1)-mer starting at s0+j+1
-    if (__all((ok_x & 0x55555555u) == 0)) return;
-    const sp_words32 x = sp_load_words32(pk, pm, s0);
-    const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
-    const uint32_t m1mask = kp.kmask >> 2;
-    const int sb = T.sb;
-    const uint32_t smask = (1u << sb) - 1u;
-    auto xf_of = [&](uint32_t V) { return (V >> sh) & m1mask; };      // the pair's shared (k-1)-mer, forward, key order
-    auto xr_of = [&](uint32_t W) { return (~W >> 2) & m1mask; };      // its reverse complement
-#pragma unroll
-    for (int g0 = 0; g0 < 8; g0 += QB) {
-        // A: the filter probes of the batch (the windows are cheap to extract again later: nothing but wd[] is kept)
-        uint32_t wd[PB];
-#pragma unroll
-        for (int q = 0; q < PB; q++) {
-            const int j = 2 * (2 * g0 + q);
-            const uint32_t xf = xf_of(sp_win_msb_at(x, j)), xr = xr_of(sp_win_lsb_at(x, j));
-            const map_bloom_probe p = map_bloom((uint64_t)(xf < xr ? xf : xr), nbits);
-#ifdef MAP_EXP_NOPROBE
-            wd[q] = xf;
-#else
-            wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
-#endif
-        }
-        // B: candidates, then one bucket load per candidate quad
-        uint32_t candm = 0;
-#pragma unroll
-        for (int q = 0; q < PB; q++) {
-            const int j = 2 * (2 * g0 + q);
-            const uint32_t xf = xf_of(sp_win_msb_at(x, j)), xr = xr_of(sp_win_lsb_at(x, j));
-            const uint32_t canon = xf < xr ? xf : xr;
-            const uint32_t want = map_bloom((uint64_t)canon, nbits).bits;
-#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)
-            const bool cand = (wd[q] & want) == want && canon == ((uint32_t)nbits | 0x20000000u);
-#else
-            const bool cand = (wd[q] & want) == want;
-#endif
-            candm |= (cand ? 1u : 0u) << q;
-        }
-        uint4 B[QB];
-#pragma unroll
-        for (int g = 0; g < QB; g++) {
-            B[g] = make_uint4(0u, 0u, 0u, 0u);
-            const uint32_t cm = (candm >> (2 * g)) & 3u;
-            if (cm) {
-                // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
-                const int j1 = 2 * (2 * (g0 + g)), j2 = j1 + 2;
-                const uint32_t s_f = (cm & 1u) ? (xf_of(sp_win_msb_at(x, j1)) & smask) : (xf_of(sp_win_msb_at(x, j2)) >> 4);
-                const uint32_t s_r = (cm & 1u) ? (xr_of(sp_win_lsb_at(x, j1)) >> 4) : (xr_of(sp_win_lsb_at(x, j2)) & smask);
-                const uint32_t t = s_f <= s_r ? s_f : s_r;
-                B[g] = T.buckets[map_ct_mix(t, sb) >> T.tb];
-            }
-        }
-#ifdef MAP_EXP_COUNT
-        {
-            unsigned long long any = 0;
-            uint32_t np = __popc(candm), nq = 0;
-            for (int g = 0; g < QB; g++) nq += ((candm >> (2 * g)) & 3u) ? 1u : 0u;
-            for (int o = 32; o > 0; o >>= 1) { np += __shfl_down(np, o, 64); nq += __shfl_down(nq, o, 64); }
-            any = __ballot(candm != 0);
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&g_map_dbg[0], (unsigned long long)np);
-                atomicAdd(&g_map_dbg[1], (unsigned long long)nq);
-                atomicAdd(&g_map_dbg[2], 1ULL);
-                atomicAdd(&g_map_dbg[3], any ? 1ULL : 0ULL);
-            }
-        }
-#endif
-        // C: the hits, in position order
-#pragma unroll
-        for (int g = 0; g < QB; g++) {
-            const uint32_t cm = (candm >> (2 * g)) & 3u;
-            if (!cm) continue;
-            const int j1 = 2 * (2 * (g0 + g)), j2 = j1 + 2;
-            const uint32_t V1 = sp_win_msb_at(x, j1), V2 = sp_win_msb_at(x, j2);
-            const uint32_t xf1 = xf_of(V1), xr1 = xr_of(sp_win_lsb_at(x, j1));
-            const uint32_t xf2 = xf_of(V2), xr2 = xr_of(sp_win_lsb_at(x, j2));
-            const uint32_t s_f = (cm & 1u) ? (xf1 & smask) : (xf2 >> 4), s_r = (cm & 1u) ? (xr1 >> 4) : (xr2 & smask);
-            const bool sfw = s_f <= s_r;
-            const uint32_t t = sfw ? s_f : s_r;
-            // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
-            const map_ct_key k1 = map_ct_key_of(T, t, sfw ? 0u : 1u, sfw ? (xf1 >> sb) : (xr1 & 15u));
-            const map_ct_key k2 = map_ct_key_of(T, t, sfw ? 1u : 0u, sfw ? (xf2 & 15u) : (xr2 >> sb));
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (!((cm >> h) & 1u)) continue;
-                const map_ct_hit r = map_ct_find(T, B[g], h ? k2 : k1);
-                if (!(r.fields & MAP_CT_ANY)) continue;
-#ifdef MAP_EXP_NOHIT    // bound experiment: probes and look-ups as they are, no hit is ever taken (wrong answers)
-                if (r.fields != ((uint32_t)nbits | 0x200000u)) continue;
-#endif
-                const int j = h ? j2 : j1;
-                const uint32_t V = h ? V2 : V1;
-                const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
-                // the fields are laid out in the orientation in which t is canonical
-                const int f0 = sfw ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
-                const int f1 = sfw ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
-                const uint32_t v0 = ((ok_k >> j) & 1u) ? (r.fields >> (FW * f0)) & FMASK : 0u;
-                const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (r.fields >> (FW * f1)) & FMASK : 0u;
-                uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
-                if ((v0 & LBL) && hit(s0 + j, (int)(v0 & LBL) - 1) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
-                if ((v1 & LBL) && hit(s0 + j + 1, (int)(v1 & LBL) - 1) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
-                if (mark) map_ct_mark(T, r.loc, mark);           // "seen": first touch only
-            }
-        }
-    }
-}
-
-// Walk the 32 starts [s0, s0+32) pair by pair: ONE filter probe per pair, ONE pair-table gather per
-// candidate pair; hit(start, sg) for every valid start that carries a labelled k-mer.  k <= 15.
-// COMPACT: the exact table is the compact one (3-bit fields; the two pairs of a QUAD of starts share one 16-byte
-// bucket load, sp_map.h), else the direct one (4-bit fields, one 4-byte gather per candidate pair).
-template <bool COMPACT, typename F>
-__device__ __forceinline__ void map_pair_scan32(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
-                                                const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
-                                                const uint32_t *__restrict__ bloom, int nbits,
-                                                const map_ptab &T, F &&hit) {
-    if (COMPACT) {
-        map_quad_scan32(pk, pm, nm, s0, kp, bloom, nbits, T, hit);
-        return;
-    }
-    constexpr int FW = 4;
-    constexpr uint32_t LBL = 7u, SEEN = 8u, FMASK = 15u;
-    constexpr uint32_t ANY = 0x77777777u;
-    constexpr int BATCH = MAP_BATCH;
-    const uint64_t bad_k1 = sp_bad_starts64(nm, s0, kp.k - 1);
-    const uint64_t inv = (uint64_t)nm[s0 >> 5] | ((uint64_t)nm[(s0 >> 5) + 1] << 32);
-    const uint32_t ok_k = ~(uint32_t)(bad_k1 | (inv >> (kp.k - 1)));   // k-mer starting at s0+j
-    const uint32_t ok_x = ~(uint32_t)(bad_k1 >> 1);                    // (k-1)-mer starting at s0+j+1
-    if (__all((ok_x & 0x55555555u) == 0)) return;
-    const sp_words32 x = sp_load_words32(pk, pm, s0);
-    const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
-    const uint32_t m1mask = kp.kmask >> 2;
-    // MAP_BATCH pairs at a time: their filter probes are issued together, then the pair-table gathers of the
-    // candidates, then the hits are taken in position order.  One probe in flight per lane left the kernel bound by
-    // the latency of the scan -> probe -> gather chain (168 G L2 requests/s at 24 waves per CU against the ~270 G/s
-    // the chip serves).
-#pragma unroll
-    for (int g = 0; g < 16; g += BATCH) {
-        uint32_t V[BATCH], canon[BATCH], fw[BATCH], want[BATCH], wd[BATCH], e[BATCH], loc[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            const int j = 2 * (g + q);
-            V[q] = sp_win_msb_at(x, j);
-            const uint32_t W = sp_win_lsb_at(x, j);
-            const uint32_t xf = (V[q] >> sh) & m1mask;       // shared (k-1)-mer, forward, key order
-            const uint32_t xr = (~W >> 2) & m1mask;          // its reverse complement
-            canon[q] = xf < xr ? xf : xr;
-            fw[q] = xf <= xr;
-            const map_bloom_probe p = map_bloom((uint64_t)canon[q], nbits);
-            want[q] = p.bits;
-#ifdef MAP_EXP_NOPROBE      // bound experiments (tools/build_variant.sh): the scan alone, wrong answers
-            wd[q] = canon[q];
-#elif defined(MAP_EXP_SKIP3)  // two probes (and look-ups) in three: what one probe per THREE starts would leave of them
-            wd[q] = (((ok_x >> j) & 1u) && (g + q) % 3 != 2) ? bloom[p.word] : 0u;
-#else
-            wd[q] = ((ok_x >> j) & 1u) ? bloom[p.word] : 0u;
-#endif
-        }
-        bool cand[BATCH];
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)   // bound experiment: scan + filter probes, no exact look-up
-            // (wrong answers; canon is below 2^28 and never equals the value it is compared with, which the compiler cannot know)
-            cand[q] = (wd[q] & want[q]) == want[q] && canon[q] == ((uint32_t)nbits | 0x20000000u);
-#else
-            cand[q] = (wd[q] & want[q]) == want[q];
-#endif
-        }
-        {
-#pragma unroll
-            for (int q = 0; q < BATCH; q++) {
-                e[q] = cand[q] ? T.direct[canon[q]] : 0u;
-                loc[q] = canon[q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < BATCH; q++) {
-            if (!(e[q] & ANY)) continue;
-            const int j = 2 * (g + q);
-            const uint32_t b0 = V[q] >> 30, b1 = (V[q] >> sh1) & 3u;
-            const int f0 = fw[q] ? (int)b0 : 7 - (int)b0;      // k-mer at s0+j   = b0 + x
-            const int f1 = fw[q] ? 4 + (int)b1 : 3 - (int)b1;  // k-mer at s0+j+1 = x + b1
-            const uint32_t v0 = ((ok_k >> j) & 1u) ? (e[q] >> (FW * f0)) & FMASK : 0u;
-            const uint32_t v1 = ((ok_k >> (j + 1)) & 1u) ? (e[q] >> (FW * f1)) & FMASK : 0u;
-            uint32_t mark = 0;   // hit() says whether the position counts (feature mode rejects boundary k-mers)
-            if ((v0 & LBL) && hit(s0 + j, (int)(v0 & LBL) - 1) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
-            if ((v1 & LBL) && hit(s0 + j + 1, (int)(v1 & LBL) - 1) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
-            if (mark) atomicOr(&T.direct[loc[q]], mark);       // "seen": first touch only
-        }
-    }
-}
-
 // K5, pair-table engine (S <= 7): one block-iteration covers MAP_BLOCK units of 64 starts.  ONE launch maps every
 // chromosome of the call: ranges are numbered through the whole genome (desc[c].range0 = first range of chromosome
 // c) and dealt to the blocks round-robin, so the tail of the launch is one range per block instead of one partly
@@ -430,97 +213,14 @@ struct map_chrom_desc {
 #ifndef MAP_MIN_WAVES
 #define MAP_MIN_WAVES 1     // waves per SIMD the register allocation must leave room for
 #endif
-template <bool COMPACT>
-__global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
-k5_map(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, sp_kparams32 kp, sp_map_params P,
-       map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
-    __shared__ int hist[MAP_LDS_ENTRIES];
-    __shared__ unsigned long long red[16];
-    unsigned long long mapped = 0;
-    int cur = -1;          // chromosome the block is accumulating `mapped` for
-    auto flush_mapped = [&]() {     // block-uniform control flow
-        if (cur < 0) return;
-        const unsigned long long t = sp_block_sum_u64(mapped, red);
-        if (threadIdx.x == 0 && t) atomicAdd(desc[cur].n_mapped, t);
-        mapped = 0;
-    };
-    for (int64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
-        int lo = 0, hi = n_chrom;              // last chromosome with range0 <= rg (uniform: scalar loads)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (desc[mid].range0 <= rg) lo = mid;
-            else hi = mid;
-        }
-        if (lo != cur) {
-            flush_mapped();
-            cur = lo;
-        }
-        const map_chrom_desc D = desc[lo];
-        const int64_t r = rg - D.range0;
-        const int64_t u = r * MAP_BLOCK + threadIdx.x;
-        const int64_t slot_lo = map_slot(r * MAP_RANGE, P, kp.k);
-        if (P.use_lds) {
-            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) hist[i] = 0;
-            __syncthreads();
-        }
-        if (u < D.n_units) {
-            // A lane's 64 starts lie in one or two output slots: hits are tallied in a register, one byte per
-            // subgenome (<= 64 hits per unit, <= 7 subgenomes), and reach the LDS histogram once per slot -- not
-            // one LDS atomic and a 64-bit slot computation per hit (the hit path runs for every pair of every wave:
-            // some lane always has one).
-            int64_t cur_end = -1, cur_os = 0;   // starts are visited in ascending order: [.., cur_end) -> cur_os
-            unsigned long long acc = 0;
-            auto flush = [&]() {
-                if (!acc) return;
-                for (int sg = 0; sg < P.S; sg++) {
-                    const int v = (int)((acc >> (8 * sg)) & 255ULL);
-                    if (!v) continue;
-                    if (P.use_lds)
-                        atomicAdd(&hist[(int)(cur_os - slot_lo) * P.S + sg], v);
-                    else if (cur_os < D.nslots)
-                        atomicAdd(&D.counts[cur_os * P.S + sg], v);
-                    mapped += v;
-                }
-                acc = 0;
-            };
-            auto hit = [&](int64_t start, int sg) {
-                if (start >= cur_end) {
-                    flush();
-                    cur_os = map_slot(start, P, kp.k);
-                    cur_end = map_slot_end(start, P, kp.k);
-                }
-                acc += 1ULL << (8 * sg);
-                return true;
-            };
-            map_pair_scan32<COMPACT>(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-            map_pair_scan32<COMPACT>(D.pk, D.pm, D.nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
-            flush();
-        }
-        if (P.use_lds) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < MAP_LDS_ENTRIES; i += MAP_BLOCK) {
-                int v = hist[i];
-                if (v) {
-                    int64_t os = slot_lo + i / P.S;
-                    if (os < D.nslots) atomicAdd(&D.counts[os * P.S + (i % P.S)], v);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    flush_mapped();
-}
-
-#ifndef MAP_MIN_WAVES
-#define MAP_MIN_WAVES 1     // waves per SIMD the register allocation must leave room for
-#endif
-// ----------------------------------------------------------------- K5, round 5: the same walk in 1/30 of the code
-// k5_map above is 258 KB of machine code (k5_map_sparse: 532 KB): sixteen fully unrolled copies of the quad walk,
-// each with four inlined copies of the hit path (64-bit divisions for the output slot, an LDS flush loop, the overflow
-// probe loop).  The instruction cache holds 64 KB.  Every wave therefore streams the whole kernel from the L2 once
-// per 64 starts -- ~14 G instruction-line requests per wheat-like pass next to the 7 G filter probes the kernel was
-// believed to be bound by, and the reason why no change to its memory accesses ever moved it (quad buckets: 1.55 G ->
-// 0.96 G look-ups, same 45.9 ms; more loads in flight per lane: slower).  k5_map2 keeps the loop over the quads of a
+// ----------------------------------------------------------------- K5: the rolled walk (round 5)
+// Rounds 2-4 unrolled the walk over a unit completely: 258 KB of machine code (the k > 15 twin: 532 KB) -- sixteen
+// copies of the quad walk, each with four inlined copies of the hit path (64-bit divisions for the output slot, an LDS
+// flush loop, the overflow probe loop) -- against 64 KB of instruction cache: every wave streamed the whole kernel from
+// the L2 once per 64 starts, ~14 G instruction-line requests per wheat-like pass next to the 7 G filter probes the
+// kernel was believed to be bound by, and the reason why no change to its memory accesses ever moved it (quad buckets:
+// 1.55 G -> 0.96 G look-ups, same 45.9 ms; more loads in flight per lane: slower).  Those kernels were removed in round
+// 6.  k5_map2 keeps the loop over the quads of a
 // unit ROLLED (windows by run-time shifts out of a rotating pair of registers per stream), records a hit as a bit in
 // three 64-bit label planes instead of calling into the slot arithmetic, and settles a unit's hits once: popcounts
 // into the range's LDS histogram when the whole range lies in one output slot run (the common case; the boundaries
@@ -591,13 +291,8 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                 const uint32_t okx = (uint32_t)(ok_x >> j);
                 okk[q] = (uint32_t)(ok_k >> j);
                 wd1[q] = wd2[q] = 0;
-#ifdef MAP_EXP_NOPROBE      // bound experiments (tools/build_variant.sh): wrong answers, conditions the compiler cannot resolve
-                wd1[q] = c1[q];
-                wd2[q] = c2[q];
-#else
                 if (okx & 1u) wd1[q] = bloom[p1[q].word];
                 if (okx & 4u) wd2[q] = bloom[p2[q].word];
-#endif
             }
             bool cand1[QI], cand2[QI], sfw[QI];
             uint4 B[QI];
@@ -605,13 +300,8 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
             uint32_t e1[QI], e2[QI];
 #pragma unroll
             for (int q = 0; q < QI; q++) {
-#if defined(MAP_EXP_NOLOOKUP) || defined(MAP_EXP_NOPROBE)
-                cand1[q] = (wd1[q] & p1[q].bits) == p1[q].bits && c1[q] == ((uint32_t)nbits | 0x200000u);
-                cand2[q] = (wd2[q] & p2[q].bits) == p2[q].bits && c2[q] == ((uint32_t)nbits | 0x200000u);
-#else
                 cand1[q] = (wd1[q] & p1[q].bits) == p1[q].bits;
                 cand2[q] = (wd2[q] & p2[q].bits) == p2[q].bits;
-#endif
                 e1[q] = e2[q] = 0;
                 B[q] = make_uint4(0u, 0u, 0u, 0u);
                 if (TABLE) {
@@ -652,9 +342,6 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                 for (int h = 0; h < 2; h++) {
                     const uint32_t e = h ? e2[q] : e1[q];
                     if (!(e & ANY)) continue;
-#ifdef MAP_EXP_NOHIT
-                    if (e != ((uint32_t)nbits | 0x200000u)) continue;
-#endif
                     const uint32_t V = h ? V2[q] : V1[q];
                     const bool fw = h ? fw2 : fw1;
                     const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
@@ -809,29 +496,11 @@ static int map_launch_dense(sp_ctx *ctx, const std::vector<map_chrom_desc> &hd, 
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
     const map_ptab T = map_ptab_of(ctx);
-    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the fully unrolled kernels of rounds 2-4 (cross-check)
-    if (!(env_mk && env_mk[0] == '1')) {
-        if (T.buckets)
-            SP_LAUNCH(ctx, "k5_map", k5_map2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
-                      (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
-        else
-            SP_LAUNCH(ctx, "k5_map", k5_map2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
-                      (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
-        return SP_OK;
-    }
     if (T.buckets)
-    {
-        SP_LAUNCH(ctx, "k5_map", k5_map<true>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+        SP_LAUNCH(ctx, "k5_map", k5_map2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
                   (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
-#ifdef MAP_EXP_COUNT
-        unsigned long long h[4];
-        hipStreamSynchronize(ctx->stream);
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_map_dbg), 32);
-        fprintf(stderr, "[sp] k5_map (cumulative): %llu candidate pairs, %llu candidate quads, %llu quad wave-steps, %llu of them load\n", h[0], h[1], h[2], h[3]);
-#endif
-    }
     else
-        SP_LAUNCH(ctx, "k5_map", k5_map<false>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
+        SP_LAUNCH(ctx, "k5_map", k5_map2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const map_chrom_desc *)ctx->b_mapdesc.p,
                   (int)hd.size(), n_ranges, kp, P, T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits);
     return SP_OK;
 }
@@ -916,25 +585,56 @@ k5_stack(const int *__restrict__ slot_counts, int64_t total_slots, int S, int C,
     atomicAdd(&win_counts[(win_off[lo] + win) * S + sg], (unsigned long long)v);
 }
 
-template <bool COMPACT>
-__global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_feat(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-            sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
-            map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
-            unsigned long long *__restrict__ counts) {
+// Feature mode on the rolled walk (round 6; it ran on the unrolled walk of rounds 2-4 until then).  The features lie back to
+// back in one packed sequence; a k-mer belongs to feature f iff it lies entirely inside [foff[f], foff[f + 1]).  Per unit of
+// 64 starts: (1) the starts whose k-mer crosses no feature boundary (`fit`) -- only those are scanned, counted and marked
+// "seen", exactly the k-mers a FASTA of the features holds; (2) the label planes of the unit; (3) one walk over the features
+// that overlap the unit: popcounts of the planes inside the feature -> counts[f][sg].
+template <int TABLE>
+__global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
+k5_map_feat2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
+             sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
+             map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
+             unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int k = kp.k;
+    auto span = [](int64_t a, int64_t b) -> unsigned long long {      // bits [a, b) of a unit, 0 <= a, b <= 64
+        if (b <= a) return 0ULL;
+        return (b >= 64 ? ~0ULL : ((1ULL << b) - 1ULL)) & ~((1ULL << a) - 1ULL);
+    };
     for (; u < n_units; u += stride) {
-        map_feat_cursor cur;
-        cur.f = -1;
-        cur.next = 0;
-        auto hit = [&](int64_t start, int sg) {
-            if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return false;
-            atomicAdd(&counts[cur.f * S + sg], 1ULL);
-            return true;
-        };
-        map_pair_scan32<COMPACT>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-        map_pair_scan32<COMPACT>(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
+        const int64_t s0 = u * SP_UNIT;
+        int64_t lo = 0, hi = n_feat;           // the feature the unit starts in: last f with foff[f] <= s0
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (foff[mid] <= s0) lo = mid;
+            else hi = mid;
+        }
+        // (1) a boundary at `e` = foff[f + 1] disqualifies the starts (e - k, e): their k-mers run into the next feature
+        unsigned long long fit = ~0ULL;
+        for (int64_t f = lo; f < n_feat; f++) {
+            const int64_t e = foff[f + 1];
+            if (e - k + 1 >= s0 + SP_UNIT) break;
+            fit &= ~span((e - k + 1 > s0 ? e - k + 1 : s0) - s0, (e < s0 + SP_UNIT ? e : s0 + SP_UNIT) - s0);
+            if (e >= s0 + SP_UNIT) break;
+        }
+        unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+        map_unit_scan64<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, ptab, lab, fit);
+        if (!(lab[0] | lab[1] | lab[2])) continue;
+        // (3) the features that overlap the unit (a start beyond the last feature's end is padding: never valid)
+        for (int64_t f = lo; f < n_feat; f++) {
+            const int64_t a = foff[f], e = foff[f + 1];
+            if (a >= s0 + SP_UNIT) break;
+            const unsigned long long within = span((a > s0 ? a : s0) - s0, (e < s0 + SP_UNIT ? e : s0 + SP_UNIT) - s0) & fit;
+            if (!((lab[0] | lab[1] | lab[2]) & within)) continue;
+            for (int sg = 0; sg < S; sg++) {
+                const int l = sg + 1;
+                const unsigned long long m = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) &
+                                             ((l & 4) ? lab[2] : ~lab[2]) & within;
+                if (m) atomicAdd(&counts[f * S + sg], (unsigned long long)__popcll(m));
+            }
+        }
     }
 }
 
@@ -993,43 +693,26 @@ kv_cover(const int32_t *__restrict__ chrom, const int64_t *__restrict__ start, c
     }
 }
 
-template <int ENGINE /* 0 = direct pair table, 1 = label table, 2 = compact pair table */>
+// (label-table engine, more than 7 subgenomes; the pair-table engines take k5_map_mask2 above)
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_mask(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
-            sp_kparams32 kp, int64_t n_units, int S, map_ptab ptab, uint8_t *__restrict__ label,
-            const uint32_t *__restrict__ bloom, int bloom_bits, const unsigned long long *__restrict__ cov,
-            unsigned long long *__restrict__ masks /* n_units x S */) {
+k5_map_mask_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams32 kp, int64_t n_units, int S,
+                uint8_t *__restrict__ label, const uint32_t *__restrict__ bloom, int bloom_bits,
+                const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks /* n_units x S */) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;         // nothing of this wave's 4096 starts lies in a feature
-        if (ENGINE != 1) {
-            unsigned long long m[MAP_PAIR_MAX_SG] = {0, 0, 0, 0, 0, 0, 0};
-            auto hit = [&](int64_t start, int sg) {
-                const unsigned long long bit = 1ULL << (start & 63);
-                if (!(cv & bit)) return false;
-#pragma unroll
-                for (int j = 0; j < MAP_PAIR_MAX_SG; j++) m[j] |= (j == sg) ? bit : 0ULL;
-                return true;
-            };
-            map_pair_scan32<ENGINE == 2>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, hit);
-            map_pair_scan32<ENGINE == 2>(pk, pm, nm, u * SP_UNIT + 32, kp, bloom, bloom_bits, ptab, hit);
-#pragma unroll
-            for (int j = 0; j < MAP_PAIR_MAX_SG; j++)
-                if (j < S) masks[u * S + j] = m[j];
-        } else {
-            map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
-                const unsigned long long bit = 1ULL << (start & 63);
-                if (!(cv & bit)) return;
-                const uint32_t slot = sp_slot_of32(fwd, rc, kp);
-                const uint32_t l = label[slot];
-                if (l) {
-                    if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
-                    atomicOr(&masks[u * S + ((int)(l & 0x7fu) - 1)], bit);
-                }
-            });
-        }
+        map_pair_scan<uint32_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint32_t fwd, uint32_t rc) {
+            const unsigned long long bit = 1ULL << (start & 63);
+            if (!(cv & bit)) return;
+            const uint32_t slot = sp_slot_of32(fwd, rc, kp);
+            const uint32_t l = label[slot];
+            if (l) {
+                if (!(l & 0x80u)) label[slot] = (uint8_t)(l | 0x80u);
+                atomicOr(&masks[u * S + ((int)(l & 0x7fu) - 1)], bit);
+            }
+        });
     }
 }
 
@@ -1122,7 +805,7 @@ k4_label_max(const uint8_t *__restrict__ sg, int64_t n, unsigned int *__restrict
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *d_counts, unsigned long long *d_n);
-int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units,
+int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_pm, const uint32_t *d_nm, int64_t n_units,
                           const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts);
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n);
 int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, const unsigned long long *d_cov,
@@ -1586,19 +1269,19 @@ int sp_map_features(sp_ctx *ctx, const uint8_t *ascii, const int64_t *off, int64
               d_pk.p + 2 * nmw, d_nm.p, nmw);
     int64_t n_units = (total + SP_UNIT - 1) / SP_UNIT;
     if (ctx->sparse_mode) {
-        int rcs = sp_sparse_feat_launch(ctx, d_pk.p, d_nm.p, n_units, d_foff.p, n_feat, S, d_counts.p);
+        int rcs = sp_sparse_feat_launch(ctx, d_pk.p, d_pk.p + 2 * nmw, d_nm.p, n_units, d_foff.p, n_feat, S, d_counts.p);
         if (rcs) return rcs;
     } else {
         const sp_kparams32 kp = sp_make_kparams32(ctx->k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
         if (ctx->map_engine == 0 && ctx->ct_bb)
-            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat<true>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
                       (const uint32_t *)(d_pk.p + 2 * nmw), (const uint32_t *)d_nm.p, kp, n_units,
                       (const int64_t *)d_foff.p, n_feat, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom,
                       ctx->bloom_bits, d_counts.p);
         else if (ctx->map_engine == 0)
-            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat<false>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
+            SP_LAUNCH(ctx, "k5_map_feat", k5_map_feat2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)d_pk.p,
                       (const uint32_t *)(d_pk.p + 2 * nmw), (const uint32_t *)d_nm.p, kp, n_units,
                       (const int64_t *)d_foff.p, n_feat, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom,
                       ctx->bloom_bits, d_counts.p);
@@ -1662,27 +1345,17 @@ int sp_map_intervals(sp_ctx *ctx, const int32_t *chrom, const int64_t *start, co
         const sp_kparams32 kp = sp_make_kparams32(k);
         int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
         if (grid > (int64_t)ctx->n_cu * MAP_GRID_MULT) grid = (int64_t)ctx->n_cu * MAP_GRID_MULT;
-        const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernels of rounds 2-4 (cross-check)
-        const bool rolled = !(env_mk && env_mk[0] == '1');
-        if (ctx->map_engine == 0 && rolled && ctx->ct_bb)
+        if (ctx->map_engine == 0 && ctx->ct_bb)
             SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
                       n_units, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
-        else if (ctx->map_engine == 0 && rolled)
+        else if (ctx->map_engine == 0)
             SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
                       n_units, S, map_ptab_of(ctx), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
-        else if (ctx->map_engine == 0 && ctx->ct_bb)
-            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<2>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
-                      n_units, S, map_ptab_of(ctx), (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
-                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
-        else if (ctx->map_engine == 0)
-            SP_LAUNCH(ctx, "k5_map_mask", k5_map_mask<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm, kp,
-                      n_units, S, map_ptab_of(ctx), (uint8_t *)nullptr, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
-                      (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
         else
-            SP_LAUNCH(ctx, "k5_map_mask_lab", k5_map_mask<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_pm, ch.d_nm,
-                      kp, n_units, S, map_ptab_of(ctx), ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
+            SP_LAUNCH(ctx, "k5_map_mask_lab", k5_map_mask_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, ch.d_pk, ch.d_nm,
+                      kp, n_units, S, ctx->d_label, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits,
                       (const unsigned long long *)(d_cov + ubase[(size_t)c]), d_masks + ubase[(size_t)c] * S);
     }
     SP_LAUNCH(ctx, "kv_count", kv_count, dim3((unsigned)gw), dim3(256), 0, (const int32_t *)d_ch, (const int64_t *)d_st,

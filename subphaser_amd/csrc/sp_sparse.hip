@@ -305,49 +305,14 @@ sps_pair_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, con
     if (threadIdx.x == 0 && t) atomicAdd(out, t);
 }
 
-// Walk one unit of 64 starts: ONE filter probe and, for candidates, ONE table look-up per PAIR of starts;
-// hit(start, sg) says whether the position counts; a counted k-mer is marked seen (first touch only).
-template <typename F>
-__device__ __forceinline__ void map_pair_scan_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm,
-                                                int64_t s0, const sp_kparams &kp, const uint32_t *__restrict__ bloom,
-                                                int nbits, unsigned long long *__restrict__ htab, uint64_t mask, F &&hit) {
-    const uint64_t m1mask = kp.kmask >> 2;
-    const int top = 2 * (kp.k - 1);
-    uint32_t e = 0, mark = 0;
-    uint64_t slot = 0;
-    bool fw = true;
-    sp_scan_unit_all<SP_UNIT, uint64_t>(pk, nm, s0, kp, [&](int64_t start, uint64_t fwd, uint64_t rc, bool valid_k, bool valid_k1) {
-        if (!(start & 1)) {   // first of the pair: b0 + x
-            e = 0;
-            mark = 0;
-            if (valid_k1) {
-                const uint64_t xf = fwd & m1mask, xr = rc >> 2;
-                const uint64_t canon = xf < xr ? xf : xr;
-                fw = xf <= xr;
-                if (map_bloom_test(bloom, nbits, canon)) e = sps_pair_get(canon, htab, mask, slot);
-            }
-            if (e & 0x77777777u) {
-                const uint32_t b0 = (uint32_t)(fwd >> top) & 3u;
-                const int f0 = fw ? (int)b0 : 7 - (int)b0;
-                const uint32_t v0 = valid_k ? (e >> (4 * f0)) & 15u : 0u;
-                if ((v0 & 7u) && hit(start, (int)(v0 & 7u) - 1) && !(v0 & 8u)) mark |= 8u << (4 * f0);
-            }
-        } else if (e & 0x77777777u) {   // second of the pair: x + b1
-            const uint32_t b1 = (uint32_t)fwd & 3u;
-            const int f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
-            const uint32_t v1 = valid_k ? (e >> (4 * f1)) & 15u : 0u;
-            if ((v1 & 7u) && hit(start, (int)(v1 & 7u) - 1) && !(v1 & 8u)) mark |= 8u << (4 * f1);
-            if (mark) atomicOr(&htab[2 * slot + 1], (unsigned long long)mark);
-            mark = 0;
-        }
-    });
-}
-
+// K5 for k > 15, per-k-mer table (more than 7 subgenomes, or SP_MAP_ENGINE=1): the rolling scan, one filter probe per pair
+// of starts, one 16-byte look-up per candidate start.  (The pair-keyed table takes k5_map_sparse2 below; the unrolled
+// pair kernel of rounds 1-4 -- 532 KB of machine code -- was removed in round 6.)
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, sp_map_params P,
-              unsigned long long *__restrict__ htab, uint64_t mask,
-              const uint32_t *__restrict__ bloom, int bloom_bits, int *__restrict__ slot_counts,
-              unsigned long long *__restrict__ n_mapped, int pairs /* htab is the pair-keyed table */) {
+k5_map_sparse_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, sp_map_params P,
+                  unsigned long long *__restrict__ htab, uint64_t mask,
+                  const uint32_t *__restrict__ bloom, int bloom_bits, int *__restrict__ slot_counts,
+                  unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
     unsigned long long mapped = 0;
@@ -360,51 +325,16 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
             __syncthreads();
         }
         if (u < P.n_units) {
-            auto count = [&](int64_t start, int sg) {
+            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+                if (sg < 0) return;
                 const int64_t os = map_slot(start, P, kp.k);
                 if (P.use_lds)
                     atomicAdd(&hist[(os - slot_lo) * P.S + sg], 1);
                 else if (os < P.nslots)
                     atomicAdd(&slot_counts[os * P.S + sg], 1);
                 mapped++;
-                return true;
-            };
-            if (pairs && P.S <= 8) {
-                // like k5_map (sp_map.hip): a lane's 64 starts lie in one or two output slots, so its hits are tallied
-                // in a register, one byte per subgenome, and reach the histogram once per slot -- not one LDS atomic
-                // and one 64-bit slot computation per hit (PMC round 3: 82 % of this kernel's LDS cycles were conflicts)
-                int64_t cur_end = -1, cur_os = 0;
-                unsigned long long acc = 0;
-                auto flush = [&]() {
-                    if (!acc) return;
-                    for (int sg = 0; sg < P.S; sg++) {
-                        const int v = (int)((acc >> (8 * sg)) & 255ULL);
-                        if (!v) continue;
-                        if (P.use_lds)
-                            atomicAdd(&hist[(int)(cur_os - slot_lo) * P.S + sg], v);
-                        else if (cur_os < P.nslots)
-                            atomicAdd(&slot_counts[cur_os * P.S + sg], v);
-                        mapped += v;
-                    }
-                    acc = 0;
-                };
-                map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
-                    if (start >= cur_end) {
-                        flush();
-                        cur_os = map_slot(start, P, kp.k);
-                        cur_end = map_slot_end(start, P, kp.k);
-                    }
-                    acc += 1ULL << (8 * sg);
-                    return true;
-                });
-                flush();
-            } else if (pairs)
-                map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, count);
-            else
-                map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                    const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
-                    if (sg >= 0) count(start, sg);
-                });
+            });
         }
         if (P.use_lds) {
             __syncthreads();
@@ -423,12 +353,12 @@ k5_map_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, 
 }
 
 // ------------------------------------------------------------------ k5_map_sparse2 (round 5)
-// k5_map_sparse is 532 KB of machine code -- the rolling scan unrolled over 95 bases with the hit path inlined at every
-// start -- against 64 KB of instruction cache, and it keeps ONE probe in flight per lane.  This is the k5_map2 walk
+// The pair kernel of rounds 1-4 was 532 KB of machine code -- the rolling scan unrolled over 95 bases with the hit path inlined
+// at every start -- against 64 KB of instruction cache, and it kept ONE probe in flight per lane.  This is the k5_map2 walk
 // (sp_map.hip) for 64-bit keys: the loop over the pairs of a unit stays rolled (32-base windows by run-time shifts out
 // of three rotating registers per stream), two pairs travel together (their filter probes, then their table look-ups),
 // a hit is a bit in three label planes and a unit's hits are settled once, by popcounts.  Pair-keyed table only
-// (S <= 7); the per-k-mer table keeps the old kernel.
+// (S <= 7); the per-k-mer table takes k5_map_sparse_lab above.
 __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                   const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
                                                   const uint32_t *__restrict__ bloom, int nbits,
@@ -578,30 +508,70 @@ k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
     if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
 }
 
+// feature mode (sp_map.hip: k5_map_feat2), pair-keyed table: the rolled walk over the starts whose k-mer crosses no feature
+// boundary, then popcounts of the label planes per overlapping feature
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_feat_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
-                   const int64_t *__restrict__ foff, int64_t n_feat, int S,
-                   unsigned long long *__restrict__ htab, uint64_t mask,
-                   const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts, int pairs) {
+k5_map_feat_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
+                    int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
+                    unsigned long long *__restrict__ htab, uint64_t hmask,
+                    const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int k = kp.k;
+    auto span = [](int64_t a, int64_t b) -> unsigned long long {      // bits [a, b) of a unit, 0 <= a, b <= 64
+        if (b <= a) return 0ULL;
+        return (b >= 64 ? ~0ULL : ((1ULL << b) - 1ULL)) & ~((1ULL << a) - 1ULL);
+    };
+    for (; u < n_units; u += stride) {
+        const int64_t s0 = u * SP_UNIT;
+        int64_t lo = 0, hi = n_feat;           // the feature the unit starts in: last f with foff[f] <= s0
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (foff[mid] <= s0) lo = mid;
+            else hi = mid;
+        }
+        unsigned long long fit = ~0ULL;        // a boundary at e = foff[f + 1] disqualifies the starts (e - k, e)
+        for (int64_t f = lo; f < n_feat; f++) {
+            const int64_t e = foff[f + 1];
+            if (e - k + 1 >= s0 + SP_UNIT) break;
+            fit &= ~span((e - k + 1 > s0 ? e - k + 1 : s0) - s0, (e < s0 + SP_UNIT ? e : s0 + SP_UNIT) - s0);
+            if (e >= s0 + SP_UNIT) break;
+        }
+        unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
+        map_unit_scan64_h(pk, pm, nm, s0, kp, bloom, bloom_bits, htab, hmask, lab, fit);
+        if (!(lab[0] | lab[1] | lab[2])) continue;
+        for (int64_t f = lo; f < n_feat; f++) {
+            const int64_t a = foff[f], e = foff[f + 1];
+            if (a >= s0 + SP_UNIT) break;
+            const unsigned long long within = span((a > s0 ? a : s0) - s0, (e < s0 + SP_UNIT ? e : s0 + SP_UNIT) - s0) & fit;
+            if (!((lab[0] | lab[1] | lab[2]) & within)) continue;
+            for (int sg = 0; sg < S; sg++) {
+                const int l = sg + 1;
+                const unsigned long long m = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) &
+                                             ((l & 4) ? lab[2] : ~lab[2]) & within;
+                if (m) atomicAdd(&counts[f * S + sg], (unsigned long long)__popcll(m));
+            }
+        }
+    }
+}
+// the same for the per-k-mer table (more than 7 subgenomes): the rolling scan, one look-up per candidate start
+__global__ void __launch_bounds__(MAP_BLOCK)
+k5_map_feat_sparse_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units,
+                       const int64_t *__restrict__ foff, int64_t n_feat, int S,
+                       unsigned long long *__restrict__ htab, uint64_t mask,
+                       const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         map_feat_cursor cur;
         cur.f = -1;
         cur.next = 0;
-        if (pairs)
-            map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
-                if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return false;   // runs into the next feature
-                atomicAdd(&counts[cur.f * S + sg], 1ULL);
-                return true;
-            });
-        else
-            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return;   // runs into the next feature
-                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
-                if (sg < 0) return;
-                atomicAdd(&counts[cur.f * S + sg], 1ULL);
-            });
+        map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            if (!map_feat_locate(cur, start, kp.k, foff, n_feat)) return;   // runs into the next feature
+            const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+            if (sg < 0) return;
+            atomicAdd(&counts[cur.f * S + sg], 1ULL);
+        });
     }
 }
 
@@ -853,27 +823,7 @@ struct sps_join_args {
     int n_rd;
 };
 
-// ONE WAVE per key range: a range holds ~100 entries, and a 256-thread workgroup per range spent its time in
-// barriers and in single-thread loops over the C lists (77 ms per wheat-like pass at k = 17 -- twice the sort it
-// replaced).  A wave needs no barriers: lane c owns list c's cursor (pivot, share, offsets by shuffles), the entries
-// are spread over the lanes, LDS traffic of one wave is in order.  Keys are held as residuals below the range's
-// common high bits (RT = u32 when 31 bits suffice).
-#define JW_T 256          // entries per round
-#define JW_H 512          // hash slots at most (2 x entries of the round, rounded up to a power of two, are used)
-#define JW_WAVES 4        // waves (= ranges in flight) per workgroup
-#define JW_Q (JW_T / 64)
-#define JW_ROWS 16        // rows a wave decides at a time
-#define JW_FS 64         // set structure held in LDS up to: sets, units, unit members
-#define JW_FU 128
-#define JW_FC 256
-template <typename RT>
-struct jw_lds {
-    RT Kk[JW_T], Hk[JW_H];
-    uint32_t Vv[JW_T], Hhead[JW_H], Hmin[JW_H];
-    uint16_t Nx[JW_T], Sl[JW_T], RL[JW_T], seg_off[SPS_MAXC + 2];
-    uint8_t Ch[JW_T];
-};
-__device__ __forceinline__ void jw_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wave-level helpers of the join (wave 0 of a workgroup runs the cursor logic: lane c owns list c)
 template <typename T>
 __device__ __forceinline__ T jw_sum(T v) {
 #pragma unroll
@@ -889,209 +839,10 @@ __device__ __forceinline__ unsigned long long jw_min(unsigned long long v) {
     return v;
 }
 
-template <typename RT>
-__global__ void __launch_bounds__(64 * JW_WAVES)
-sps_join(sps_join_args A) {
-    __shared__ jw_lds<RT> lds[JW_WAVES];
-    extern __shared__ uint32_t jw_rows[];      // [JW_WAVES][JW_ROWS][C]: rows being decided
-    // the set structure the decision walks: in LDS (a chain of dependent look-ups per unit -- from global memory that
-    // is half a microsecond each and was most of this kernel)
-    __shared__ int32_t s_set_off[JW_FS + 1], s_unit_off[JW_FU + 1], s_unit_chrom[JW_FC];
-    __shared__ double s_unit_den[2 * JW_FU];
-    __shared__ unsigned long long s_csets[SPS_MAXC];
-    const int C = A.C, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    jw_lds<RT> &L = lds[w];
-    sp_fsets F = A.F;
-    {
-        const int n_units = A.F.set_off[A.F.n_sets], n_uc = A.F.unit_off[n_units];
-        if (A.F.n_sets <= JW_FS && n_units <= JW_FU && n_uc <= JW_FC) {
-            for (int i = threadIdx.x; i <= A.F.n_sets; i += blockDim.x) s_set_off[i] = A.F.set_off[i];
-            for (int i = threadIdx.x; i <= n_units; i += blockDim.x) s_unit_off[i] = A.F.unit_off[i];
-            for (int i = threadIdx.x; i < n_uc; i += blockDim.x) s_unit_chrom[i] = A.F.unit_chrom[i];
-            for (int i = threadIdx.x; i < n_units; i += blockDim.x) {
-                s_unit_den[i] = A.F.unit_den[i];
-                s_unit_den[n_units + i] = A.F.unit_inv[i];
-            }
-            F.set_off = s_set_off;
-            F.unit_off = s_unit_off;
-            F.unit_chrom = s_unit_chrom;
-            F.unit_den = s_unit_den;
-            F.unit_inv = s_unit_den + n_units;
-        }
-        for (int i = threadIdx.x; i < C; i += blockDim.x) s_csets[i] = A.chrom_sets[i];
-        __syncthreads();
-    }
-    const RT EMPTY = (RT)~(RT)0;
-    const unsigned long long rmask = A.shift >= 64 ? ~0ULL : ((1ULL << A.shift) - 1ULL);
-    const unsigned long long *my_keys = nullptr;
-    const uint32_t *my_cnts = nullptr;
-    if (lane < C) {
-        my_keys = A.lists[lane].keys;
-        my_cnts = A.lists[lane].cnts;
-    }
-    unsigned long long uni = 0, chunk_pos = 0, chunk_end = 0;     // (the chunk state is wave-uniform)
-    const uint32_t per = JW_T / (uint32_t)C;
-    for (long long r = (long long)blockIdx.x * JW_WAVES + w; r < A.R; r += (long long)gridDim.x * JW_WAVES) {
-        uint32_t cur = 0, endp = 0;
-        if (lane < C) {
-            cur = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r];
-            endp = A.bnd[(size_t)lane * (size_t)(A.R + 1) + (size_t)r + 1];
-        }
-        const unsigned long long hist_pos = jw_sum((unsigned long long)cur);   // the range's place in the virtual concatenation
-        const unsigned long long hi_bits = A.shift >= 64 ? 0ULL : ((unsigned long long)r << A.shift);
-        uint32_t rows_before = 0, hist_before = 0;
-        for (;;) {
-            // ---- the round's share of every list: everything, or everything below the pivot key
-            const uint32_t left = endp - cur;
-            unsigned long long pivot = SPS_SENTINEL;
-            if (jw_sum(left) > JW_T) pivot = jw_min((lane < C && left > per) ? my_keys[cur + per] : SPS_SENTINEL);
-            uint32_t take = left;
-            if (pivot != SPS_SENTINEL && lane < C) {     // entries below the pivot: at most `per` (the per-th is >= pivot)
-                const unsigned long long *kk = my_keys + cur;
-                uint32_t lo = 0, hi = left < per ? left : per;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (kk[mid] < pivot) lo = mid + 1;
-                    else hi = mid;
-                }
-                take = lo;
-            }
-            uint32_t incl = take;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t x = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += x;
-            }
-            const uint32_t T = __shfl(incl, 63, 64);                 // <= JW_T by construction
-            const bool more = __any(cur + take < endp);
-            if (lane <= C) L.seg_off[lane] = (uint16_t)(lane < C ? incl - take : T);
-            uint32_t Hn = 64;
-            while (Hn < 2 * T) Hn <<= 1;
-            for (uint32_t i = lane; i < Hn; i += 64) {
-                L.Hk[i] = EMPTY;
-                L.Hhead[i] = 0xFFFFu;
-                L.Hmin[i] = 0xFFFFFFFFu;
-            }
-            jw_fence();
-            // ---- load + hash-insert (chain per key; owner = the entry of the lowest chromosome)
-#pragma unroll
-            for (int q = 0; q < JW_Q; q++) {
-                const uint32_t e = lane + 64 * q;
-                int lo = 0, hi = C;       // list of entry e: last c with seg_off[c] <= e
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (L.seg_off[mid] <= e) lo = mid;
-                    else hi = mid;
-                }
-                const int c = e < T ? lo : 0;
-                const unsigned long long *kp_ = (const unsigned long long *)__shfl((unsigned long long)my_keys, c, 64);
-                const uint32_t *cp_ = (const uint32_t *)__shfl((unsigned long long)my_cnts, c, 64);
-                const uint32_t cur_c = __shfl(cur, c, 64);
-                if (e < T) {
-                    const size_t i = (size_t)cur_c + (e - L.seg_off[c]);
-                    const RT res = (RT)(kp_[i] & rmask);
-                    L.Kk[e] = res;
-                    L.Vv[e] = cp_[i];
-                    L.Ch[e] = (uint8_t)c;
-                    uint32_t h = (uint32_t)sps_mix((uint64_t)res) & (Hn - 1);
-                    for (;;) {
-                        const RT prev = atomicCAS(&L.Hk[h], EMPTY, res);
-                        if (prev == EMPTY || prev == res) break;
-                        h = (h + 1) & (Hn - 1);
-                    }
-                    L.Sl[e] = (uint16_t)h;
-                    L.Nx[e] = (uint16_t)atomicExch(&L.Hhead[h], e);
-                    atomicMin(&L.Hmin[h], ((uint32_t)c << 16) | e);
-                }
-            }
-            jw_fence();
-            // ---- owners rebuild their row and decide
-            bool is_row[JW_Q], is_hist[JW_Q];
-            unsigned long long tots[JW_Q];
-            uint32_t nrow = 0;
-#pragma unroll
-            for (int q = 0; q < JW_Q; q++) {
-                const uint32_t e = lane + 64 * q;
-                is_row[q] = is_hist[q] = false;
-                tots[q] = 0;
-                bool pending = false;      // an owner that passed the screen and still needs the full decision
-                if (e < T && (L.Hmin[L.Sl[e]] & 0xFFFFu) == e) {
-                    uni++;
-                    // screen: a set without any count fails the fold test, so a k-mer present in too few non-singleton
-                    // sets to reach `ratio` is rejected exactly as the full decision would (monotone quotient) -- most
-                    // of the union never builds a row
-                    unsigned long long sets = 0, tot = 0;
-                    for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) {
-                        sets |= s_csets[L.Ch[x]];
-                        tot += L.Vv[x];
-                    }
-                    tots[q] = tot;
-                    pending = !A.screen || !((double)__popcll(sets) / (double)F.n_multi < F.ratio);
-                }
-                // the survivors -- a handful per wave -- rebuild their rows in LDS, JW_ROWS of them at a time (a row in
-                // private memory is scratch = global memory: the decision reads it dozens of times)
-                for (unsigned long long pb = __ballot(pending); pb; pb = __ballot(pending)) {
-                    const int slot = __popcll(pb & ((1ULL << lane) - 1ULL));
-                    if (pending && slot < JW_ROWS) {
-                        uint32_t *row = jw_rows + ((size_t)w * JW_ROWS + slot) * (size_t)C;
-                        for (int c = 0; c < C; c++) row[c] = 0;
-                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) row[L.Ch[x]] = L.Vv[x];
-                        sp_filter_decide([&](int c) -> uint32_t { return row[c]; }, tots[q], F, is_row[q], is_hist[q]);
-                        pending = false;
-                    }
-                }
-                // fold-passing totals: range start + tally so far + position inside the round (any order)
-                const unsigned long long bh = __ballot(is_hist[q]);
-                if (is_hist[q]) A.hist_stage[hist_pos + hist_before + __popcll(bh & ((1ULL << lane) - 1ULL))] = tots[q];
-                hist_before += (uint32_t)__popcll(bh);
-                const unsigned long long br = __ballot(is_row[q]);
-                if (is_row[q]) L.RL[nrow + __popcll(br & ((1ULL << lane) - 1ULL))] = (uint16_t)e;
-                nrow += (uint32_t)__popcll(br);
-            }
-            if (nrow) {       // rare: rows to the staging area, ranked by key inside the round
-                jw_fence();
-                if (chunk_pos + nrow > chunk_end) {      // wave-uniform
-                    const unsigned long long grab = nrow > JOIN_CHUNK ? nrow : JOIN_CHUNK;
-                    unsigned long long got = 0;
-                    if (lane == 0) got = atomicAdd(A.row_cursor, grab);
-                    chunk_pos = __shfl(got, 0, 64);
-                    chunk_end = chunk_pos + grab;
-                }
-#pragma unroll
-                for (int q = 0; q < JW_Q; q++) {
-                    if (!is_row[q]) continue;
-                    const uint32_t e = lane + 64 * q;
-                    const RT res = L.Kk[e];
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < nrow; j++) rank += L.Kk[L.RL[j]] < res;
-                    const unsigned long long pos = chunk_pos + rank;
-                    if (pos < A.row_cap) {
-                        A.row_keys[pos] = hi_bits | (unsigned long long)res;
-                        A.row_tot[pos] = tots[q];
-                        A.row_rank[pos] = rows_before + rank;
-                        uint32_t *out = A.row_counts + pos * (size_t)C;
-                        for (int c = 0; c < C; c++) out[c] = 0;
-                        for (uint32_t x = L.Hhead[L.Sl[e]]; x != 0xFFFFu; x = L.Nx[x]) out[L.Ch[x]] = L.Vv[x];
-                    }
-                }
-                chunk_pos += nrow;
-                rows_before += nrow;
-            }
-            jw_fence();
-            if (!more) break;
-            cur += take;
-        }
-        if (lane == 0) {
-            A.n_rows[r] = rows_before;
-            A.n_hist[r] = hist_before;
-        }
-    }
-    uni = jw_sum(uni);
-    if (lane == 0 && uni) atomicAdd(A.n_union, uni);
-}
-
-// ------------------------------------------------------------------ sps_join_blk (round 5): the same join, one WORKGROUP per range
-// The wave-per-range join reads ~90 bytes per list entry for 12 useful ones (PMC, round 4): a range of ~100 entries is
+// ------------------------------------------------------------------ sps_join_blk (round 5): the join, one WORKGROUP per range
+// (Rounds 3-4 ran one WAVE per ~100-entry range; that kernel was the `SP_LIST_FILTER=wave` cross-check until round 6 and is gone:
+// the independent check of the list filter is `SP_LIST_FILTER=sort`, the device-wide sort + run evaluation.)
+// The wave-per-range join read ~90 bytes per list entry for 12 useful ones (PMC, round 4): a range of ~100 entries is
 // 21 list segments of ~5 entries -- one or two 64-byte lines of keys and one of counts per segment, used to a tenth --
 // plus two strided range-edge words per list and range.  With ranges of ~BJ_T / 1.5 entries (a segment is ~35 entries:
 // four lines of keys, used in full) the fixed costs -- edges, cursors, hash clear, the tallies -- are paid once per ~700
@@ -1661,11 +1412,8 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
         while ((1LL << bits) < ctx->nslots) bits++;
     }
     if (bits > 64) bits = 64;
-    // SP_LIST_FILTER=wave: the one-wave-per-range kernel of round 3 on ~100-entry ranges (cross-check); default: one
-    // workgroup per range of ~2/3 of a round
-    const char *env_lf = getenv("SP_LIST_FILTER");
-    const bool wave_join = env_lf && !strcmp(env_lf, "wave");
-    const int64_t per_range = wave_join ? 96 : (int64_t)BJ_T * 2 / 3;
+    // one workgroup per range of ~2/3 of a round
+    const int64_t per_range = (int64_t)BJ_T * 2 / 3;
     int rb = 0;
     while (rb < bits && rb < 23 && ((int64_t)1 << rb) * per_range < total) rb++;
     if (bits - rb > 63) rb = bits - 63;      // k = 32 and a handful of k-mers: `key >> 64` is not a shift (fuzz case k32_join)
@@ -1679,8 +1427,8 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
                  o_set = o_hoff + al((size_t)(R + 1) * 8), o_uo = o_set + al((size_t)(n_sets + 1) * 4),
                  o_uc = o_uo + al((size_t)(n_units + 1) * 4), o_den = o_uc + al((size_t)(n_uc + 1) * 4),
                  o_small = o_den + al((size_t)n_units * 16), o_cs = o_small + 256, o_bs = o_cs + al((size_t)C * 8),
-                 o_rd = o_bs + 2 * al((size_t)(R / TALLY_CHUNK + 2) * 8), o_rinv = o_rd + al((size_t)JW_FC * 4),
-                 a_bytes = o_rinv + al((size_t)JW_FC * 4);
+                 o_rd = o_bs + 2 * al((size_t)(R / TALLY_CHUNK + 2) * 8), o_rinv = o_rd + al((size_t)BJ_FC * 4),
+                 a_bytes = o_rinv + al((size_t)BJ_FC * 4);
     int rc = sp_buf_ensure(ctx, ctx->b_sp_a, (int64_t)a_bytes);
     if (rc) return rc;
     rc = sp_buf_ensure(ctx, ctx->b_sp_b, total * 8 + 64);
@@ -1800,15 +1548,7 @@ static int sps_filter_join(sp_ctx *ctx, int n_sets, const int32_t *set_off, cons
         A.row_counts = (uint32_t *)(S0 + 2 * al(row_cap * 8) + al(row_cap * 4));
         SP_HIP(ctx, hipMemsetAsync(A.row_keys, 0xff, row_cap * 8, ctx->stream));
         SP_HIP(ctx, hipMemsetAsync(small, 0, 64, ctx->stream));
-        if (wave_join) {
-            int64_t grid = (R + JW_WAVES - 1) / JW_WAVES;
-            if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-            const size_t row_lds = (size_t)JW_WAVES * JW_ROWS * (size_t)C * 4;     // <= 16 KiB
-            if (shift <= 31)
-                SP_LAUNCH(ctx, "sps_join", sps_join<uint32_t>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
-            else
-                SP_LAUNCH(ctx, "sps_join", sps_join<unsigned long long>, dim3((unsigned)grid), dim3(64 * JW_WAVES), row_lds, A);
-        } else {
+        {
             int64_t grid = R;
             if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
             const size_t row_lds = (size_t)BJ_NR * (size_t)(C | 1) * 4;     // <= 16.3 KiB
@@ -1972,59 +1712,51 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
     int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernel of rounds 1-4 (cross-check)
-    if (ctx->map_engine == 0 && P.S <= 7 && !(env_mk && env_mk[0] == '1')) {
+    if (ctx->map_engine == 0 && P.S <= 7) {
         SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
                   (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
         return SP_OK;
     }
-    SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
-              (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts,
-              d_n, ctx->map_engine == 0 ? 1 : 0);
+    if (ctx->map_engine == 0) return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
+    SP_LAUNCH(ctx, "k5_map_sparse_lab", k5_map_sparse_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_nm, kp, P,
+              (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
     return SP_OK;
 }
 
-int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_nm, int64_t n_units, const int64_t *d_foff,
-                          int64_t n_feat, int S, unsigned long long *d_counts) {
+int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_pm, const uint32_t *d_nm, int64_t n_units,
+                          const int64_t *d_foff, int64_t n_feat, int S, unsigned long long *d_counts) {
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-    SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
-              n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys,
-              (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, ctx->map_engine == 0 ? 1 : 0);
+    if (ctx->map_engine == 0 && S <= 7)
+        SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_pm, d_nm,
+                  kp, n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom,
+                  ctx->bloom_bits, d_counts);
+    else if (ctx->map_engine == 0)
+        return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
+    else
+        SP_LAUNCH(ctx, "k5_map_feat_sparse_lab", k5_map_feat_sparse_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
+                  n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom,
+                  ctx->bloom_bits, d_counts);
     return SP_OK;
 }
 
 // interval mode (sp_map.hip: kv_cover / kv_count): the k > 15 scan that fills the per-unit subgenome masks
 __global__ void __launch_bounds__(MAP_BLOCK)
-k5_map_mask_sparse(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units, int S,
-                   unsigned long long *__restrict__ htab, uint64_t mask, const uint32_t *__restrict__ bloom, int bloom_bits,
-                   const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks, int pairs) {
+k5_map_mask_sparse_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ nm, sp_kparams kp, int64_t n_units, int S,
+                       unsigned long long *__restrict__ htab, uint64_t mask, const uint32_t *__restrict__ bloom, int bloom_bits,
+                       const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;
-        if (pairs) {
-            unsigned long long m[MAP_PAIR_MAX_SG] = {0, 0, 0, 0, 0, 0, 0};
-            map_pair_scan_h(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, mask, [&](int64_t start, int sg) {
-                const unsigned long long bit = 1ULL << (start & 63);
-                if (!(cv & bit)) return false;
-#pragma unroll
-                for (int j = 0; j < MAP_PAIR_MAX_SG; j++) m[j] |= (j == sg) ? bit : 0ULL;
-                return true;
-            });
-#pragma unroll
-            for (int j = 0; j < MAP_PAIR_MAX_SG; j++)
-                if (j < S) masks[u * S + j] = m[j];
-        } else {
-            map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
-                const unsigned long long bit = 1ULL << (start & 63);
-                if (!(cv & bit)) return;
-                const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
-                if (sg >= 0) atomicOr(&masks[u * S + sg], bit);
-            });
-        }
+        map_pair_scan<uint64_t>(pk, nm, u * SP_UNIT, kp, bloom, bloom_bits, [&](int64_t start, uint64_t fwd, uint64_t rc) {
+            const unsigned long long bit = 1ULL << (start & 63);
+            if (!(cv & bit)) return;
+            const int sg = sps_lookup(fwd < rc ? fwd : rc, htab, mask);
+            if (sg >= 0) atomicOr(&masks[u * S + sg], bit);
+        });
     }
 }
 
@@ -2051,16 +1783,16 @@ int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, cons
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-    const char *env_mk = getenv("SP_MAP_KERNEL");        // "1": the unrolled kernel (cross-check)
-    if (ctx->map_engine == 0 && S <= 7 && !(env_mk && env_mk[0] == '1')) {
+    if (ctx->map_engine == 0 && S <= 7) {
         SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
                   (const uint32_t *)c.d_pm, (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys,
                   (uint64_t)(ctx->hcap - 1), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
         return SP_OK;
     }
-    SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
+    if (ctx->map_engine == 0) return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
+    SP_LAUNCH(ctx, "k5_map_mask_sparse_lab", k5_map_mask_sparse_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
               (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1),
-              (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks, ctx->map_engine == 0 ? 1 : 0);
+              (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
     return SP_OK;
 }
 

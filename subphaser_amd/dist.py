@@ -297,11 +297,15 @@ class DistHotPath:
             ctx.filter_view(ptrs, base, self.nview, lengths, self.k, self.lower_count, optrs, ons)
             n_union, n_rows, n_hist = ctx.filter(*self.csr, self.min_fold, self.baseline, self.min_freq,
                                                  self.max_freq, self.ratio)
-        if self.shared_rows and not host_rows_on_all_ranks and self.nview and hasattr(ctx, "filter_fetch_async_ptr"):
+        if self.shared_rows and not host_rows_on_all_ranks and hasattr(ctx, "filter_fetch_async_ptr"):
             # round 5: every rank's rows travel straight from the filter's buffers to ITS row range of the shared
-            # page-locked segment on the copy stream, behind the map stage; `result.wait()` = copy done + barrier
-            r = self._rows_shared_async(n_rows, n_union, n_hist, lengths)
-            ctx.filter_view(None, 0, 0, None, 0, 0)
+            # page-locked segment on the copy stream, behind the map stage; `result.wait()` = copy done + barrier.
+            # (round 6, advisor: the choice depends on nothing rank-specific -- a rank with an empty slot range takes the
+            # same path with zero rows, so every rank meets the same collectives in the same order -- and the merged
+            # overflow lists k3_emit still reads on the context's own stream stay referenced until wait() has run)
+            r = self._rows_shared_async(n_rows if self.nview else 0, n_union, n_hist, lengths, keep=self._merged)
+            if self.nview:
+                ctx.filter_view(None, 0, 0, None, 0, 0)
             self._merged = []
             self._t("filter+fetch", tt)
             return r
@@ -316,7 +320,7 @@ class DistHotPath:
         tt = self._t("filter+fetch", tt)
         return self._gather_rows(keys_t, counts_t, n_rows, n_union, n_hist, lengths, host_rows_on_all_ranks, tt)
 
-    def _rows_shared_async(self, n_rows, n_union, n_hist, lengths):
+    def _rows_shared_async(self, n_rows, n_union, n_hist, lengths, keep=None):
         t, dist = self.torch, self.dist
         r = HotPathResult()
         r.kmer_lengths = lengths
@@ -335,14 +339,18 @@ class DistHotPath:
         koff = (kbytes + 4095) & ~4095
         self._shm_ensure(koff + cbytes)
         base = self._shm_addr
-        self.ctx.filter_fetch_async_ptr(base + 8 * first, base + koff + 4 * self.C * first, n_rows)
+        if n_rows:
+            self.ctx.filter_fetch_async_ptr(base + 8 * first, base + koff + 4 * self.C * first, n_rows)
         buf = self._shm.buf
         r.keys = np.frombuffer(buf, np.uint64, M, 0)
         r.counts = np.frombuffer(buf, np.uint32, M * self.C, koff).reshape(M, self.C)
         ctx, world = self.ctx, self.world
 
+        held = [keep]
+
         def wait():
             ctx.filter_fetch_wait()
+            held[0] = None          # (the emit kernel is done: its overflow lists may go back to the allocator)
             if world > 1:
                 dist.barrier()      # every rank's rows are in place
 

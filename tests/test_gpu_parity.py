@@ -353,18 +353,17 @@ def test_list_filter_handful_of_kmers(gpu_ctx, oracle_ctx):
             assert a.shape == b.shape and (a == b).all(), (k, lower)
 
 
-@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer", "pairs-unrolled+wave-join"])
+@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer", "pairs+sort-filter"])
 @pytest.mark.parametrize("k", [17, 21, 32])
 def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkeypatch):
     """k = 17 / 21 (BASELINE config 5) and 32: matrix rows and bin counts bit-exact vs the oracle, with the
-    pair-keyed label table (one look-up per pair of starts, <= 7 subgenomes) and with the per-k-mer table; the third
-    variant keeps the round-3/4 kernels behind their switches covered (the unrolled map walk, the wave-per-range join) --
-    the defaults since round 5 are the rolled walk (k5_map_sparse2) and the workgroup-per-range join (sps_join_blk)."""
+    pair-keyed label table (one look-up per pair of starts, <= 7 subgenomes; the rolled walk k5_map_sparse2) and with the
+    per-k-mer table (k5_map_sparse_lab); the third variant runs the list filter's independent cross-check
+    (SP_LIST_FILTER=sort: device-wide sort + run evaluation instead of the workgroup-per-range join sps_join_blk)."""
     if map_engine == "per-kmer":
         monkeypatch.setenv("SP_MAP_ENGINE", "1")
-    if map_engine == "pairs-unrolled+wave-join":
-        monkeypatch.setenv("SP_MAP_KERNEL", "1")
-        monkeypatch.setenv("SP_LIST_FILTER", "wave")
+    if map_engine == "pairs+sort-filter":
+        monkeypatch.setenv("SP_LIST_FILTER", "sort")
     rng = np.random.RandomState(400 + k)
     reps = [_rand_seq(rng, 350, 0, 0) for _ in range(6)]
     seqs = []
@@ -421,17 +420,17 @@ def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkey
     assert int(gpu_ctx.lengths()[0]) == int(po.count(seqs[0], 15, 3)[1].astype(np.int64).sum())
 
 
-@pytest.mark.parametrize("variant", ["walk", "generic", "baseline2", "wave"])
+@pytest.mark.parametrize("variant", ["walk", "generic", "baseline2", "sort"])
 def test_list_join_decision_paths(gpu_ctx, oracle_ctx, variant, monkeypatch):
     """The workgroup-per-range join (sps_join_blk) decides a k-mer with a uniform fp32 walk over row descriptors
     (baselines 1 / -1), with the generic fp64 code (SP_JOIN_GENERIC=1, or a baseline the walk does not cover), and the
-    wave-per-range kernel stays as a cross-check: all bit-exact vs the oracle, on a set structure with units of several
+    sort-based list filter stays as the independent cross-check: all bit-exact vs the oracle, on a set structure with units of several
     chromosomes, a singleton set, thresholds that keep hundreds of rows per round (several row chunks per round) and a
     ratio below one (k-mers missing from a set are decided, not screened out)."""
     if variant == "generic":
         monkeypatch.setenv("SP_JOIN_GENERIC", "1")
-    if variant == "wave":
-        monkeypatch.setenv("SP_LIST_FILTER", "wave")
+    if variant == "sort":
+        monkeypatch.setenv("SP_LIST_FILTER", "sort")
     rng = np.random.RandomState(977)
     C = 11
     reps = [_rand_seq(rng, 4000, 0, 0) for _ in range(8)]
@@ -506,16 +505,43 @@ def test_list_join_many_chromosomes(gpu_ctx, oracle_ctx, layout):
     assert g[1] > 100
 
 
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(__file__), "..", "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 @pytest.mark.parametrize("k", [15, 19])
 def test_count_with_streams_equals_single_stream(k):
-    """Tripwire for timing-dependent miscounts (tools/stress_lanes.py): 300 counts of a 21-chromosome synthetic genome with
+    """Tripwire for timing-dependent miscounts (tools/stress_lanes.py): 100 counts of a 21-chromosome synthetic genome with
     the default streams, each compared chromosome by chromosome with a single-stream count.  (Round 5: a missing barrier
-    in s3_part1 miscounted one k > 15 pass in a few hundred when three chains were in flight; no parity test saw it.)"""
+    in s3_part1 miscounted one k > 15 pass in a few hundred when three chains were in flight; no parity test saw it.
+    Round 6: 100 counts instead of 300 -- the oracle-compared loops below carry the weight now.)"""
     import subprocess, sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_lanes.py")
-    out = subprocess.run([sys.executable, tool, "wheat", str(k), "300", "0.01"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, tool, "wheat", str(k), "100", "0.01"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "300 iterations, 0 bad" in out.stdout, out.stdout[-2000:]
+    assert "100 iterations, 0 bad" in out.stdout, out.stdout[-2000:]
+
+
+def test_stress_medium_with_streams(gpu_ctx):
+    """tools/stress_medium.py in the suite (round 6): the medium-scale scenario (three 6-Mb chromosomes with planted repeat
+    families) at k = 15 / 17 / 19 / 22, every pass with 3, 5 or 7 chains forced in flight and a second context busy on the
+    same GPU, FULL dumps, matrix rows, histogram totals and bin counts against the oracle."""
+    sm = _tool("stress_medium")
+    assert sm.run(12, [15, 17, 19, 22], gpu_ctx, lanes=[3, 5, 7], busy=True, verbose=False) == 0
+
+
+@pytest.mark.parametrize("k", [15, 17, 19, 22])
+def test_stress_pass_with_streams(gpu_ctx, k):
+    """tools/stress_pass.py in the suite (round 6): count -> filter -> labels -> map of the wheat-like genome at 1 / 100
+    scale (21 chromosomes), six passes with 3 / 5 / 7 chains in flight and a busy neighbour, every chromosome's full dump, the
+    matrix rows, totals, histogram and bins hashed and compared with a single-stream pass."""
+    sp = _tool("stress_pass")
+    bad, rows = sp.run("wheat", k, 6, 0.01, gpu_ctx, lanes=[3, 5, 7], busy=True, verbose=False)
+    assert bad == 0 and rows > 100
 
 
 def test_count_edges(gpu_ctx):
@@ -956,18 +982,20 @@ def test_labels_set_device(gpu_ctx, k):
     lab.release_device()
 
 
-@pytest.mark.parametrize("k", [2, 5, 9, 13, 14, 15])
-@pytest.mark.parametrize("mode", ["compact", "compact-crowded", "direct", "compact-unrolled", "direct-unrolled"])
-def test_map_compact_pair_table(gpu_ctx, monkeypatch, k, mode):
-    """The compact exact pair table (S <= 3: buckets of two tagged entries + overflow table, sp_map.h) against the
-    oracle and against the direct table: forced on at every k (tag bits 0..7), with a load that sends many keys to the
-    overflow table, with palindromic (k-1)-mers, N runs, both strands; bins, n_mapped, labels_hit, features and BED
-    intervals go through the same look-up."""
-    monkeypatch.setenv("SP_CTAB", "0" if mode.startswith("direct") else "1")
-    if mode.endswith("unrolled"):       # the kernels of rounds 2-4 (258 KB of code), kept as a cross-check of k5_map2
-        monkeypatch.setenv("SP_MAP_KERNEL", "1")
+@pytest.mark.parametrize("k,mode", [(k, "direct") for k in (2, 5, 9, 13, 14, 15)] +
+                         [(k, m) for k in (13, 14, 15) for m in ("compact", "compact-crowded")])
+def test_map_compact_pair_table(gpu_ctx, monkeypatch, capfd, k, mode):
+    """The compact exact pair table (S <= 3: QUAD buckets of four tagged entries addressed by the (k-3)-mer two pairs share +
+    overflow table, sp_map.h) against the oracle and against the direct table, with a load that sends many keys to the
+    overflow table, with palindromic (k-1)-mers, N runs, both strands; bins, n_mapped, labels_hit go through the same look-up.
+    The compact layout needs k >= 5 and 2^bb buckets with 2 (k - 3) - 2 <= bb <= 2 (k - 3): with this test's ~10^5 labels
+    that is k = 13 .. 15 (smaller k silently take the direct table -- advisor r05), and the test ASSERTS which table the
+    library chose from its SP_DEBUG_FILTER line."""
+    monkeypatch.setenv("SP_CTAB", "0" if mode == "direct" else "1")
+    monkeypatch.setenv("SP_DEBUG_FILTER", "1")
     if mode == "compact-crowded":
-        monkeypatch.setenv("SP_CTAB_FACTOR", "1")      # ~2 keys per bucket of two: a fifth of the keys overflow
+        monkeypatch.setenv("SP_CTAB_FACTOR", "1")      # ~4 keys per bucket of four: many keys overflow
+    capfd.readouterr()
     rng = np.random.RandomState(4100 + k)
     pal = np.frombuffer(b"ACGTACGTACGTACGTACGTAATTAATTAATTAATTGGCCGGCCGGCC", dtype=np.uint8)
     s = np.concatenate([_rand_seq(rng, 90_000, 0.01, 0.1), np.tile(pal, 40), _rand_seq(rng, 30_000)])
@@ -982,6 +1010,7 @@ def test_map_compact_pair_table(gpu_ctx, monkeypatch, k, mode):
     for S in (1, 2, 3):
         sg = (np.arange(sel.size) % S).astype(np.uint8)
         gpu_ctx.labels_set(sel, sg, S)
+        assert ("compact pair table" in capfd.readouterr().err) == (mode != "direct"), (k, mode, S)
         hit_all = np.zeros(sel.size, bool)
         for bin_size, chunk in ((1000, 10_000), (7, 0)):
             for ci, seq in enumerate((s, s2)):
@@ -1190,14 +1219,13 @@ def test_wheat_sized_chromosome_properties_sparse(gpu_ctx, k):
         gpu_ctx.dev_free(d)
 
 
-def test_fuzz_against_oracle(gpu_ctx, oracle_ctx, count_engine):
+@pytest.mark.parametrize("mode", ["one-stream", "streams"])
+def test_fuzz_against_oracle(gpu_ctx, oracle_ctx, count_engine, mode):
     """150 random cases of tools/fuzz_parity.py (random genomes, k in 1..32, thresholds, engines, labels,
-    bin / chunk sizes, set structures): counts, matrix rows, bin counts, feature totals, bit-exact."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.run(150, 12345, gpu_ctx, oracle_ctx, verbose=False) == 0
+    bin / chunk sizes, set structures): counts, matrix rows, bin counts, feature totals, bit-exact.  "streams" (round 6):
+    3..7 chains forced in flight at every count, chromosomes of several tiles, a second context busy on the same GPU."""
+    mod = _tool("fuzz_parity")
+    assert mod.run(150, 12345, gpu_ctx, oracle_ctx, verbose=False, streams=(mode == "streams")) == 0
 
 
 @pytest.mark.parametrize("k", [15, 17, 22])

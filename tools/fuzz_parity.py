@@ -2,7 +2,10 @@
 """Randomised differential test of the HIP path against the oracle (dev tool, needs a GPU):
 random genomes (N runs, lower case, homopolymers, tandem repeats, empty / shorter-than-k chromosomes),
 random k in 1..32, thresholds, engines, label sets, bin / chunk sizes and set structures.
-usage: fuzz_parity.py [iterations=200] [seed=0]"""
+Stream mode (round 6): every count runs with 3..7 chains in flight (SP_LANES_DENSE / SP_LANES_SPARSE / SP_LANES forced -- the
+library keeps toy genomes on one stream by default, which is why 250 K iterations never met the round-5 `s3_part1` race), some
+chromosomes are several tiles long, and a second context (tools/gpu_busy.py) competes for the CUs.
+usage: fuzz_parity.py [iterations=200] [seed=0] [streams]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,13 +18,13 @@ from subphaser_amd.config import sets_to_csr
 ALPHA = np.frombuffer(b"ACGTacgtNRY", np.uint8)
 
 
-def rand_chrom(rng):
+def rand_chrom(rng, streams=False):
     kind = rng.randint(0, 10)
     if kind == 0:
         return np.empty(0, np.uint8)
     if kind == 1:
         return ALPHA[rng.randint(0, 4, size=rng.randint(1, 40))]
-    n = int(rng.choice([200, 3000, 20000, 70000]))
+    n = int(rng.choice([200, 3000, 20000, 70000, 70000, 250000] if streams else [200, 3000, 20000, 70000]))
     p = np.array([.23, .23, .23, .23, .015, .015, .015, .015, .006, .002, .002])
     s = ALPHA[rng.choice(len(ALPHA), size=n, p=p / p.sum())].copy()
     for _ in range(rng.randint(0, 6)):                       # repeats, homopolymers, tandem arrays, N blocks
@@ -43,16 +46,53 @@ def _tr(what):
         print("   " + what, file=sys.stderr, flush=True)
 
 
-def run(iters, seed, gpu, ora, verbose=True):
+LANE_VARS = ("SP_LANES_DENSE", "SP_LANES_SPARSE", "SP_LANES", "SP_C2_BATCH")
+
+
+def run(iters, seed, gpu, ora, verbose=True, streams=False):
+    if not streams:
+        return _run(iters, seed, gpu, ora, verbose, False)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_busy import busy_neighbour
+    saved = {n: os.environ.get(n) for n in LANE_VARS}
+    try:
+        with busy_neighbour():
+            return _run(iters, seed, gpu, ora, verbose, True)
+    finally:
+        for n, v in saved.items():
+            if v is None:
+                os.environ.pop(n, None)
+            else:
+                os.environ[n] = v
+
+
+def _run(iters, seed, gpu, ora, verbose, streams):
+    import time
     rng = np.random.RandomState(seed)
     bad = 0
+    t0, limit = time.time(), float(os.environ.get("SP_FUZZ_SECONDS", "0"))      # (a time budget: stop early, report what ran)
+    it = -1
     for it in range(iters):
-        C = int(rng.randint(1, 6))
-        seqs = [rand_chrom(rng) for _ in range(C)]
+        if limit and time.time() - t0 > limit:
+            it -= 1
+            break
+        C = int(rng.randint(2, 7) if streams else rng.randint(1, 6))
+        seqs = [rand_chrom(rng, streams) for _ in range(C)]
+        if streams:      # the library reads these at every count
+            for n in LANE_VARS[:3]:
+                os.environ[n] = str(int(rng.randint(3, 8)))
+            b = int(rng.randint(0, 3))
+            if b == 2:
+                os.environ.pop("SP_C2_BATCH", None)
+            else:
+                os.environ["SP_C2_BATCH"] = str(b)
         k = int(rng.choice([1, 2, 3, 5, 8, 11, 12, 13, 14, 15, 16, 17, 19, 21, 24, 27, 31, 32]))
         lower = int(rng.randint(1, 4))
         engine = int(rng.choice([0, 1, 2, 3])) if k <= 15 else int(rng.choice([0, 1]))      # 3: lists (k >= 9), else falls back
-        tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s" % (it, C, k, lower, engine, [len(s) for s in seqs])
+        if streams and k <= 15 and engine in (0, 1) and rng.randint(0, 2):
+            engine = int(rng.choice([2, 3]))      # (engines 0 / 1 on toy genomes run no chains side by side)
+        tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s%s" % (it, C, k, lower, engine, [len(s) for s in seqs],
+                                                       " lanes=%s" % [os.environ.get(n) for n in LANE_VARS] if streams else "")
         if os.environ.get("SP_FUZZ_TRACE"):      # a GPU fault kills the process: leave the case on stderr first
             print(tag, file=sys.stderr, flush=True)
         try:
@@ -130,11 +170,12 @@ def run(iters, seed, gpu, ora, verbose=True):
             if bad >= 5:
                 break
     if verbose:
-        print("fuzz: %d iterations, %d mismatches" % (it + 1, bad))
+        print("fuzz%s seed %d: %d iterations, %d mismatches" % (" (streams)" if streams else "", seed, it + 1, bad), flush=True)
     return bad
 
 
 if __name__ == "__main__":
     n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    sys.exit(1 if run(n_it, sd, _native.Context(0), OracleContext(nthreads=4)) else 0)
+    st = len(sys.argv) > 3 and sys.argv[3] == "streams"
+    sys.exit(1 if run(n_it, sd, _native.Context(0), OracleContext(nthreads=4), streams=st) else 0)

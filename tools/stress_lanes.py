@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Repeat the k > 15 count of a synthetic genome with the default streams and compare every chromosome's (length sum, dump size)
-with a single-stream reference count (dev tool: hunts timing-dependent miscounts).  usage: stress_lanes.py [config] [k] [iterations] [scale]"""
-import os, sys
+"""Repeat the count of a synthetic genome with the default streams and compare every chromosome's length sum, dump size and -- at
+reduced scales, where the dumps can travel -- a hash of its FULL dump with a single-stream reference count (dev tool: hunts
+timing-dependent miscounts).  usage: stress_lanes.py [config] [k] [iterations] [scale]"""
+import os, sys, hashlib
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from subphaser_amd import _native
 from subphaser_amd.synth import SynthGenome
@@ -22,9 +24,14 @@ names = ["SP_LANES_SPARSE"] if K > 15 else ["SP_LANES_DENSE", "SP_LANES", "SP_C2
 saved = {n: os.environ.pop(n, None) for n in names}
 for n in names:
     os.environ[n] = "0"
+full = scale <= 0.05
+def dump_hashes():
+    if not full:
+        return []
+    return [hashlib.sha1(np.concatenate([a.view(np.uint8) for a in ctx.dump(i)]).tobytes()).hexdigest()[:12] for i in range(len(gen.chroms))]
 ctx.count(K, 3, 0)
-ref = (ctx.lengths().tolist(), [ctx.dump_size(i) for i in range(len(gen.chroms))])
-ref_dumps = [ctx.dump(i) for i in range(len(gen.chroms))] if scale <= 0.05 and K > 15 else None
+ref = (ctx.lengths().tolist(), [ctx.dump_size(i) for i in range(len(gen.chroms))], dump_hashes())
+ref_dumps = [ctx.dump(i) for i in range(len(gen.chroms))] if full and K > 15 else None
 for n in names:
     if saved[n] is None:
         del os.environ[n]
@@ -33,10 +40,10 @@ for n in names:
 bad = 0
 for it in range(iters):
     ctx.count(K, 3, 0)
-    got = (ctx.lengths().tolist(), [ctx.dump_size(i) for i in range(len(gen.chroms))])
+    got = (ctx.lengths().tolist(), [ctx.dump_size(i) for i in range(len(gen.chroms))], dump_hashes())
     if got != ref:
         bad += 1
-        d = [i for i in range(len(gen.chroms)) if got[0][i] != ref[0][i] or got[1][i] != ref[1][i]]
+        d = [i for i in range(len(gen.chroms)) if got[0][i] != ref[0][i] or got[1][i] != ref[1][i] or (full and got[2][i] != ref[2][i])]
         print("it=%d: chromosomes %s differ: %s vs %s" % (it, d, [(got[0][i], got[1][i]) for i in d], [(ref[0][i], ref[1][i]) for i in d]), flush=True)
         if ref_dumps is not None:
             for i in d:
