@@ -49,6 +49,9 @@ def parse():
 # host wall-clock phases of DistHotPath that contain a collective (reported per rank as `exchange_ms_per_rank`)
 EXCHANGE_KEYS = ["count(+exchange issue)", "exchange wait", "exchange+lengths", "merge+lengths", "rows to shared host memory",
                  "gather rows", "windows all-reduce+enrich"]
+# ... and the phases without one, so that a scaling curve explains itself: what each rank spent packing, filtering, building the
+# label tables (on every rank: the part that does not shrink with N) and mapping (`stage_ms_per_rank`)
+LOCAL_KEYS = ["pack", "count", "split+export", "filter+fetch", "labels", "map+stack"]
 
 
 def want_selfcheck(args, world):
@@ -224,13 +227,18 @@ def main():
     ms_per_step_no_events = dt_plain / n_plain * 1e3
     gbases = gen.total_bases / (dt / args.steps) / 1e9
     # what every rank spent waiting for / issuing the table (or key-range) exchange and the other collectives
-    rank_wall = None
+    rank_wall = rank_local = None
     if runner is not None:
         mine = torch.tensor([wall_timed.get(k_, 0.0) / args.steps * 1e3 for k_ in EXCHANGE_KEYS], dtype=torch.float64, device="cuda")
         allw = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allw, mine)
         rank_wall = [{"rank": r_, **{k_: round(float(v_), 3) for k_, v_ in zip(EXCHANGE_KEYS, w_.tolist()) if v_}}
                      for r_, w_ in enumerate(allw)]
+        mine = torch.tensor([wall_timed.get(k_, 0.0) / args.steps * 1e3 for k_ in LOCAL_KEYS], dtype=torch.float64, device="cuda")
+        allw = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allw, mine)
+        rank_local = [{"rank": r_, **{k_: round(float(v_), 3) for k_, v_ in zip(LOCAL_KEYS, w_.tolist()) if v_}}
+                      for r_, w_ in enumerate(allw)]
 
     # sum over chromosomes of D_c = distinct k-mers with count >= L (the lines of the jellyfish dumps)
     n_dumped = sum(ctx.dump_size(i) for i in range(len(pieces)))
@@ -345,6 +353,11 @@ def main():
             roofline = price(COUNT_CHAIN, "count engine: " + "+".join(COUNT_CHAIN))
         else:
             roofline = price([name], name, per_chrom=name not in FILTER_CHAIN)
+        if roofline:
+            # how "dominant" was decided (a reader of profiles/ sees c2_part1 lead by rocprof TOTAL: its 21 launches overlap
+            # on the counting lanes, so their event times add up to more than the stage's wall, which is what is compared)
+            roofline["dominant_by"] = ("stage wall: per-kernel event time per step, the overlapped count-chain kernels scaled by "
+                                       "pack+count wall / their event sum (%.2f)" % lane_scale) if LANE_KERNELS else "kernel event time per step"
     # the three stages of the path, each against its own SURVEY 8(d) bytes (context for the line above)
     stage_roofline = {}
     for label, names in (("count", COUNT_CHAIN), ("filter", FILTER_CHAIN), ("map", ["k5_map"] if args.k <= 15 else ["k5_map_sparse"])):
@@ -383,7 +396,7 @@ def main():
         "rccl_ranks": rccl_ranks, "dist_selfcheck": selfcheck,
         # how the M x C matrix reached rank 0
         "rows": (getattr(runner, "rows_handover", None) if runner is not None else "device->host copy stream"),
-        "exchange_ms_per_rank": rank_wall,
+        "exchange_ms_per_rank": rank_wall, "stage_ms_per_rank": rank_local,
         "pieces_per_rank": ([{"rank": r_, "pieces": len(p_), "bases": int(sum(e_ - a_ for _, a_, e_ in p_))}
                              for r_, p_ in enumerate(runner.pieces)] if runner is not None else None),
         "traffic_commit": traffic_commit, "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu, "verified": bool(cpu and cpu.get("verified")), "stage_roofline": stage_roofline, "stages": stages, "synth_s": round(t_synth, 2),

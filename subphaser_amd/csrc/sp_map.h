@@ -13,20 +13,64 @@
 #define MAP_FILL_MAX 0.40
 #endif
 // Blocked Bloom filter: one 32-bit word per key (ONE memory access per probe), three bits in it.
+//
+// Round 6 -- WHICH word.  The map stage is bound by the number of these probes: one scattered 4-byte gather per pair of starts,
+// priced per ACTIVE lane (tools/ubench_gather.hip: two gathers per quad issued by 2/3 of the lanes each cost 2/3).  Until now the
+// word was the hashed (k-1)-mer x itself, so neighbouring pairs never met in a word.  A (k-1)-mer has two (k-3)-mer CORES, its
+// first and its last k-3 bases, and the pairs along a scan form a chain: the last core of the pair at s is the first core of the
+// pair at s + 2.  With MAP_BLOOM_CORE the word of x is addressed by the core of x with the SMALLER hash (canonical cores, so
+// both strands agree): a core that beats both of its neighbours in the chain answers BOTH of its pairs with one gather, and a
+// lane needs a fresh word for 2/3 of its pairs -- a third of the probes gone, with ONE insertion per (k-1)-mer: the filter keeps
+// its size (2 MiB for the wheat-like label set: it must stay inside an XCD's L2 next to the table lines streaming through) and
+// its false-positive rate.  (The alternative of the round-5 review -- an 8-byte block addressed by the core two pairs of a quad
+// share, every (k-1)-mer under both cores -- halves the gathers but doubles the entries: 34 % false-positive quads at 2 MiB, and
+// at 4 MiB the filter falls out of the L2 and the gain is gone: profiles/r06_notes.md, section 3.)  The minimum of two uniform
+// hashes is not uniform (density 2 (1 - u)); 1 - (1 - u)^2 is, and that is what indexes the words, so the fill stays even.
+// The three bits inside the word still come from the hashed (k-1)-mer.  k < 5 (cores of fewer than two bases): the old addressing.
+#define MAP_BLOOM_CORE 0x100          // flag in the `nbits` argument of everything below (ctx->bloom_bits carries it)
+#define MAP_BLOOM_NBITS(nb) ((nb) & 0xFF)
 struct map_bloom_probe {
     uint32_t word, bits;
 };
-__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t x64, int nbits) {
+__host__ __device__ __forceinline__ uint32_t map_core_hash(uint64_t t) {       // of a canonical (k-3)-mer; well mixed in its HIGH bits
+    uint32_t x = (uint32_t)t ^ (uint32_t)(t >> 32);
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    return x * 0xC2B2AE35u;
+}
+__host__ __device__ __forceinline__ uint32_t map_core_word(uint32_t hmin /* the smaller of a (k-1)-mer's two core hashes */, int nbits) {
+    const uint32_t n = ~hmin;
+    const uint32_t sq = (uint32_t)(((unsigned long long)n * (unsigned long long)n) >> 32);      // (1 - u)^2
+    return (~sq) >> (32 - (MAP_BLOOM_NBITS(nbits) - 5));
+}
+__host__ __device__ __forceinline__ uint32_t map_bloom_bits3(uint64_t x64, uint32_t &h) {      // the three bits of a canonical (k-1)-mer
     const uint32_t x = (uint32_t)x64 ^ (uint32_t)(x64 >> 32);
-    const uint32_t h = x * 0x9E3779B1u;
+    h = x * 0x9E3779B1u;
     const uint32_t h2 = x * 0x85EBCA6Bu;
+    return (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)) | (1u << (h2 >> 27));
+}
+// word + bits of the CANONICAL (k-1)-mer x64 of a k-mer pair (generic form: the filter build and the rolling scans; the rolled
+// scans of sp_map.hip / sp_sparse.hip compute the same from the windows they already hold)
+__host__ __device__ __forceinline__ map_bloom_probe map_bloom(uint64_t x64, int k, int nbits) {
     map_bloom_probe p;
-    p.word = h >> (32 - (nbits - 5));
-    p.bits = (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)) | (1u << (h2 >> 27));
+    uint32_t h;
+    p.bits = map_bloom_bits3(x64, h);
+    if (!(nbits & MAP_BLOOM_CORE) || k < 5) {
+        p.word = h >> (32 - (MAP_BLOOM_NBITS(nbits) - 5));
+        return p;
+    }
+    const int cb = 2 * (k - 3);
+    const uint64_t smask = (1ULL << cb) - 1ULL;
+    const uint64_t a = x64 >> 4, b = x64 & smask;               // first / last k-3 bases
+    const uint64_t ar = sp_revcomp(a, k - 3), br = sp_revcomp(b, k - 3);
+    const uint32_t ha = map_core_hash(a < ar ? a : ar), hb = map_core_hash(b < br ? b : br);
+    p.word = map_core_word(ha < hb ? ha : hb, nbits);
     return p;
 }
-__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, int nbits, uint64_t x) {
-    const map_bloom_probe p = map_bloom(x, nbits);
+__device__ __forceinline__ bool map_bloom_test(const uint32_t *__restrict__ bloom, int nbits, int k, uint64_t x) {
+    const map_bloom_probe p = map_bloom(x, k, nbits);
     return (bloom[p.word] & p.bits) == p.bits;
 }
 
@@ -42,7 +86,7 @@ __device__ __forceinline__ void map_pair_scan(const uint32_t *__restrict__ pk, c
             pairhit = false;
             if (valid_k1) {
                 const KeyT mf = fwd & m1mask, mr = rc >> 2;
-                pairhit = map_bloom_test(bloom, nbits, (uint64_t)(mf < mr ? mf : mr));
+                pairhit = map_bloom_test(bloom, nbits, kp.k, (uint64_t)(mf < mr ? mf : mr));
             }
         }
         if (pairhit && valid_k) hit(start, fwd, rc);

@@ -39,9 +39,9 @@ k4_pair_filter(const unsigned long long *__restrict__ keys, int64_t n, int k, ui
         pre = pre < rpre ? pre : rpre;
         suf = suf < rsuf ? suf : rsuf;
     }
-    const map_bloom_probe p = map_bloom(pre, nbits);
+    const map_bloom_probe p = map_bloom(pre, k, nbits);
     atomicOr(&bloom[p.word], p.bits);
-    const map_bloom_probe q = map_bloom(suf, nbits);
+    const map_bloom_probe q = map_bloom(suf, k, nbits);
     atomicOr(&bloom[q.word], q.bits);
 }
 
@@ -265,13 +265,17 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     const uint32_t smask = TABLE ? ((1u << sb) - 1u) : 0u;
     constexpr int QI = MAP2_QI;
     static_assert(QI == 1 || QI == 2 || QI == 4, "quads per inner iteration");
+    // the filter's addressing (sp_map.h): by the smaller-hashed core of the (k-1)-mer, or by the (k-1)-mer itself
+    const bool core = (nbits & MAP_BLOOM_CORE) && kp.k >= 5;      // (uniform)
+    const uint32_t cmask = kp.k >= 5 ? ((1u << (2 * (kp.k - 3))) - 1u) : 0u;
+    const int wsh = 32 - (MAP_BLOOM_NBITS(nbits) - 5);
+    uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                  // the word this lane fetched last (index, content)
 #pragma unroll 1
     for (int w = 0; w < 4; w++) {
 #pragma unroll 1
         for (int r0 = 0; r0 < 16; r0 += 4 * QI) {
             // QI quads per iteration: their filter probes travel together, then the bucket loads of the candidate quads
-            uint32_t V1[QI], V2[QI], xf1[QI], xr1[QI], xf2[QI], xr2[QI], c1[QI], c2[QI], wd1[QI], wd2[QI], okk[QI];
-            map_bloom_probe p1[QI], p2[QI];
+            uint32_t V1[QI], V2[QI], xf1[QI], xr1[QI], xf2[QI], xr2[QI], c1[QI], c2[QI], wd1[QI], wd2[QI], okk[QI], bt1[QI], bt2[QI];
 #pragma unroll
             for (int q = 0; q < QI; q++) {
                 const int r = r0 + 4 * q, j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
@@ -286,13 +290,39 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                 xr2[q] = (~W2 >> 2) & m1mask;
                 c1[q] = xf1[q] < xr1[q] ? xf1[q] : xr1[q];
                 c2[q] = xf2[q] < xr2[q] ? xf2[q] : xr2[q];
-                p1[q] = map_bloom((uint64_t)c1[q], nbits);
-                p2[q] = map_bloom((uint64_t)c2[q], nbits);
+                uint32_t h1, h2;
+                bt1[q] = map_bloom_bits3((uint64_t)c1[q], h1);
+                bt2[q] = map_bloom_bits3((uint64_t)c2[q], h2);
                 const uint32_t okx = (uint32_t)(ok_x >> j);
                 okk[q] = (uint32_t)(ok_k >> j);
-                wd1[q] = wd2[q] = 0;
-                if (okx & 1u) wd1[q] = bloom[p1[q].word];
-                if (okx & 4u) wd2[q] = bloom[p2[q].word];
+                const bool v1 = okx & 1u, v2 = okx & 4u;
+                uint32_t wi1, wi2;          // the filter words of x1 and x2
+                if (core) {
+                    // the chain of cores: a = first k-3 bases of x1, b = last of x1 = first of x2, c = last of x2 (= the next
+                    // quad's a); canonical = the smaller of the forward reading and its reverse complement, which is the
+                    // OTHER end of the reverse-complemented (k-1)-mer
+                    const uint32_t ta_f = xf1[q] >> 4, ta_r = xr1[q] & cmask, tb_f = xf1[q] & cmask, tb_r = xr1[q] >> 4;
+                    const uint32_t tc_f = xf2[q] & cmask, tc_r = xr2[q] >> 4;
+                    const uint32_t ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
+                    const uint32_t hb = map_core_hash((uint64_t)(tb_f < tb_r ? tb_f : tb_r));
+                    const uint32_t hc = map_core_hash((uint64_t)(tc_f < tc_r ? tc_f : tc_r));
+                    wi1 = map_core_word(ha < hb ? ha : hb, nbits);
+                    wi2 = map_core_word(hb < hc ? hb : hc, nbits);
+                } else {
+                    wi1 = h1 >> wsh;
+                    wi2 = h2 >> wsh;
+                }
+                // a word this lane holds already (the previous pair's) is not fetched again: with the core addressing that
+                // is the case for a third of the pairs -- and a gather is priced per active lane
+                const bool need1 = v1 && wi1 != last_wi;
+                const bool need2 = v2 && wi2 != (v1 ? wi1 : last_wi);
+                uint32_t f1 = 0, f2 = 0;
+                if (need1) f1 = bloom[wi1];
+                if (need2) f2 = bloom[wi2];
+                wd1[q] = v1 ? (need1 ? f1 : last_w) : 0u;
+                wd2[q] = v2 ? (need2 ? f2 : (v1 ? wd1[q] : last_w)) : 0u;
+                if (v2) { last_wi = wi2; last_w = wd2[q]; }
+                else if (v1) { last_wi = wi1; last_w = wd1[q]; }
             }
             bool cand1[QI], cand2[QI], sfw[QI];
             uint4 B[QI];
@@ -300,8 +330,8 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
             uint32_t e1[QI], e2[QI];
 #pragma unroll
             for (int q = 0; q < QI; q++) {
-                cand1[q] = (wd1[q] & p1[q].bits) == p1[q].bits;
-                cand2[q] = (wd2[q] & p2[q].bits) == p2[q].bits;
+                cand1[q] = (wd1[q] & bt1[q]) == bt1[q];       // (an invalid pair's word is 0: never a candidate)
+                cand2[q] = (wd2[q] & bt2[q]) == bt2[q];
                 e1[q] = e2[q] = 0;
                 B[q] = make_uint4(0u, 0u, 0u, 0u);
                 if (TABLE) {
@@ -823,13 +853,17 @@ int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n
     const bool cached = n > 0 && n == ctx->bloom_last_n && ctx->k == ctx->bloom_last_k && ctx->bloom_last_bits >= bits;
     if (cached) bits = ctx->bloom_last_bits;
     unsigned long long *d_small = (unsigned long long *)((char *)ctx->d_bloom + ((size_t)1 << MAP_BLOOM_MAX_BITS) / 8);
+    // round 6: words addressed by the smaller-hashed core of the (k-1)-mer (sp_map.h); SP_MAP_FILTER=x keeps the round-1
+    // addressing by the (k-1)-mer itself (cross-check).  ctx->bloom_bits carries the flag to every kernel that probes.
+    const char *env_mf = getenv("SP_MAP_FILTER");
+    const int mode = (env_mf && env_mf[0] == 'x') ? 0 : MAP_BLOOM_CORE;
     for (;;) {
         const size_t bytes = ((size_t)1 << bits) / 8;
         SP_HIP(ctx, hipMemsetAsync(ctx->d_bloom, 0, bytes, ctx->stream));
-        ctx->bloom_bits = bits;
+        ctx->bloom_bits = bits | mode;
         if (n == 0) break;
         SP_LAUNCH(ctx, "k4_pair_filter", k4_pair_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_keys, n,
-                  ctx->k, ctx->d_bloom, bits);
+                  ctx->k, ctx->d_bloom, bits | mode);
         if (bits >= MAP_BLOOM_MAX_BITS || cached) break;
         SP_HIP(ctx, hipMemsetAsync(d_small, 0, 8, ctx->stream));
         SP_LAUNCH(ctx, "k4_filter_fill", k4_filter_fill, dim3(256), dim3(256), 0, (const uint32_t *)ctx->d_bloom,

@@ -388,42 +388,70 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
 #endif
     const int sh = 64 - 2 * kp.k;
     const uint64_t m1mask = kp.kmask >> 2;
+    const bool core = (nbits & MAP_BLOOM_CORE) != 0;                   // (uniform; k >= 16 here)
+    const uint64_t cmask = (1ULL << (2 * (kp.k - 3))) - 1ULL;
+    const int wsh = 32 - (MAP_BLOOM_NBITS(nbits) - 5);
+    uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                       // the word this lane fetched last (index, content)
 #pragma unroll 1
     for (int w = 0; w < 4; w++) {
 #pragma unroll 1
         for (int r = 0; r < 16; r += 4) {
             const int j = 16 * w + r;           // two pairs: x1 at j + 1 (starts j, j + 1), x2 at j + 3 (starts j + 2, j + 3)
-            uint64_t V[2], xf[2], xr[2], canon[2];
-            uint32_t wd[2], b1[2];
-            map_bloom_probe pr[2];
+            uint64_t xf[2], xr[2], canon[2];
+            uint32_t wd[2], b0[2], b1[2], bt[2], hx[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int rr = r + 2 * h;       // <= 14: the 32-base window at 16 w + rr lies in words w .. w + 2
                 const uint64_t W = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, 2 * rr) |
                                    ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, 2 * rr) << 32);
                 const unsigned long long mA = ((unsigned long long)m0 << 32) | m1, mB = ((unsigned long long)m1 << 32) | m2;
-                V[h] = (((mA << (2 * rr)) >> 32) << 32) | ((mB << (2 * rr)) >> 32);
-                xf[h] = (V[h] >> sh) & m1mask;          // x forward (the k-mer at the pair's first start without its first base)
+                const uint64_t V = (((mA << (2 * rr)) >> 32) << 32) | ((mB << (2 * rr)) >> 32);
+                b0[h] = (uint32_t)(V >> 62);            // the base in front of x (first base of the pair's first k-mer)
+                xf[h] = (V >> sh) & m1mask;             // x forward (the k-mer at the pair's first start without its first base)
                 xr[h] = (~W >> 2) & m1mask;             // its reverse complement
                 canon[h] = xf[h] < xr[h] ? xf[h] : xr[h];
-                pr[h] = map_bloom(canon[h], nbits);
-                wd[h] = ((ok_x >> (j + 2 * h)) & 1ULL) ? bloom[pr[h].word] : 0u;
+                bt[h] = map_bloom_bits3(canon[h], hx[h]);
                 // the base behind x (last base of the pair's second k-mer): position rr + k of the current words, k >= 16
                 const int pb = rr + kp.k;
                 const uint32_t lw = (pb >> 4) == 1 ? l1 : ((pb >> 4) == 2 ? l2 : l3);
                 b1[h] = (lw >> (2 * (pb & 15))) & 3u;
             }
+            {
+                // the filter words of x1 and x2 (sp_map.h): by the smaller-hashed core of the chain a - x1 - b - x2 - c, or by
+                // the (k-1)-mer itself; a word the lane fetched for the previous pair is not fetched again
+                uint32_t wi1, wi2;
+                if (core) {
+                    const uint64_t ta_f = xf[0] >> 4, ta_r = xr[0] & cmask, tb_f = xf[0] & cmask, tb_r = xr[0] >> 4;
+                    const uint64_t tc_f = xf[1] & cmask, tc_r = xr[1] >> 4;
+                    const uint32_t ha = map_core_hash(ta_f < ta_r ? ta_f : ta_r), hb = map_core_hash(tb_f < tb_r ? tb_f : tb_r),
+                                   hc = map_core_hash(tc_f < tc_r ? tc_f : tc_r);
+                    wi1 = map_core_word(ha < hb ? ha : hb, nbits);
+                    wi2 = map_core_word(hb < hc ? hb : hc, nbits);
+                } else {
+                    wi1 = hx[0] >> wsh;
+                    wi2 = hx[1] >> wsh;
+                }
+                const bool v1 = (ok_x >> j) & 1ULL, v2 = (ok_x >> (j + 2)) & 1ULL;
+                const bool need1 = v1 && wi1 != last_wi;
+                const bool need2 = v2 && wi2 != (v1 ? wi1 : last_wi);
+                uint32_t f1 = 0, f2 = 0;
+                if (need1) f1 = bloom[wi1];
+                if (need2) f2 = bloom[wi2];
+                wd[0] = v1 ? (need1 ? f1 : last_w) : 0u;
+                wd[1] = v2 ? (need2 ? f2 : (v1 ? wd[0] : last_w)) : 0u;
+                if (v2) { last_wi = wi2; last_w = wd[1]; }
+                else if (v1) { last_wi = wi1; last_w = wd[0]; }
+            }
             uint32_t e[2] = {0u, 0u};
             uint64_t slot[2] = {0, 0};
 #pragma unroll
             for (int h = 0; h < 2; h++)
-                if ((wd[h] & pr[h].bits) == pr[h].bits) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);
+                if ((wd[h] & bt[h]) == bt[h]) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);      // (an invalid pair's word is 0)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (!(e[h] & 0x77777777u)) continue;
                 const bool fw = xf[h] <= xr[h];
-                const uint32_t b0 = (uint32_t)(V[h] >> 62);
-                const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
+                const int f0 = fw ? (int)b0[h] : 7 - (int)b0[h], f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
                 const uint32_t okk = (uint32_t)((ok_k & cm) >> (j + 2 * h));     // (not covered: neither counted nor marked seen)
                 const uint32_t v0 = (okk & 1u) ? (e[h] >> (4 * f0)) & 15u : 0u;
                 const uint32_t v1 = (okk & 2u) ? (e[h] >> (4 * f1)) & 15u : 0u;
@@ -443,7 +471,8 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
     }
 }
 
-__global__ void __launch_bounds__(MAP_BLOCK)
+// (six waves per SIMD = TWO 768-thread workgroups per CU: at 82 VGPRs -- one more than that allows -- the kernel ran one: 52.6 -> 66.6 ms)
+__global__ void __launch_bounds__(MAP_BLOCK, 6)
 k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
                sp_map_params P, unsigned long long *__restrict__ htab, uint64_t hmask, const uint32_t *__restrict__ bloom,
                int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {

@@ -569,6 +569,7 @@ class DistHotPath:
         r.bins, r.n_mapped = [], 0
         if mine:
             ctx.labels_set_from(kmer_labels, n_sg)
+            tt = self._t("labels", tt)      # (the label tables are built on EVERY rank: the part of a pass that does not shrink with N)
             all_slots, n_mapped = ctx.map_bins_all(self.bin_size, self.chunk_size)
             r.bins = all_slots
             r.n_mapped = int(n_mapped.sum())

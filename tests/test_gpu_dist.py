@@ -126,6 +126,21 @@ def test_two_processes_one_gpu_key_range(gpu_ctx, tmp_path):
     _spawn(tmp_path, 2, 17)
 
 
+def test_eight_processes_one_gpu_wheat_shape_position_pieces(gpu_ctx, tmp_path):
+    """Rehearsal of the first 8-GPU lease (round 6): EIGHT ranks on the wheat shape (21 chromosomes / 7 sets x 3), byte-table
+    engine: eight position pieces = seven chromosomes cut inside, every cut chromosome merged by sp_table_merge on the rank
+    that owns the slot range, slot-range filter on all eight, shared-segment rows, window all-reduce -- against the
+    single-process oracle.  (k = 13: the same code as k = 15 with 2^25-slot tables; 28 pieces x 512 MiB through the
+    host-staged gloo all_to_all of this test would take minutes.)"""
+    _spawn(tmp_path, 8, 13, engine=2, shape="wheat")
+
+
+def test_eight_processes_one_gpu_wheat_shape_key_range(gpu_ctx, tmp_path):
+    """... and k = 17 on eight ranks: whole chromosomes dealt by LPT, sorted lists, splitters, the uneven all_to_all of
+    key-range pieces."""
+    _spawn(tmp_path, 8, 17, shape="wheat")
+
+
 def test_bench_line_single_and_forced_dist(tmp_path):
     """bench.py end to end on the `small` genome: the JSON contract (metric / value / roofline / cpu_baseline with the
     jellyfish leg / verified), then the multi-GPU code path through RCCL with one rank (`--force-dist`) including
@@ -152,5 +167,6 @@ def test_bench_line_single_and_forced_dist(tmp_path):
     d2 = json.loads(out.stdout.strip().splitlines()[-1])
     assert d2["rccl_ranks"] == 1 and d2["dist_selfcheck"]["ok"] is True and d2["pieces_per_rank"][0]["rank"] == 0
     assert d2["exchange_ms_per_rank"][0]["rank"] == 0 and d2["exchange_ms_per_rank"][0].get("exchange wait", 0.0) >= 0
+    assert d2["stage_ms_per_rank"][0]["rank"] == 0 and d2["stage_ms_per_rank"][0]["labels"] > 0 and d2["stage_ms_per_rank"][0]["map+stack"] > 0
     assert d2["pieces_per_rank"][0]["bases"] > 0 and d2["config"]["differential_kmers"] == d["config"]["differential_kmers"]
     assert d2["config"]["mapped_positions"] == d["config"]["mapped_positions"]

@@ -927,9 +927,16 @@ def test_pipeline_cli_background_writers(gpu_ctx, golden, toy, tmp_path, monkeyp
     pc.check_pipeline_cli(gpu_ctx, golden, toy, tmp_path)
 
 
-def test_map_vs_oracle_random(gpu_ctx):
+@pytest.mark.parametrize("k,S,flt", [(13, 3, "core"), (13, 3, "x"), (15, 2, "core"), (15, 5, "x"), (4, 2, "core"), (17, 3, "core"), (17, 3, "x"),
+                                     (13, 9, "core"), (21, 9, "core")])
+def test_map_vs_oracle_random(gpu_ctx, monkeypatch, k, S, flt):
+    """Bins, n_mapped, labels_hit against the oracle through every map engine (compact / direct pair table, label table for
+    S > 7, k > 15 pair-keyed and per-k-mer tables) with both addressings of the pair filter: "core" = the word of a (k-1)-mer is
+    addressed by its smaller-hashed (k-3)-mer core (round 6: a lane re-uses the previous pair's word for a third of its pairs),
+    "x" = by the (k-1)-mer itself (SP_MAP_FILTER=x, the cross-check); k = 4: cores too short, the old addressing either way."""
+    if flt == "x":
+        monkeypatch.setenv("SP_MAP_FILTER", "x")
     rng = np.random.RandomState(33)
-    k = 13
     s = _rand_seq(rng, 250000)
     rep = _rand_seq(rng, 500, 0, 0)
     for _ in range(100):
@@ -940,11 +947,11 @@ def test_map_vs_oracle_random(gpu_ctx):
     gpu_ctx.count(k, 1, 1)
     keys, cnts = gpu_ctx.dump(0)
     sel = keys[cnts >= 20]
-    sg = (np.arange(sel.size) % 3).astype(np.uint8)
-    gpu_ctx.labels_set(sel, sg, 3)
+    sg = (np.arange(sel.size) % S).astype(np.uint8)
+    gpu_ctx.labels_set(sel, sg, S)
     for bin_size, chunk in ((10000, 10_000_000), (100, 2000), (7, 0), (333, 1000), (1, 0), (50000, 100000)):
         got, n = gpu_ctx.map_bins(0, bin_size, chunk)
-        exp, hit, n2 = po.map_bins(s, k, sel, sg, 3, bin_size, chunk, nthreads=4)
+        exp, hit, n2 = po.map_bins(s, k, sel, sg, S, bin_size, chunk, nthreads=4)
         assert got.shape == exp.shape, (bin_size, chunk)
         assert (got == exp).all() and n == n2, (bin_size, chunk)
     allb, nm = gpu_ctx.map_bins_all(50000, 100000)       # batched entry point, same numbers

@@ -39,15 +39,33 @@ cmd = [sys.executable] + prof + ["-m", "subphaser_amd", "-i", fa, "-c", os.path.
        os.path.join(work, "assigned.tsv"), "-o", os.path.join(work, "out"), "-tmpdir", os.path.join(work, "tmp"),
        "-disable_ltr", "-disable_circos", "-overwrite", "-figfmt", "png"]
 t0 = time.perf_counter()
-r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, SP_STACKS_AFTER=os.environ.get("SP_STACKS_AFTER", "240")))
+# the CLI's log lines are stamped as they ARRIVE (its own timestamps have one-second resolution): the per-phase wall table
+proc = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, bufsize=1,
+                        env=dict(os.environ, SP_STACKS_AFTER=os.environ.get("SP_STACKS_AFTER", "240")))
+stamped = []
+for line in proc.stderr:
+    stamped.append((time.perf_counter() - t0, line.rstrip("\n")))
+proc.wait()
 dt = time.perf_counter() - t0
+
+
+class _R:
+    returncode = proc.returncode
+    stderr = "\n".join(l for _, l in stamped)
+
+
+r = _R()
 open(os.path.join(work, "cli.stderr"), "w").write(r.stderr)
 keep = ("per-chromosome FASTA", "chromosomes, in config order", "Genome size", "###Step", "Counting", "matrix", "filter (K3)",
         "After filtering", "kmers in total", "bootstrap", "Bootstrap", "->", "significant subgenome", "Processed",
         "enrichment", "wrote", "writer", "Pipeline completed", "New check point")
-for line in r.stderr.splitlines():
+prev = 0.0
+print("   at s   +delta   (wall clock from process start; a line is printed when its phase BEGINS or an output is done)")
+for t, line in stamped:
     if any(k in line for k in keep) and "Loading /" not in line:
-        print(line[:160])
+        print("%7.2f  %+6.2f   %s" % (t, t - prev, line[:150]))
+        prev = t
+print("%7.2f  %+6.2f   (process exit: background writers joined, interpreter torn down)" % (dt, dt - prev))
 if r.returncode:
     print(r.stderr[-3000:])
 print("exit", r.returncode)

@@ -22,8 +22,10 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
     return x;
 }
 
-// G gathers of W bytes per quad (W = 4: uint32, 8: uint2, 16: uint4), QI quads in flight per lane
-template <int W, int G, int QI>
+// G gathers of W bytes per quad (W = 4: uint32, 8: uint2, 16: uint4), QI quads in flight per lane; NT: the table's bucket loads
+// carry the non-temporal hint (streaming lines are the first the L2 gives up: does a 4-MiB filter then stay resident?)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <int W, int G, int QI, int NT = 0, int PRED = 256 /* a lane issues each of its gathers with probability PRED / 256 */>
 __global__ void __launch_bounds__(768)
 k_quads(const uint32_t *__restrict__ filt, uint32_t fmask /* W-byte blocks - 1 */, const uint4 *__restrict__ tab, uint32_t tmask,
         uint32_t p16 /* candidate rate x 65536 */, long long n_units, unsigned long long *__restrict__ sink) {
@@ -39,7 +41,12 @@ k_quads(const uint32_t *__restrict__ filt, uint32_t fmask /* W-byte blocks - 1 *
                 h[q] = s = mix(s + 0x632BE5ABu);
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const uint32_t idx = mix(h[q] + 77u * g) & fmask;
+                    const uint32_t idx = (uint32_t)(((unsigned long long)mix(h[q] + 77u * g) * (unsigned long long)(fmask + 1u)) >> 32);
+                    if (PRED < 256) {
+                        w[q][g][0] = 0;
+                        if (((mix(h[q] ^ (0x51ED27u * (g + 1))) >> 11) & 255u) < (uint32_t)PRED) w[q][g][0] = filt[idx];
+                        continue;
+                    }
                     if (W == 4) w[q][g][0] = filt[idx];
                     else if (W == 8) {
                         const uint2 v = reinterpret_cast<const uint2 *>(filt)[idx];
@@ -61,7 +68,14 @@ k_quads(const uint32_t *__restrict__ filt, uint32_t fmask /* W-byte blocks - 1 *
                 // candidate: decided by the hash (rate p), but only once the filter words are here (the dependency of the real loop)
                 const bool cand = ((h[q] >> 8) & 0xFFFFu) < p16 + (x == 0xDEADBEEFu ? 1u : 0u);
                 B[q] = make_uint4(0, 0, 0, 0);
-                if (cand) B[q] = tab[mix(h[q] ^ 0x5bd1e995u) & tmask];
+                if (cand) {
+                    if (NT) {
+                        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(tab) + (mix(h[q] ^ 0x5bd1e995u) & tmask));
+                        B[q] = make_uint4(t.x, t.y, t.z, t.w);
+                    } else {
+                        B[q] = tab[mix(h[q] ^ 0x5bd1e995u) & tmask];
+                    }
+                }
                 acc += x;
             }
 #pragma unroll
@@ -71,7 +85,7 @@ k_quads(const uint32_t *__restrict__ filt, uint32_t fmask /* W-byte blocks - 1 *
     if (acc == 0x1234567u) atomicAdd(sink, 1ULL);
 }
 
-template <int W, int G, int QI>
+template <int W, int G, int QI, int NT = 0, int PRED = 256>
 static void run(const char *what, const uint32_t *filt, size_t fbytes, const uint4 *tab, size_t tbytes, double p, long long n_units,
                 unsigned long long *sink, int cus) {
     hipEvent_t e0, e1;
@@ -80,7 +94,7 @@ static void run(const char *what, const uint32_t *filt, size_t fbytes, const uin
     float best = 1e9;
     for (int t = 0; t < 3; t++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_quads<W, G, QI>), dim3(cus * 16), dim3(768), 0, 0, filt, (uint32_t)(fbytes / W - 1), tab, (uint32_t)(tbytes / 16 - 1),
+        hipLaunchKernelGGL((k_quads<W, G, QI, NT, PRED>), dim3(cus * 16), dim3(768), 0, 0, filt, (uint32_t)(fbytes / W - 1), tab, (uint32_t)(tbytes / 16 - 1),
                            (uint32_t)(p * 65536.0), n_units, sink);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -110,14 +124,24 @@ int main(int argc, char **argv) {
     CK(hipMemset(tab, 0x3c, tbytes));
     const long long n_units = 14070000000LL / 64;      // the wheat-like genome: 3.5 G quads
     for (double p : {0.0, 0.27, 0.33}) {
-        for (size_t mb : {1, 2, 4, 8, 16}) {
+        for (size_t mb : {1, 2, 3, 4, 8, 16}) {
             const size_t fb = mb << 20;
-            if (mb <= 4) run<4, 2, 1>("2 x 4 B per quad (today)", filt, fb, tab, tbytes, p, n_units, sink, cus);
+            if (mb <= 4 && mb != 3) run<4, 2, 1>("2 x 4 B per quad (today)", filt, fb, tab, tbytes, p, n_units, sink, cus);
             run<8, 1, 1>("1 x 8 B per quad", filt, fb, tab, tbytes, p, n_units, sink, cus);
             if (mb >= 2) run<16, 1, 1>("1 x 16 B per quad", filt, fb, tab, tbytes, p, n_units, sink, cus);
         }
         run<8, 1, 2>("1 x 8 B per quad", filt, 4u << 20, tab, tbytes, p, n_units, sink, cus);
         run<4, 2, 2>("2 x 4 B per quad (today)", filt, 2u << 20, tab, tbytes, p, n_units, sink, cus);
+    }
+    printf("-- is a gather priced per ACTIVE lane?  2 x 4 B per quad, each issued by a lane with probability 2/3, 1/2 (2-MiB filter)\n");
+    for (double p : {0.0, 0.27}) {
+        run<4, 2, 1, 0, 171>("2 x 4 B, 2/3 of the lanes each", filt, 2u << 20, tab, tbytes, p, n_units, sink, cus);
+        run<4, 2, 1, 0, 128>("2 x 4 B, 1/2 of the lanes each", filt, 2u << 20, tab, tbytes, p, n_units, sink, cus);
+    }
+    printf("-- the table's bucket loads non-temporal\n");
+    for (double p : {0.27, 0.33}) {
+        run<4, 2, 1, 1>("2 x 4 B per quad (today), NT table", filt, 2u << 20, tab, tbytes, p, n_units, sink, cus);
+        for (size_t mb : {2, 3, 4, 6, 8}) run<8, 1, 1, 1>("1 x 8 B per quad, NT table", filt, mb << 20, tab, tbytes, p, n_units, sink, cus);
     }
     // one gather per SIX starts (a (k-5)-mer core, 16-byte blocks): 2/3 of the quads' count of gathers, three insertions per (k-1)-mer
     printf("-- one 16-byte gather per six starts: the same kernel over 2/3 of the units\n");
