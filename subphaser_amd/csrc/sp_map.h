@@ -36,9 +36,7 @@ __host__ __device__ __forceinline__ uint32_t map_core_hash(uint64_t t) {       /
     uint32_t x = (uint32_t)t ^ (uint32_t)(t >> 32);
     x *= 0x9E3779B1u;
     x ^= x >> 15;
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    return x * 0xC2B2AE35u;
+    return x * 0x85EBCA6Bu;      // (multiply - xorshift - multiply: the scan computes one of these per pair)
 }
 __host__ __device__ __forceinline__ uint32_t map_core_word(uint32_t hmin /* the smaller of a (k-1)-mer's two core hashes */, int nbits) {
     const uint32_t n = ~hmin;

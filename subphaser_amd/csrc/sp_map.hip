@@ -270,6 +270,7 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     const uint32_t cmask = kp.k >= 5 ? ((1u << (2 * (kp.k - 3))) - 1u) : 0u;
     const int wsh = 32 - (MAP_BLOOM_NBITS(nbits) - 5);
     uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                  // the word this lane fetched last (index, content)
+    uint32_t h_carry = 0u;                                         // hash of the core the previous quad ended with
 #pragma unroll 1
     for (int w = 0; w < 4; w++) {
 #pragma unroll 1
@@ -301,11 +302,15 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                     // the chain of cores: a = first k-3 bases of x1, b = last of x1 = first of x2, c = last of x2 (= the next
                     // quad's a); canonical = the smaller of the forward reading and its reverse complement, which is the
                     // OTHER end of the reverse-complemented (k-1)-mer
-                    const uint32_t ta_f = xf1[q] >> 4, ta_r = xr1[q] & cmask, tb_f = xf1[q] & cmask, tb_r = xr1[q] >> 4;
-                    const uint32_t tc_f = xf2[q] & cmask, tc_r = xr2[q] >> 4;
-                    const uint32_t ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
+                    const uint32_t tb_f = xf1[q] & cmask, tb_r = xr1[q] >> 4, tc_f = xf2[q] & cmask, tc_r = xr2[q] >> 4;
+                    uint32_t ha = h_carry;              // (this quad's a IS the previous quad's c: the same bases)
+                    if (j == 0) {                       // (uniform: the unit's first quad)
+                        const uint32_t ta_f = xf1[q] >> 4, ta_r = xr1[q] & cmask;
+                        ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
+                    }
                     const uint32_t hb = map_core_hash((uint64_t)(tb_f < tb_r ? tb_f : tb_r));
                     const uint32_t hc = map_core_hash((uint64_t)(tc_f < tc_r ? tc_f : tc_r));
+                    h_carry = hc;
                     wi1 = map_core_word(ha < hb ? ha : hb, nbits);
                     wi2 = map_core_word(hb < hc ? hb : hc, nbits);
                 } else {

@@ -392,6 +392,7 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
     const uint64_t cmask = (1ULL << (2 * (kp.k - 3))) - 1ULL;
     const int wsh = 32 - (MAP_BLOOM_NBITS(nbits) - 5);
     uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                       // the word this lane fetched last (index, content)
+    uint32_t h_carry = 0u;                                              // hash of the core the previous two pairs ended with
 #pragma unroll 1
     for (int w = 0; w < 4; w++) {
 #pragma unroll 1
@@ -421,10 +422,14 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                 // the (k-1)-mer itself; a word the lane fetched for the previous pair is not fetched again
                 uint32_t wi1, wi2;
                 if (core) {
-                    const uint64_t ta_f = xf[0] >> 4, ta_r = xr[0] & cmask, tb_f = xf[0] & cmask, tb_r = xr[0] >> 4;
-                    const uint64_t tc_f = xf[1] & cmask, tc_r = xr[1] >> 4;
-                    const uint32_t ha = map_core_hash(ta_f < ta_r ? ta_f : ta_r), hb = map_core_hash(tb_f < tb_r ? tb_f : tb_r),
-                                   hc = map_core_hash(tc_f < tc_r ? tc_f : tc_r);
+                    const uint64_t tb_f = xf[0] & cmask, tb_r = xr[0] >> 4, tc_f = xf[1] & cmask, tc_r = xr[1] >> 4;
+                    uint32_t ha = h_carry;              // (this iteration's a IS the previous one's c: the same bases)
+                    if (j == 0) {                       // (uniform: the unit's first two pairs)
+                        const uint64_t ta_f = xf[0] >> 4, ta_r = xr[0] & cmask;
+                        ha = map_core_hash(ta_f < ta_r ? ta_f : ta_r);
+                    }
+                    const uint32_t hb = map_core_hash(tb_f < tb_r ? tb_f : tb_r), hc = map_core_hash(tc_f < tc_r ? tc_f : tc_r);
+                    h_carry = hc;
                     wi1 = map_core_word(ha < hb ? ha : hb, nbits);
                     wi2 = map_core_word(hb < hc ? hb : hc, nbits);
                 } else {
