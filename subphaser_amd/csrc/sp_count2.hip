@@ -875,6 +875,7 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
 #define C2L_PF 2         // 8-byte loads per thread and bucket held in registers (8 K keys per bucket)
 #endif
 #define C2L_MAXB 256      // fine buckets per block at most (the launch sizes the grid accordingly)
+template <int C2L_DEPTH_, int C2L_PF_>
 __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
               unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n*/,
               uint2 *__restrict__ stage, unsigned long long stage_cap, uint32_t *__restrict__ seg_base,
@@ -896,9 +897,9 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
     __syncthreads();
     // per prefetched bucket: aligned address of its first quad, offset of the first key in that quad (0..3), number of
     // keys, segment base.  Everything inside a bucket is 32-bit arithmetic (a region holds < 2^32 keys: host check).
-    uint2 pf[C2L_DEPTH][C2L_PF];
-    unsigned long long p_a0[C2L_DEPTH];
-    uint32_t p_off[C2L_DEPTH], p_n[C2L_DEPTH], p_base[C2L_DEPTH];
+    uint2 pf[C2L_DEPTH_][C2L_PF_];
+    unsigned long long p_a0[C2L_DEPTH_];
+    uint32_t p_off[C2L_DEPTH_], p_n[C2L_DEPTH_], p_base[C2L_DEPTH_];
     auto issue = [&](int d, int64_t fbn, int64_t j) {      // d is a constant after unrolling: the arrays live in registers
         p_a0[d] = 0;
         p_off[d] = p_n[d] = p_base[d] = 0;
@@ -913,7 +914,7 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
         // (kept under their condition: unconditional clamped loads -- what helped c2_count16 -- cost the list counter
         // 12 % on 20-Mb chromosomes, where most lanes have nothing to load; round 5)
 #pragma unroll
-        for (int q = 0; q < C2L_PF; q++) {
+        for (int q = 0; q < C2L_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nq) pf[d][q] = p2[i];
         }
@@ -928,28 +929,28 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
         if (k0 + 3 >= off && k0 + 3 < end && !(v.y & 0x80000000u)) f(v.y >> 16);
     };
 #pragma unroll
-    for (int d = 0; d < C2L_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
+    for (int d = 0; d < C2L_DEPTH_; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
     int par = 0;
     int64_t j0 = 0;
     // one bucket, full 32-bit counters (any size)
-    uint2 cur[C2L_DEPTH][C2L_PF];
-    unsigned long long c_a0[C2L_DEPTH];
-    uint32_t c_off[C2L_DEPTH], c_n[C2L_DEPTH], c_base[C2L_DEPTH];
+    uint2 cur[C2L_DEPTH_][C2L_PF_];
+    unsigned long long c_a0[C2L_DEPTH_];
+    uint32_t c_off[C2L_DEPTH_], c_n[C2L_DEPTH_], c_base[C2L_DEPTH_];
     auto single = [&](int d, int64_t fb) {
         const uint32_t off = c_off[d], end = c_off[d] + c_n[d], nq = (end + 3u) >> 2;
-        const bool in_regs = nq <= (uint32_t)C2L_PF * C2_COUNT_THREADS;      // block-uniform
+        const bool in_regs = nq <= (uint32_t)C2L_PF_ * C2_COUNT_THREADS;      // block-uniform
         const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
         const unsigned long long base = c_base[d];
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + c_a0[d]);
         auto add = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
         // ---- pass 1: count
 #pragma unroll
-        for (int q = 0; q < C2L_PF; q++) {
+        for (int q = 0; q < C2L_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nq) quad(cur[d][q], i, off, end, add);
         }
         if (!in_regs)      // (four clamped loads per round: one load per round trip held this loop at a quarter of its rate)
-            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L_PF * C2_COUNT_THREADS; i0 < nq; i0 += 4u * C2_COUNT_THREADS) {
+            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L_PF_ * C2_COUNT_THREADS; i0 < nq; i0 += 4u * C2_COUNT_THREADS) {
                 uint2 vv[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -978,7 +979,7 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
                 if (c) emit(r, c);
             };
 #pragma unroll
-            for (int q = 0; q < C2L_PF; q++) {
+            for (int q = 0; q < C2L_PF_; q++) {
                 const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
                 if (i < nq) quad(cur[d][q], i, off, end, take);
             }
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
         auto addA = [&](uint32_t r) { atomicAdd(&cnt[r], 1u); };
         auto addB = [&](uint32_t r) { atomicAdd(&cnt[r], 0x10000u); };
 #pragma unroll
-        for (int q = 0; q < C2L_PF; q++) {
+        for (int q = 0; q < C2L_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nqA) quad(cur[d][q], i, offA, endA, addA);
             if (i < nqB) quad(cur[d + 1][q], i, offB, endB, addB);
@@ -1040,7 +1041,7 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
             }
         };
 #pragma unroll
-        for (int q = 0; q < C2L_PF; q++) {
+        for (int q = 0; q < C2L_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2_COUNT_THREADS;
             if (i < nqA) quad(cur[d][q], i, offA, endA, takeA);
             if (i < nqB) quad(cur[d + 1][q], i, offB, endB, takeB);
@@ -1056,31 +1057,31 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
         }
         par ^= 1;
     };
-    static_assert(C2L_DEPTH % 2 == 0, "buckets are taken in pairs");
-    // A GROUP of C2L_DEPTH buckets per iteration.  Their keys move to `cur` FIRST (the compiler waits for every load in
+    static_assert(C2L_DEPTH_ % 2 == 0, "buckets are taken in pairs");
+    // A GROUP of C2L_DEPTH_ buckets per iteration.  Their keys move to `cur` FIRST (the compiler waits for every load in
     // flight at the first use of a loaded register -- vmcnt(0): it cannot count the conditional loads), THEN the loads
     // of the next group are issued, THEN the group is processed bucket by bucket: the wait at the top of the next
     // iteration finds loads that are a whole group old, and one memory round trip is paid per group, not per bucket
     // (per bucket, issued after the work: 1.75 ms per Arabidopsis-like pass; copy-issue-work: 1.49; groups of 4: see
     // profiles/r03_notes.md).
-    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L_DEPTH * gridDim.x, j0 += C2L_DEPTH) {
+    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L_DEPTH_ * gridDim.x, j0 += C2L_DEPTH_) {
 #pragma unroll
-        for (int d = 0; d < C2L_DEPTH; d++) {
+        for (int d = 0; d < C2L_DEPTH_; d++) {
 #pragma unroll
-            for (int q = 0; q < C2L_PF; q++) cur[d][q] = pf[d][q];
+            for (int q = 0; q < C2L_PF_; q++) cur[d][q] = pf[d][q];
             c_a0[d] = p_a0[d];
             c_off[d] = p_off[d];
             c_n[d] = p_n[d];
             c_base[d] = p_base[d];
         }
 #pragma unroll
-        for (int d = 0; d < C2L_DEPTH; d++)
-            issue(d, fb0 + (int64_t)(d + C2L_DEPTH) * gridDim.x, j0 + d + C2L_DEPTH);
+        for (int d = 0; d < C2L_DEPTH_; d++)
+            issue(d, fb0 + (int64_t)(d + C2L_DEPTH_) * gridDim.x, j0 + d + C2L_DEPTH_);
 #pragma unroll
-        for (int d = 0; d < C2L_DEPTH; d += 2) {
+        for (int d = 0; d < C2L_DEPTH_; d += 2) {
             const int64_t fbA = fb0 + (int64_t)d * gridDim.x, fbB = fbA + gridDim.x;
             if (fbA >= n_fine) break;           // block-uniform
-            const uint32_t lim = (uint32_t)C2L_PF * C2_COUNT_THREADS * 4u - 8u;
+            const uint32_t lim = (uint32_t)C2L_PF_ * C2_COUNT_THREADS * 4u - 8u;
             if (fbB < n_fine && c_n[d] < 65536u && c_n[d + 1] < 65536u && c_n[d] <= lim && c_n[d + 1] <= lim) {
                 pair(d, fbA, fbB);
             } else {
@@ -1165,16 +1166,21 @@ c2_spans_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t list_div)
     const c2_bdesc D = desc[blockIdx.y];
     c2_spans_body(D.off_fine, D.cur2, n_fine, D.span, D.d_len4 + 3, list_div);
 }
+// BIG: chromosomes of 2^26 bases or more (peanut-like 128 Mb: ~8 K keys per fine bucket) hold FOUR quads per thread and bucket
+// in registers, two buckets per group -- 16 K keys per bucket never leave the registers, where the default geometry (two quads,
+// groups of four: made for 20-Mb chromosomes with ~1.2 K keys per bucket) sent every bucket above 8 K keys through the
+// crowded path (re-read from memory, all 2^15 counters walked): peanut-like pass 23.23 -> 22.82 ms (round 6)
+template <bool BIG>
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
               unsigned long long *__restrict__ out3, uint2 *__restrict__ stage, unsigned long long stage_cap,
               uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
-    c2_count_list_body(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
+    c2_count_list_body<(BIG ? 2 : C2L_DEPTH), (BIG ? 4 : C2L_PF)>(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
 }
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count_list_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
     const c2_bdesc D = desc[blockIdx.y];
-    c2_count_list_body(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
+    c2_count_list_body<C2L_DEPTH, C2L_PF>(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
 }
 
 int sp_ovf_finalize(sp_ctx *ctx, sp_chrom &c, const uint2 *tmp, const uint32_t *seg_base, const uint32_t *seg_cnt,
@@ -1327,9 +1333,15 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
               (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3, (uint32_t)(list ? lower : 0));
     if (list) {
         if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
-        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
-        SP_LAUNCH(ctx, "c2_count_list", c2_count_list, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
-                  (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+        if (c.len >= (1LL << 26)) {
+            SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+            SP_LAUNCH(ctx, "c2_count_list", c2_count_list<true>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
+                      (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+        } else {
+            SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+            SP_LAUNCH(ctx, "c2_count_list", c2_count_list<false>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
+                      (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+        }
         return sp_ovf_finalize_split(ctx, (unsigned long long *)list->d_keys, list->d_cnts, ovf_tmp, seg_base, seg_cnt, seg_off,
                                      (int64_t)nf, d_len4 + 2);
     }

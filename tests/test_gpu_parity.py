@@ -1137,6 +1137,31 @@ def test_full_size_properties(gpu_ctx):
     assert gpu_ctx.labels_hit() == keys3.size
 
 
+def test_peanut_sized_chromosomes_list_engine(gpu_ctx):
+    """Two chromosomes of 2^26 + bases (the peanut-like size class: ~8 K keys per fine bucket) counted as LISTS (engine 3: the
+    four-quads-per-thread geometry of c2_count_list, round 6, chains side by side) and as byte tables (engine 2): same lengths,
+    identical dumps at two thresholds."""
+    n = (1 << 26) + 5_000_000
+    ds = [gpu_ctx.dev_alloc(n), gpu_ctx.dev_alloc(n)]
+    try:
+        for i, d in enumerate(ds):
+            gpu_ctx.synth_chrom(d, n, seed=2, set_id=i, sg_id=i, n_sg=2, chrom_id=i)
+        gpu_ctx.genome_reset(2)
+        for i, d in enumerate(ds):
+            gpu_ctx.genome_add_device(i, d, n)
+        for lower in (2, 3):
+            res = {}
+            for eng in (3, 2):
+                gpu_ctx.count(15, lower, eng)
+                res[eng] = (gpu_ctx.lengths().tolist(), [gpu_ctx.dump(i) for i in range(2)])
+            assert res[3][0] == res[2][0] and min(res[3][0]) > 100_000, (lower, res[3][0], res[2][0])
+            for i in range(2):
+                assert (res[3][1][i][0] == res[2][1][i][0]).all() and (res[3][1][i][1] == res[2][1][i][1]).all(), (lower, i)
+    finally:
+        for d in ds:
+            gpu_ctx.dev_free(d)
+
+
 def test_wheat_sized_chromosome_properties(gpu_ctx):
     """A chromosome of the size BASELINE.json's headline config uses (667 Mb) is far beyond what the
     CPU oracle finishes in seconds, so the check is by size-independent properties:
