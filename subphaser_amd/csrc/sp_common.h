@@ -129,6 +129,8 @@ struct sp_ctx {
     sp_buf b_ctab, b_covf;       // compact pair table (S <= 3: buckets of two tagged entries) and its overflow table (sp_map.h)
     int ct_bb = 0;               // bucket bits of the compact table the current label set lives in (0: the direct table)
     uint32_t ct_ovf_mask = 0;
+    int sq_bb = 0;               // k > 15: bucket bits of the quad-bucket table (sp_sparse.hip; lives in b_ctab / b_covf), 0: hash table
+    uint64_t sq_ovf_mask = 0;
     int map_engine = 0;          // 0 = pair table (S <= 7), 1 = label table
     bool labels_ready = false;
     uint32_t *d_bloom = nullptr; // L2-resident pair filter over hashed (k-1)-mers (sp_map.hip), 2^bloom_bits bits

@@ -352,17 +352,182 @@ k5_map_sparse_lab(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ 
     if (threadIdx.x == 0 && t) atomicAdd(n_mapped, t);
 }
 
+// ------------------------------------------------------------------ quad-bucket label table for k > 15 (round 6)
+// The k <= 15 compact table (sp_map.h) with 64-bit entries: the two pairs of a QUAD of starts share the (k-3)-mer core t =
+// last k-3 bases of x1 = first k-3 bases of x2, the table is addressed by the canonical core -- bucket = top bb bits of a
+// bijective mix of t -- and ONE 32-byte bucket of four tagged entries answers all four starts, where the pair-keyed hash table
+// above costs one 16-byte look-up per candidate PAIR (1.5 G against 0.96 G per wheat-like pass; the look-ups are what the
+// kernel waits for).  An entry belongs to a (k-1)-mer y read in the orientation in which its core at one end is canonical:
+// side 0 ("L") y = e + t, side 1 ("R") y = t + e, e = the two bases beyond t; it holds the labels of the eight k-mers b + y,
+// y + b in THAT orientation (eight 3-bit fields: label 1..3, "seen" in the third bit).  Entry = tag << 25 | overflow flag << 24 |
+// fields; tag = the tb = 2 (k - 3) - bb low bits of mix(t) << 5 | side << 4 | e: bucket + tag determine (t, side, e), a tag
+// match is exact; tb + 5 <= 39 bits (else -- k = 31 / 32 with a small label set -- the hash table stays).  0 = empty.  A key
+// that finds its bucket full goes to an open-addressing overflow table of {key id + 1, fields} pairs.  S <= 3.
+#define SQ_FIELD 3
+#define SQ_ANY 0x6DB6DBULL
+#define SQ_PAYLOAD 0xFFFFFFULL
+#define SQ_OVF (1ULL << 24)
+#define SQ_TAG_BITS 39
+struct sq_tab {
+    unsigned long long *buckets;      // 4 entries (32 bytes) per bucket, or NULL: the pair-keyed hash table is in use
+    unsigned long long *ovf;          // overflow table: {key id + 1, fields} pairs, 0 = empty
+    uint64_t ovf_mask;                // its pairs - 1
+    int sb, tb;                       // bits of the core 2 (k - 3); bits of mix(t) kept in the tag
+};
+__host__ __device__ __forceinline__ uint64_t sq_mix(uint64_t x, int kb) {      // a bijection of the kb-bit values (kb <= 58)
+    const uint64_t m = (1ULL << kb) - 1ULL;
+    x = (x * 0x9E3779B97F4A7C15ULL) & m;
+    x ^= x >> ((kb + 1) / 2);
+    x = (x * 0xD6E8FEB86659FD93ULL) & m;
+    x ^= x >> ((kb + 1) / 2);
+    return x;
+}
+struct sq_key {
+    uint64_t bucket, tag, kid;
+};
+__host__ __device__ __forceinline__ sq_key sq_key_of(const sq_tab &T, uint64_t t, uint32_t side, uint32_t e) {
+    const uint64_t h = sq_mix(t, T.sb);
+    sq_key r;
+    r.bucket = h >> T.tb;
+    r.tag = ((h & ((1ULL << T.tb) - 1ULL)) << 5) | ((uint64_t)side << 4) | e;
+    r.kid = (t << 5) | ((uint64_t)side << 4) | e;
+    return r;
+}
+__device__ __forceinline__ void sq_insert(const sq_tab &T, const sq_key &q, uint64_t bits, unsigned long long *fail) {
+    unsigned long long *e = T.buckets + 4 * q.bucket;
+    const unsigned long long fresh = (q.tag << 25) | bits;
+    for (int j = 0; j < 4; j++) {
+        const int i = (int)((q.tag + (uint64_t)j) & 3ULL);      // (every key starts at the entry its own tag names)
+        const unsigned long long old = atomicCAS(&e[i], 0ULL, fresh);
+        if (old == 0ULL) return;
+        if ((old >> 25) == q.tag && (old & SQ_PAYLOAD)) {
+            atomicOr(&e[i], (unsigned long long)bits);
+            return;
+        }
+    }
+    atomicOr(&e[0], (unsigned long long)SQ_OVF);
+    uint64_t i = (sps_mix(q.kid) >> 7) & T.ovf_mask;
+    for (uint64_t probes = 0; probes <= T.ovf_mask; probes++) {
+        const unsigned long long old = atomicCAS(&T.ovf[2 * i], 0ULL, (unsigned long long)(q.kid + 1ULL));
+        if (old == 0ULL) atomicAdd(fail + 1, 1ULL);      // (statistics: keys in the overflow table)
+        if (old == 0ULL || old == q.kid + 1ULL) {
+            atomicOr(&T.ovf[2 * i + 1], (unsigned long long)bits);
+            return;
+        }
+        i = (i + 1ULL) & T.ovf_mask;
+    }
+    atomicAdd(fail, 1ULL);      // the overflow table is full: the host falls back to the hash table
+}
+struct sq_hit {
+    uint32_t fields, loc;             // loc: 4 * bucket + entry, or 0x80000000 | overflow pair: where the "seen" bits go
+};
+__device__ __forceinline__ sq_hit sq_find(const sq_tab &T, const ulonglong2 &B0, const ulonglong2 &B1, uint64_t bucket, uint64_t tag,
+                                          uint64_t t, uint32_t side_e /* side << 4 | e */) {
+    sq_hit r;
+    const unsigned long long w[4] = {B0.x, B0.y, B1.x, B1.y};
+    r.fields = 0;
+    r.loc = (uint32_t)(4ULL * bucket);
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+        if ((w[i] >> 25) == tag && (w[i] & SQ_PAYLOAD)) {
+            r.fields = (uint32_t)(w[i] & SQ_PAYLOAD);
+            r.loc = (uint32_t)(4ULL * bucket) + (uint32_t)i;
+        }
+    if (!r.fields && (B0.x & SQ_OVF)) {         // rare: the bucket overflowed and the key is in none of its entries
+        const uint64_t kid = (t << 5) | side_e;
+        uint64_t i = (sps_mix(kid) >> 7) & T.ovf_mask;
+        for (uint64_t probes = 0; probes <= T.ovf_mask; probes++) {      // (bounded: a full table has no empty slot to stop at)
+            const unsigned long long o = T.ovf[2 * i];
+            if (o == 0ULL) break;
+            if (o == kid + 1ULL) {
+                r.fields = (uint32_t)(T.ovf[2 * i + 1] & SQ_PAYLOAD);
+                r.loc = 0x80000000u | (uint32_t)i;
+                break;
+            }
+            i = (i + 1ULL) & T.ovf_mask;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ void sq_mark(const sq_tab &T, uint32_t loc, uint32_t bits) {
+    if (loc & 0x80000000u) atomicOr(&T.ovf[2 * (size_t)(loc & 0x7fffffffu) + 1], (unsigned long long)bits);
+    else atomicOr(&T.buckets[loc], (unsigned long long)bits);
+}
+// The (up to four) table keys under which the k-mer `o` (ONE orientation, as given) is entered / found: its prefix and its
+// suffix (k-1)-mer, each under its first and its last (k-3)-mer -- but only where that core is canonical AS READ in this
+// orientation; the other orientation of the k-mer supplies the rest (a palindromic core is entered from both).  k >= 16.
+struct sq_site {
+    uint64_t t;
+    uint32_t side, e;
+    int field;
+};
+__host__ __device__ __forceinline__ int sq_sites(uint64_t o, int k, sq_site out[4]) {
+    const int sb = 2 * (k - 3);
+    const uint64_t m1mask = (1ULL << (2 * (k - 1))) - 1ULL, smask = (1ULL << sb) - 1ULL;
+    const uint64_t x[2] = {o >> 2, o & m1mask};                                          // prefix / suffix (k-1)-mer
+    const int field[2] = {4 + (int)(o & 3ULL), (int)((o >> (2 * (k - 1))) & 3ULL)};      // o = x + b  /  o = b + x
+    int n = 0;
+    for (int i = 0; i < 2; i++) {
+        const uint64_t u1 = x[i] >> 4, u2 = x[i] & smask;
+        if (u1 <= sp_revcomp(u1, k - 3)) {       // x = u1 + e: side R
+            out[n].t = u1; out[n].side = 1u; out[n].e = (uint32_t)(x[i] & 15ULL); out[n].field = field[i];
+            n++;
+        }
+        if (u2 <= sp_revcomp(u2, k - 3)) {       // x = e + u2: side L
+            out[n].t = u2; out[n].side = 0u; out[n].e = (uint32_t)(x[i] >> sb); out[n].field = field[i];
+            n++;
+        }
+    }
+    return n;
+}
+__global__ void __launch_bounds__(256)
+sq_build(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ sg, int64_t n, int k, sq_tab T,
+         unsigned long long *__restrict__ fail) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t o2[2] = {keys[i], sp_revcomp(keys[i], k)};
+    const uint64_t l = 1ULL + sg[i];
+    for (int r = 0; r < 2; r++) {
+        sq_site st[4];
+        const int ns = sq_sites(o2[r], k, st);
+        for (int j = 0; j < ns; j++) sq_insert(T, sq_key_of(T, st[j].t, st[j].side, st[j].e), l << (SQ_FIELD * st[j].field), fail);
+    }
+}
+__global__ void __launch_bounds__(256)
+sq_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, sq_tab T, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t o2[2] = {keys[i], sp_revcomp(keys[i], k)};
+        uint32_t seen = 0;
+        for (int r = 0; r < 2; r++) {
+            sq_site st[4];
+            const int ns = sq_sites(o2[r], k, st);
+            for (int j = 0; j < ns; j++) {
+                const sq_key q = sq_key_of(T, st[j].t, st[j].side, st[j].e);
+                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(T.buckets + 4 * q.bucket);
+                seen |= (sq_find(T, bp[0], bp[1], q.bucket, q.tag, st[j].t, (st[j].side << 4) | st[j].e).fields >> (SQ_FIELD * st[j].field)) & 4u;
+            }
+        }
+        c += seen ? 1 : 0;
+    }
+    const unsigned long long t = sp_block_sum_u64(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(out, t);
+}
+
 // ------------------------------------------------------------------ k5_map_sparse2 (round 5)
 // The pair kernel of rounds 1-4 was 532 KB of machine code -- the rolling scan unrolled over 95 bases with the hit path inlined
 // at every start -- against 64 KB of instruction cache, and it kept ONE probe in flight per lane.  This is the k5_map2 walk
 // (sp_map.hip) for 64-bit keys: the loop over the pairs of a unit stays rolled (32-base windows by run-time shifts out
 // of three rotating registers per stream), two pairs travel together (their filter probes, then their table look-ups),
 // a hit is a bit in three label planes and a unit's hits are settled once, by popcounts.  Pair-keyed table only
-// (S <= 7); the per-k-mer table takes k5_map_sparse_lab above.
+// (S <= 7); the per-k-mer table takes k5_map_sparse_lab above.  TABLE: 0 = the pair-keyed hash table (one look-up per candidate
+// pair, S <= 7), 1 = the quad buckets above (one per candidate quad, S <= 3; `htab` / `hmask` unused).
+template <int TABLE>
 __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                   const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
                                                   const uint32_t *__restrict__ bloom, int nbits,
-                                                  unsigned long long *__restrict__ htab, uint64_t hmask,
+                                                  unsigned long long *__restrict__ htab, uint64_t hmask, const sq_tab &T,
                                                   unsigned long long lab[3], unsigned long long cm = ~0ULL /* starts that count */) {
     unsigned long long ok_k, ok_x;      // k-mer at s0+j valid; shared (k-1)-mer at s0+j+1 valid
     {
@@ -371,7 +536,7 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
         const uint64_t invB = (uint64_t)nm[(s0 >> 5) + 1] | ((uint64_t)nm[(s0 >> 5) + 2] << 32);
         const uint32_t kA = ~(uint32_t)(badA | (invA >> (kp.k - 1))), kB = ~(uint32_t)(badB | (invB >> (kp.k - 1)));
         const uint32_t xA = ~(uint32_t)(badA >> 1), xB = ~(uint32_t)(badB >> 1);
-        ok_k = (unsigned long long)kA | ((unsigned long long)kB << 32);
+        ok_k = ((unsigned long long)kA | ((unsigned long long)kB << 32)) & cm;      // (not covered: neither counted nor marked seen)
         ok_x = (unsigned long long)xA | ((unsigned long long)xB << 32);
     }
     if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
@@ -447,28 +612,64 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                 if (v2) { last_wi = wi2; last_w = wd[1]; }
                 else if (v1) { last_wi = wi1; last_w = wd[0]; }
             }
+            constexpr int FW = TABLE ? SQ_FIELD : 4;
+            constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
+            constexpr uint32_t ANY = TABLE ? (uint32_t)SQ_ANY : 0x77777777u;
+            const bool cand[2] = {(wd[0] & bt[0]) == bt[0], (wd[1] & bt[1]) == bt[1]};      // (an invalid pair's word is 0)
             uint32_t e[2] = {0u, 0u};
-            uint64_t slot[2] = {0, 0};
+            uint32_t loc[2] = {0u, 0u};                               // TABLE: where a hit's "seen" bits go (sq_mark)
+            uint64_t slot[2] = {0, 0};                                // hash table: the pair's slot
+            bool fwd_[2] = {xf[0] <= xr[0], xf[1] <= xr[1]};          // orientation the fields are laid out in
+            if (TABLE) {
+                if (cand[0] || cand[1]) {
+                    // the core the two pairs share: last k-3 bases of x1 = first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so it is)
+                    const uint64_t s_f = cand[0] ? (xf[0] & cmask) : (xf[1] >> 4), s_r = cand[0] ? (xr[0] >> 4) : (xr[1] & cmask);
+                    const bool sfw = s_f <= s_r;
+                    const uint64_t t = sfw ? s_f : s_r;
+                    const uint64_t hm = sq_mix(t, T.sb);
+                    const uint64_t bucket = hm >> T.tb, tagb = (hm & ((1ULL << T.tb) - 1ULL)) << 5;
+                    // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+                    const uint32_t se1 = (sfw ? 0u : 16u) | (uint32_t)(sfw ? (xf[0] >> T.sb) : (xr[0] & 15ULL));
+                    const uint32_t se2 = (sfw ? 16u : 0u) | (uint32_t)(sfw ? (xf[1] & 15ULL) : (xr[1] >> T.sb));
+                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(T.buckets + 4 * bucket);
+                    const ulonglong2 B0 = bp[0], B1 = bp[1];
+                    if (cand[0]) {
+                        const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se1, t, se1);
+                        e[0] = hh.fields;
+                        loc[0] = hh.loc;
+                    }
+                    if (cand[1]) {
+                        const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se2, t, se2);
+                        e[1] = hh.fields;
+                        loc[1] = hh.loc;
+                    }
+                    fwd_[0] = fwd_[1] = sfw;      // the fields are laid out in the orientation in which t is canonical
+                }
+            } else {
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-                if ((wd[h] & bt[h]) == bt[h]) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);      // (an invalid pair's word is 0)
+                for (int h = 0; h < 2; h++)
+                    if (cand[h]) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                if (!(e[h] & 0x77777777u)) continue;
-                const bool fw = xf[h] <= xr[h];
+                if (!(e[h] & ANY)) continue;
+                const bool fw = fwd_[h];
                 const int f0 = fw ? (int)b0[h] : 7 - (int)b0[h], f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
-                const uint32_t okk = (uint32_t)((ok_k & cm) >> (j + 2 * h));     // (not covered: neither counted nor marked seen)
-                const uint32_t v0 = (okk & 1u) ? (e[h] >> (4 * f0)) & 15u : 0u;
-                const uint32_t v1 = (okk & 2u) ? (e[h] >> (4 * f1)) & 15u : 0u;
-                const uint32_t two = (v0 & 7u) | ((v1 & 7u) << 8);
+                const uint32_t okk = (uint32_t)(ok_k >> (j + 2 * h));
+                const uint32_t v0 = (okk & 1u) ? (e[h] >> (FW * f0)) & FMASK : 0u;
+                const uint32_t v1 = (okk & 2u) ? (e[h] >> (FW * f1)) & FMASK : 0u;
+                const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);
                 if (!two) continue;
 #pragma unroll
-                for (int bit = 0; bit < 3; bit++)
+                for (int bit = 0; bit < (TABLE ? 2 : 3); bit++)
                     lab[bit] |= (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1)) << (j + 2 * h);
                 uint32_t mark = 0;       // "seen": first touch only
-                if ((v0 & 7u) && !(v0 & 8u)) mark |= 8u << (4 * f0);
-                if ((v1 & 7u) && !(v1 & 8u)) mark |= 8u << (4 * f1);
-                if (mark) atomicOr(&htab[2 * slot[h] + 1], (unsigned long long)mark);
+                if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+                if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+                if (mark) {
+                    if (TABLE) sq_mark(T, loc[h], mark);
+                    else atomicOr(&htab[2 * slot[h] + 1], (unsigned long long)mark);
+                }
             }
         }
         l0 = l1; l1 = l2; l2 = l3; l3 = l4; l4 = l5;
@@ -477,9 +678,10 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
 }
 
 // (six waves per SIMD = TWO 768-thread workgroups per CU: at 82 VGPRs -- one more than that allows -- the kernel ran one: 52.6 -> 66.6 ms)
+template <int TABLE>
 __global__ void __launch_bounds__(MAP_BLOCK, 6)
 k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
-               sp_map_params P, unsigned long long *__restrict__ htab, uint64_t hmask, const uint32_t *__restrict__ bloom,
+               sp_map_params P, unsigned long long *__restrict__ htab, uint64_t hmask, sq_tab T, const uint32_t *__restrict__ bloom,
                int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
@@ -496,7 +698,7 @@ k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
         }
         if (u < P.n_units) {
             unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-            map_unit_scan64_h(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, lab);
+            map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab);
             if (lab[0] | lab[1] | lab[2]) {
                 auto add = [&](int64_t os, unsigned long long within) {
                     for (int sg = 0; sg < P.S; sg++) {
@@ -544,10 +746,11 @@ k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
 
 // feature mode (sp_map.hip: k5_map_feat2), pair-keyed table: the rolled walk over the starts whose k-mer crosses no feature
 // boundary, then popcounts of the label planes per overlapping feature
+template <int TABLE>
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_feat_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
                     int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
-                    unsigned long long *__restrict__ htab, uint64_t hmask,
+                    unsigned long long *__restrict__ htab, uint64_t hmask, sq_tab T,
                     const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -572,7 +775,7 @@ k5_map_feat_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict_
             if (e >= s0 + SP_UNIT) break;
         }
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64_h(pk, pm, nm, s0, kp, bloom, bloom_bits, htab, hmask, lab, fit);
+        map_unit_scan64_h<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, htab, hmask, T, lab, fit);
         if (!(lab[0] | lab[1] | lab[2])) continue;
         for (int64_t f = lo; f < n_feat; f++) {
             const int64_t a = foff[f], e = foff[f + 1];
@@ -1694,20 +1897,58 @@ int sp_sparse_fetch(sp_ctx *ctx, bool hist, uint64_t *keys, uint32_t *counts, do
 
 int sp_map_filter_build(sp_ctx *ctx, const unsigned long long *d_keys, int64_t n);   // sp_map.hip
 
+// the quad-bucket table the current k > 15 label set lives in (buckets = NULL: the pair-keyed / per-k-mer hash table)
+static sq_tab sq_tab_of(const sp_ctx *ctx) {
+    sq_tab T;
+    T.buckets = ctx->sq_bb ? (unsigned long long *)ctx->b_ctab.p : nullptr;
+    T.ovf = (unsigned long long *)ctx->b_covf.p;
+    T.ovf_mask = ctx->sq_ovf_mask;
+    T.sb = 2 * (ctx->k - 3);
+    T.tb = ctx->sq_bb ? T.sb - ctx->sq_bb : 0;
+    return T;
+}
+
 int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, int64_t n, bool on_device) {
     // <= 7 subgenomes: the pair-keyed table (one look-up per candidate PAIR of starts); else one entry per k-mer
     const char *eng = getenv("SP_MAP_ENGINE");
     ctx->map_engine = (ctx->n_sg > 7 || (eng && eng[0] == '1')) ? 1 : 0;
     const bool pairs = ctx->map_engine == 0;
+    // round 6: <= 3 subgenomes -> the quad-bucket table (one 32-byte look-up per candidate QUAD of starts) when its tag fits;
+    // SP_CTAB=0 keeps the pair-keyed hash table (cross-check), SP_CTAB_FACTOR sizes the buckets (default: >= 2 n of them)
+    ctx->sq_bb = 0;
+    int bb = 8;
+    bool quad = false;
+    if (pairs && ctx->n_sg <= 3) {
+        const char *env_ct = getenv("SP_CTAB"), *env_f = getenv("SP_CTAB_FACTOR");
+        const int64_t factor = env_f && atoll(env_f) > 0 ? atoll(env_f) : 2;
+        const int sb = 2 * (ctx->k - 3);
+        while (bb < 30 && ((int64_t)1 << bb) < factor * (n > 0 ? n : 1)) bb++;
+        if (bb < sb - (SQ_TAG_BITS - 5)) bb = sb - (SQ_TAG_BITS - 5);      // the tag holds sb - bb bits of the mixed core + side + e
+        quad = bb <= 27 && bb <= sb && !(env_ct && env_ct[0] == '0');
+    }
     int64_t cap = 1024;
-    while (cap < (pairs ? 4 : 2) * n + 16) cap <<= 1;
+    if (!quad)
+        while (cap < (pairs ? 4 : 2) * n + 16) cap <<= 1;
     if (cap != ctx->hcap) {
         if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
         ctx->d_hkeys = nullptr;
         SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 16));
         ctx->hcap = cap;
     }
-    if (pairs) {
+    if (quad) {
+        // (d_hkeys stays allocated -- it is what "labels are set" is tested by -- but unused)
+        const int64_t nb = (int64_t)1 << bb;
+        int64_t ovf_n = 4096;
+        while (ovf_n < n / 2) ovf_n <<= 1;
+        int rcq = sp_buf_ensure(ctx, ctx->b_ctab, nb * 32);
+        if (rcq) return rcq;
+        rcq = sp_buf_ensure(ctx, ctx->b_covf, ovf_n * 16);
+        if (rcq) return rcq;
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_ctab.p, 0, (size_t)nb * 32, ctx->stream));
+        SP_HIP(ctx, hipMemsetAsync(ctx->b_covf.p, 0, (size_t)ovf_n * 16, ctx->stream));
+        ctx->sq_bb = bb;
+        ctx->sq_ovf_mask = (uint64_t)(ovf_n - 1);
+    } else if (pairs) {
         SP_LAUNCH(ctx, "sps_pair_init", sps_pair_init, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
                   (unsigned long long *)ctx->d_hkeys, cap);
     } else {
@@ -1727,14 +1968,45 @@ int sp_sparse_labels_set(sp_ctx *ctx, const uint64_t *keys, const uint8_t *sg, i
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     SP_HIP(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n * 8, kind, ctx->stream));
     SP_HIP(ctx, hipMemcpyAsync(d_sg, sg, (size_t)n, kind, ctx->stream));
-    if (pairs)
+    auto build_pairs = [&]() -> int {
         SP_LAUNCH(ctx, "sps_pair_insert", sps_pair_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                   (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, ctx->k, (unsigned long long *)ctx->d_hkeys,
-                  (uint64_t)(cap - 1));
-    else
+                  (uint64_t)(ctx->hcap - 1));
+        return SP_OK;
+    };
+    if (quad) {
+        // [2] = overflow table full, [3] = keys in the overflow table (the flags of this call: sp_labels_set zeroed them)
+        unsigned long long *d_flags = (unsigned long long *)ctx->b_lflags.p;
+        SP_LAUNCH(ctx, "sq_build", sq_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const unsigned long long *)d_keys,
+                  (const uint8_t *)d_sg, n, ctx->k, sq_tab_of(ctx), d_flags + 2);
+        unsigned long long hf[2] = {0, 0};
+        SP_HIP(ctx, hipMemcpyAsync(hf, d_flags + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (getenv("SP_DEBUG_FILTER"))
+            fprintf(stderr, "[sp] quad-bucket table (k > 15): 2^%d buckets, %llu entries in the overflow table (%lld labelled k-mers)\n",
+                    bb, hf[1], (long long)n);
+        if (hf[0]) {          // overflow table full (adversarial key sets only): the pair-keyed hash table takes over
+            ctx->sq_bb = 0;
+            cap = 1024;
+            while (cap < 4 * n + 16) cap <<= 1;
+            if (cap != ctx->hcap) {
+                if (ctx->d_hkeys) hipFree(ctx->d_hkeys);
+                ctx->d_hkeys = nullptr;
+                SP_HIP(ctx, hipMalloc(&ctx->d_hkeys, (size_t)cap * 16));
+                ctx->hcap = cap;
+            }
+            SP_LAUNCH(ctx, "sps_pair_init", sps_pair_init, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0,
+                      (unsigned long long *)ctx->d_hkeys, cap);
+            const int rcp = build_pairs();
+            if (rcp) return rcp;
+        }
+    } else if (pairs) {
+        const int rcp = build_pairs();
+        if (rcp) return rcp;
+    } else
         SP_LAUNCH(ctx, "sps_hash_insert", sps_hash_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                   (const unsigned long long *)d_keys, (const uint8_t *)d_sg, n, (unsigned long long *)ctx->d_hkeys,
-                  (uint64_t)(cap - 1));
+                  (uint64_t)(ctx->hcap - 1));
     const int rcf = sp_map_filter_build(ctx, d_keys, n);
     SP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rcf;
@@ -1747,8 +2019,13 @@ int sp_sparse_map_launch(sp_ctx *ctx, sp_chrom &c, const sp_map_params &P, int *
     int64_t grid = n_ranges;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     if (ctx->map_engine == 0 && P.S <= 7) {
-        SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
-                  (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
+        const sq_tab T = sq_tab_of(ctx);
+        if (T.buckets)
+            SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
+                      (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), T, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
+        else
+            SP_LAUNCH(ctx, "k5_map_sparse", k5_map_sparse2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, c.d_pk, c.d_pm, c.d_nm, kp, P,
+                      (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), T, ctx->d_bloom, ctx->bloom_bits, d_counts, d_n);
         return SP_OK;
     }
     if (ctx->map_engine == 0) return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
@@ -1762,11 +2039,17 @@ int sp_sparse_feat_launch(sp_ctx *ctx, const uint32_t *d_pk, const uint32_t *d_p
     const sp_kparams kp = sp_make_kparams(ctx->k);
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
-    if (ctx->map_engine == 0 && S <= 7)
-        SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_pm, d_nm,
-                  kp, n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), ctx->d_bloom,
-                  ctx->bloom_bits, d_counts);
-    else if (ctx->map_engine == 0)
+    if (ctx->map_engine == 0 && S <= 7) {
+        const sq_tab T = sq_tab_of(ctx);
+        if (T.buckets)
+            SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_pm, d_nm,
+                      kp, n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), T, ctx->d_bloom,
+                      ctx->bloom_bits, d_counts);
+        else
+            SP_LAUNCH(ctx, "k5_map_feat_sparse", k5_map_feat_sparse2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_pm, d_nm,
+                      kp, n_units, d_foff, n_feat, S, (unsigned long long *)ctx->d_hkeys, (uint64_t)(ctx->hcap - 1), T, ctx->d_bloom,
+                      ctx->bloom_bits, d_counts);
+    } else if (ctx->map_engine == 0)
         return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
     else
         SP_LAUNCH(ctx, "k5_map_feat_sparse_lab", k5_map_feat_sparse_lab, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, d_pk, d_nm, kp,
@@ -1794,9 +2077,10 @@ k5_map_mask_sparse_lab(const uint32_t *__restrict__ pk, const uint32_t *__restri
     }
 }
 
+template <int TABLE>
 __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_mask_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
-                    int64_t n_units, int S, unsigned long long *__restrict__ htab, uint64_t hmask, const uint32_t *__restrict__ bloom,
+                    int64_t n_units, int S, unsigned long long *__restrict__ htab, uint64_t hmask, sq_tab T, const uint32_t *__restrict__ bloom,
                     int bloom_bits, const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks) {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1804,7 +2088,7 @@ k5_map_mask_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict_
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64_h(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, lab, cv);
+        map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab, cv);
         for (int sg = 0; sg < S; sg++) {
             const int l = sg + 1;
             masks[u * S + sg] = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) & ((l & 4) ? lab[2] : ~lab[2]) & cv;
@@ -1818,9 +2102,15 @@ int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, cons
     int64_t grid = (n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     if (grid > (int64_t)ctx->n_cu * 16) grid = (int64_t)ctx->n_cu * 16;
     if (ctx->map_engine == 0 && S <= 7) {
-        SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse2, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
-                  (const uint32_t *)c.d_pm, (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys,
-                  (uint64_t)(ctx->hcap - 1), (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
+        const sq_tab T = sq_tab_of(ctx);
+        if (T.buckets)
+            SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse2<1>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
+                      (const uint32_t *)c.d_pm, (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys,
+                      (uint64_t)(ctx->hcap - 1), T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
+        else
+            SP_LAUNCH(ctx, "k5_map_mask_sparse", k5_map_mask_sparse2<0>, dim3((unsigned)grid), dim3(MAP_BLOCK), 0, (const uint32_t *)c.d_pk,
+                      (const uint32_t *)c.d_pm, (const uint32_t *)c.d_nm, kp, n_units, S, (unsigned long long *)ctx->d_hkeys,
+                      (uint64_t)(ctx->hcap - 1), T, (const uint32_t *)ctx->d_bloom, ctx->bloom_bits, d_cov, d_masks);
         return SP_OK;
     }
     if (ctx->map_engine == 0) return sp_fail(ctx, SP_ESTATE, "k > 15 map: the pair-keyed table holds at most 7 subgenomes");
@@ -1831,6 +2121,12 @@ int sp_sparse_mask_launch(sp_ctx *ctx, sp_chrom &c, int64_t n_units, int S, cons
 }
 
 int sp_sparse_hit(sp_ctx *ctx, unsigned long long *d_n) {
+    if (ctx->map_engine == 0 && ctx->sq_bb) {
+        if (ctx->n_labels > 0)
+            SP_LAUNCH(ctx, "sq_seen", sq_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,
+                      (const unsigned long long *)ctx->b_labkeys.p, ctx->n_labels, ctx->k, sq_tab_of(ctx), d_n);
+        return SP_OK;
+    }
     if (ctx->map_engine == 0) {
         if (ctx->n_labels > 0)
             SP_LAUNCH(ctx, "sps_pair_seen", sps_pair_seen, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0,

@@ -353,7 +353,7 @@ def test_list_filter_handful_of_kmers(gpu_ctx, oracle_ctx):
             assert a.shape == b.shape and (a == b).all(), (k, lower)
 
 
-@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer", "pairs+sort-filter"])
+@pytest.mark.parametrize("map_engine", ["pairs", "per-kmer", "pairs+sort-filter", "pairs-hash", "pairs-crowded"])
 @pytest.mark.parametrize("k", [17, 21, 32])
 def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkeypatch):
     """k = 17 / 21 (BASELINE config 5) and 32: matrix rows and bin counts bit-exact vs the oracle, with the
@@ -364,6 +364,13 @@ def test_filter_and_map_sparse_engine(gpu_ctx, oracle_ctx, k, map_engine, monkey
         monkeypatch.setenv("SP_MAP_ENGINE", "1")
     if map_engine == "pairs+sort-filter":
         monkeypatch.setenv("SP_LIST_FILTER", "sort")
+    # "pairs" = the quad-bucket table since round 6 (<= 3 subgenomes: one 32-byte bucket per candidate QUAD of starts);
+    # "pairs-hash" = the pair-keyed hash table it replaced (SP_CTAB=0, still the table for 4..7 subgenomes); "pairs-crowded" = the
+    # quad buckets at ~4 keys per bucket of four, so that many keys live in the overflow table
+    if map_engine == "pairs-hash":
+        monkeypatch.setenv("SP_CTAB", "0")
+    if map_engine == "pairs-crowded":
+        monkeypatch.setenv("SP_CTAB_FACTOR", "1")
     rng = np.random.RandomState(400 + k)
     reps = [_rand_seq(rng, 350, 0, 0) for _ in range(6)]
     seqs = []
