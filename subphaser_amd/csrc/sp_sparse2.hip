@@ -52,7 +52,12 @@ static s3_plan s3_make_plan(int k) {
 #ifndef S3_B2
 #define S3_B2 9
 #endif
-    p.B2 = S3_B2;
+    // Round 6: k = 16 / 17 split level 2 into 2^8 instead of 2^9: the bitmap finish takes 16-bit residuals anyway, and with
+    // half as many fine buckets of twice the keys (2.6 K on a wheat-sized chromosome) s3_part2 writes runs of twice the
+    // length and every per-bucket step of the finish -- seven barriers, two block scans -- is paid half as often:
+    // wheat-like k = 17 pass 213.2 -> 195.5 ms (s3_part2 149 -> 115 ms of events).  k >= 18 (hash finish) stays at 2^9:
+    // 2^8 sends its buckets past the table's capacity (k = 21: 429 ms), 2^10 is slower as well (228 against 220).
+    p.B2 = k <= 17 ? 8 : S3_B2;
     p.R1 = p.T - p.B1;
     p.R2 = p.R1 - p.B2;
     p.F1 = 1 << p.B1;
@@ -943,7 +948,7 @@ s3_final_small(const KR2 *__restrict__ buf2, const ulonglong2 *__restrict__ span
 // counter accesses; a variant whose first-arriving copy writes the pair out instead of the bit walk was no faster).
 #define S3_BM_MAXBITS 16
 #ifndef S3_BM_CAP
-#define S3_BM_CAP 2048      // distinct residuals per bucket this kernel takes (cnt[] entries); beyond: s3_final
+#define S3_BM_CAP 4096      // distinct residuals per bucket this kernel takes (cnt[] entries); beyond: s3_final
 #endif
 #define S3_BM_NMAX (1u << 22)   // keys per bucket it is willing to stream (hot buckets: few distinct, many copies)
 #define S3_BM_PER 8             // keys per thread prefetched into registers (buckets up to 2048 keys never re-read)
