@@ -275,7 +275,7 @@ def main():
         from subphaser_amd._native import csrc_fingerprint
         # one table per measured (genome, k): profiles/r04_wheat_pmc.json, r04_wheat_k17_pmc.json, r04_peanut_pmc.json ...
         pmc = "%s_pmc.json" % args.config if args.k == 15 else "%s_k%d_pmc.json" % (args.config, args.k)
-        for rnd in ("r05", "r04", "r03"):
+        for rnd in ("r06", "r05", "r04", "r03"):
             path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, pmc))
             if os.path.exists(path):
                 pj = json.load(open(path))

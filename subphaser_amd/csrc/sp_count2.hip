@@ -1098,6 +1098,176 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- c2_count_list16 (round 6)
+// c2_count_list holds ONE 1024-thread workgroup per CU (128 KiB of counters), and on a 20-Mb chromosome a fine bucket is ~1.2 K keys:
+// two barriers and a chain of dependent LDS round trips per bucket (or pair of buckets) with nothing else resident to fill
+// the CU.  A bucket of fewer than 65536 keys cannot push a counter past 16 bits, so its counters are packed two to a word
+// (64 KiB) and TWO 512-thread workgroups share a CU, one in its barrier while the other works -- the step c2_count16 took for
+// the table engine in round 4.  One bucket at a time (no pairs: the halves of a word are two SLOTS here), groups of four
+// buckets per memory round trip as before.  A bucket of 65536 keys or more (a hot repeat) raises the chromosome's overrun
+// flag: the host counts that chromosome again with exact sizes, which takes the 32-bit kernel above.
+#define C2L16_THREADS 512
+#define C2L16_DEPTH 4
+#define C2L16_PF 2       // quads per thread and bucket held in registers: 4096 keys
+__device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine,
+              uint32_t lower, unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[3]=overrun flag*/,
+              uint2 *__restrict__ stage, unsigned long long stage_cap, uint32_t *__restrict__ seg_base,
+              uint32_t *__restrict__ seg_cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // C2_FINE / 2 words: slot r in half (r & 1) of word r >> 1
+    __shared__ unsigned long long red[16];
+    __shared__ uint32_t s_nov[2];
+    __shared__ ulonglong2 s_span[C2L_MAXB];
+    unsigned long long s = 0, n = 0;
+    {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = threadIdx.x; i < C2_FINE / 8; i += C2L16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < 2) s_nov[threadIdx.x] = 0;
+        for (int64_t j = threadIdx.x, fbn = blockIdx.x + (int64_t)threadIdx.x * gridDim.x; j < C2L_MAXB && fbn < n_fine;
+             j += C2L16_THREADS, fbn += (int64_t)C2L16_THREADS * gridDim.x)
+            s_span[j] = span[fbn];
+    }
+    __syncthreads();
+    uint2 pf[C2L16_DEPTH][C2L16_PF];
+    unsigned long long p_a0[C2L16_DEPTH];
+    uint32_t p_off[C2L16_DEPTH], p_n[C2L16_DEPTH], p_base[C2L16_DEPTH];
+    auto issue = [&](int d, int64_t fbn, int64_t j) {
+        p_a0[d] = 0;
+        p_off[d] = p_n[d] = p_base[d] = 0;
+        if (fbn >= n_fine) return;
+        const ulonglong2 sp = s_span[j];
+        p_a0[d] = sp.x & ~3ULL;
+        p_off[d] = (uint32_t)(sp.x & 3ULL);
+        p_n[d] = (uint32_t)sp.y;
+        p_base[d] = (uint32_t)(sp.y >> 32);
+        if (p_n[d] >= 65536u) return;      // (not this kernel's: no loads)
+        const uint32_t nq = (p_off[d] + p_n[d] + 3u) >> 2;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + p_a0[d]);
+#pragma unroll
+        for (int q = 0; q < C2L16_PF; q++) {
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
+            if (i < nq) pf[d][q] = p2[i];
+        }
+    };
+    auto quad = [&](const uint2 v, uint32_t i, uint32_t off, uint32_t end, auto &&f) {
+        const uint32_t k0 = 4u * i;
+        if (k0 + 0 >= off && k0 + 0 < end && !(v.x & 0x8000u)) f(v.x & 0xffffu);
+        if (k0 + 1 >= off && k0 + 1 < end && !(v.x & 0x80000000u)) f(v.x >> 16);
+        if (k0 + 2 >= off && k0 + 2 < end && !(v.y & 0x8000u)) f(v.y & 0xffffu);
+        if (k0 + 3 >= off && k0 + 3 < end && !(v.y & 0x80000000u)) f(v.y >> 16);
+    };
+#pragma unroll
+    for (int d = 0; d < C2L16_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
+    int par = 0;
+    int64_t j0 = 0;
+    uint2 cur[C2L16_DEPTH][C2L16_PF];
+    unsigned long long c_a0[C2L16_DEPTH];
+    uint32_t c_off[C2L16_DEPTH], c_n[C2L16_DEPTH], c_base[C2L16_DEPTH];
+    auto one = [&](int d, int64_t fb) {
+        if (c_n[d] >= 65536u) {      // block-uniform: the chromosome is counted again by the 32-bit kernel
+            if (threadIdx.x == 0) {
+                atomicAdd(&out3[3], 1ULL);
+                seg_cnt[fb] = 0;
+            }
+            return;
+        }
+        const uint32_t off = c_off[d], end = c_off[d] + c_n[d], nq = (end + 3u) >> 2;
+        const bool in_regs = nq <= (uint32_t)C2L16_PF * C2L16_THREADS;      // block-uniform
+        const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
+        const unsigned long long base = c_base[d];
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + c_a0[d]);
+        auto add = [&](uint32_t r) { atomicAdd(&cnt[r >> 1], 1u << (16u * (r & 1u))); };
+        // ---- pass 1: count
+#pragma unroll
+        for (int q = 0; q < C2L16_PF; q++) {
+            const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
+            if (i < nq) quad(cur[d][q], i, off, end, add);
+        }
+        if (!in_regs)
+            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L16_PF * C2L16_THREADS; i0 < nq; i0 += 4u * C2L16_THREADS) {
+                uint2 vv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t i = i0 + (uint32_t)t * C2L16_THREADS;
+                    vv[t] = p2[i < nq ? i : nq - 1u];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t i = i0 + (uint32_t)t * C2L16_THREADS;
+                    if (i < nq) quad(vv[t], i, off, end, add);
+                }
+            }
+        sp_barrier_lds();   // (A) counts complete
+        auto emit = [&](uint32_t r, uint32_t c) {
+            if (c >= lower) {
+                s += c;
+                n++;
+                const unsigned long long pos = base + atomicAdd(&s_nov[par], 1u);
+                if (pos < stage_cap) stage[pos] = make_uint2(slot0 + r, c);
+            }
+        };
+        // ---- pass 2: every key clears its half of its word; the one lane that gets the count back owns the slot
+        if (in_regs) {
+            auto take = [&](uint32_t r) {
+                const uint32_t sh = 16u * (r & 1u);
+                const uint32_t c = (atomicAnd(&cnt[r >> 1], ~(0xffffu << sh)) >> sh) & 0xffffu;
+                if (c) emit(r, c);
+            };
+#pragma unroll
+            for (int q = 0; q < C2L16_PF; q++) {
+                const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
+                if (i < nq) quad(cur[d][q], i, off, end, take);
+            }
+        } else {           // a crowded bucket: walk the counters instead of the keys
+            uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+            for (int i = threadIdx.x; i < C2_FINE / 8; i += C2L16_THREADS) {
+                const uint4 v = c4[i];
+                if (v.x | v.y | v.z | v.w) {
+                    c4[i] = make_uint4(0, 0, 0, 0);
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        emit(8 * i + 2 * q, w4[q] & 0xffffu);
+                        emit(8 * i + 2 * q + 1, w4[q] >> 16);
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) s_nov[par ^ 1] = 0;     // the other parity's tally was read after the previous (B)
+        sp_barrier_lds();   // (B) counters clean, tally final
+        if (threadIdx.x == 0) {
+            seg_cnt[fb] = s_nov[par];
+            seg_base[fb] = (uint32_t)base;
+        }
+        par ^= 1;
+    };
+    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L16_DEPTH * gridDim.x, j0 += C2L16_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < C2L16_DEPTH; d++) {
+#pragma unroll
+            for (int q = 0; q < C2L16_PF; q++) cur[d][q] = pf[d][q];
+            c_a0[d] = p_a0[d];
+            c_off[d] = p_off[d];
+            c_n[d] = p_n[d];
+            c_base[d] = p_base[d];
+        }
+#pragma unroll
+        for (int d = 0; d < C2L16_DEPTH; d++)
+            issue(d, fb0 + (int64_t)(d + C2L16_DEPTH) * gridDim.x, j0 + d + C2L16_DEPTH);
+#pragma unroll
+        for (int d = 0; d < C2L16_DEPTH; d++) {
+            const int64_t fb = fb0 + (int64_t)d * gridDim.x;
+            if (fb >= n_fine) break;           // block-uniform
+            one(d, fb);
+        }
+    }
+    unsigned long long ts = sp_block_sum_u64(s, red);
+    unsigned long long tn = sp_block_sum_u64(n, red);
+    if (threadIdx.x == 0) {
+        if (ts) atomicAdd(&out3[0], ts);
+        if (tn) atomicAdd(&out3[1], tn);
+    }
+}
+
 // ---------------------------------------------------------------- kernels: one chromosome, or one per blockIdx.y
 __global__ void __launch_bounds__(C2_P1_THREADS)
 c2_hist_fine(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm,
@@ -1176,6 +1346,17 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
               unsigned long long *__restrict__ out3, uint2 *__restrict__ stage, unsigned long long stage_cap,
               uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
     c2_count_list_body<(BIG ? 2 : C2L_DEPTH), (BIG ? 4 : C2L_PF)>(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
+}
+__global__ void __launch_bounds__(C2L16_THREADS)
+c2_count_list16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
+                unsigned long long *__restrict__ out3, uint2 *__restrict__ stage, unsigned long long stage_cap,
+                uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
+    c2_count_list16_body(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
+}
+__global__ void __launch_bounds__(C2L16_THREADS)
+c2_count_list16_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
+    const c2_bdesc D = desc[blockIdx.y];
+    c2_count_list16_body(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
 }
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count_list_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
@@ -1333,7 +1514,15 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
               (const unsigned long long *)cur2, (int64_t)nf, span, d_len4 + 3, (uint32_t)(list ? lower : 0));
     if (list) {
         if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
-        if (c.len >= (1LL << 26)) {
+        const char *env_l16 = getenv("SP_C2_LIST16");      // "0": the 32-bit list counter everywhere (cross-check)
+        if (!exact && c.len < (1LL << 26) && !(env_l16 && env_l16[0] == '0')) {
+            // (estimate mode only: a bucket of 65536 keys or more raises the overrun flag and the exact recount takes the kernel below)
+            int g16 = (int)((int64_t)nf < (int64_t)ctx->n_cu * 2 ? (int64_t)nf : (int64_t)ctx->n_cu * 2);
+            if ((int64_t)g16 * C2L_MAXB < (int64_t)nf) g16 = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
+            SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list16, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 2));
+            SP_LAUNCH(ctx, "c2_count_list", c2_count_list16, dim3(g16), dim3(C2L16_THREADS), C2_FINE * 2, buf2,
+                      (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+        } else if (c.len >= (1LL << 26)) {
             SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
             SP_LAUNCH(ctx, "c2_count_list", c2_count_list<true>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
                       (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
@@ -1510,10 +1699,21 @@ int sp_count_engine3_batch(sp_ctx *ctx, const int *chrom_idx, int n, const sp_kp
     SP_LAUNCH(ctx, "c2_part2", c2_part2_b, dim3(cap_grid(max_tiles2, 8), un), dim3(C2_P2_THREADS), 0, (const c2_bdesc *)d_desc, V1, P.F2, C2_B3);
     SP_LAUNCH(ctx, "c2_spans", c2_spans_b, dim3((unsigned)((nf + 255) / 256), un), dim3(256), 0, (const c2_bdesc *)d_desc, (int64_t)nf,
               (uint32_t)lower);
-    unsigned gridc = cap_grid((int64_t)nf, 1);
-    if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (unsigned)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
-    SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list_b, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
-    SP_LAUNCH(ctx, "c2_count_list", c2_count_list_b, dim3(gridc, un), dim3(C2_COUNT_THREADS), C2_FINE * 4, (const c2_bdesc *)d_desc, (int64_t)nf,
-              (uint32_t)lower);
+    const char *env_l16 = getenv("SP_C2_LIST16");      // "0": the 32-bit list counter (cross-check)
+    if (!(env_l16 && env_l16[0] == '0')) {
+        // two 512-thread workgroups per CU on 16-bit counters (a bucket of >= 65536 keys raises the chromosome's overrun flag: the
+        // caller counts it again, alone, with exact sizes and the 32-bit kernel)
+        unsigned g16 = cap_grid((int64_t)nf, 2);
+        if ((int64_t)g16 * C2L_MAXB < (int64_t)nf) g16 = (unsigned)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list16_b, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 2));
+        SP_LAUNCH(ctx, "c2_count_list", c2_count_list16_b, dim3(g16, un), dim3(C2L16_THREADS), C2_FINE * 2, (const c2_bdesc *)d_desc, (int64_t)nf,
+                  (uint32_t)lower);
+    } else {
+        unsigned gridc = cap_grid((int64_t)nf, 1);
+        if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (unsigned)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
+        SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list_b, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
+        SP_LAUNCH(ctx, "c2_count_list", c2_count_list_b, dim3(gridc, un), dim3(C2_COUNT_THREADS), C2_FINE * 4, (const c2_bdesc *)d_desc, (int64_t)nf,
+                  (uint32_t)lower);
+    }
     return sp_ovf_finalize_split_batch(ctx, d_desc, n, (int64_t)nf);
 }

@@ -167,6 +167,25 @@ def test_count_engine3_lists(gpu_ctx, k):
         gpu_ctx.count(5, 3, 3)            # 2^9 slots: no partition plan
 
 
+@pytest.mark.parametrize("counters", ["16-bit", "32-bit"])
+def test_count_engine3_list_counter_widths(gpu_ctx, monkeypatch, counters):
+    """The list counter of small genomes (round 6): c2_count_list16 -- two 512-thread workgroups per CU on 16-bit counters -- hands
+    a chromosome with a bucket of 65536 keys or more (300 K copies of one k-mer) back through the overrun flag, and the exact
+    recount takes the 32-bit kernel; SP_C2_LIST16=0 runs the 32-bit kernel everywhere.  Batched (several chromosomes per launch) and
+    per-chromosome chains, dumps against the oracle."""
+    if counters == "32-bit":
+        monkeypatch.setenv("SP_C2_LIST16", "0")
+    rng = np.random.RandomState(4242)
+    hot = np.concatenate([_rand_seq(rng, 40000), np.frombuffer(b"A" * 300000, np.uint8), _rand_seq(rng, 40000)])
+    seqs = [_rand_seq(rng, 900_001), hot, _rand_seq(rng, 333), _rand_seq(rng, 250_000)]
+    for batch in ("1", "0"):
+        monkeypatch.setenv("SP_C2_BATCH", batch)
+        r0 = gpu_ctx.count_recounts()
+        _count_both(gpu_ctx, seqs, 15, 2, engine=3)
+        if counters == "16-bit":
+            assert gpu_ctx.count_recounts() > r0      # the hot chromosome went through the exact recount
+
+
 def test_count_engine2_unsupported_small_k(gpu_ctx):
     gpu_ctx.genome_reset(1)
     gpu_ctx.genome_add(0, b"ACGT" * 100)

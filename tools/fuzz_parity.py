@@ -55,8 +55,10 @@ def run(iters, seed, gpu, ora, verbose=True, streams=False):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from gpu_busy import busy_neighbour
     saved = {n: os.environ.get(n) for n in LANE_VARS}
+    from contextlib import nullcontext
     try:
-        with busy_neighbour():
+        # (SP_FUZZ_NO_BUSY=1: several fuzz processes side by side share ONE neighbour -- tools/fuzz_parallel.sh)
+        with (nullcontext() if os.environ.get("SP_FUZZ_NO_BUSY") else busy_neighbour()):
             return _run(iters, seed, gpu, ora, verbose, True)
     finally:
         for n, v in saved.items():

@@ -16,12 +16,12 @@ GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_REA
 rm -rf $O/${TAG}_prof
 CMD=${SP_PMC_CMD:-"python $R/bench.py --no-cpu-baseline"}
 CMD1=${SP_PMC_CMD:-"python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"}
-rocprofv3 --kernel-trace -d $O/${TAG}_prof -o run -- $CMD "$@" > $O/${TAG}_prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_prof -o run -- $CMD "$@" > $O/${TAG}_prof.log 2>&1
 python $R/tools/rocpd_summary.py $O/${TAG}_prof/run_results.db > $O/${TAG}_kernel_stats.md 2>> $O/${TAG}_prof.log
 i=0
 for g in "${GROUPS_[@]}"; do
   rm -rf $O/${TAG}_pmc$i
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $O/${TAG}_pmc$i -o run -- $CMD1 "$@" > $O/${TAG}_pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $O/${TAG}_pmc$i -o run -- $CMD1 "$@" > $O/${TAG}_pmc$i.log 2>&1
   i=$((i+1))
 done
 python $R/tools/pmc_table.py $O/${TAG}_pmc*/run_counter_collection.csv > $O/${TAG}_pmc.json 2>> $O/${TAG}_prof.log
