@@ -494,7 +494,9 @@ static int count_impl(sp_ctx *ctx, int k, int lower_count, int engine, int first
                        (longest < (1LL << 26) || (env_batch && env_batch[0] == '1'));
     if ((list_mode && C > 1) || dense_lanes) {
         const char *el = getenv(list_mode ? "SP_LANES" : "SP_LANES_DENSE");
-        n_lanes = el ? atoi(el) : 3;
+        // (batched list counts: two groups since round 6 -- with c2_count_list16's two workgroups per CU a launch fills the chip
+        // better, and Arabidopsis-like passes take 4.10 / 4.13 / 4.24 / 4.42 / 4.45 ms with 1 / 2 / 3 / 5 / 7 extra streams)
+        n_lanes = el ? atoi(el) : (batch ? 1 : 3);
         // (toy inputs: chains that last microseconds gain nothing from side-by-side streams and pay for their events
         // and joins -- 105 against 41 ms per iteration of the fuzzer; the streams are for genomes)
         int64_t total_len = 0;
