@@ -1107,8 +1107,16 @@ __device__ __forceinline__ void c2_count_list_body(const uint16_t *__restrict__ 
 // buckets per memory round trip as before.  A bucket of 65536 keys or more (a hot repeat) raises the chromosome's overrun
 // flag: the host counts that chromosome again with exact sizes, which takes the 32-bit kernel above.
 #define C2L16_THREADS 512
+#ifndef C2L16_DEPTH
 #define C2L16_DEPTH 4
+#endif
+#ifndef C2L16_PF
 #define C2L16_PF 2       // quads per thread and bucket held in registers: 4096 keys
+#endif
+#ifndef C2L16_MAXLEN
+#define C2L16_MAXLEN (1LL << 26)      // longer chromosomes (~8 K keys per bucket and more): the BIG geometry
+#endif
+template <int C2L16_DEPTH_, int C2L16_PF_>
 __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine,
               uint32_t lower, unsigned long long *__restrict__ out3 /*[0]=sum,[1]=n,[3]=overrun flag*/,
               uint2 *__restrict__ stage, unsigned long long stage_cap, uint32_t *__restrict__ seg_base,
@@ -1127,9 +1135,9 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
             s_span[j] = span[fbn];
     }
     __syncthreads();
-    uint2 pf[C2L16_DEPTH][C2L16_PF];
-    unsigned long long p_a0[C2L16_DEPTH];
-    uint32_t p_off[C2L16_DEPTH], p_n[C2L16_DEPTH], p_base[C2L16_DEPTH];
+    uint2 pf[C2L16_DEPTH_][C2L16_PF_];
+    unsigned long long p_a0[C2L16_DEPTH_];
+    uint32_t p_off[C2L16_DEPTH_], p_n[C2L16_DEPTH_], p_base[C2L16_DEPTH_];
     auto issue = [&](int d, int64_t fbn, int64_t j) {
         p_a0[d] = 0;
         p_off[d] = p_n[d] = p_base[d] = 0;
@@ -1143,7 +1151,7 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
         const uint32_t nq = (p_off[d] + p_n[d] + 3u) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + p_a0[d]);
 #pragma unroll
-        for (int q = 0; q < C2L16_PF; q++) {
+        for (int q = 0; q < C2L16_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
             if (i < nq) pf[d][q] = p2[i];
         }
@@ -1156,12 +1164,12 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
         if (k0 + 3 >= off && k0 + 3 < end && !(v.y & 0x80000000u)) f(v.y >> 16);
     };
 #pragma unroll
-    for (int d = 0; d < C2L16_DEPTH; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
+    for (int d = 0; d < C2L16_DEPTH_; d++) issue(d, (int64_t)blockIdx.x + (int64_t)d * gridDim.x, d);
     int par = 0;
     int64_t j0 = 0;
-    uint2 cur[C2L16_DEPTH][C2L16_PF];
-    unsigned long long c_a0[C2L16_DEPTH];
-    uint32_t c_off[C2L16_DEPTH], c_n[C2L16_DEPTH], c_base[C2L16_DEPTH];
+    uint2 cur[C2L16_DEPTH_][C2L16_PF_];
+    unsigned long long c_a0[C2L16_DEPTH_];
+    uint32_t c_off[C2L16_DEPTH_], c_n[C2L16_DEPTH_], c_base[C2L16_DEPTH_];
     auto one = [&](int d, int64_t fb) {
         if (c_n[d] >= 65536u) {      // block-uniform: the chromosome is counted again by the 32-bit kernel
             if (threadIdx.x == 0) {
@@ -1171,19 +1179,19 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
             return;
         }
         const uint32_t off = c_off[d], end = c_off[d] + c_n[d], nq = (end + 3u) >> 2;
-        const bool in_regs = nq <= (uint32_t)C2L16_PF * C2L16_THREADS;      // block-uniform
+        const bool in_regs = nq <= (uint32_t)C2L16_PF_ * C2L16_THREADS;      // block-uniform
         const uint32_t slot0 = (uint32_t)(fb * C2_FINE);
         const unsigned long long base = c_base[d];
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + c_a0[d]);
         auto add = [&](uint32_t r) { atomicAdd(&cnt[r >> 1], 1u << (16u * (r & 1u))); };
         // ---- pass 1: count
 #pragma unroll
-        for (int q = 0; q < C2L16_PF; q++) {
+        for (int q = 0; q < C2L16_PF_; q++) {
             const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
             if (i < nq) quad(cur[d][q], i, off, end, add);
         }
         if (!in_regs)
-            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L16_PF * C2L16_THREADS; i0 < nq; i0 += 4u * C2L16_THREADS) {
+            for (uint32_t i0 = threadIdx.x + (uint32_t)C2L16_PF_ * C2L16_THREADS; i0 < nq; i0 += 4u * C2L16_THREADS) {
                 uint2 vv[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -1213,7 +1221,7 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
                 if (c) emit(r, c);
             };
 #pragma unroll
-            for (int q = 0; q < C2L16_PF; q++) {
+            for (int q = 0; q < C2L16_PF_; q++) {
                 const uint32_t i = threadIdx.x + (uint32_t)q * C2L16_THREADS;
                 if (i < nq) quad(cur[d][q], i, off, end, take);
             }
@@ -1240,21 +1248,21 @@ __device__ __forceinline__ void c2_count_list16_body(const uint16_t *__restrict_
         }
         par ^= 1;
     };
-    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L16_DEPTH * gridDim.x, j0 += C2L16_DEPTH) {
+    for (int64_t fb0 = blockIdx.x; fb0 < n_fine; fb0 += (int64_t)C2L16_DEPTH_ * gridDim.x, j0 += C2L16_DEPTH_) {
 #pragma unroll
-        for (int d = 0; d < C2L16_DEPTH; d++) {
+        for (int d = 0; d < C2L16_DEPTH_; d++) {
 #pragma unroll
-            for (int q = 0; q < C2L16_PF; q++) cur[d][q] = pf[d][q];
+            for (int q = 0; q < C2L16_PF_; q++) cur[d][q] = pf[d][q];
             c_a0[d] = p_a0[d];
             c_off[d] = p_off[d];
             c_n[d] = p_n[d];
             c_base[d] = p_base[d];
         }
 #pragma unroll
-        for (int d = 0; d < C2L16_DEPTH; d++)
-            issue(d, fb0 + (int64_t)(d + C2L16_DEPTH) * gridDim.x, j0 + d + C2L16_DEPTH);
+        for (int d = 0; d < C2L16_DEPTH_; d++)
+            issue(d, fb0 + (int64_t)(d + C2L16_DEPTH_) * gridDim.x, j0 + d + C2L16_DEPTH_);
 #pragma unroll
-        for (int d = 0; d < C2L16_DEPTH; d++) {
+        for (int d = 0; d < C2L16_DEPTH_; d++) {
             const int64_t fb = fb0 + (int64_t)d * gridDim.x;
             if (fb >= n_fine) break;           // block-uniform
             one(d, fb);
@@ -1347,16 +1355,18 @@ c2_count_list(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ 
               uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
     c2_count_list_body<(BIG ? 2 : C2L_DEPTH), (BIG ? 4 : C2L_PF)>(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
 }
+// BIG: chromosomes of 2^26 bases or more (~8 K keys per fine bucket): four quads per thread in registers, groups of two buckets
+template <bool BIG>
 __global__ void __launch_bounds__(C2L16_THREADS)
 c2_count_list16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
                 unsigned long long *__restrict__ out3, uint2 *__restrict__ stage, unsigned long long stage_cap,
                 uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
-    c2_count_list16_body(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
+    c2_count_list16_body<(BIG ? 2 : C2L16_DEPTH), (BIG ? 4 : C2L16_PF)>(buf2, span, n_fine, lower, out3, stage, stage_cap, seg_base, seg_cnt);
 }
 __global__ void __launch_bounds__(C2L16_THREADS)
 c2_count_list16_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
     const c2_bdesc D = desc[blockIdx.y];
-    c2_count_list16_body(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
+    c2_count_list16_body<C2L16_DEPTH, C2L16_PF>(D.buf2, D.span, n_fine, lower, D.d_len4, D.stage, D.stage_cap, D.seg_base, D.seg_cnt);
 }
 __global__ void __launch_bounds__(C2_COUNT_THREADS)
 c2_count_list_b(const c2_bdesc *__restrict__ desc, int64_t n_fine, uint32_t lower) {
@@ -1515,13 +1525,19 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     if (list) {
         if ((int64_t)gridc * C2L_MAXB < (int64_t)nf) gridc = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
         const char *env_l16 = getenv("SP_C2_LIST16");      // "0": the 32-bit list counter everywhere (cross-check)
-        if (!exact && c.len < (1LL << 26) && !(env_l16 && env_l16[0] == '0')) {
-            // (estimate mode only: a bucket of 65536 keys or more raises the overrun flag and the exact recount takes the kernel below)
+        if (!exact && !(env_l16 && env_l16[0] == '0')) {
+            // (estimate mode only: a bucket of 65536 keys or more raises the overrun flag and the exact recount takes the kernels below)
             int g16 = (int)((int64_t)nf < (int64_t)ctx->n_cu * 2 ? (int64_t)nf : (int64_t)ctx->n_cu * 2);
             if ((int64_t)g16 * C2L_MAXB < (int64_t)nf) g16 = (int)(((int64_t)nf + C2L_MAXB - 1) / C2L_MAXB);
-            SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list16, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 2));
-            SP_LAUNCH(ctx, "c2_count_list", c2_count_list16, dim3(g16), dim3(C2L16_THREADS), C2_FINE * 2, buf2,
-                      (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+            if (c.len >= C2L16_MAXLEN) {
+                SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 2));
+                SP_LAUNCH(ctx, "c2_count_list", c2_count_list16<true>, dim3(g16), dim3(C2L16_THREADS), C2_FINE * 2, buf2,
+                          (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+            } else {
+                SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 2));
+                SP_LAUNCH(ctx, "c2_count_list", c2_count_list16<false>, dim3(g16), dim3(C2L16_THREADS), C2_FINE * 2, buf2,
+                          (const ulonglong2 *)span, (int64_t)nf, (uint32_t)lower, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
+            }
         } else if (c.len >= (1LL << 26)) {
             SP_HIP(ctx, hipFuncSetAttribute((const void *)c2_count_list<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_FINE * 4));
             SP_LAUNCH(ctx, "c2_count_list", c2_count_list<true>, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2,
