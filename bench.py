@@ -307,11 +307,12 @@ def main():
         traffic = None
         # the profiler's labels -> the kernel symbols rocprofv3 reports (one kernel launched under two labels)
         sym = {"k5_map": "k5_map2", "k5_map_sparse": "k5_map_sparse2", "sps_join": "sps_join_blk",
-               "c2_hist_sample": "c2_hist_fine", "ovf_place_list": "ovf_place", "k5_map_mask_lab": "k5_map_mask",
+               "c2_hist_sample": "c2_hist_fine", "ovf_place_list": "ovf_place",
                "sps_emit_hist": "sps_emit", "k3_emit_hist": "k3_emit", "s3_hist1_sample": "s3_hist1",
                "s3_hist2_sample": "s3_hist2"}
         def _sym(n):       # the symbol a label's kernel has in the PMC table (batched wrappers carry a _b suffix)
-            for cand in (sym.get(n, n), n, sym.get(n, n) + "_b", n + "_b"):
+            # (round 6: the list counter of small genomes is c2_count_list16 / c2_count_list16_b under the label c2_count_list)
+            for cand in (sym.get(n, n), n, sym.get(n, n) + "_b", n + "_b", n + "16_b", n + "16"):
                 if cand in tj:
                     return cand
             return None

@@ -11,7 +11,7 @@ if [ "$mode" = "streams" ]; then
 fi
 pids=""
 for i in $(seq 0 $((n - 1))); do
-    SP_FUZZ_SECONDS=$secs python tools/fuzz_parity.py $iters $((seed + 7919 * i)) $mode 2>&1 | grep -E "^fuzz|MISMATCH|Error|error" &
+    (SP_FUZZ_SECONDS=$secs python tools/fuzz_parity.py $iters $((seed + 7919 * i)) $mode > gpurun_out/fuzz_proc_$i.log 2>&1; grep -E "^fuzz|MISMATCH|Error|error" gpurun_out/fuzz_proc_$i.log) &
     pids="$pids $!"
 done
 wait $pids

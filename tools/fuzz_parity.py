@@ -93,6 +93,10 @@ def _run(iters, seed, gpu, ora, verbose, streams):
         engine = int(rng.choice([0, 1, 2, 3])) if k <= 15 else int(rng.choice([0, 1]))      # 3: lists (k >= 9), else falls back
         if streams and k <= 15 and engine in (0, 1) and rng.randint(0, 2):
             engine = int(rng.choice([2, 3]))      # (engines 0 / 1 on toy genomes run no chains side by side)
+        if streams and k > 15 and int(os.environ.get("SP_LANES_SPARSE", "3")) > 3:
+            # (a k > 15 lane owns ~6.5 GB of partition buffers whatever the genome's size -- 15 GB with 64-bit residuals -- and they
+            # are never given back: several fuzz processes side by side run out of a 288-GB device at seven lanes each)
+            os.environ["SP_LANES_SPARSE"] = "3"
         tag = "it=%d C=%d k=%d L=%d eng=%d lens=%s%s" % (it, C, k, lower, engine, [len(s) for s in seqs],
                                                        " lanes=%s" % [os.environ.get(n) for n in LANE_VARS] if streams else "")
         if os.environ.get("SP_FUZZ_TRACE"):      # a GPU fault kills the process: leave the case on stderr first
