@@ -2098,6 +2098,38 @@ int sp_sparse_count3(sp_ctx *ctx, int k, int lower) {
     if (!el && total_len < (1LL << 24)) n_lanes = 0;      // (toy inputs: see sp_count)
     if (n_lanes > SP_MAX_LANES) n_lanes = SP_MAX_LANES;
     if (n_lanes < 0 || C < 2) n_lanes = 0;
+    if (n_lanes > 0) {
+        // Every lane owns the partition buffers of one chain, and their floor does not shrink with the genome: the level-2
+        // regions carry S3_CAP_SLACK entries of slack per fine bucket -- 2^18..2^19 buckets x 1024 x (residual + scratch +
+        // count) = 3.2 GB (k <= 17), 6.4 GB (k <= 25), 10.7 GB (64-bit residuals) per lane.  Lanes whose buffers are not
+        // allocated yet must fit what the device has free (round 6: several processes on one GPU with seven lanes forced ran
+        // out of 288 GB); the chains then share fewer streams, down to the context's own.
+        int64_t longest = 0;
+        for (const auto &c : ctx->chroms) longest = c.len > longest ? c.len : longest;
+        const double n_fine = (double)P.F1 * (double)P.F2;
+        const double s_max = (double)longest / 8.0 + (double)P.F1 * 64.0 * S3_P2_PER;
+        const double cap_tot = 10.0 * s_max + 8.0 * (7.0 * sqrt(n_fine * s_max) + n_fine) + (double)S3_CAP_SLACK * n_fine + 4096.0;
+        const double r2 = P.wide2 ? 8.0 : 4.0, r1 = P.wide1 ? 8.0 : 4.0;
+        const double l1 = ((double)longest * 33.0 / 32.0 + (double)P.F1 * (8192.0 + (double)(longest >> 16)) + 32768.0) * r1;
+        const int64_t per_lane = (int64_t)((cap_tot * r2 > l1 ? cap_tot * r2 : l1) + cap_tot * r2 + cap_tot * (r2 + 4.0)) + (64LL << 20);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            int64_t budget = (int64_t)free_b - (int64_t)(total_b / 16);      // keep a sixteenth of the device free
+            int fit = 0;
+            for (int l = 0; l < n_lanes; l++) {
+                const sp_ctx::lane_t &ln = ctx->lanes[l];
+                const int64_t have = ln.b_sp_a.cap + ln.b_sp_b.cap + ln.b_sp_c.cap;
+                const int64_t need = have >= per_lane ? 0 : per_lane - have;
+                if (need > budget) break;
+                budget -= need;
+                fit++;
+            }
+            if (fit < n_lanes) {
+                if (getenv("SP_DEBUG_COUNT")) fprintf(stderr, "[sp] k > 15 count: %d of %d lanes fit the free device memory\n", fit, n_lanes);
+                n_lanes = fit;
+            }
+        }
+    }
     if (!ctx->h_s3) SP_HIP(ctx, hipHostMalloc((void **)&ctx->h_s3, (size_t)(SP_MAX_LANES + 1) * 8 * sizeof(unsigned long long), hipHostMallocDefault));
     for (auto &e : ctx->s3_ev)
         if (!e) SP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

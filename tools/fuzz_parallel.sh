@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 n=$1; iters=$2; seed=$3; secs=$4; mode=$5
 if [ "$mode" = "streams" ]; then
     export SP_FUZZ_NO_BUSY=1
-    sleep $((secs + 30)) | python tools/gpu_busy.py 0.01 > /dev/null 2>&1 &
+    sleep $((secs + 30)) | python tools/gpu_busy.py ${SP_BUSY_SCALE:-0.01} > /dev/null 2>&1 &
     busy=$!
 fi
 pids=""
