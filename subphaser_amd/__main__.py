@@ -1,4 +1,4 @@
-from .pipeline import main
+from .pipeline import cli
 
 if __name__ == "__main__":
-    main()
+    cli()

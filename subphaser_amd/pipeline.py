@@ -504,5 +504,30 @@ def main(argv=None):
     Pipeline(**args.__dict__).run()
 
 
+def cli(argv=None):
+    """Process entry point (`python -m subphaser_amd`, the `subphaser` script): main(), then leave without the interpreter's
+    teardown.  When run() returns every output file is closed and every background writer joined; what is left is returning
+    ~40 GB of device and page-locked memory buffer by buffer and unwinding numpy / matplotlib -- 1.1 of the 6.1 s of a
+    wheat-sized run (profiles/r06_e2e_cli_wheat.log) that the operating system does in one piece when the process ends.
+    `SP_SLOW_EXIT=1` keeps the ordinary exit (and, with `SP_EXIT_TRACE=1`, stamps its steps on stderr)."""
+    main(argv)
+    trace = bool(os.environ.get("SP_EXIT_TRACE"))
+    if trace:
+        sys.stderr.write("[exit] run() returned\n")
+        sys.stderr.flush()
+    if os.environ.get("SP_SLOW_EXIT") == "1":
+        if trace:
+            from .runtime import close_context
+            close_context()
+            sys.stderr.write("[exit] context closed\n")
+            sys.stderr.flush()
+        return
+    import logging
+    logging.shutdown()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
+
+
 if __name__ == "__main__":
-    main()
+    cli()

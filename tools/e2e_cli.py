@@ -56,7 +56,7 @@ class _R:
 
 r = _R()
 open(os.path.join(work, "cli.stderr"), "w").write(r.stderr)
-keep = ("per-chromosome FASTA", "chromosomes, in config order", "Genome size", "###Step", "Counting", "matrix", "filter (K3)",
+keep = ("[exit]", "per-chromosome FASTA", "chromosomes, in config order", "Genome size", "###Step", "Counting", "matrix", "filter (K3)",
         "After filtering", "kmers in total", "bootstrap", "Bootstrap", "->", "significant subgenome", "Processed",
         "enrichment", "wrote", "writer", "Pipeline completed", "New check point")
 prev = 0.0
