@@ -61,11 +61,17 @@ __device__ __forceinline__ uint32_t k3_ge_mask(uint32_t x, uint32_t addL /* (0x8
     return (((x & 0x7f7f7f7fu) + addL) | x) & 0x80808080u;
 }
 
-// NCH > 0: the column has at most 8 * NCH rows and every loop over rows is unrolled, so that the row
-// descriptors (set / unit boundaries, reciprocal lengths) are uniform values held in scalar registers.
+// NCH > 0: the column has at most 32 rows: the row descriptors (set / unit boundaries) are bit masks in scalar
+// registers, the reciprocal lengths one per lane.
 // NCH = 0: any number of rows; every qualifying slot takes the generic decision.
 #ifndef K3_STAGE
 #define K3_STAGE 8      // 16-byte loads a thread keeps in flight while a tile is staged
+#endif
+#ifndef K3_SCAN_CH
+#define K3_SCAN_CH 4    // rows whose words a thread of the scan reads from LDS before it looks at any
+#endif
+#ifndef K3_WALK_CH
+#define K3_WALK_CH 8    // ... and bytes per chunk of the decision walk
 #endif
 template <bool SWAR, int NCH>
 __global__ void __launch_bounds__(F_BLOCK)
@@ -80,7 +86,6 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
     __shared__ uint32_t s_qn, s_q2n, s_q3n;
     __shared__ unsigned long long s_gq0;
     const int TS = P.TS, R = P.R;
-    constexpr int RMAX = NCH > 0 ? 8 * NCH : 1;
     const int32_t *__restrict__ rowdesc = P.rowdesc;   // padded with zeros to a multiple of 8 (and at least 32)
     const float *__restrict__ rowinv = P.rowinv;
     uint16_t *queue = reinterpret_cast<uint16_t *>(tile + (size_t)R * TS), *queue2 = queue + TS;
@@ -94,18 +99,20 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         l_ovf[r] = tabs[c].ovf;
         l_novf[r] = (unsigned long long)tabs[c].n_ovf;
     }
-    // row descriptors of the unrolled walk: loaded ONCE, uniform, packed into four bit masks (one bit per row) and
-    // the reciprocal lengths -- everything the decision loop needs lives in a few scalar registers
+    // row descriptors of the fast walk: loaded ONCE, uniform, packed into four bit masks (one bit per row, R <= 32) in scalar
+    // registers; the reciprocal lengths sit one per LANE and are fetched with v_readlane where a unit ends.
+    // Round 6: the scan and the walk were unrolled over all 8 * NCH rows.  Every one of the 4 x 24 bit tests is loop-invariant:
+    // the compiler hoisted them out of the tile loop as lane masks, ran out of scalar registers, spilled them to VGPR lanes and
+    // paid two v_readlane per test -- 563 VALU instructions per scan and thread, every LDS read waited for on its own.  Both are
+    // loops over chunks of rows now (the row index is a loop variable: s_bitcmp + s_cbranch_scc where a flag is used).
     uint32_t mk_unit = 0, mk_set = 0, mk_bi1 = 0, mk_tot = 0;
-    float inv[RMAX];
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        const int d = NCH > 0 ? rowdesc[r] : 0;
-        mk_unit |= (d & F3_UNIT_END) ? 1u << r : 0u;
-        mk_set |= (d & F3_SET_END) ? 1u << r : 0u;
-        mk_bi1 |= (d & F3_BI1) ? 1u << r : 0u;
-        mk_tot |= (d & F3_TOT) ? 1u << r : 0u;
-        inv[r] = NCH > 0 ? rowinv[r] : 0.0f;
+    int inv_bits = 0;
+    if (NCH > 0) {
+        const int d = rowdesc[threadIdx.x & 31];
+        const unsigned long long b_unit = __ballot((d & F3_UNIT_END) != 0), b_set = __ballot((d & F3_SET_END) != 0);
+        const unsigned long long b_bi1 = __ballot((d & F3_BI1) != 0), b_tot = __ballot((d & F3_TOT) != 0);
+        mk_unit = (uint32_t)b_unit; mk_set = (uint32_t)b_set; mk_bi1 = (uint32_t)b_bi1; mk_tot = (uint32_t)b_tot;
+        inv_bits = __float_as_int(rowinv[threadIdx.x & 31]);
     }
     mk_unit = __builtin_amdgcn_readfirstlane(mk_unit);
     mk_set = __builtin_amdgcn_readfirstlane(mk_set);
@@ -201,20 +208,28 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
             if (SWAR) {
                 uint32_t act = 0, m = 0;
                 if (NCH > 0) {
+                    const uint32_t *col = tw + g;
+                    for (int r0 = 0; r0 < R; r0 += K3_SCAN_CH) {         // R is uniform: a scalar loop
+                        uint32_t x[K3_SCAN_CH];
 #pragma unroll
-                    for (int r = 0; r < RMAX; r++) {
-                        if (r < R) {
-                            const uint32_t x = tw[r * nw + g];
-                            const uint32_t ge = k3_ge_mask(x, addL);
-                            any |= ge;
-                            is255 |= ((x & 0x7f7f7f7fu) + 0x01010101u) & x;
-                            m |= ge;
-                            if ((mk_set >> r) & 1u) {   // uniform
-                                act += m >> 7;
-                                m = 0;
+                        for (int i = 0; i < K3_SCAN_CH; i++) x[i] = col[(r0 + i < R ? r0 + i : R - 1) * nw];     // independent LDS reads
+#pragma unroll
+                        for (int i = 0; i < K3_SCAN_CH; i++) {
+                            if (r0 + i < R) {
+                                const uint32_t lo = x[i] & 0x7f7f7f7fu;
+                                m |= (lo + addL) | x[i];        // bit 7 of a byte: >= lower (the other bits are masked at the set's end)
+                                is255 |= (lo + 0x01010101u) & x[i];
+                                if ((mk_set >> (r0 + i)) & 1u) {
+                                    asm volatile("");       // a real (scalar) branch: if-converted, every row pays the six instructions of a set's end
+                                    m &= 0x80808080u;
+                                    any |= m;
+                                    act += m >> 7;
+                                    m = 0;
+                                }
                             }
                         }
                     }
+                    any |= m & 0x80808080u;                 // rows behind the last set: chromosomes of no non-singleton set
                 } else {
                     for (int r = 0; r < R; r++) {
                         const uint32_t x = tw[r * nw + g];
@@ -278,6 +293,9 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         if (NCH > 0) {
             const uint32_t qn = s_qn;
             for (uint32_t q0 = 0; q0 < qn; q0 += F_BLOCK) {
+                // a tile queues ~1 slot in 10: the last waves of the block have nothing to decide (the kernel is bound by
+                // instruction issue: 245 instructions per wave and walk)
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 + (threadIdx.x & ~63u))) >= qn) continue;
                 const uint32_t q = q0 + threadIdx.x;
                 const bool live = q < qn;
                 const int sl = live ? (int)queue[q] : 0;
@@ -285,30 +303,33 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
                 bool exact = false;
                 uint32_t tot = 0, num = 0;
                 float m1 = -1.0f, m2 = -1.0f, mn = 3e38f;
+                for (int r0 = 0; r0 < R; r0 += K3_WALK_CH) {
+                    uint32_t y[K3_WALK_CH];
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) {
-                    uint32_t y[8];
+                    for (int i = 0; i < K3_WALK_CH; i++) y[i] = (uint32_t)tile[(size_t)(r0 + i < R ? r0 + i : R - 1) * TS + sl];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) y[i] = (8 * ch + i < R) ? (uint32_t)tile[(size_t)(8 * ch + i) * TS + sl] : 0u;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int r = 8 * ch + i;
-                        const uint32_t c = y[i] >= P.lower ? y[i] : 0u;
-                        if ((mk_tot >> r) & 1u) tot += c;            // uniform branches on register bits
-                        num += c;
-                        if ((mk_unit >> r) & 1u) {
-                            const float x = (float)num * inv[r];
-                            m2 = fmaxf(m2, fminf(m1, x));            // running max / second max / min, branch-free
-                            m1 = fmaxf(m1, x);
-                            mn = fminf(mn, x);
-                            num = 0;
-                        }
-                        if ((mk_set >> r) & 1u) {
-                            const float thr = fold32 * ((((mk_bi1 >> r) & 1u) ? m2 : mn) + 1e-20f);
-                            const bool pass = m1 > thr * (1.0f + 1e-5f);
-                            include += pass ? 1 : 0;
-                            exact = exact || (!pass && !(m1 < thr * (1.0f - 1e-5f)));
-                            m1 = -1.0f; m2 = -1.0f; mn = 3e38f;
+                    for (int i = 0; i < K3_WALK_CH; i++) {
+                        const int r = r0 + i;
+                        if (r < R) {
+                            const uint32_t c = y[i] >= P.lower ? y[i] : 0u;
+                            if ((mk_tot >> r) & 1u) tot += c;            // uniform branches on register bits
+                            num += c;
+                            if ((mk_unit >> r) & 1u) {
+                                asm volatile("");
+                                const float x = (float)num * __int_as_float(__builtin_amdgcn_readlane(inv_bits, r));
+                                m2 = fmaxf(m2, fminf(m1, x));            // running max / second max / min, branch-free
+                                m1 = fmaxf(m1, x);
+                                mn = fminf(mn, x);
+                                num = 0;
+                            }
+                            if ((mk_set >> r) & 1u) {
+                                asm volatile("");
+                                const float thr = fold32 * ((((mk_bi1 >> r) & 1u) ? m2 : mn) + 1e-20f);
+                                const bool pass = m1 > thr * (1.0f + 1e-5f);
+                                include += pass ? 1 : 0;
+                                exact = exact || (!pass && !(m1 < thr * (1.0f - 1e-5f)));
+                                m1 = -1.0f; m2 = -1.0f; mn = 3e38f;
+                            }
                         }
                     }
                 }
@@ -334,8 +355,8 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
         // the whole machine (their decisions start with binary searches in the overflow lists -- chains of ~17
         // dependent global loads; decided here, a handful of them per tile kept every wave of the block waiting at the
         // barrier and tripled the kernel's time).  Only when the queue is full are they decided in place.
-        {
-            const uint32_t q2n = s_q2n;
+        const uint32_t q2n = s_q2n;      // (block-uniform: read behind a barrier, reset behind the tile's last one)
+        if (q2n) {
             const int EW = 1 + (R + 3) / 4;
             // ONE reservation per tile, not one returning same-address atomic per slow slot
             if (threadIdx.x == 0) {
@@ -812,7 +833,7 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     }
     const size_t shmem = (size_t)P.R * TS + (size_t)TS * 4 + (size_t)TS / 4 + (size_t)P.R * 16 + (size_t)P.R * 4 * F_WAVES;
     const bool swar = ctx->lower >= 1 && ctx->lower <= 128;
-    const int nch = (swar && P.fast && P.R <= 32) ? (P.R + 7) / 8 : 0;
+    const int nch = (swar && P.fast && P.R <= 32) ? 1 : 0;
 #define K3_LAUNCH(SW, N)                                                                                          \
     do {                                                                                                          \
         SP_HIP(ctx, hipFuncSetAttribute((const void *)k3_eval<SW, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -824,9 +845,6 @@ int sp_filter(sp_ctx *ctx, int n_sets, const int32_t *set_off, const int32_t *un
     } while (0)
     if (!swar) K3_LAUNCH(false, 0);
     else if (nch == 1) K3_LAUNCH(true, 1);
-    else if (nch == 2) K3_LAUNCH(true, 2);
-    else if (nch == 3) K3_LAUNCH(true, 3);
-    else if (nch == 4) K3_LAUNCH(true, 4);
     else K3_LAUNCH(true, 0);
 #undef K3_LAUNCH
     {   // the slow queue: its length comes back with the other totals; launched over the capacity-bounded count
