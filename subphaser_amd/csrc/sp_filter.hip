@@ -65,7 +65,9 @@ __device__ __forceinline__ uint32_t k3_ge_mask(uint32_t x, uint32_t addL /* (0x8
 // registers, the reciprocal lengths one per lane.
 // NCH = 0: any number of rows; every qualifying slot takes the generic decision.
 #ifndef K3_STAGE
-#define K3_STAGE 8      // 16-byte loads a thread keeps in flight while a tile is staged
+#define K3_STAGE 6      // 16-byte loads a thread keeps in flight while a tile is staged: 6 x F_BLOCK x 16 B = F_TILE_BYTES, one batch
+                        // per tile (8: 3.96 ms, 6: 3.76 -- pieces past the tile's end are loaded again from a clamped index; a uniform
+                        // branch around them instead: 4.56 ms, the loads no longer go out together)
 #endif
 #ifndef K3_SCAN_CH
 #define K3_SCAN_CH 4    // rows whose words a thread of the scan reads from LDS before it looks at any
@@ -137,7 +139,7 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
     F.max_freq = P.max_freq;
     F.ratio = P.ratio;
     for (int64_t base = blk_base; base < blk_base + F_SLOTS_PER_BLOCK && base < P.nslots; base += TS) {
-        // ---- stage the tile: 16 slots per load, eight loads in flight per thread
+        // ---- stage the tile: 16 slots per load, K3_STAGE loads in flight per thread
         const int n16 = TS / 16, total16 = R * n16;
         if (threadIdx.x == 0) s_qn = s_q2n = 0;
         for (int i = threadIdx.x; i < TS / 16; i += F_BLOCK) reinterpret_cast<uint32_t *>(bmr)[i] = 0;   // both bitmaps: 2*TS/32 words
@@ -260,25 +262,46 @@ k3_eval(const sp_tabref *__restrict__ tabs, sp_filter_params P,
             }
             // columns with a saturated byte (or every column when the rows are not unrolled) take the generic decision
             const uint32_t slow = (SWAR && NCH > 0 && P.fast) ? is255 : 0x80808080u;
+            // queue the qualifying slots: ONE reservation per wave and queue (it was one per byte lane of the word -- four returning
+            // LDS atomics and four cross-lane broadcasts per wave, one after the other).  A wave of this loop is whole (TS / 4 is a
+            // multiple of 64), so lane 0 is there to reserve.
+            const uint32_t q_fast = qual & ~slow & 0x80808080u, q_slow = qual & slow & 0x80808080u;
+            {
+                unsigned long long bal[4];
+                uint32_t n = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const bool occ = (qual >> (8 * b + 7)) & 1u;
-                const bool sl_ = occ && ((slow >> (8 * b + 7)) & 1u);
-                const bool fa_ = occ && !sl_;
-                const unsigned long long balf = __ballot(fa_), bals = __ballot(sl_);
-                if (balf) {
-                    const int leader = __ffsll((long long)balf) - 1;
-                    uint32_t qb = 0;
-                    if (lane == leader) qb = atomicAdd(&s_qn, (uint32_t)__popcll(balf));
-                    qb = __shfl(qb, leader, 64);
-                    if (fa_) queue[qb + __popcll(balf & ((1ULL << lane) - 1ULL))] = (uint16_t)(4 * g + b);
+                for (int b = 0; b < 4; b++) {
+                    bal[b] = __ballot((q_fast >> (8 * b + 7)) & 1u);
+                    n += (uint32_t)__popcll(bal[b]);
                 }
-                if (bals) {
-                    const int leader = __ffsll((long long)bals) - 1;
+                if (n) {
                     uint32_t qb = 0;
-                    if (lane == leader) qb = atomicAdd(&s_q2n, (uint32_t)__popcll(bals));
-                    qb = __shfl(qb, leader, 64);
-                    if (sl_) queue2[qb + __popcll(bals & ((1ULL << lane) - 1ULL))] = (uint16_t)(4 * g + b);
+                    if (lane == 0) qb = atomicAdd(&s_qn, n);
+                    qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if ((q_fast >> (8 * b + 7)) & 1u)
+                            queue[qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[b], 0u))] = (uint16_t)(4 * g + b);
+                        qb += (uint32_t)__popcll(bal[b]);
+                    }
+                }
+            }
+            if (__ballot(q_slow != 0u)) {
+                unsigned long long bal[4];
+                uint32_t n = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    bal[b] = __ballot((q_slow >> (8 * b + 7)) & 1u);
+                    n += (uint32_t)__popcll(bal[b]);
+                }
+                uint32_t qb = 0;
+                if (lane == 0) qb = atomicAdd(&s_q2n, n);
+                qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if ((q_slow >> (8 * b + 7)) & 1u)
+                        queue2[qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[b], 0u))] = (uint16_t)(4 * g + b);
+                    qb += (uint32_t)__popcll(bal[b]);
                 }
             }
         }
