@@ -226,17 +226,52 @@ struct map_chrom_desc {
 // into the range's LDS histogram when the whole range lies in one output slot run (the common case; the boundaries
 // are found once per range), the general walk otherwise.  TABLE: 1 = compact quad buckets (S <= 3), 0 = direct pair
 // table (S <= 7).
-#ifndef MAP2_QI
-#define MAP2_QI 1      // quads per inner iteration (their probes, then their bucket loads, travel together)
-#endif
+// Round 6, second half: the walk over a unit has TWO phases, and the second is shared out over the wave.  PMC counters put
+// k5_map2 at 70 % VALU utilisation (15.9 G wave instructions per wheat-like pass = 289 per quad and lane), half of them in the
+// candidate path -- bucket key, tag compares, label fields, planes -- which every wave executed for every quad, because SOME lane
+// of 64 is a candidate (27 % each; inside a repeat copy all sixteen quads of a lane are, so compacting per lane gains nothing:
+// measured, same instruction count).  Phase 1 is the filter alone: it leaves the candidate quads of the WAVE in an LDS queue
+// (lane, quad, which pairs).  Phase 2 deals the queue out to all lanes: ~280 candidates per 1024 quads are 4-5 iterations of the
+// candidate path per unit instead of 16.  A lane rebuilds the windows of the quad it was dealt from the owner's ten packed words,
+// parked in LDS (one column per thread), and ORs the labels it finds into the owner's planes there.
+struct map_unit_lds {
+    uint32_t *words;                 // [MAP_UNIT_WORDS][MAP_BLOCK]: the unit's packed words LSB-first (0..4), MSB-first (5..9), countable starts (10, 11)
+    unsigned long long *planes;      // [2 or 3][MAP_BLOCK]: the label planes of every thread's unit
+    uint16_t *queue;                 // [MAP_BLOCK / 64][MAP_QCAP]: the wave's candidate quads
+};
+#define MAP_UNIT_WORDS 12
+#define MAP_QCAP(TABLE) ((TABLE) ? 512 : 256)       // two / one 16-start word of every lane per round
+#define MAP_UNIT_LDS_DECL(TABLE)                                                          \
+    __shared__ uint32_t s_uw[MAP_UNIT_WORDS * MAP_BLOCK];                                 \
+    __shared__ unsigned long long s_up[((TABLE) ? 2 : 3) * MAP_BLOCK];                    \
+    __shared__ uint16_t s_uq[(MAP_BLOCK / 64) * MAP_QCAP(TABLE)];                         \
+    const map_unit_lds ulds = {s_uw, s_up, s_uq}
+struct map_quad_win {
+    uint32_t V1, V2, xf1, xr1, xf2, xr2;       // 16-base windows at j / j + 2 (MSB-first), x1 / x2 forward and reverse complement
+};
+__device__ __forceinline__ map_quad_win map_quad_windows(uint32_t l0, uint32_t l1, uint32_t m0, uint32_t m1, int r /* 0, 4, 8, 12 */,
+                                                         int sh, uint32_t m1mask) {
+    map_quad_win q;
+    const uint32_t W1 = __builtin_amdgcn_alignbit(l1, l0, 2 * r), W2 = __builtin_amdgcn_alignbit(l1, l0, 2 * r + 4);
+    const unsigned long long mm = ((unsigned long long)m0 << 32) | m1;
+    q.V1 = (uint32_t)((mm << (2 * r)) >> 32);
+    q.V2 = (uint32_t)((mm << (2 * r + 4)) >> 32);
+    q.xf1 = (q.V1 >> sh) & m1mask;       // x1 forward / reverse complement, key order
+    q.xr1 = (~W1 >> 2) & m1mask;
+    q.xf2 = (q.V2 >> sh) & m1mask;
+    q.xr2 = (~W2 >> 2) & m1mask;
+    return q;
+}
 template <int TABLE>
 __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                 const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams32 &kp,
                                                 const uint32_t *__restrict__ bloom, int nbits, const map_ptab &T,
-                                                unsigned long long lab[3], unsigned long long cm = ~0ULL /* starts that count */) {
+                                                unsigned long long lab[3], const map_unit_lds &U,
+                                                unsigned long long cm = ~0ULL /* starts that count */) {
     constexpr int FW = TABLE ? MAP_CT_FIELD : 4;
     constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
     constexpr uint32_t ANY = TABLE ? MAP_CT_ANY : 0x77777777u;
+    constexpr int NP = TABLE ? 2 : 3, ROUND_W = TABLE ? 2 : 1;
     // validity of the 64 starts: k-mer at s0+j, shared (k-1)-mer at s0+j+1
     unsigned long long ok_k, ok_x;
     {
@@ -249,6 +284,13 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
         ok_x = (unsigned long long)xA | ((unsigned long long)xB << 32);
     }
     if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
+    // the lanes of the wave that are here (a range's last wave, a grid-stride loop's last round): they share the candidates
+    const unsigned long long here = __ballot(1);
+    const int n_here = __popcll(here);
+    const int me = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
+    uint32_t *sw = U.words + tid;
+    uint16_t *queue = U.queue + (tid >> 6) * MAP_QCAP(TABLE);
     const int64_t w0 = s0 >> 4;   // a multiple of 4: 16-byte aligned
     const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0);
     uint32_t l0 = la.x, l1 = la.y, l2 = la.z, l3 = la.w, l4 = pk[w0 + 4];
@@ -259,12 +301,18 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     const uint4 ma = *reinterpret_cast<const uint4 *>(pm + w0);
     uint32_t m0 = ma.x, m1 = ma.y, m2 = ma.z, m3 = ma.w, m4 = pm[w0 + 4];
 #endif
+    {
+        const unsigned long long okc = ok_k & cm;      // (a start outside `cm` -- interval mode: not covered by a feature -- is neither counted nor marked seen)
+        sw[0 * MAP_BLOCK] = l0; sw[1 * MAP_BLOCK] = l1; sw[2 * MAP_BLOCK] = l2; sw[3 * MAP_BLOCK] = l3; sw[4 * MAP_BLOCK] = l4;
+        sw[5 * MAP_BLOCK] = m0; sw[6 * MAP_BLOCK] = m1; sw[7 * MAP_BLOCK] = m2; sw[8 * MAP_BLOCK] = m3; sw[9 * MAP_BLOCK] = m4;
+        sw[10 * MAP_BLOCK] = (uint32_t)okc; sw[11 * MAP_BLOCK] = (uint32_t)(okc >> 32);
+#pragma unroll
+        for (int bit = 0; bit < NP; bit++) U.planes[bit * MAP_BLOCK + tid] = 0ULL;
+    }
     const int sh = 32 - 2 * kp.k, sh1 = 30 - 2 * kp.k;
     const uint32_t m1mask = kp.kmask >> 2;
     const int sb = T.sb;
     const uint32_t smask = TABLE ? ((1u << sb) - 1u) : 0u;
-    constexpr int QI = MAP2_QI;
-    static_assert(QI == 1 || QI == 2 || QI == 4, "quads per inner iteration");
     // the filter's addressing (sp_map.h): by the smaller-hashed core of the (k-1)-mer, or by the (k-1)-mer itself
     const bool core = (nbits & MAP_BLOOM_CORE) && kp.k >= 5;      // (uniform)
     const uint32_t cmask = kp.k >= 5 ? ((1u << (2 * (kp.k - 3))) - 1u) : 0u;
@@ -272,40 +320,29 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                  // the word this lane fetched last (index, content)
     uint32_t h_carry = 0u;                                         // hash of the core the previous quad ended with
 #pragma unroll 1
-    for (int w = 0; w < 4; w++) {
+    for (int wr = 0; wr < 4; wr += ROUND_W) {
+        // ---- phase 1: the filter over ROUND_W words of sixteen starts; the wave's candidate quads go to its queue
+        uint32_t qn = 0;                                           // (uniform)
 #pragma unroll 1
-        for (int r0 = 0; r0 < 16; r0 += 4 * QI) {
-            // QI quads per iteration: their filter probes travel together, then the bucket loads of the candidate quads
-            uint32_t V1[QI], V2[QI], xf1[QI], xr1[QI], xf2[QI], xr2[QI], c1[QI], c2[QI], wd1[QI], wd2[QI], okk[QI], bt1[QI], bt2[QI];
-#pragma unroll
-            for (int q = 0; q < QI; q++) {
-                const int r = r0 + 4 * q, j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
-                // 16-base windows at j and j + 2: LSB-first out of {l1, l0}, MSB-first out of {m0, m1}
-                const uint32_t W1 = __builtin_amdgcn_alignbit(l1, l0, 2 * r), W2 = __builtin_amdgcn_alignbit(l1, l0, 2 * r + 4);
-                const unsigned long long mm = ((unsigned long long)m0 << 32) | m1;
-                V1[q] = (uint32_t)((mm << (2 * r)) >> 32);
-                V2[q] = (uint32_t)((mm << (2 * r + 4)) >> 32);
-                xf1[q] = (V1[q] >> sh) & m1mask;       // x1 forward / reverse complement, key order
-                xr1[q] = (~W1 >> 2) & m1mask;
-                xf2[q] = (V2[q] >> sh) & m1mask;
-                xr2[q] = (~W2 >> 2) & m1mask;
-                c1[q] = xf1[q] < xr1[q] ? xf1[q] : xr1[q];
-                c2[q] = xf2[q] < xr2[q] ? xf2[q] : xr2[q];
+        for (int w = wr; w < wr + ROUND_W; w++) {
+#pragma unroll 1
+            for (int r = 0; r < 16; r += 4) {
+                const int j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
+                const map_quad_win Q = map_quad_windows(l0, l1, m0, m1, r, sh, m1mask);
+                const uint32_t c1 = Q.xf1 < Q.xr1 ? Q.xf1 : Q.xr1, c2 = Q.xf2 < Q.xr2 ? Q.xf2 : Q.xr2;
                 uint32_t h1, h2;
-                bt1[q] = map_bloom_bits3((uint64_t)c1[q], h1);
-                bt2[q] = map_bloom_bits3((uint64_t)c2[q], h2);
+                const uint32_t bt1 = map_bloom_bits3((uint64_t)c1, h1), bt2 = map_bloom_bits3((uint64_t)c2, h2);
                 const uint32_t okx = (uint32_t)(ok_x >> j);
-                okk[q] = (uint32_t)(ok_k >> j);
                 const bool v1 = okx & 1u, v2 = okx & 4u;
                 uint32_t wi1, wi2;          // the filter words of x1 and x2
                 if (core) {
                     // the chain of cores: a = first k-3 bases of x1, b = last of x1 = first of x2, c = last of x2 (= the next
                     // quad's a); canonical = the smaller of the forward reading and its reverse complement, which is the
                     // OTHER end of the reverse-complemented (k-1)-mer
-                    const uint32_t tb_f = xf1[q] & cmask, tb_r = xr1[q] >> 4, tc_f = xf2[q] & cmask, tc_r = xr2[q] >> 4;
+                    const uint32_t tb_f = Q.xf1 & cmask, tb_r = Q.xr1 >> 4, tc_f = Q.xf2 & cmask, tc_r = Q.xr2 >> 4;
                     uint32_t ha = h_carry;              // (this quad's a IS the previous quad's c: the same bases)
                     if (j == 0) {                       // (uniform: the unit's first quad)
-                        const uint32_t ta_f = xf1[q] >> 4, ta_r = xr1[q] & cmask;
+                        const uint32_t ta_f = Q.xf1 >> 4, ta_r = Q.xr1 & cmask;
                         ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
                     }
                     const uint32_t hb = map_core_hash((uint64_t)(tb_f < tb_r ? tb_f : tb_r));
@@ -324,85 +361,93 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
                 uint32_t f1 = 0, f2 = 0;
                 if (need1) f1 = bloom[wi1];
                 if (need2) f2 = bloom[wi2];
-                wd1[q] = v1 ? (need1 ? f1 : last_w) : 0u;
-                wd2[q] = v2 ? (need2 ? f2 : (v1 ? wd1[q] : last_w)) : 0u;
-                if (v2) { last_wi = wi2; last_w = wd2[q]; }
-                else if (v1) { last_wi = wi1; last_w = wd1[q]; }
+                const uint32_t wd1 = v1 ? (need1 ? f1 : last_w) : 0u;
+                const uint32_t wd2 = v2 ? (need2 ? f2 : (v1 ? wd1 : last_w)) : 0u;
+                if (v2) { last_wi = wi2; last_w = wd2; }
+                else if (v1) { last_wi = wi1; last_w = wd1; }
+                const bool cand1 = (wd1 & bt1) == bt1, cand2 = (wd2 & bt2) == bt2;       // (an invalid pair's word is 0: never a candidate)
+                const unsigned long long bal = __ballot(cand1 || cand2);
+                if (cand1 || cand2)
+                    queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                        (uint16_t)((uint32_t)lane | ((uint32_t)(j >> 2) << 6) | (cand1 ? 0x400u : 0u) | (cand2 ? 0x800u : 0u));
+                qn += (uint32_t)__popcll(bal);
             }
-            bool cand1[QI], cand2[QI], sfw[QI];
-            uint4 B[QI];
-            map_ct_key k1[QI], k2[QI];
-            uint32_t e1[QI], e2[QI];
-#pragma unroll
-            for (int q = 0; q < QI; q++) {
-                cand1[q] = (wd1[q] & bt1[q]) == bt1[q];       // (an invalid pair's word is 0: never a candidate)
-                cand2[q] = (wd2[q] & bt2[q]) == bt2[q];
-                e1[q] = e2[q] = 0;
-                B[q] = make_uint4(0u, 0u, 0u, 0u);
-                if (TABLE) {
-                    // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
-                    const uint32_t s_f = cand1[q] ? (xf1[q] & smask) : (xf2[q] >> 4), s_r = cand1[q] ? (xr1[q] >> 4) : (xr2[q] & smask);
-                    sfw[q] = s_f <= s_r;
-                    const uint32_t t = sfw[q] ? s_f : s_r;
-                    // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
-                    k1[q] = map_ct_key_of(T, t, sfw[q] ? 0u : 1u, sfw[q] ? (xf1[q] >> sb) : (xr1[q] & 15u));
-                    k2[q] = map_ct_key_of(T, t, sfw[q] ? 1u : 0u, sfw[q] ? (xf2[q] & 15u) : (xr2[q] >> sb));
-                    if (cand1[q] || cand2[q]) B[q] = T.buckets[k1[q].bucket];
-                } else {
-                    if (cand1[q]) e1[q] = T.direct[c1[q]];
-                    if (cand2[q]) e2[q] = T.direct[c2[q]];
+            l0 = l1; l1 = l2; l2 = l3; l3 = l4;
+            m0 = m1; m1 = m2; m2 = m3; m3 = m4;
+        }
+        // ---- phase 2: the queue, dealt out to the lanes that are here (LDS operations of a wave complete in program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t e = (uint32_t)me; e < qn; e += (uint32_t)n_here) {
+            const uint32_t ent = queue[e];
+            const int owner = wave0 + (int)(ent & 63u), qi = (int)((ent >> 6) & 15u), j = 4 * qi, w = qi >> 2;
+            const bool cand1 = ent & 0x400u, cand2 = ent & 0x800u;
+            const uint32_t *ow = U.words + owner;
+            const map_quad_win Q = map_quad_windows(ow[w * MAP_BLOCK], ow[(w + 1) * MAP_BLOCK], ow[(5 + w) * MAP_BLOCK], ow[(6 + w) * MAP_BLOCK],
+                                                    j & 15, sh, m1mask);
+            const uint32_t okk = ow[(10 + (w >> 1)) * MAP_BLOCK] >> (j & 31);      // countable starts j .. j + 3 of the owner's unit
+            uint32_t e1 = 0, e2 = 0;
+            uint32_t loc1 = Q.xf1 < Q.xr1 ? Q.xf1 : Q.xr1, loc2 = Q.xf2 < Q.xr2 ? Q.xf2 : Q.xr2;
+            bool fw1 = Q.xf1 <= Q.xr1, fw2 = Q.xf2 <= Q.xr2;
+            if (TABLE) {
+                // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
+                const uint32_t s_f = cand1 ? (Q.xf1 & smask) : (Q.xf2 >> 4), s_r = cand1 ? (Q.xr1 >> 4) : (Q.xr2 & smask);
+                const bool sfw = s_f <= s_r;
+                const uint32_t t = sfw ? s_f : s_r;
+                // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+                const map_ct_key k1 = map_ct_key_of(T, t, sfw ? 0u : 1u, sfw ? (Q.xf1 >> sb) : (Q.xr1 & 15u));
+                const map_ct_key k2 = map_ct_key_of(T, t, sfw ? 1u : 0u, sfw ? (Q.xf2 & 15u) : (Q.xr2 >> sb));
+                const uint4 B = T.buckets[k1.bucket];
+                if (cand1) {
+                    const map_ct_hit h = map_ct_find(T, B, k1);
+                    e1 = h.fields;
+                    loc1 = h.loc;
                 }
+                if (cand2) {
+                    const map_ct_hit h = map_ct_find(T, B, k2);
+                    e2 = h.fields;
+                    loc2 = h.loc;
+                }
+                fw1 = fw2 = sfw;       // the fields are laid out in the orientation in which t is canonical
+            } else {
+                if (cand1) e1 = T.direct[loc1];
+                if (cand2) e2 = T.direct[loc2];
             }
+            // the (up to four) labelled starts of the quad: start j + 2h = b0 + x, start j + 2h + 1 = x + b1
 #pragma unroll
-            for (int q = 0; q < QI; q++) {
-                if (!(cand1[q] || cand2[q])) continue;
-                const int j = 16 * w + r0 + 4 * q;
-                uint32_t loc1 = c1[q], loc2 = c2[q];
-                bool fw1 = xf1[q] <= xr1[q], fw2 = xf2[q] <= xr2[q];
-                if (TABLE) {
-                    if (cand1[q]) {
-                        const map_ct_hit h = map_ct_find(T, B[q], k1[q]);
-                        e1[q] = h.fields;
-                        loc1 = h.loc;
-                    }
-                    if (cand2[q]) {
-                        const map_ct_hit h = map_ct_find(T, B[q], k2[q]);
-                        e2[q] = h.fields;
-                        loc2 = h.loc;
-                    }
-                    fw1 = fw2 = sfw[q];       // the fields are laid out in the orientation in which t is canonical
+            for (int h = 0; h < 2; h++) {
+                const uint32_t ee = h ? e2 : e1;
+                if (!(ee & ANY)) continue;
+                const uint32_t V = h ? Q.V2 : Q.V1;
+                const bool fw = h ? fw2 : fw1;
+                const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
+                const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
+                const uint32_t cnt2 = okk >> (2 * h);
+                const uint32_t v0 = (cnt2 & 1u) ? (ee >> (FW * f0)) & FMASK : 0u;
+                const uint32_t v1 = (cnt2 & 2u) ? (ee >> (FW * f1)) & FMASK : 0u;
+                const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
+                if (!two) continue;
+#pragma unroll
+                for (int bit = 0; bit < NP; bit++) {
+                    const unsigned long long b2 = (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1));
+                    if (b2) atomicOr(&U.planes[bit * MAP_BLOCK + owner], b2 << (j + 2 * h));
                 }
-                // the (up to four) labelled starts of the quad: start j + 2h = b0 + x, start j + 2h + 1 = x + b1
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t e = h ? e2[q] : e1[q];
-                    if (!(e & ANY)) continue;
-                    const uint32_t V = h ? V2[q] : V1[q];
-                    const bool fw = h ? fw2 : fw1;
-                    const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
-                    const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
-                    // (a start outside `cm` -- interval mode: not covered by a feature -- is neither counted nor marked seen)
-                    const uint32_t cnt2 = (uint32_t)(cm >> (j + 2 * h)) & okk[q] >> (2 * h);
-                    const uint32_t v0 = (cnt2 & 1u) ? (e >> (FW * f0)) & FMASK : 0u;
-                    const uint32_t v1 = (cnt2 & 2u) ? (e >> (FW * f1)) & FMASK : 0u;
-                    const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
-                    if (!two) continue;
-#pragma unroll
-                    for (int bit = 0; bit < (TABLE ? 2 : 3); bit++)
-                        lab[bit] |= (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1)) << (j + 2 * h);
-                    uint32_t mark = 0;       // "seen": first touch only
-                    if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
-                    if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
-                    if (mark) {
-                        if (TABLE) map_ct_mark(T, h ? loc2 : loc1, mark);
-                        else atomicOr(&T.direct[h ? loc2 : loc1], mark);
-                    }
+                uint32_t mark = 0;       // "seen": first touch only
+                if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+                if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+                if (mark) {
+                    if (TABLE) map_ct_mark(T, h ? loc2 : loc1, mark);
+                    else atomicOr(&T.direct[h ? loc2 : loc1], mark);
                 }
             }
         }
-        l0 = l1; l1 = l2; l2 = l3; l3 = l4;
-        m0 = m1; m1 = m2; m2 = m3; m3 = m4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#pragma unroll
+    for (int bit = 0; bit < NP; bit++) lab[bit] = U.planes[bit * MAP_BLOCK + tid];
 }
 
 template <int TABLE>
@@ -411,6 +456,7 @@ k5_map2(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, 
         map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
+    MAP_UNIT_LDS_DECL(TABLE);
     unsigned long long mapped = 0;
     int cur = -1;          // chromosome the block is accumulating `mapped` for
     auto flush_mapped = [&]() {     // block-uniform control flow
@@ -442,7 +488,7 @@ k5_map2(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, 
         }
         if (u < D.n_units) {
             unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-            map_unit_scan64<TABLE>(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab);
+            map_unit_scan64<TABLE>(D.pk, D.pm, D.nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab, ulds);
             if (lab[0] | lab[1] | lab[2]) {
                 auto add = [&](int64_t os, unsigned long long within) {       // the unit's hits among the starts `within` -> slot os
                     for (int sg = 0; sg < P.S; sg++) {
@@ -493,13 +539,14 @@ __global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
 k5_map_mask2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams32 kp,
              int64_t n_units, int S, map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
              const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks /* n_units x S */) {
+    MAP_UNIT_LDS_DECL(TABLE);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;         // nothing of this wave's 4096 starts lies in a feature
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab, cv);
+        map_unit_scan64<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, ptab, lab, ulds, cv);
         for (int sg = 0; sg < S; sg++) {
             const int l = sg + 1;
             masks[u * S + sg] = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) & ((l & 4) ? lab[2] : ~lab[2]) & cv;
@@ -631,6 +678,7 @@ k5_map_feat2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
              sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
              map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
              unsigned long long *__restrict__ counts) {
+    MAP_UNIT_LDS_DECL(TABLE);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int k = kp.k;
@@ -655,7 +703,7 @@ k5_map_feat2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
             if (e >= s0 + SP_UNIT) break;
         }
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, ptab, lab, fit);
+        map_unit_scan64<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, ptab, lab, ulds, fit);
         if (!(lab[0] | lab[1] | lab[2])) continue;
         // (3) the features that overlap the unit (a start beyond the last feature's end is padding: never valid)
         for (int64_t f = lo; f < n_feat; f++) {
