@@ -241,11 +241,14 @@ __host__ __device__ __forceinline__ int map_ct_sites(uint64_t o, int k, map_ct_s
 #define MAP_GRID_MULT 16
 #endif
 #ifndef MAP_BLOCK
-#define MAP_BLOCK 768   // measured: 256 -> 70.5 ms, 512 -> 68.3, 768 -> 66.2, 1024 -> 73.8 (640 / 896: 76-79)
+#define MAP_BLOCK 512   // rounds 2-5 (one-phase walks): 256 -> 70.5 ms, 512 -> 68.3, 768 -> 66.2, 1024 -> 73.8.  Round 6 (two-phase walk,
+                        // bound by waiting, not by instruction issue): 768 x 2 workgroups per CU (6 waves per SIMD) 34.5 ms,
+                        // 512 x 4 (8 per SIMD, 64 VGPRs) 32.6, 256 x 8 33.0, 384 x 5 35.4, 1024 x 2 33.6
 #endif
 #define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // starts per block iteration
 #ifndef MAP_LDS_ENTRIES
-#define MAP_LDS_ENTRIES 4096
+#define MAP_LDS_ENTRIES 1024      // (4096 until round 6: the LDS went to the walk's candidate queue; a range of 49 152 starts needs
+                                   // ~ 10 x S entries at 10-kb bins, 1024 cover bins down to ~150 bases at S = 3 -- below that: global atomics)
 #endif
 
 struct sp_map_params {

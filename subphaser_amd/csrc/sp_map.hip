@@ -211,7 +211,7 @@ struct map_chrom_desc {
 };
 
 #ifndef MAP_MIN_WAVES
-#define MAP_MIN_WAVES 1     // waves per SIMD the register allocation must leave room for
+#define MAP_MIN_WAVES 8     // waves per SIMD the register allocation must leave room for (four 512-thread workgroups per CU)
 #endif
 // ----------------------------------------------------------------- K5: the rolled walk (round 5)
 // Rounds 2-4 unrolled the walk over a unit completely: 258 KB of machine code (the k > 15 twin: 532 KB) -- sixteen
@@ -234,13 +234,23 @@ struct map_chrom_desc {
 // (lane, quad, which pairs).  Phase 2 deals the queue out to all lanes: ~280 candidates per 1024 quads are 4-5 iterations of the
 // candidate path per unit instead of 16.  A lane rebuilds the windows of the quad it was dealt from the owner's ten packed words,
 // parked in LDS (one column per thread), and ORs the labels it finds into the owner's planes there.
+#ifndef MAP2_QI
+#define MAP2_QI 1      // quads per iteration of the filter phase
+#endif
+#ifndef MAP2_P2
+#define MAP2_P2 1      // queue entries per lane and iteration of the candidate phase (2: 34.5 against 34.3 ms -- the wait is not per wave)
+#endif
 struct map_unit_lds {
-    uint32_t *words;                 // [MAP_UNIT_WORDS][MAP_BLOCK]: the unit's packed words LSB-first (0..4), MSB-first (5..9), countable starts (10, 11)
+    uint32_t *words;                 // [MAP_UNIT_WORDS][MAP_BLOCK]: the unit's five packed words (LSB-first; the MSB-first twin is derived), countable starts (5, 6)
     unsigned long long *planes;      // [2 or 3][MAP_BLOCK]: the label planes of every thread's unit
     uint16_t *queue;                 // [MAP_BLOCK / 64][MAP_QCAP]: the wave's candidate quads
 };
-#define MAP_UNIT_WORDS 12
-#define MAP_QCAP(TABLE) ((TABLE) ? 512 : 256)       // two / one 16-start word of every lane per round
+#define MAP_UNIT_WORDS 7
+#ifndef MAP2_ROUND_W
+#define MAP2_ROUND_W 2      // 16-start words of every lane per round of the two phases (compact table; 4 = the whole unit: one
+                            // partly filled iteration fewer per unit, but the queue's LDS then allows three workgroups per CU, not four)
+#endif
+#define MAP_QCAP(TABLE) ((TABLE) ? 256 * MAP2_ROUND_W : 512)      // the whole unit / two of the four 16-start words of every lane per round
 #define MAP_UNIT_LDS_DECL(TABLE)                                                          \
     __shared__ uint32_t s_uw[MAP_UNIT_WORDS * MAP_BLOCK];                                 \
     __shared__ unsigned long long s_up[((TABLE) ? 2 : 3) * MAP_BLOCK];                    \
@@ -271,7 +281,7 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     constexpr int FW = TABLE ? MAP_CT_FIELD : 4;
     constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
     constexpr uint32_t ANY = TABLE ? MAP_CT_ANY : 0x77777777u;
-    constexpr int NP = TABLE ? 2 : 3, ROUND_W = TABLE ? 2 : 1;
+    constexpr int NP = TABLE ? 2 : 3, ROUND_W = TABLE ? MAP2_ROUND_W : 2;
     // validity of the 64 starts: k-mer at s0+j, shared (k-1)-mer at s0+j+1
     unsigned long long ok_k, ok_x;
     {
@@ -304,8 +314,7 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
     {
         const unsigned long long okc = ok_k & cm;      // (a start outside `cm` -- interval mode: not covered by a feature -- is neither counted nor marked seen)
         sw[0 * MAP_BLOCK] = l0; sw[1 * MAP_BLOCK] = l1; sw[2 * MAP_BLOCK] = l2; sw[3 * MAP_BLOCK] = l3; sw[4 * MAP_BLOCK] = l4;
-        sw[5 * MAP_BLOCK] = m0; sw[6 * MAP_BLOCK] = m1; sw[7 * MAP_BLOCK] = m2; sw[8 * MAP_BLOCK] = m3; sw[9 * MAP_BLOCK] = m4;
-        sw[10 * MAP_BLOCK] = (uint32_t)okc; sw[11 * MAP_BLOCK] = (uint32_t)(okc >> 32);
+        sw[5 * MAP_BLOCK] = (uint32_t)okc; sw[6 * MAP_BLOCK] = (uint32_t)(okc >> 32);
 #pragma unroll
         for (int bit = 0; bit < NP; bit++) U.planes[bit * MAP_BLOCK + tid] = 0ULL;
     }
@@ -326,51 +335,67 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
 #pragma unroll 1
         for (int w = wr; w < wr + ROUND_W; w++) {
 #pragma unroll 1
-            for (int r = 0; r < 16; r += 4) {
-                const int j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
-                const map_quad_win Q = map_quad_windows(l0, l1, m0, m1, r, sh, m1mask);
-                const uint32_t c1 = Q.xf1 < Q.xr1 ? Q.xf1 : Q.xr1, c2 = Q.xf2 < Q.xr2 ? Q.xf2 : Q.xr2;
-                uint32_t h1, h2;
-                const uint32_t bt1 = map_bloom_bits3((uint64_t)c1, h1), bt2 = map_bloom_bits3((uint64_t)c2, h2);
-                const uint32_t okx = (uint32_t)(ok_x >> j);
-                const bool v1 = okx & 1u, v2 = okx & 4u;
-                uint32_t wi1, wi2;          // the filter words of x1 and x2
-                if (core) {
-                    // the chain of cores: a = first k-3 bases of x1, b = last of x1 = first of x2, c = last of x2 (= the next
-                    // quad's a); canonical = the smaller of the forward reading and its reverse complement, which is the
-                    // OTHER end of the reverse-complemented (k-1)-mer
-                    const uint32_t tb_f = Q.xf1 & cmask, tb_r = Q.xr1 >> 4, tc_f = Q.xf2 & cmask, tc_r = Q.xr2 >> 4;
-                    uint32_t ha = h_carry;              // (this quad's a IS the previous quad's c: the same bases)
-                    if (j == 0) {                       // (uniform: the unit's first quad)
-                        const uint32_t ta_f = Q.xf1 >> 4, ta_r = Q.xr1 & cmask;
-                        ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
+            for (int r0 = 0; r0 < 16; r0 += 4 * MAP2_QI) {
+                // MAP2_QI quads per iteration: their filter words are requested together (the word a pair re-uses is known from the
+                // indices alone), then looked at
+                uint32_t bt1[MAP2_QI], bt2[MAP2_QI], wi1[MAP2_QI], wi2[MAP2_QI], f1[MAP2_QI], f2[MAP2_QI];
+                bool v1[MAP2_QI], v2[MAP2_QI], need1[MAP2_QI], need2[MAP2_QI];
+                uint32_t lw = last_wi;
+#pragma unroll
+                for (int q = 0; q < MAP2_QI; q++) {
+                    const int r = r0 + 4 * q, j = 16 * w + r;     // the quad's first start; its pairs share x1 (at j + 1) and x2 (at j + 3)
+                    const map_quad_win Q = map_quad_windows(l0, l1, m0, m1, r, sh, m1mask);
+                    const uint32_t c1 = Q.xf1 < Q.xr1 ? Q.xf1 : Q.xr1, c2 = Q.xf2 < Q.xr2 ? Q.xf2 : Q.xr2;
+                    uint32_t h1, h2;
+                    bt1[q] = map_bloom_bits3((uint64_t)c1, h1);
+                    bt2[q] = map_bloom_bits3((uint64_t)c2, h2);
+                    const uint32_t okx = (uint32_t)(ok_x >> j);
+                    v1[q] = okx & 1u;
+                    v2[q] = okx & 4u;
+                    if (core) {
+                        // the chain of cores: a = first k-3 bases of x1, b = last of x1 = first of x2, c = last of x2 (= the next
+                        // quad's a); canonical = the smaller of the forward reading and its reverse complement, which is the
+                        // OTHER end of the reverse-complemented (k-1)-mer
+                        const uint32_t tb_f = Q.xf1 & cmask, tb_r = Q.xr1 >> 4, tc_f = Q.xf2 & cmask, tc_r = Q.xr2 >> 4;
+                        uint32_t ha = h_carry;              // (this quad's a IS the previous quad's c: the same bases)
+                        if (j == 0) {                       // (uniform: the unit's first quad)
+                            const uint32_t ta_f = Q.xf1 >> 4, ta_r = Q.xr1 & cmask;
+                            ha = map_core_hash((uint64_t)(ta_f < ta_r ? ta_f : ta_r));
+                        }
+                        const uint32_t hb = map_core_hash((uint64_t)(tb_f < tb_r ? tb_f : tb_r));
+                        const uint32_t hc = map_core_hash((uint64_t)(tc_f < tc_r ? tc_f : tc_r));
+                        h_carry = hc;
+                        wi1[q] = map_core_word(ha < hb ? ha : hb, nbits);
+                        wi2[q] = map_core_word(hb < hc ? hb : hc, nbits);
+                    } else {
+                        wi1[q] = h1 >> wsh;
+                        wi2[q] = h2 >> wsh;
                     }
-                    const uint32_t hb = map_core_hash((uint64_t)(tb_f < tb_r ? tb_f : tb_r));
-                    const uint32_t hc = map_core_hash((uint64_t)(tc_f < tc_r ? tc_f : tc_r));
-                    h_carry = hc;
-                    wi1 = map_core_word(ha < hb ? ha : hb, nbits);
-                    wi2 = map_core_word(hb < hc ? hb : hc, nbits);
-                } else {
-                    wi1 = h1 >> wsh;
-                    wi2 = h2 >> wsh;
+                    // a word this lane holds already (the previous pair's) is not fetched again: with the core addressing that
+                    // is the case for a third of the pairs -- and a gather is priced per active lane
+                    need1[q] = v1[q] && wi1[q] != lw;
+                    need2[q] = v2[q] && wi2[q] != (v1[q] ? wi1[q] : lw);
+                    f1[q] = f2[q] = 0;
+                    if (need1[q]) f1[q] = bloom[wi1[q]];
+                    if (need2[q]) f2[q] = bloom[wi2[q]];
+                    if (v2[q]) lw = wi2[q];
+                    else if (v1[q]) lw = wi1[q];
                 }
-                // a word this lane holds already (the previous pair's) is not fetched again: with the core addressing that
-                // is the case for a third of the pairs -- and a gather is priced per active lane
-                const bool need1 = v1 && wi1 != last_wi;
-                const bool need2 = v2 && wi2 != (v1 ? wi1 : last_wi);
-                uint32_t f1 = 0, f2 = 0;
-                if (need1) f1 = bloom[wi1];
-                if (need2) f2 = bloom[wi2];
-                const uint32_t wd1 = v1 ? (need1 ? f1 : last_w) : 0u;
-                const uint32_t wd2 = v2 ? (need2 ? f2 : (v1 ? wd1 : last_w)) : 0u;
-                if (v2) { last_wi = wi2; last_w = wd2; }
-                else if (v1) { last_wi = wi1; last_w = wd1; }
-                const bool cand1 = (wd1 & bt1) == bt1, cand2 = (wd2 & bt2) == bt2;       // (an invalid pair's word is 0: never a candidate)
-                const unsigned long long bal = __ballot(cand1 || cand2);
-                if (cand1 || cand2)
-                    queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
-                        (uint16_t)((uint32_t)lane | ((uint32_t)(j >> 2) << 6) | (cand1 ? 0x400u : 0u) | (cand2 ? 0x800u : 0u));
-                qn += (uint32_t)__popcll(bal);
+                last_wi = lw;
+#pragma unroll
+                for (int q = 0; q < MAP2_QI; q++) {
+                    const int j = 16 * w + r0 + 4 * q;
+                    const uint32_t wd1 = v1[q] ? (need1[q] ? f1[q] : last_w) : 0u;
+                    const uint32_t wd2 = v2[q] ? (need2[q] ? f2[q] : (v1[q] ? wd1 : last_w)) : 0u;
+                    if (v2[q]) last_w = wd2;
+                    else if (v1[q]) last_w = wd1;
+                    const bool cand1 = (wd1 & bt1[q]) == bt1[q], cand2 = (wd2 & bt2[q]) == bt2[q];       // (an invalid pair's word is 0: never a candidate)
+                    const unsigned long long bal = __ballot(cand1 || cand2);
+                    if (cand1 || cand2)
+                        queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                            (uint16_t)((uint32_t)lane | ((uint32_t)(j >> 2) << 6) | (cand1 ? 0x400u : 0u) | (cand2 ? 0x800u : 0u));
+                    qn += (uint32_t)__popcll(bal);
+                }
             }
             l0 = l1; l1 = l2; l2 = l3; l3 = l4;
             m0 = m1; m1 = m2; m2 = m3; m3 = m4;
@@ -379,66 +404,90 @@ __device__ __forceinline__ void map_unit_scan64(const uint32_t *__restrict__ pk,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t e = (uint32_t)me; e < qn; e += (uint32_t)n_here) {
-            const uint32_t ent = queue[e];
-            const int owner = wave0 + (int)(ent & 63u), qi = (int)((ent >> 6) & 15u), j = 4 * qi, w = qi >> 2;
-            const bool cand1 = ent & 0x400u, cand2 = ent & 0x800u;
-            const uint32_t *ow = U.words + owner;
-            const map_quad_win Q = map_quad_windows(ow[w * MAP_BLOCK], ow[(w + 1) * MAP_BLOCK], ow[(5 + w) * MAP_BLOCK], ow[(6 + w) * MAP_BLOCK],
-                                                    j & 15, sh, m1mask);
-            const uint32_t okk = ow[(10 + (w >> 1)) * MAP_BLOCK] >> (j & 31);      // countable starts j .. j + 3 of the owner's unit
-            uint32_t e1 = 0, e2 = 0;
-            uint32_t loc1 = Q.xf1 < Q.xr1 ? Q.xf1 : Q.xr1, loc2 = Q.xf2 < Q.xr2 ? Q.xf2 : Q.xr2;
-            bool fw1 = Q.xf1 <= Q.xr1, fw2 = Q.xf2 <= Q.xr2;
-            if (TABLE) {
-                // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
-                const uint32_t s_f = cand1 ? (Q.xf1 & smask) : (Q.xf2 >> 4), s_r = cand1 ? (Q.xr1 >> 4) : (Q.xr2 & smask);
-                const bool sfw = s_f <= s_r;
-                const uint32_t t = sfw ? s_f : s_r;
-                // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
-                const map_ct_key k1 = map_ct_key_of(T, t, sfw ? 0u : 1u, sfw ? (Q.xf1 >> sb) : (Q.xr1 & 15u));
-                const map_ct_key k2 = map_ct_key_of(T, t, sfw ? 1u : 0u, sfw ? (Q.xf2 & 15u) : (Q.xr2 >> sb));
-                const uint4 B = T.buckets[k1.bucket];
-                if (cand1) {
-                    const map_ct_hit h = map_ct_find(T, B, k1);
-                    e1 = h.fields;
-                    loc1 = h.loc;
+        for (uint32_t e0 = (uint32_t)me; e0 < qn; e0 += (uint32_t)(MAP2_P2 * n_here)) {
+            // MAP2_P2 entries per lane and iteration: their bucket loads (Infinity Cache: the longest wait of the kernel) travel together
+            bool live[MAP2_P2], cand1[MAP2_P2], cand2[MAP2_P2], sfw[MAP2_P2];
+            int owner[MAP2_P2], jj[MAP2_P2];
+            map_quad_win Q[MAP2_P2];
+            uint32_t okk[MAP2_P2], e1[MAP2_P2], e2[MAP2_P2];
+            map_ct_key k1[MAP2_P2], k2[MAP2_P2];
+            uint4 B[MAP2_P2];
+#pragma unroll
+            for (int p = 0; p < MAP2_P2; p++) {
+                const uint32_t e = e0 + (uint32_t)(p * n_here);
+                live[p] = e < qn;
+                const uint32_t ent = live[p] ? (uint32_t)queue[e] : 0u;
+                const int qi = (int)((ent >> 6) & 15u), w = qi >> 2;
+                owner[p] = wave0 + (int)(ent & 63u);
+                jj[p] = 4 * qi;
+                cand1[p] = ent & 0x400u;
+                cand2[p] = ent & 0x800u;
+                const uint32_t *ow = U.words + owner[p];
+                const uint32_t ola = ow[w * MAP_BLOCK], olb = ow[(w + 1) * MAP_BLOCK];
+                Q[p] = map_quad_windows(ola, olb, sp_msb_of_lsb(ola), sp_msb_of_lsb(olb), jj[p] & 15, sh, m1mask);
+                okk[p] = ow[(5 + (w >> 1)) * MAP_BLOCK] >> (jj[p] & 31);      // countable starts j .. j + 3 of the owner's unit
+                e1[p] = e2[p] = 0;
+                sfw[p] = false;
+                B[p] = make_uint4(0u, 0u, 0u, 0u);
+                if (TABLE) {
+                    // s = the last k-3 bases of x1 = the first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so s is)
+                    const uint32_t s_f = cand1[p] ? (Q[p].xf1 & smask) : (Q[p].xf2 >> 4), s_r = cand1[p] ? (Q[p].xr1 >> 4) : (Q[p].xr2 & smask);
+                    sfw[p] = s_f <= s_r;
+                    const uint32_t t = sfw[p] ? s_f : s_r;
+                    // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+                    k1[p] = map_ct_key_of(T, t, sfw[p] ? 0u : 1u, sfw[p] ? (Q[p].xf1 >> sb) : (Q[p].xr1 & 15u));
+                    k2[p] = map_ct_key_of(T, t, sfw[p] ? 1u : 0u, sfw[p] ? (Q[p].xf2 & 15u) : (Q[p].xr2 >> sb));
+                    if (live[p]) B[p] = T.buckets[k1[p].bucket];
+                } else {
+                    if (cand1[p]) e1[p] = T.direct[Q[p].xf1 < Q[p].xr1 ? Q[p].xf1 : Q[p].xr1];
+                    if (cand2[p]) e2[p] = T.direct[Q[p].xf2 < Q[p].xr2 ? Q[p].xf2 : Q[p].xr2];
                 }
-                if (cand2) {
-                    const map_ct_hit h = map_ct_find(T, B, k2);
-                    e2 = h.fields;
-                    loc2 = h.loc;
-                }
-                fw1 = fw2 = sfw;       // the fields are laid out in the orientation in which t is canonical
-            } else {
-                if (cand1) e1 = T.direct[loc1];
-                if (cand2) e2 = T.direct[loc2];
             }
-            // the (up to four) labelled starts of the quad: start j + 2h = b0 + x, start j + 2h + 1 = x + b1
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t ee = h ? e2 : e1;
-                if (!(ee & ANY)) continue;
-                const uint32_t V = h ? Q.V2 : Q.V1;
-                const bool fw = h ? fw2 : fw1;
-                const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
-                const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
-                const uint32_t cnt2 = okk >> (2 * h);
-                const uint32_t v0 = (cnt2 & 1u) ? (ee >> (FW * f0)) & FMASK : 0u;
-                const uint32_t v1 = (cnt2 & 2u) ? (ee >> (FW * f1)) & FMASK : 0u;
-                const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
-                if (!two) continue;
-#pragma unroll
-                for (int bit = 0; bit < NP; bit++) {
-                    const unsigned long long b2 = (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1));
-                    if (b2) atomicOr(&U.planes[bit * MAP_BLOCK + owner], b2 << (j + 2 * h));
+            for (int p = 0; p < MAP2_P2; p++) {
+                if (!live[p]) continue;
+                const int j = jj[p];
+                uint32_t loc1 = Q[p].xf1 < Q[p].xr1 ? Q[p].xf1 : Q[p].xr1, loc2 = Q[p].xf2 < Q[p].xr2 ? Q[p].xf2 : Q[p].xr2;
+                bool fw1 = Q[p].xf1 <= Q[p].xr1, fw2 = Q[p].xf2 <= Q[p].xr2;
+                if (TABLE) {
+                    if (cand1[p]) {
+                        const map_ct_hit h = map_ct_find(T, B[p], k1[p]);
+                        e1[p] = h.fields;
+                        loc1 = h.loc;
+                    }
+                    if (cand2[p]) {
+                        const map_ct_hit h = map_ct_find(T, B[p], k2[p]);
+                        e2[p] = h.fields;
+                        loc2 = h.loc;
+                    }
+                    fw1 = fw2 = sfw[p];       // the fields are laid out in the orientation in which t is canonical
                 }
-                uint32_t mark = 0;       // "seen": first touch only
-                if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
-                if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
-                if (mark) {
-                    if (TABLE) map_ct_mark(T, h ? loc2 : loc1, mark);
-                    else atomicOr(&T.direct[h ? loc2 : loc1], mark);
+                // the (up to four) labelled starts of the quad: start j + 2h = b0 + x, start j + 2h + 1 = x + b1
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t ee = h ? e2[p] : e1[p];
+                    if (!(ee & ANY)) continue;
+                    const uint32_t V = h ? Q[p].V2 : Q[p].V1;
+                    const bool fw = h ? fw2 : fw1;
+                    const uint32_t b0 = V >> 30, b1 = (V >> sh1) & 3u;
+                    const int f0 = fw ? (int)b0 : 7 - (int)b0, f1 = fw ? 4 + (int)b1 : 3 - (int)b1;
+                    const uint32_t cnt2 = okk[p] >> (2 * h);
+                    const uint32_t v0 = (cnt2 & 1u) ? (ee >> (FW * f0)) & FMASK : 0u;
+                    const uint32_t v1 = (cnt2 & 2u) ? (ee >> (FW * f1)) & FMASK : 0u;
+                    const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);      // labels of the two starts
+                    if (!two) continue;
+#pragma unroll
+                    for (int bit = 0; bit < NP; bit++) {
+                        const unsigned long long b2 = (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1));
+                        if (b2) atomicOr(&U.planes[bit * MAP_BLOCK + owner[p]], b2 << (j + 2 * h));
+                    }
+                    uint32_t mark = 0;       // "seen": first touch only
+                    if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
+                    if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
+                    if (mark) {
+                        if (TABLE) map_ct_mark(T, h ? loc2 : loc1, mark);
+                        else atomicOr(&T.direct[h ? loc2 : loc1], mark);
+                    }
                 }
             }
         }
