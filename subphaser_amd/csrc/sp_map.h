@@ -246,6 +246,26 @@ __host__ __device__ __forceinline__ int map_ct_sites(uint64_t o, int k, map_ct_s
                         // 512 x 4 (8 per SIMD, 64 VGPRs) 32.6, 256 x 8 33.0, 384 x 5 35.4, 1024 x 2 33.6
 #endif
 #define MAP_RANGE (MAP_BLOCK * SP_UNIT)  // starts per block iteration
+// ---- LDS of the two-phase walks over a unit (map_unit_scan64 in sp_map.hip, map_unit_scan64_h in sp_sparse.hip)
+#ifndef MAP2_P2
+#define MAP2_P2 1      // queue entries per lane and iteration of the candidate phase (2: 34.5 against 34.3 ms -- the wait is not per wave)
+#endif
+struct map_unit_lds {
+    uint32_t *words;                 // [5 + 2 or 6 + 2][MAP_BLOCK]: the unit's packed words (LSB-first; the MSB-first twin is derived), then its countable starts
+    unsigned long long *planes;      // [2 or 3][MAP_BLOCK]: the label planes of every thread's unit
+    uint16_t *queue;                 // [MAP_BLOCK / 64][MAP_QCAP]: the wave's candidate quads
+};
+#ifndef MAP2_ROUND_W
+#define MAP2_ROUND_W 2      // 16-start words of every lane per round of the two phases (compact table; 4 = the whole unit: one
+                            // partly filled iteration fewer per unit, but the queue's LDS then allows three workgroups per CU, not four)
+#endif
+#define MAP_QCAP(TABLE) ((TABLE) ? 256 * MAP2_ROUND_W : 512)      // the whole unit / two of the four 16-start words of every lane per round
+#define MAP_UNIT_LDS_DECL(TABLE, WORDS)                                                   \
+    __shared__ uint32_t s_uw[(WORDS) * MAP_BLOCK];                                        \
+    __shared__ unsigned long long s_up[((TABLE) ? 2 : 3) * MAP_BLOCK];                    \
+    __shared__ uint16_t s_uq[(MAP_BLOCK / 64) * MAP_QCAP(TABLE)];                         \
+    const map_unit_lds ulds = {s_uw, s_up, s_uq}
+
 #ifndef MAP_LDS_ENTRIES
 #define MAP_LDS_ENTRIES 1024      // (4096 until round 6: the LDS went to the walk's candidate queue; a range of 49 152 starts needs
                                    // ~ 10 x S entries at 10-kb bins, 1024 cover bins down to ~150 bases at S = 3 -- below that: global atomics)

@@ -237,25 +237,6 @@ struct map_chrom_desc {
 #ifndef MAP2_QI
 #define MAP2_QI 1      // quads per iteration of the filter phase
 #endif
-#ifndef MAP2_P2
-#define MAP2_P2 1      // queue entries per lane and iteration of the candidate phase (2: 34.5 against 34.3 ms -- the wait is not per wave)
-#endif
-struct map_unit_lds {
-    uint32_t *words;                 // [MAP_UNIT_WORDS][MAP_BLOCK]: the unit's five packed words (LSB-first; the MSB-first twin is derived), countable starts (5, 6)
-    unsigned long long *planes;      // [2 or 3][MAP_BLOCK]: the label planes of every thread's unit
-    uint16_t *queue;                 // [MAP_BLOCK / 64][MAP_QCAP]: the wave's candidate quads
-};
-#define MAP_UNIT_WORDS 7
-#ifndef MAP2_ROUND_W
-#define MAP2_ROUND_W 2      // 16-start words of every lane per round of the two phases (compact table; 4 = the whole unit: one
-                            // partly filled iteration fewer per unit, but the queue's LDS then allows three workgroups per CU, not four)
-#endif
-#define MAP_QCAP(TABLE) ((TABLE) ? 256 * MAP2_ROUND_W : 512)      // the whole unit / two of the four 16-start words of every lane per round
-#define MAP_UNIT_LDS_DECL(TABLE)                                                          \
-    __shared__ uint32_t s_uw[MAP_UNIT_WORDS * MAP_BLOCK];                                 \
-    __shared__ unsigned long long s_up[((TABLE) ? 2 : 3) * MAP_BLOCK];                    \
-    __shared__ uint16_t s_uq[(MAP_BLOCK / 64) * MAP_QCAP(TABLE)];                         \
-    const map_unit_lds ulds = {s_uw, s_up, s_uq}
 struct map_quad_win {
     uint32_t V1, V2, xf1, xr1, xf2, xr2;       // 16-base windows at j / j + 2 (MSB-first), x1 / x2 forward and reverse complement
 };
@@ -505,7 +486,7 @@ k5_map2(const map_chrom_desc *__restrict__ desc, int n_chrom, int64_t n_ranges, 
         map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
-    MAP_UNIT_LDS_DECL(TABLE);
+    MAP_UNIT_LDS_DECL(TABLE, 7);
     unsigned long long mapped = 0;
     int cur = -1;          // chromosome the block is accumulating `mapped` for
     auto flush_mapped = [&]() {     // block-uniform control flow
@@ -588,7 +569,7 @@ __global__ void __launch_bounds__(MAP_BLOCK, MAP_MIN_WAVES)
 k5_map_mask2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams32 kp,
              int64_t n_units, int S, map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
              const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks /* n_units x S */) {
-    MAP_UNIT_LDS_DECL(TABLE);
+    MAP_UNIT_LDS_DECL(TABLE, 7);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
@@ -727,7 +708,7 @@ k5_map_feat2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, c
              sp_kparams32 kp, int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
              map_ptab ptab, const uint32_t *__restrict__ bloom, int bloom_bits,
              unsigned long long *__restrict__ counts) {
-    MAP_UNIT_LDS_DECL(TABLE);
+    MAP_UNIT_LDS_DECL(TABLE, 7);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int k = kp.k;

@@ -523,12 +523,39 @@ sq_seen(const unsigned long long *__restrict__ keys, int64_t n, int k, sq_tab T,
 // a hit is a bit in three label planes and a unit's hits are settled once, by popcounts.  Pair-keyed table only
 // (S <= 7); the per-k-mer table takes k5_map_sparse_lab above.  TABLE: 0 = the pair-keyed hash table (one look-up per candidate
 // pair, S <= 7), 1 = the quad buckets above (one per candidate quad, S <= 3; `htab` / `hmask` unused).
+// Round 6: two phases, as map_unit_scan64 (sp_map.hip): the filter leaves the wave's candidate quads in an LDS queue, the
+// look-ups are dealt out to all lanes (a lane rebuilds the windows of the quad it was dealt from the owner's six packed words
+// in LDS and ORs the labels it finds into the owner's planes).
+struct map_pair_win {
+    uint64_t xf, xr;       // the shared (k-1)-mer of a pair of starts, forward / reverse complement
+    uint32_t b0, b1;       // the base in front of it / behind it
+};
+// the pair whose first start is base rr (0 .. 14) of the word la: the 32-base window lies in la, lb, lc
+__device__ __forceinline__ map_pair_win map_pair_window(uint32_t la, uint32_t lb, uint32_t lc, uint32_t ma, uint32_t mb, uint32_t mc,
+                                                        int rr, int k, int sh, uint64_t m1mask) {
+    map_pair_win q;
+    const uint64_t W = (uint64_t)__builtin_amdgcn_alignbit(lb, la, 2 * rr) | ((uint64_t)__builtin_amdgcn_alignbit(lc, lb, 2 * rr) << 32);
+    const unsigned long long mA = ((unsigned long long)ma << 32) | mb, mB = ((unsigned long long)mb << 32) | mc;
+    const uint64_t V = (((mA << (2 * rr)) >> 32) << 32) | ((mB << (2 * rr)) >> 32);
+    q.b0 = (uint32_t)(V >> 62);            // the base in front of x (first base of the pair's first k-mer)
+    q.xf = (V >> sh) & m1mask;             // x forward (the k-mer at the pair's first start without its first base)
+    q.xr = (~W >> 2) & m1mask;             // its reverse complement
+    // the base behind x (last base of the pair's second k-mer): position rr + k of the words, 16 <= k <= 32: in lb or lc
+    const int pb = rr + k;
+    q.b1 = (((pb >> 4) == 1 ? lb : lc) >> (2 * (pb & 15))) & 3u;
+    return q;
+}
 template <int TABLE>
 __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                                                   const uint32_t *__restrict__ nm, int64_t s0, const sp_kparams &kp,
                                                   const uint32_t *__restrict__ bloom, int nbits,
                                                   unsigned long long *__restrict__ htab, uint64_t hmask, const sq_tab &T,
-                                                  unsigned long long lab[3], unsigned long long cm = ~0ULL /* starts that count */) {
+                                                  unsigned long long lab[3], const map_unit_lds &U,
+                                                  unsigned long long cm = ~0ULL /* starts that count */) {
+    constexpr int FW = TABLE ? SQ_FIELD : 4;
+    constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
+    constexpr uint32_t ANY = TABLE ? (uint32_t)SQ_ANY : 0x77777777u;
+    constexpr int NP = TABLE ? 2 : 3, ROUND_W = TABLE ? MAP2_ROUND_W : 2;
     unsigned long long ok_k, ok_x;      // k-mer at s0+j valid; shared (k-1)-mer at s0+j+1 valid
     {
         const uint64_t badA = sp_bad_starts64(nm, s0, kp.k - 1), badB = sp_bad_starts64(nm, s0 + 32, kp.k - 1);
@@ -540,6 +567,13 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
         ok_x = (unsigned long long)xA | ((unsigned long long)xB << 32);
     }
     if (__all((ok_x & 0x5555555555555555ULL) == 0)) return;
+    // the lanes of the wave that are here (a range's last wave, a grid-stride loop's last round): they share the candidates
+    const unsigned long long here = __ballot(1);
+    const int n_here = __popcll(here);
+    const int me = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
+    uint32_t *sw = U.words + tid;
+    uint16_t *queue = U.queue + (tid >> 6) * MAP_QCAP(TABLE);
     const int64_t w0 = s0 >> 4;   // a multiple of 4: 16-byte aligned
     const uint4 la = *reinterpret_cast<const uint4 *>(pk + w0);
     uint32_t l0 = la.x, l1 = la.y, l2 = la.z, l3 = la.w, l4 = pk[w0 + 4], l5 = pk[w0 + 5];
@@ -551,6 +585,10 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
     const uint4 ma = *reinterpret_cast<const uint4 *>(pm + w0);
     uint32_t m0 = ma.x, m1 = ma.y, m2 = ma.z, m3 = ma.w, m4 = pm[w0 + 4], m5 = pm[w0 + 5];
 #endif
+    sw[0 * MAP_BLOCK] = l0; sw[1 * MAP_BLOCK] = l1; sw[2 * MAP_BLOCK] = l2; sw[3 * MAP_BLOCK] = l3; sw[4 * MAP_BLOCK] = l4; sw[5 * MAP_BLOCK] = l5;
+    sw[6 * MAP_BLOCK] = (uint32_t)ok_k; sw[7 * MAP_BLOCK] = (uint32_t)(ok_k >> 32);
+#pragma unroll
+    for (int bit = 0; bit < NP; bit++) U.planes[bit * MAP_BLOCK + tid] = 0ULL;
     const int sh = 64 - 2 * kp.k;
     const uint64_t m1mask = kp.kmask >> 2;
     const bool core = (nbits & MAP_BLOOM_CORE) != 0;                   // (uniform; k >= 16 here)
@@ -559,38 +597,26 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
     uint32_t last_wi = 0xFFFFFFFFu, last_w = 0u;                       // the word this lane fetched last (index, content)
     uint32_t h_carry = 0u;                                              // hash of the core the previous two pairs ended with
 #pragma unroll 1
-    for (int w = 0; w < 4; w++) {
+    for (int wr = 0; wr < 4; wr += ROUND_W) {
+        // ---- phase 1: the filter over ROUND_W words of sixteen starts
+        uint32_t qn = 0;                                                // (uniform)
 #pragma unroll 1
-        for (int r = 0; r < 16; r += 4) {
-            const int j = 16 * w + r;           // two pairs: x1 at j + 1 (starts j, j + 1), x2 at j + 3 (starts j + 2, j + 3)
-            uint64_t xf[2], xr[2], canon[2];
-            uint32_t wd[2], b0[2], b1[2], bt[2], hx[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int rr = r + 2 * h;       // <= 14: the 32-base window at 16 w + rr lies in words w .. w + 2
-                const uint64_t W = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, 2 * rr) |
-                                   ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, 2 * rr) << 32);
-                const unsigned long long mA = ((unsigned long long)m0 << 32) | m1, mB = ((unsigned long long)m1 << 32) | m2;
-                const uint64_t V = (((mA << (2 * rr)) >> 32) << 32) | ((mB << (2 * rr)) >> 32);
-                b0[h] = (uint32_t)(V >> 62);            // the base in front of x (first base of the pair's first k-mer)
-                xf[h] = (V >> sh) & m1mask;             // x forward (the k-mer at the pair's first start without its first base)
-                xr[h] = (~W >> 2) & m1mask;             // its reverse complement
-                canon[h] = xf[h] < xr[h] ? xf[h] : xr[h];
-                bt[h] = map_bloom_bits3(canon[h], hx[h]);
-                // the base behind x (last base of the pair's second k-mer): position rr + k of the current words, k >= 16
-                const int pb = rr + kp.k;
-                const uint32_t lw = (pb >> 4) == 1 ? l1 : ((pb >> 4) == 2 ? l2 : l3);
-                b1[h] = (lw >> (2 * (pb & 15))) & 3u;
-            }
-            {
+        for (int w = wr; w < wr + ROUND_W; w++) {
+#pragma unroll 1
+            for (int r = 0; r < 16; r += 4) {
+                const int j = 16 * w + r;           // two pairs: x1 at j + 1 (starts j, j + 1), x2 at j + 3 (starts j + 2, j + 3)
+                const map_pair_win A = map_pair_window(l0, l1, l2, m0, m1, m2, r, kp.k, sh, m1mask);
+                const map_pair_win B = map_pair_window(l0, l1, l2, m0, m1, m2, r + 2, kp.k, sh, m1mask);
+                uint32_t hx1, hx2;
+                const uint32_t bt1 = map_bloom_bits3(A.xf < A.xr ? A.xf : A.xr, hx1), bt2 = map_bloom_bits3(B.xf < B.xr ? B.xf : B.xr, hx2);
                 // the filter words of x1 and x2 (sp_map.h): by the smaller-hashed core of the chain a - x1 - b - x2 - c, or by
                 // the (k-1)-mer itself; a word the lane fetched for the previous pair is not fetched again
                 uint32_t wi1, wi2;
                 if (core) {
-                    const uint64_t tb_f = xf[0] & cmask, tb_r = xr[0] >> 4, tc_f = xf[1] & cmask, tc_r = xr[1] >> 4;
+                    const uint64_t tb_f = A.xf & cmask, tb_r = A.xr >> 4, tc_f = B.xf & cmask, tc_r = B.xr >> 4;
                     uint32_t ha = h_carry;              // (this iteration's a IS the previous one's c: the same bases)
                     if (j == 0) {                       // (uniform: the unit's first two pairs)
-                        const uint64_t ta_f = xf[0] >> 4, ta_r = xr[0] & cmask;
+                        const uint64_t ta_f = A.xf >> 4, ta_r = A.xr & cmask;
                         ha = map_core_hash(ta_f < ta_r ? ta_f : ta_r);
                     }
                     const uint32_t hb = map_core_hash(tb_f < tb_r ? tb_f : tb_r), hc = map_core_hash(tc_f < tc_r ? tc_f : tc_r);
@@ -598,8 +624,8 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                     wi1 = map_core_word(ha < hb ? ha : hb, nbits);
                     wi2 = map_core_word(hb < hc ? hb : hc, nbits);
                 } else {
-                    wi1 = hx[0] >> wsh;
-                    wi2 = hx[1] >> wsh;
+                    wi1 = hx1 >> wsh;
+                    wi2 = hx2 >> wsh;
                 }
                 const bool v1 = (ok_x >> j) & 1ULL, v2 = (ok_x >> (j + 2)) & 1ULL;
                 const bool need1 = v1 && wi1 != last_wi;
@@ -607,62 +633,81 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                 uint32_t f1 = 0, f2 = 0;
                 if (need1) f1 = bloom[wi1];
                 if (need2) f2 = bloom[wi2];
-                wd[0] = v1 ? (need1 ? f1 : last_w) : 0u;
-                wd[1] = v2 ? (need2 ? f2 : (v1 ? wd[0] : last_w)) : 0u;
-                if (v2) { last_wi = wi2; last_w = wd[1]; }
-                else if (v1) { last_wi = wi1; last_w = wd[0]; }
+                const uint32_t wd1 = v1 ? (need1 ? f1 : last_w) : 0u;
+                const uint32_t wd2 = v2 ? (need2 ? f2 : (v1 ? wd1 : last_w)) : 0u;
+                if (v2) { last_wi = wi2; last_w = wd2; }
+                else if (v1) { last_wi = wi1; last_w = wd1; }
+                const bool cand1 = (wd1 & bt1) == bt1, cand2 = (wd2 & bt2) == bt2;      // (an invalid pair's word is 0)
+                const unsigned long long bal = __ballot(cand1 || cand2);
+                if (cand1 || cand2)
+                    queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                        (uint16_t)((uint32_t)lane | ((uint32_t)(j >> 2) << 6) | (cand1 ? 0x400u : 0u) | (cand2 ? 0x800u : 0u));
+                qn += (uint32_t)__popcll(bal);
             }
-            constexpr int FW = TABLE ? SQ_FIELD : 4;
-            constexpr uint32_t LBL = TABLE ? 3u : 7u, SEEN = TABLE ? 4u : 8u, FMASK = TABLE ? 7u : 15u;
-            constexpr uint32_t ANY = TABLE ? (uint32_t)SQ_ANY : 0x77777777u;
-            const bool cand[2] = {(wd[0] & bt[0]) == bt[0], (wd[1] & bt[1]) == bt[1]};      // (an invalid pair's word is 0)
+            l0 = l1; l1 = l2; l2 = l3; l3 = l4; l4 = l5;
+            m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5;
+        }
+        // ---- phase 2: the queue, dealt out to the lanes that are here (LDS operations of a wave complete in program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t e0 = (uint32_t)me; e0 < qn; e0 += (uint32_t)n_here) {
+            const uint32_t ent = queue[e0];
+            const int owner = wave0 + (int)(ent & 63u), qi = (int)((ent >> 6) & 15u), j = 4 * qi, w = qi >> 2, r = j & 15;
+            const bool cand[2] = {(ent & 0x400u) != 0u, (ent & 0x800u) != 0u};
+            const uint32_t *ow = U.words + owner;
+            const uint32_t oa = ow[w * MAP_BLOCK], ob = ow[(w + 1) * MAP_BLOCK], oc = ow[(w + 2) * MAP_BLOCK];
+            const uint32_t okq = ow[(6 + (w >> 1)) * MAP_BLOCK] >> (j & 31);       // countable starts j .. j + 3 of the owner's unit
+            const uint32_t pa = sp_msb_of_lsb(oa), pb_ = sp_msb_of_lsb(ob), pc = sp_msb_of_lsb(oc);
+            const map_pair_win Pw[2] = {map_pair_window(oa, ob, oc, pa, pb_, pc, r, kp.k, sh, m1mask),
+                                        map_pair_window(oa, ob, oc, pa, pb_, pc, r + 2, kp.k, sh, m1mask)};
             uint32_t e[2] = {0u, 0u};
             uint32_t loc[2] = {0u, 0u};                               // TABLE: where a hit's "seen" bits go (sq_mark)
             uint64_t slot[2] = {0, 0};                                // hash table: the pair's slot
-            bool fwd_[2] = {xf[0] <= xr[0], xf[1] <= xr[1]};          // orientation the fields are laid out in
+            bool fwd_[2] = {Pw[0].xf <= Pw[0].xr, Pw[1].xf <= Pw[1].xr};          // orientation the fields are laid out in
             if (TABLE) {
-                if (cand[0] || cand[1]) {
-                    // the core the two pairs share: last k-3 bases of x1 = first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so it is)
-                    const uint64_t s_f = cand[0] ? (xf[0] & cmask) : (xf[1] >> 4), s_r = cand[0] ? (xr[0] >> 4) : (xr[1] & cmask);
-                    const bool sfw = s_f <= s_r;
-                    const uint64_t t = sfw ? s_f : s_r;
-                    const uint64_t hm = sq_mix(t, T.sb);
-                    const uint64_t bucket = hm >> T.tb, tagb = (hm & ((1ULL << T.tb) - 1ULL)) << 5;
-                    // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
-                    const uint32_t se1 = (sfw ? 0u : 16u) | (uint32_t)(sfw ? (xf[0] >> T.sb) : (xr[0] & 15ULL));
-                    const uint32_t se2 = (sfw ? 16u : 0u) | (uint32_t)(sfw ? (xf[1] & 15ULL) : (xr[1] >> T.sb));
-                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(T.buckets + 4 * bucket);
-                    const ulonglong2 B0 = bp[0], B1 = bp[1];
-                    if (cand[0]) {
-                        const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se1, t, se1);
-                        e[0] = hh.fields;
-                        loc[0] = hh.loc;
-                    }
-                    if (cand[1]) {
-                        const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se2, t, se2);
-                        e[1] = hh.fields;
-                        loc[1] = hh.loc;
-                    }
-                    fwd_[0] = fwd_[1] = sfw;      // the fields are laid out in the orientation in which t is canonical
+                // the core the two pairs share: last k-3 bases of x1 = first k-3 bases of x2 (a candidate's (k-1)-mer is valid, so it is)
+                const uint64_t s_f = cand[0] ? (Pw[0].xf & cmask) : (Pw[1].xf >> 4), s_r = cand[0] ? (Pw[0].xr >> 4) : (Pw[1].xr & cmask);
+                const bool sfw = s_f <= s_r;
+                const uint64_t t = sfw ? s_f : s_r;
+                const uint64_t hm = sq_mix(t, T.sb);
+                const uint64_t bucket = hm >> T.tb, tagb = (hm & ((1ULL << T.tb) - 1ULL)) << 5;
+                // x1 = e + s: side L read forward, side R (e reverse-complemented) read backward; x2 = s + e: the mirror image
+                const uint32_t se1 = (sfw ? 0u : 16u) | (uint32_t)(sfw ? (Pw[0].xf >> T.sb) : (Pw[0].xr & 15ULL));
+                const uint32_t se2 = (sfw ? 16u : 0u) | (uint32_t)(sfw ? (Pw[1].xf & 15ULL) : (Pw[1].xr >> T.sb));
+                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(T.buckets + 4 * bucket);
+                const ulonglong2 B0 = bp[0], B1 = bp[1];
+                if (cand[0]) {
+                    const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se1, t, se1);
+                    e[0] = hh.fields;
+                    loc[0] = hh.loc;
                 }
+                if (cand[1]) {
+                    const sq_hit hh = sq_find(T, B0, B1, bucket, tagb | se2, t, se2);
+                    e[1] = hh.fields;
+                    loc[1] = hh.loc;
+                }
+                fwd_[0] = fwd_[1] = sfw;      // the fields are laid out in the orientation in which t is canonical
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    if (cand[h]) e[h] = sps_pair_get(canon[h], htab, hmask, slot[h]);
+                    if (cand[h]) e[h] = sps_pair_get(Pw[h].xf < Pw[h].xr ? Pw[h].xf : Pw[h].xr, htab, hmask, slot[h]);
             }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (!(e[h] & ANY)) continue;
                 const bool fw = fwd_[h];
-                const int f0 = fw ? (int)b0[h] : 7 - (int)b0[h], f1 = fw ? 4 + (int)b1[h] : 3 - (int)b1[h];
-                const uint32_t okk = (uint32_t)(ok_k >> (j + 2 * h));
+                const int f0 = fw ? (int)Pw[h].b0 : 7 - (int)Pw[h].b0, f1 = fw ? 4 + (int)Pw[h].b1 : 3 - (int)Pw[h].b1;
+                const uint32_t okk = okq >> (2 * h);
                 const uint32_t v0 = (okk & 1u) ? (e[h] >> (FW * f0)) & FMASK : 0u;
                 const uint32_t v1 = (okk & 2u) ? (e[h] >> (FW * f1)) & FMASK : 0u;
                 const uint32_t two = (v0 & LBL) | ((v1 & LBL) << 8);
                 if (!two) continue;
 #pragma unroll
-                for (int bit = 0; bit < (TABLE ? 2 : 3); bit++)
-                    lab[bit] |= (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1)) << (j + 2 * h);
+                for (int bit = 0; bit < NP; bit++) {
+                    const unsigned long long b2 = (unsigned long long)(((two >> bit) & 1u) | (((two >> (8 + bit)) & 1u) << 1));
+                    if (b2) atomicOr(&U.planes[bit * MAP_BLOCK + owner], b2 << (j + 2 * h));
+                }
                 uint32_t mark = 0;       // "seen": first touch only
                 if ((v0 & LBL) && !(v0 & SEEN)) mark |= SEEN << (FW * f0);
                 if ((v1 & LBL) && !(v1 & SEEN)) mark |= SEEN << (FW * f1);
@@ -672,9 +717,12 @@ __device__ __forceinline__ void map_unit_scan64_h(const uint32_t *__restrict__ p
                 }
             }
         }
-        l0 = l1; l1 = l2; l2 = l3; l3 = l4; l4 = l5;
-        m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#pragma unroll
+    for (int bit = 0; bit < NP; bit++) lab[bit] = U.planes[bit * MAP_BLOCK + tid];
 }
 
 // (six waves per SIMD = TWO 768-thread workgroups per CU: at 82 VGPRs -- one more than that allows -- the kernel ran one: 52.6 -> 66.6 ms)
@@ -685,6 +733,7 @@ k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
                int bloom_bits, int *__restrict__ slot_counts, unsigned long long *__restrict__ n_mapped) {
     __shared__ int hist[MAP_LDS_ENTRIES];
     __shared__ unsigned long long red[16];
+    MAP_UNIT_LDS_DECL(TABLE, 8);
     unsigned long long mapped = 0;
     const int64_t n_ranges = (P.n_units + MAP_BLOCK - 1) / MAP_BLOCK;
     for (int64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
@@ -698,7 +747,7 @@ k5_map_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm,
         }
         if (u < P.n_units) {
             unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-            map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab);
+            map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab, ulds);
             if (lab[0] | lab[1] | lab[2]) {
                 auto add = [&](int64_t os, unsigned long long within) {
                     for (int sg = 0; sg < P.S; sg++) {
@@ -752,6 +801,7 @@ k5_map_feat_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict_
                     int64_t n_units, const int64_t *__restrict__ foff, int64_t n_feat, int S,
                     unsigned long long *__restrict__ htab, uint64_t hmask, sq_tab T,
                     const uint32_t *__restrict__ bloom, int bloom_bits, unsigned long long *__restrict__ counts) {
+    MAP_UNIT_LDS_DECL(TABLE, 8);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int k = kp.k;
@@ -775,7 +825,7 @@ k5_map_feat_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict_
             if (e >= s0 + SP_UNIT) break;
         }
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64_h<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, htab, hmask, T, lab, fit);
+        map_unit_scan64_h<TABLE>(pk, pm, nm, s0, kp, bloom, bloom_bits, htab, hmask, T, lab, ulds, fit);
         if (!(lab[0] | lab[1] | lab[2])) continue;
         for (int64_t f = lo; f < n_feat; f++) {
             const int64_t a = foff[f], e = foff[f + 1];
@@ -2082,13 +2132,14 @@ __global__ void __launch_bounds__(MAP_BLOCK)
 k5_map_mask_sparse2(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nm, sp_kparams kp,
                     int64_t n_units, int S, unsigned long long *__restrict__ htab, uint64_t hmask, sq_tab T, const uint32_t *__restrict__ bloom,
                     int bloom_bits, const unsigned long long *__restrict__ cov, unsigned long long *__restrict__ masks) {
+    MAP_UNIT_LDS_DECL(TABLE, 8);
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; u < n_units; u += stride) {
         const unsigned long long cv = cov[u];
         if (__all(cv == 0ULL)) continue;
         unsigned long long lab[3] = {0ULL, 0ULL, 0ULL};
-        map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab, cv);
+        map_unit_scan64_h<TABLE>(pk, pm, nm, u * SP_UNIT, kp, bloom, bloom_bits, htab, hmask, T, lab, ulds, cv);
         for (int sg = 0; sg < S; sg++) {
             const int l = sg + 1;
             masks[u * S + sg] = ((l & 1) ? lab[0] : ~lab[0]) & ((l & 2) ? lab[1] : ~lab[1]) & ((l & 4) ? lab[2] : ~lab[2]) & cv;
