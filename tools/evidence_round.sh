@@ -22,7 +22,7 @@ MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python bench.py --no-cpu-bas
 python tools/stage_ms.py gpurun_out/${R}_bench_*.json
 for c in wheat peanut ara; do timeout 600 python tools/e2e_cli.py $c /tmp/sp_e2e_$c > gpurun_out/${R}_e2e_cli_$c.log 2>&1; rm -rf /tmp/sp_e2e_$c; done
 timeout 900 python tools/feat_bench.py wheat 2e6 > gpurun_out/${R}_feature_mode_2M.log 2>&1
-: > gpurun_out/${R}_fuzz_final.txt
-(echo "# single-stream fuzz, 4 processes x 300 s"; bash tools/fuzz_parallel.sh 4 1000000 601 300) >> gpurun_out/${R}_fuzz_final.txt 2>&1
-(echo "# stream-mode fuzz (3..7 chains forced in flight, a busy neighbour), 8 processes x ${SP_FUZZ_STREAM_SECS:-540} s"; bash tools/fuzz_parallel.sh 8 1000000 9101 ${SP_FUZZ_STREAM_SECS:-540} streams) >> gpurun_out/${R}_fuzz_final.txt 2>&1
-cat gpurun_out/${R}_final_pytest_gpu.txt gpurun_out/${R}_fuzz_final.txt
+: > gpurun_out/${R}_fuzz_evidence.txt
+(echo "# single-stream fuzz, 4 processes x 300 s"; bash tools/fuzz_parallel.sh 4 1000000 ${SP_FUZZ_SEED:-601} 300) >> gpurun_out/${R}_fuzz_evidence.txt 2>&1
+(echo "# stream-mode fuzz (3..7 chains forced in flight, a busy neighbour), 2 processes x ${SP_FUZZ_STREAM_SECS:-900} s"; SP_BUSY_SCALE=0.002 bash tools/fuzz_parallel.sh 2 1000000 $((${SP_FUZZ_SEED:-601} + 8500)) ${SP_FUZZ_STREAM_SECS:-900} streams) >> gpurun_out/${R}_fuzz_evidence.txt 2>&1
+cat gpurun_out/${R}_final_pytest_gpu.txt gpurun_out/${R}_fuzz_evidence.txt

@@ -1,4 +1,8 @@
-# one SQ counter pass of bench.py per library variant: tools/_pmc1.sh name[:lib] ...
+#!/bin/bash
+# One SQ counter pass (wave / busy / wait cycles, VALU and LDS instruction counts) of bench.py per library variant, seconds each:
+#   tools/pmc_sq.sh name[:lib.so] ...   ->  gpurun_out/pmc1_<name>.json   (SP_PMC_ARGS="-k 17" etc. go to bench.py)
+# VALU utilisation of a kernel = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x its time x 2.4 GHz): how round 6 found that k3_eval
+# and k5_map2 were bound by instruction issue (0.88, 0.70) and what the two-phase walk removed (15.9 G -> 11.3 G instructions).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for spec in "$@"; do
