@@ -553,3 +553,30 @@ def test_rank_tests_in_array_form_equal_scipy_row_by_row():
             got = _scipy_rows("wilcoxon", a, b)
             exp = np.array([stats.wilcoxon(a[i], b[i])[1] for i in range(M)])
         assert np.array_equal(got, exp, equal_nan=True), ("wilcoxon", n, np.nanmax(np.abs(got - exp)))
+
+
+def test_cli_entry_point_leaves_without_teardown(tmp_path):
+    """`python -m subphaser_amd` / the `subphaser` script go through pipeline.cli: main(), flush, os._exit(0) -- output written before
+    the call returns is on disk, buffered stdout / stderr are flushed, argparse's own exits (-h) keep their codes, and SP_SLOW_EXIT=1
+    takes the interpreter's ordinary way out (atexit handlers run)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "subphaser_amd", "-h"], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "-sg_cfgs" in out.stdout or "sg_cfgs" in out.stdout
+    marker, atexit_marker = tmp_path / "written", tmp_path / "atexit"
+    prog = ("import atexit, sys\n"
+            "from subphaser_amd import pipeline\n"
+            "atexit.register(lambda: open(%r, 'w').write('x'))\n"
+            "def fake_main(argv=None):\n"
+            "    open(%r, 'w').write('done')\n"
+            "    sys.stdout.write('buffered-out'); sys.stderr.write('buffered-err')\n"
+            "pipeline.main = fake_main\n"
+            "pipeline.cli([])\n"
+            "print('not reached')\n") % (str(atexit_marker), str(marker))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("SP_SLOW_EXIT", None)
+    fast = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120, env=env)
+    assert fast.returncode == 0 and fast.stdout == "buffered-out" and "buffered-err" in fast.stderr
+    assert marker.read_text() == "done" and not atexit_marker.exists()
+    slow = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120, env=dict(env, SP_SLOW_EXIT="1"))
+    assert slow.returncode == 0 and "not reached" in slow.stdout and atexit_marker.exists()
