@@ -722,9 +722,13 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
 // c2_count holds ONE 1024-thread block per CU (128 KiB of counters) whose phases -- count, write out + clear -- run one
 // after the other with nothing else resident to fill the CU.  A fine bucket that receives fewer than 65536 records
 // cannot push any counter past 16 bits, so its counters are packed two to a word (64 KiB): two blocks per CU, one
-// counting while the other writes out.  Buckets with more records (repeat-rich ones) are put on a list for c2_count.
-// Same outputs: byte table, overflow segments (at most 257 slots of such a bucket reach 255: they always fit the
-// stage), tallies.  The write-out clears the counters it has read.
+// counting while the other writes out.
+// Round 6: the buckets with MORE records (repeat-rich ones: 10 % of the buckets of the wheat-like genome, and through c2_count
+// 14 of the 38 ms the two kernels took per pass) are counted here as well -- a counter passes 16 bits only where ONE k-mer
+// has 65536 copies in the chromosome.  Their adds look at what they got back: an add that finds its half at 0xFFFF wrapped it,
+// the bucket's counters are thrown away and the bucket is counted again on 32-bit counters, half of its slots at a time, in the
+// same 64 KiB.  c2_count stays as the cross-check (SP_C2_COUNT16=0) and for engine-3-less configurations that ask for it.
+// Same outputs: byte table, overflow segments, tallies.  The write-out clears the counters it has read.
 #ifndef C2_C16_THREADS
 #define C2_C16_THREADS 512
 #endif
@@ -734,12 +738,10 @@ c2_count(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span 
 __global__ void __launch_bounds__(C2_C16_THREADS)
 c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ span, int64_t n_fine, uint32_t lower,
            uint8_t *__restrict__ tab, unsigned long long *__restrict__ out3, uint2 *__restrict__ ovf_tmp, unsigned long long ovf_cap,
-           uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ big_list,
-           unsigned long long *__restrict__ n_big) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[C2_FINE / 2];      // two 16-bit counters per word
+           uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[C2_FINE / 2];      // two 16-bit counters per word (a wrapped bucket: 2^14 32-bit counters)
     __shared__ unsigned long long red[16];
-    __shared__ uint32_t s_nov;
-    __shared__ uint2 stage[512];
+    __shared__ uint32_t s_nov, s_over;
     unsigned long long s = 0, n = 0;
     uint2 pf[C2_C16_PF];
     unsigned long long pf_lo = 0, pf_hi = 0;
@@ -748,7 +750,6 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
         const ulonglong2 d = span[fbn];
         pf_lo = d.x;                             // (a multiple of 4 records, like the size: whole quads)
         pf_hi = d.y;
-        if (pf_hi - pf_lo >= 65536ULL) return;   // not ours: no loads
         const unsigned long long n4 = (pf_hi - pf_lo) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + pf_lo);
 #pragma unroll
@@ -760,60 +761,116 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
     {
         uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
         for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x == 0) s_nov = 0;
+        if (threadIdx.x == 0) s_nov = s_over = 0;
     }
     prefetch(blockIdx.x);
     __syncthreads();
-    // a record adds 1 to its half of the word; a pad record (0xFFFF) adds 0 to the last word
-    auto add = [&](uint32_t r) { atomicAdd(&cnt[(r & (C2_FINE - 1)) >> 1], ((r >> C2_B3) ^ 1u) << (16u * (r & 1u))); };
     for (int64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
-        // (round 6 audit: the tally is cleared HERE, behind the barrier that ends the previous bucket.  It used to be cleared
-        // by thread 0 right after it had read `nov` below -- with no barrier between that store and the other waves' read
+        // (round 6 audit: the tallies are cleared HERE, behind the barrier that ends the previous bucket.  s_nov used to be
+        // cleared by thread 0 right after it had read `nov` below -- with no barrier between that store and the other waves' read
         // of s_nov, so a wave that left the barrier late could read 0 and skip its share of the staged overflow pairs.)
-        if (threadIdx.x == 0) s_nov = 0;
+        if (threadIdx.x == 0) s_nov = s_over = 0;
         const unsigned long long lo = pf_lo, hi = pf_hi;
-        if (hi - lo >= 65536ULL) {               // block-uniform: c2_count takes this bucket
-            if (threadIdx.x == 0) big_list[atomicAdd(n_big, 1ULL)] = (uint32_t)fb;
-            prefetch(fb + gridDim.x);
-            continue;
-        }
+        const bool big = hi - lo >= 65536ULL;    // block-uniform: a counter of this bucket CAN pass 16 bits
         const unsigned long long n4 = (hi - lo) >> 2;
         const uint2 *p2 = reinterpret_cast<const uint2 *>(buf2 + lo);
-#pragma unroll
-        for (int q = 0; q < C2_C16_PF; q++) {
-            if (threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
-                add(pf[q].x & 0xffffu);
-                add(pf[q].x >> 16);
-                add(pf[q].y & 0xffffu);
-                add(pf[q].y >> 16);
-            }
-        }
-        // the rest of the bucket (an average bucket holds 2.5 x what the prefetch covers) in rounds of C2_C16_PF loads
-        // per lane: one load per round trip -- what this loop was -- kept 8 KB in flight per CU, i.e. ~1.4 TB/s for the
-        // whole chip at 1.5 us per trip, and that, not the LDS, was the kernel's rate (round 5)
-        for (unsigned long long base = (unsigned long long)C2_C16_PF * C2_C16_THREADS; base < n4;
-             base += (unsigned long long)C2_C16_PF * C2_C16_THREADS) {
-            uint2 v[C2_C16_PF];
+        // the bucket's records: the prefetched ones, then the rest (an average bucket holds 2.5 x what the prefetch covers) in rounds
+        // of C2_C16_PF loads per lane: one load per round trip -- what this loop was -- kept 8 KB in flight per CU, i.e. ~1.4 TB/s
+        // for the whole chip at 1.5 us per trip, and that, not the LDS, was the kernel's rate (round 5)
+        auto all_records = [&](auto add) {
 #pragma unroll
             for (int q = 0; q < C2_C16_PF; q++) {
-                // (unconditional, from a clamped index: a load under a condition is followed by a wait of its own)
-                const unsigned long long i = base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS;
-                v[q] = p2[i < n4 ? i : n4 - 1ULL];
-            }
-#pragma unroll
-            for (int q = 0; q < C2_C16_PF; q++) {
-                if (base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
-                    add(v[q].x & 0xffffu);
-                    add(v[q].x >> 16);
-                    add(v[q].y & 0xffffu);
-                    add(v[q].y >> 16);
+                if (threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
+                    add(pf[q].x & 0xffffu);
+                    add(pf[q].x >> 16);
+                    add(pf[q].y & 0xffffu);
+                    add(pf[q].y >> 16);
                 }
             }
+            for (unsigned long long base = (unsigned long long)C2_C16_PF * C2_C16_THREADS; base < n4;
+                 base += (unsigned long long)C2_C16_PF * C2_C16_THREADS) {
+                uint2 v[C2_C16_PF];
+#pragma unroll
+                for (int q = 0; q < C2_C16_PF; q++) {
+                    // (unconditional, from a clamped index: a load under a condition is followed by a wait of its own)
+                    const unsigned long long i = base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS;
+                    v[q] = p2[i < n4 ? i : n4 - 1ULL];
+                }
+#pragma unroll
+                for (int q = 0; q < C2_C16_PF; q++) {
+                    if (base + threadIdx.x + (unsigned long long)q * C2_C16_THREADS < n4) {
+                        add(v[q].x & 0xffffu);
+                        add(v[q].x >> 16);
+                        add(v[q].y & 0xffffu);
+                        add(v[q].y >> 16);
+                    }
+                }
+            }
+        };
+        // a record adds 1 to its half of the word; a pad record (0xFFFF) adds 0 to the last word
+        if (!big) {
+            all_records([&](uint32_t r) { atomicAdd(&cnt[(r & (C2_FINE - 1)) >> 1], ((r >> C2_B3) ^ 1u) << (16u * (r & 1u))); });
+        } else {
+            uint32_t wrapped = 0;
+            all_records([&](uint32_t r) {
+                const uint32_t sh = 16u * (r & 1u), inc = ((r >> C2_B3) ^ 1u) << sh;
+                const uint32_t old = atomicAdd(&cnt[(r & (C2_FINE - 1)) >> 1], inc);
+                wrapped |= (inc != 0u && ((old >> sh) & 0xffffu) == 0xffffu) ? 1u : 0u;
+            });
+            if (wrapped) s_over = 1u;
         }
         prefetch(fb + gridDim.x);   // in flight across the write-out below
         __syncthreads();
-        // write-out: 8 slots per 16-byte LDS read -> 8 table bytes; the words are cleared for the next bucket
         uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        const unsigned long long seg = lo / 255ULL;
+        if (big && s_over) {
+            // (block-uniform) a counter wrapped -- one k-mer with 65536 copies or more in this chromosome: the bucket again, on
+            // 32-bit counters, HALF of its slots at a time in the same 64 KiB (nothing is pipelined here: a handful of buckets per
+            // genome).  Until round 6 such buckets -- and every bucket of 65536 records or more -- went to c2_count, whose
+            // 128 KiB of counters need a CU to themselves: with four chains side by side its workgroups mostly waited for one.
+            for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) c4[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            for (uint32_t h = 0; h < 2u; h++) {
+                for (unsigned long long i = threadIdx.x; i < n4; i += C2_C16_THREADS) {
+                    const uint2 v = p2[i];
+                    const uint32_t r4[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (!(r4[q] >> C2_B3) && ((r4[q] >> (C2_B3 - 1)) & 1u) == h) atomicAdd(&cnt[r4[q] & (C2_FINE / 2 - 1)], 1u);
+                }
+                __syncthreads();
+                uint32_t *t32 = reinterpret_cast<uint32_t *>(tab + fb * C2_FINE + (int64_t)h * (C2_FINE / 2));
+                for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) {
+                    const uint4 v = c4[i];
+                    c4[i] = make_uint4(0, 0, 0, 0);
+                    const uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t c = a4[j];
+                        if (c >= lower) { s += c; n++; }
+                        if (c >= 255u) {
+                            const unsigned long long pos = seg + atomicAdd(&s_nov, 1u);
+                            if (pos < ovf_cap) ovf_tmp[pos] = make_uint2((uint32_t)(fb * C2_FINE + h * (C2_FINE / 2) + 4 * i + j), c);
+                        }
+                        packed |= (c < 255u ? c : 255u) << (8 * j);
+                    }
+                    t32[i] = packed;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t nov = s_nov;
+                if (nov) seg_base[fb] = (uint32_t)seg;
+                seg_cnt[fb] = nov;
+            }
+            __syncthreads();
+            continue;
+        }
+        // write-out: 8 slots per 16-byte LDS read -> 8 table bytes; the words are cleared for the next bucket.  A saturated slot's
+        // (slot, count) pair goes straight to the bucket's segment of the staging list (c2_count: its closed-form place
+        // floor(first record / 255) -- a slot that overflows accounts for >= 255 records, so the segment holds them whatever the
+        // bucket's size; ovf_place ranks a segment by slot afterwards, the order of arrival does not matter)
         uint2 *t64 = reinterpret_cast<uint2 *>(tab + fb * C2_FINE);
         for (int i = threadIdx.x; i < C2_FINE / 8; i += C2_C16_THREADS) {
             const uint4 v = c4[i];
@@ -825,22 +882,19 @@ c2_count16(const uint16_t *__restrict__ buf2, const ulonglong2 *__restrict__ spa
                 const uint32_t c = (w4[j >> 1] >> (16 * (j & 1))) & 0xffffu;
                 if (c >= lower) { s += c; n++; }
                 if (c >= 255u) {
-                    const uint32_t pos = atomicAdd(&s_nov, 1u);
-                    if (pos < 512u) stage[pos] = make_uint2((uint32_t)(fb * C2_FINE + 8 * i + j), c);
+                    const unsigned long long pos = seg + atomicAdd(&s_nov, 1u);
+                    if (pos < ovf_cap) ovf_tmp[pos] = make_uint2((uint32_t)(fb * C2_FINE + 8 * i + j), c);
                 }
                 packed[j >> 2] |= (c < 255u ? c : 255u) << (8 * (j & 3));
             }
             t64[i] = make_uint2(packed[0], packed[1]);
         }
         __syncthreads();
-        const uint32_t nov = s_nov;   // block-uniform; < 65536 / 255 + 1 <= 257
-        if (nov) {
-            const unsigned long long base = lo / 255ULL;     // (c2_count: the segment's closed-form place)
-            for (uint32_t p = threadIdx.x; p < nov; p += C2_C16_THREADS)
-                if (base + p < ovf_cap) ovf_tmp[base + p] = stage[p];
-            if (threadIdx.x == 0) seg_base[fb] = (uint32_t)base;
+        if (threadIdx.x == 0) {
+            const uint32_t nov = s_nov;
+            if (nov) seg_base[fb] = (uint32_t)seg;
+            seg_cnt[fb] = nov;
         }
-        if (threadIdx.x == 0) seg_cnt[fb] = nov;
         __syncthreads();
     }
     unsigned long long ts = sp_block_sum_u64(s, red);
@@ -1451,7 +1505,7 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
     size_t o_segb = o_buf2 + al(cap_keys2 * 2 + 64);               // overflow segments: base, count, offsets per fine bucket
     size_t o_segc = o_segb + al(nf * 4);
     size_t o_sego = o_segc + al(nf * 4);
-    size_t o_bigl = o_sego + al((nf + 1) * 4);                    // buckets c2_count16 leaves to c2_count
+    size_t o_bigl = o_sego + al((nf + 1) * 4);                    // (unused since round 6: c2_count16 keeps every bucket)
     size_t total = o_bigl + al(nf * 4);
     void *&d_ws2 = ctx->lane ? ctx->lane->d_ws2 : ctx->d_ws2;           // this lane's workspace (sp_common.h)
     int64_t &ws2_bytes = ctx->lane ? ctx->lane->ws2_bytes : ctx->ws2_bytes;
@@ -1557,15 +1611,9 @@ int sp_count_engine2(sp_ctx *ctx, sp_chrom &c, const sp_kparams &kp, int lower, 
                   (int64_t)nf, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, (uint32_t)lower, c.d_tab, d_len4,
                   ovf_tmp, ovf_cap, seg_base, seg_cnt);
     } else {
-        uint32_t *big_list = (uint32_t *)(ws + o_bigl);
-        unsigned long long *n_big = ghist;      // (the histogram is dead by now; its first word was zeroed with the head... re-zero)
-        SP_HIP(ctx, hipMemsetAsync(n_big, 0, 8, ctx->stream));
         int grid16 = (int)((int64_t)nf < (int64_t)ctx->n_cu * 2 ? (int64_t)nf : (int64_t)ctx->n_cu * 2);
         SP_LAUNCH(ctx, "c2_count16", c2_count16, dim3(grid16), dim3(C2_C16_THREADS), 0, buf2, (const ulonglong2 *)span, (int64_t)nf,
-                  (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt, big_list, n_big);
-        SP_LAUNCH(ctx, "c2_count", c2_count, dim3(gridc), dim3(C2_COUNT_THREADS), C2_FINE * 4, buf2, (const ulonglong2 *)span,
-                  (int64_t)nf, (const uint32_t *)big_list, (const unsigned long long *)n_big, (uint32_t)lower, c.d_tab, d_len4,
-                  ovf_tmp, ovf_cap, seg_base, seg_cnt);
+                  (uint32_t)lower, c.d_tab, d_len4, ovf_tmp, ovf_cap, seg_base, seg_cnt);
     }
     return sp_ovf_finalize(ctx, c, ovf_tmp, seg_base, seg_cnt, seg_off, (int64_t)nf, d_len4 + 2);
 }

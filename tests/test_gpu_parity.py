@@ -117,6 +117,18 @@ def test_count_engine2_hot_slots(gpu_ctx, k):
     _count_both(gpu_ctx, seqs, k, 2, engine=2)
 
 
+def test_count_engine2_big_buckets_on_16_bit_counters(gpu_ctx):
+    """Round 6: c2_count16 counts the fine buckets of 65536 records and more as well (their adds check for a wrapped half; a bucket
+    with a wrapped counter is handed to c2_count) and writes the pairs of saturated slots (>= 255) straight to the bucket's segment
+    of the staging list.  k = 9 on 34 Mb of random sequence: four fine buckets of ~8 M records, about half of their 32768 slots at
+    255 or more; then the same with a 100 K-copy homopolymer (a wrapped counter) in one of them."""
+    rng = np.random.RandomState(909)
+    big = _rand_seq(rng, 34_000_000)
+    _count_both(gpu_ctx, [big, _rand_seq(rng, 5000)], 9, 3, engine=2)
+    big[1_000_000:1_100_000] = ord("A")
+    _count_both(gpu_ctx, [big, _rand_seq(rng, 70_000)], 9, 1, engine=2)
+
+
 def test_count_engine2_sampled_sizing_and_recount(gpu_ctx, monkeypatch):
     """Engine 2 lays its partition buckets out from a 1-in-16 stripe sample (round 3).  (a) on ordinary sequence
     nothing overruns and nothing is recounted; (b) with the slack removed and the multiplier halved (test hooks)
